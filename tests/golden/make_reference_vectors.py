@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by EXECUTING THE REFERENCE'S OWN CODE (build container only).
+
+Run from the repo root:   python tests/golden/make_reference_vectors.py
+Needs /root/reference (absent on the GPU box; nothing at test time reads it).
+
+The reference (katotetsuro/chainer-maskrcnn) cannot be imported as is: chainer, chainercv
+and cv2 are not installed and cannot be (no network).  This script registers in-memory
+placeholder modules in ``sys.modules`` -- nothing is written to disk and no reference
+source is copied -- so that two in-tree reference functions execute:
+
+  1. ``map_rois_to_fpn_levels`` (model/rpn/multilevel_region_proposal_network.py:16-31):
+     pure NumPy once ``chainer.backends.cuda.get_array_module`` returns numpy.
+     => levels_reference.npz  PINS the oracle's arithmetic for that function.
+
+  2. ``ProposalTargetCreator.__call__`` (utils/proposal_target_creator.py:26-137): its
+     third-party calls (ChainerCV ``bbox_iou`` / ``bbox2loc``, ``cv2.resize``) are served by
+     THIS REPO'S ORACLE restatements, so the fixture pins only the reference's control flow
+     (candidate sets, sample counts, np.random.choice draw order, label shifting, mask crop
+     indices, keypoint index arithmetic incl. the in-place mutation quirk), not the
+     third-party arithmetic.  => ptc_reference.npz, ptc_keypoint_reference.npz
+
+Only data (inputs + outputs) is stored in the fixtures.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from oracle import boxes as oboxes      # noqa: E402
+from oracle import targets as otargets  # noqa: E402
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_placeholders():
+    cuda = _mod('chainer.cuda', get_array_module=lambda *a: np, to_cpu=lambda x: x,
+                to_gpu=lambda x: x)
+    backends = _mod('chainer.backends', cuda=cuda)
+    _mod('chainer.backends.cuda', get_array_module=lambda *a: np)
+    links = _mod('chainer.links')
+    functions = _mod('chainer.functions')
+    _mod('chainer', cuda=cuda, backends=backends, links=links, functions=functions,
+         Chain=object, Variable=type('Variable', (), {}))
+    base = 'chainercv.links.model.faster_rcnn'
+    for n in ('chainercv', 'chainercv.links', 'chainercv.links.model', base, base + '.utils',
+              'chainercv.utils', 'chainercv.utils.bbox'):
+        _mod(n)
+    _mod(base + '.region_proposal_network',
+         _enumerate_shifted_anchor=oboxes.enumerate_shifted_anchor)
+    _mod(base + '.utils.generate_anchor_base', generate_anchor_base=oboxes.generate_anchor_base)
+    _mod(base + '.utils.proposal_creator', ProposalCreator=object)
+    _mod(base + '.utils.bbox2loc', bbox2loc=oboxes.bbox2loc)
+    _mod('chainercv.utils.bbox.bbox_iou', bbox_iou=oboxes.bbox_iou)
+    _mod('cv2', resize=lambda a, dsize: otargets.cv2_resize_linear_u8(a, dsize))
+
+
+def synth_case(seed, n_roi, G, H, W, keypoints=False):
+    rs = np.random.RandomState(seed)
+    hw = np.exp(rs.uniform(np.log(24), np.log(min(H, W) * 0.6), (G, 2)))
+    cy = rs.uniform(0, H, G); cx = rs.uniform(0, W, G)
+    bbox = np.stack([np.clip(cy - hw[:, 0] / 2, 0, H - 2), np.clip(cx - hw[:, 1] / 2, 0, W - 2),
+                     np.clip(cy + hw[:, 0] / 2, 2, H), np.clip(cx + hw[:, 1] / 2, 2, W)], 1)
+    bbox = bbox.astype(np.float32)
+    bbox[:, 2:] = np.maximum(bbox[:, 2:], bbox[:, :2] + 4)
+    label = rs.randint(0, 80, G).astype(np.int32)
+    # proposals: jittered copies of gt boxes (some positives) + random boxes
+    jit = bbox[rs.randint(0, G, n_roi // 2)] + rs.normal(0, 6, (n_roi // 2, 4)).astype(np.float32)
+    rh = np.exp(rs.uniform(np.log(16), np.log(min(H, W) * 0.8), (n_roi - n_roi // 2, 2)))
+    ry = rs.uniform(0, H, n_roi - n_roi // 2); rx = rs.uniform(0, W, n_roi - n_roi // 2)
+    rnd = np.stack([ry - rh[:, 0] / 2, rx - rh[:, 1] / 2, ry + rh[:, 0] / 2, rx + rh[:, 1] / 2], 1)
+    roi = np.concatenate([jit, rnd], 0).astype(np.float32)
+    roi[:, 0::2] = np.clip(roi[:, 0::2], 0, H)
+    roi[:, 1::2] = np.clip(roi[:, 1::2], 0, W)
+    roi[:, 2:] = np.maximum(roi[:, 2:], roi[:, :2] + 2)
+    if keypoints:
+        kp = np.zeros((G, 17, 3), np.float32)
+        kp[:, :, 0] = bbox[:, None, 0] + rs.rand(G, 17) * (bbox[:, None, 2] - bbox[:, None, 0])
+        kp[:, :, 1] = bbox[:, None, 1] + rs.rand(G, 17) * (bbox[:, None, 3] - bbox[:, None, 1])
+        kp[:, :, 2] = rs.choice([0, 1, 2], (G, 17), p=[0.1, 0.1, 0.8])
+        mask = kp
+    else:
+        yy, xx = np.mgrid[0:H, 0:W]
+        mask = np.zeros((G, H, W), np.uint8)
+        for g in range(G):
+            cy_, cx_ = (bbox[g, 0] + bbox[g, 2]) / 2, (bbox[g, 1] + bbox[g, 3]) / 2
+            ry_, rx_ = (bbox[g, 2] - bbox[g, 0]) / 2, (bbox[g, 3] - bbox[g, 1]) / 2
+            mask[g] = (((yy - cy_) / ry_) ** 2 + ((xx - cx_) / rx_) ** 2 <= 1).astype(np.uint8)
+    return roi, bbox, label, mask
+
+
+def main():
+    install_placeholders()
+    sys.path.insert(0, REF)
+    from chainer_maskrcnn.model.rpn.multilevel_region_proposal_network import \
+        map_rois_to_fpn_levels as ref_levels
+    from chainer_maskrcnn.utils.proposal_target_creator import \
+        ProposalTargetCreator as RefPTC
+
+    # ---- 1. FPN level map -------------------------------------------------------------
+    rs = np.random.RandomState(7)
+    special = np.array([[0, 0, 224, 224], [0, 0, 112, 112], [0, 0, 56, 56], [0, 0, 28, 28],
+                        [0, 0, 14, 14], [0, 0, 0, 0], [0, 0, 1000, 1000], [0, 0, 223.99, 224],
+                        [0, 0, 224.01, 224], [10, 20, 122, 132], [3, 3, 3, 100]], np.float32)
+    side = np.exp(rs.uniform(np.log(1), np.log(1200), (4000, 2))).astype(np.float32)
+    tl = rs.uniform(0, 800, (4000, 2)).astype(np.float32)
+    rois = np.concatenate([special, np.concatenate([tl, tl + side], 1)], 0).astype(np.float32)
+    lv = ref_levels(rois)
+    assert lv.dtype == np.float32
+    np.savez_compressed(os.path.join(OUT, 'levels_reference.npz'), rois=rois, levels=lv)
+    print('levels_reference.npz', rois.shape, np.bincount(lv.astype(int)))
+
+    # ---- 2. ProposalTargetCreator control flow ---------------------------------------
+    cases = {}
+    for ci, (seed, n_roi, G, H, W) in enumerate([(11, 300, 5, 160, 200), (12, 64, 1, 96, 96),
+                                                 (13, 600, 9, 200, 176), (14, 40, 3, 128, 128)]):
+        roi, bbox, label, mask = synth_case(seed, n_roi, G, H, W)
+        levels = ref_levels(roi)
+        np.random.seed(1000 + seed)
+        out = RefPTC([32, 64, 128, 256, 512])(roi, bbox, label, mask, levels, mask_size=28,
+                                              binary_mask=True)
+        cases[ci] = (seed, out)
+        for k, v in zip(('roi', 'bbox', 'label', 'mask', 'levels', 'np_seed'),
+                        (roi, bbox, label, np.packbits(mask, axis=-1), levels, 1000 + seed)):
+            cases['c%d_in_%s' % (ci, k)] = v
+        cases['c%d_in_mask_shape' % ci] = np.array(mask.shape)
+        for k, v in zip(('sample_roi', 'sample_levels', 'gt_roi_loc', 'gt_roi_label',
+                         'gt_roi_mask'), out):
+            cases['c%d_out_%s' % (ci, k)] = np.asarray(v)
+        print('ptc case', ci, [np.asarray(v).shape for v in out])
+        del cases[ci]
+    np.savez_compressed(os.path.join(OUT, 'ptc_reference.npz'), **cases)
+
+    kc = {}
+    for ci, (seed, n_roi, G, H, W) in enumerate([(21, 200, 4, 160, 160), (22, 80, 2, 128, 96)]):
+        roi, bbox, label, kp = synth_case(seed, n_roi, G, H, W, keypoints=True)
+        label[:] = 0
+        levels = ref_levels(roi)
+        kp_in = kp.copy()
+        np.random.seed(2000 + seed)
+        out = RefPTC([32, 64, 128, 256, 512])(roi, bbox, label, kp, levels, mask_size=56,
+                                              binary_mask=False)
+        for k, v in zip(('roi', 'bbox', 'label', 'kp', 'levels', 'np_seed'),
+                        (roi, bbox, label, kp_in, levels, 2000 + seed)):
+            kc['c%d_in_%s' % (ci, k)] = v
+        for k, v in zip(('sample_roi', 'sample_levels', 'gt_roi_loc', 'gt_roi_label',
+                         'gt_roi_mask'), out):
+            kc['c%d_out_%s' % (ci, k)] = np.asarray(v)
+        kc['c%d_out_kp_after' % ci] = kp       # in-place mutation quirk (Appendix B-11)
+        print('ptc keypoint case', ci, [np.asarray(v).shape for v in out])
+    np.savez_compressed(os.path.join(OUT, 'ptc_keypoint_reference.npz'), **kc)
+
+
+if __name__ == '__main__':
+    main()
