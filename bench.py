@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py - headline measurement (contract in the task statement; BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload roialign|step]
+
+Workloads
+  roialign  BASELINE.json configs[1]: roi_align_2d fwd+bwd, 512 RoIs on a 256x200x272 map,
+            7x7, fp32.  One "step" = one forward + one backward over the 512-RoI batch, inputs
+            resident in HBM.  value = algorithmic ROIAlign-backward GB/s (the second half of
+            BASELINE.json's metric), whole job (sum over ranks; ranks run independent batches).
+  step      BASELINE.json configs[2]: full ResNet50-FPN Mask R-CNN training step, bs=2/GPU,
+            1024x1024 (images/sec) - selected automatically once the training path is built.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, measured with HIP
+events inside the timed region on the launch stream; `cpu_baseline` is the NumPy oracle timed
+on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'chainer-maskrcnn_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = 'images/sec (1024^2 COCO, bs=2/GPU) at 1/2/4/8 MI355X; ROIAlign bwd HBM GB/s'
+
+
+def roialign_inputs(seed_shift=0):
+    from tests.util import config2_inputs
+    x, yx, gy = config2_inputs()
+    if seed_shift:          # distinct batches per rank
+        rs = np.random.RandomState(100 + seed_shift)
+        yx = yx[rs.permutation(yx.shape[0])]
+    return x, yx, gy
+
+
+def bench_roialign(args, rank, world):
+    from chainer_maskrcnn.functions.roi_align_2d_yx import _roi_align_2d_yx
+    from chainer_maskrcnn.functions.roi_align.roi_align_2d import roi_align_2d
+    from chainer_maskrcnn import _hip
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(dev)
+    x, yx, gy = roialign_inputs(rank)
+    N, C, H, W = x.shape
+    R, _, PH, PW = gy.shape
+    xt = torch.from_numpy(x).to(dev).contiguous(memory_format=torch.channels_last)
+    rois_xy = torch.from_numpy(yx[:, [0, 2, 1, 4, 3]].copy()).to(dev)
+    gyt = torch.from_numpy(gy).to(dev).contiguous(memory_format=torch.channels_last)
+    y = torch.empty((R, C, PH, PW), device=dev).contiguous(memory_format=torch.channels_last)
+    gx = torch.empty_like(xt)
+    lib = _hip.lib()
+    algo_bytes = 4 * (N * C * H * W + R * C * PH * PW) + 20 * R
+
+    def fwd():
+        _hip.check(lib.mrcnn_roi_align_fwd_f32(_hip.ptr(xt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
+                                               0.25, 2, _hip.ptr(y), _hip.stream_ptr()))
+
+    def bwd():
+        _hip.check(lib.mrcnn_roi_align_bwd_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
+                                               0.25, 2, _hip.ptr(gx), _hip.stream_ptr()))
+
+    for _ in range(args.warmup):
+        fwd(); bwd()
+    K = args.steps
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    sync_all(world)
+    t0 = time.perf_counter()
+    for k in range(K):
+        ev[k][0].record(); fwd(); ev[k][1].record(); bwd(); ev[k][2].record()
+    sync_all(world)
+    dt = time.perf_counter() - t0
+    fwd_ms = np.array([ev[k][0].elapsed_time(ev[k][1]) for k in range(K)])
+    bwd_ms = np.array([ev[k][1].elapsed_time(ev[k][2]) for k in range(K)])
+    dt = max_over_ranks(dt, world, dev)
+    bwd_avg_s = float(bwd_ms.mean()) * 1e-3
+    fwd_avg_s = float(fwd_ms.mean()) * 1e-3
+    bwd_gbps = algo_bytes / bwd_avg_s / 1e9
+    out = {
+        'metric': METRIC, 'value': round(bwd_gbps * world, 2), 'unit': 'GB/s (ROIAlign bwd, algorithmic bytes)',
+        'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': round(dt / K * 1e3, 5),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[1] roi_align_2d fwd+bwd microbench: 512 RoIs, x=(1,256,200,272) NHWC, '
+                               '7x7, sampling 2x2, spatial_scale 0.25', 'rois_per_step': R * world,
+                   'parallelism': 'independent batch per rank, no collective'},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_roi_align_bwd_nhwc', 'achieved': round(bwd_gbps, 2),
+                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(bwd_gbps / HBM_PEAK_GBPS, 4),
+                     'traffic': None, 'algorithmic_bytes_per_launch': algo_bytes,
+                     'avg_launch_us': round(bwd_avg_s * 1e6, 3), 'median_launch_us': round(float(np.median(bwd_ms)) * 1e3, 3)},
+        'roi_align_fwd': {'avg_launch_us': round(fwd_avg_s * 1e6, 3),
+                          'achieved_GBps': round(algo_bytes / fwd_avg_s / 1e9, 2),
+                          'frac': round(algo_bytes / fwd_avg_s / 1e9 / HBM_PEAK_GBPS, 4)},
+    }
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline_roialign(x, yx, gy, algo_bytes)
+    return out
+
+
+def cpu_baseline_roialign(x, yx, gy, algo_bytes):
+    """NumPy oracle ("port" of the reference algorithm) on the host: the same 512-RoI batch, once."""
+    from oracle import roi_align as ora
+    xy = yx[:, [0, 2, 1, 4, 3]]
+    t0 = time.perf_counter()
+    ora.roi_align_fwd(x, xy, 7, 7, 0.25, 2)
+    t1 = time.perf_counter()
+    ora.roi_align_bwd(gy, xy, x.shape, 0.25, 2)
+    t2 = time.perf_counter()
+    return {'value': round(algo_bytes / (t2 - t1) / 1e9, 4), 'unit': 'GB/s (ROIAlign bwd, algorithmic bytes)',
+            'cores': 1, 'kind': 'port',
+            'sample': 'full configs[1] batch (512 RoIs) once: fwd %.2f s, bwd %.2f s, single-thread NumPy oracle'
+                      % (t1 - t0, t2 - t1),
+            'fwd_GBps': round(algo_bytes / (t1 - t0) / 1e9, 4), 'host_cpus': os.cpu_count()}
+
+
+def sync_all(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(v, world, dev):
+    if world == 1:
+        return v
+    t = torch.tensor([v], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--workload', default='auto', choices=['auto', 'roialign', 'step'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        torch.distributed.init_process_group('nccl')
+    if args.gpus != world and rank == 0 and world > 1:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    workload = args.workload
+    if workload == 'auto':
+        workload = 'roialign'
+        try:
+            from chainer_maskrcnn import train_step_available
+            if train_step_available():
+                workload = 'step'
+        except ImportError:
+            pass
+    if workload == 'step':
+        from chainer_maskrcnn.bench_step import bench_step
+        args.steps = args.steps or 20
+        args.warmup = 3 if args.warmup is None else args.warmup
+        out = bench_step(args, rank, world)
+    else:
+        args.steps = args.steps or 200
+        args.warmup = 20 if args.warmup is None else args.warmup
+        out = bench_roialign(args, rank, world)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

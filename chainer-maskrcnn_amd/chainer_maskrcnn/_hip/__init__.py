@@ -1,0 +1,86 @@
+"""ctypes binding of libmrcnn_hip.so (include/mrcnn_hip.h).
+
+This is the whole host<->device boundary: plain pointers and sizes, the caller's HIP
+stream, integer return codes.  It is the stub a maintainer of the reference would add
+ - here over torch tensors, which serve only as device-memory handles.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'csrc', 'libmrcnn_hip.so'))
+
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_void_p = ctypes.c_void_p
+c_size_t = ctypes.c_size_t
+_P = ctypes.POINTER
+
+# name -> (restype, argtypes); must list every symbol declared in include/mrcnn_hip.h
+SIGNATURES = {
+    'mrcnn_abi_version': (c_int, []),
+    'mrcnn_last_error': (ctypes.c_char_p, []),
+    'mrcnn_roi_align_fwd_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                        c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    'mrcnn_roi_align_bwd_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                        c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    'mrcnn_roi_align_fpn_fwd_f32': (c_int, [_P(c_void_p), _P(c_int), _P(c_int), _P(c_float), c_int,
+                                            c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                            c_int, c_void_p, c_void_p]),
+    'mrcnn_roi_align_fpn_bwd_f32': (c_int, [c_void_p, _P(c_void_p), _P(c_int), _P(c_int), _P(c_float),
+                                            c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                            c_int, c_int, c_void_p]),
+    'mrcnn_roi_align_sample_tables': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                              c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class MrcnnHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library once.  Fails loudly: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MrcnnHipError(
+                'libmrcnn_hip.so not found at %s - build it with '
+                '`python -c "import __graft_entry__ as g; g.build()"` or `make -C %s`'
+                % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)      # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if l.mrcnn_abi_version() != 1:
+            raise MrcnnHipError('ABI version mismatch: library %d, binding 1' % l.mrcnn_abi_version())
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().mrcnn_last_error().decode('utf-8', 'replace')
+        raise MrcnnHipError('libmrcnn_hip call failed (code %d): %s' % (rc, msg))
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MrcnnHipError('this op runs only on a HIP device (got a %s tensor); '
+                                'there is no CPU fallback' % t.device)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1

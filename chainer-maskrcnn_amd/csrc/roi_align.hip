@@ -1,0 +1,529 @@
+// ROIAlign forward (bilinear gather) and backward (owner-computes scatter) for gfx950.
+//
+// Replaces chainer_maskrcnn.functions.roi_align.roi_align_2d (un-vendored submodule, called
+// through chainer_maskrcnn/functions/roi_align_2d_yx.py:4-7) and the per-RoI Python loops of
+// chainer_maskrcnn/model/head/fpn_roi_mask_head.py:59-61,75-77.
+//
+// Layout: channel-innermost (NHWC).  One wavefront (64 lanes) covers 256 channels as one
+// float4 per lane, so every bilinear tap and every output row is one coalesced 1-KiB
+// segment.  The coordinate arithmetic is compiled with FP contraction OFF and follows
+// oracle/roi_align.py operation for operation, so sample indices and weights are bit-exact.
+//
+// Backward design (see DESIGN.md "roi_align_bwd"): no global atomics.  The gradient map is cut
+// into 8x8-cell tiles; one workgroup owns a tile and every wave owns whole cells, so gx is
+// written exactly once, coalesced, and sums are bit-reproducible.  Because bilinear weights
+// are separable, a RoI's contribution to cell (Y,X) is
+//     sum_ph sum_pw Wy[Y][ph] * Wx[X][pw] * gy[r,ph,pw,:] / (gh*gw)
+// where Wy[Y][ph] is the summed weight that bin-row ph's samples put on map row Y.  The
+// workgroup builds these tiny per-(RoI,tile) tables in LDS (lane-parallel geometry), then
+// each wave walks the non-zero (ph,pw) pairs of its cell with wave-uniform control flow
+// (ballot + readlane), streaming gy rows through L1/L2.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct RoiGeom {
+    float x1f, y1f, bw, bh, rw, rh;
+    int gh, gw, n;
+};
+
+__device__ __forceinline__ RoiGeom roi_geom(const float *roi, float s, int PH, int PW, int sr) {
+    RoiGeom g;
+    g.n = (int)roi[0];
+    g.x1f = roi[1] * s;
+    g.y1f = roi[2] * s;
+    float x2f = roi[3] * s, y2f = roi[4] * s;
+    g.rw = fmaxf(x2f - g.x1f, 1.0f);
+    g.rh = fmaxf(y2f - g.y1f, 1.0f);
+    g.bw = g.rw / (float)PW;
+    g.bh = g.rh / (float)PH;
+    if (sr > 0) {
+        g.gh = g.gw = sr;
+    } else {
+        g.gh = (int)ceilf(g.rh / (float)PH);
+        g.gw = (int)ceilf(g.rw / (float)PW);
+    }
+    return g;
+}
+
+struct Samp {
+    int lo, hi;      // corner cells, -1 when the sample is void
+    float wl, wh;    // weight of lo / hi cell (hy / ly in the Caffe2 formula)
+};
+
+// One axis of one sample: c = (start + p*bin) + ((i+0.5)*bin)/grid, in exactly this order.
+__device__ __forceinline__ Samp axis_sample(float start, float bin, int p, int i, int grid, int size) {
+    float c = (start + (float)p * bin) + (((float)i + 0.5f) * bin) / (float)grid;
+    bool valid = !(c < -1.0f || c > (float)size);
+    c = fmaxf(c, 0.0f);
+    int lo = (int)c, hi;
+    if (lo >= size - 1) {
+        lo = hi = size - 1;
+        c = (float)lo;
+    } else {
+        hi = lo + 1;
+    }
+    Samp s;
+    s.wh = c - (float)lo;
+    s.wl = 1.0f - s.wh;
+    if (!valid) {
+        s.lo = s.hi = -1;
+        s.wl = s.wh = 0.0f;
+    } else {
+        s.lo = lo;
+        s.hi = hi;
+    }
+    return s;
+}
+
+struct Levels {
+    const float *x[MRCNN_MAX_LEVELS];
+    float *gx[MRCNN_MAX_LEVELS];
+    int H[MRCNN_MAX_LEVELS], W[MRCNN_MAX_LEVELS];
+    float scale[MRCNN_MAX_LEVELS];
+    int tile_begin[MRCNN_MAX_LEVELS + 1];
+    int tiles_x[MRCNN_MAX_LEVELS], tiles_y[MRCNN_MAX_LEVELS];
+    int L;
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward, NHWC: one wave per (roi, ph, pw) bin; lane = 4 channels.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_roi_align_fwd_nhwc(Levels lv, const float *__restrict__ rois,
+                                                            const int32_t *__restrict__ levels, int R,
+                                                            int N, int C, int PH, int PW, int sr,
+                                                            float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long long bin_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int bins = PH * PW;
+    if (bin_id >= (long long)R * bins) return;
+    const int r = (int)(bin_id / bins);
+    const int b = (int)(bin_id - (long long)r * bins);
+    const int ph = b / PW, pw = b - ph * PW;
+    int l = levels ? levels[r] : 0;
+    l = min(max(l, 0), lv.L - 1);
+    const int H = lv.H[l], W = lv.W[l];
+    const RoiGeom g = roi_geom(rois + (size_t)r * 5, lv.scale[l], PH, PW, sr);
+    const int C4 = C >> 2;
+    float *yo = y + ((size_t)r * bins + b) * C;
+    const bool bad = g.n < 0 || g.n >= N;
+    const float *xb = lv.x[l] + (size_t)(bad ? 0 : g.n) * H * W * C;
+    const float cnt = (float)(g.gh * g.gw);
+    for (int c4 = lane; c4 < C4; c4 += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!bad) {
+            for (int iy = 0; iy < g.gh; ++iy) {
+                const Samp sy = axis_sample(g.y1f, g.bh, ph, iy, g.gh, H);
+                if (sy.lo < 0) continue;
+                const float *rl = xb + (size_t)sy.lo * W * C + c4 * 4;
+                const float *rh = xb + (size_t)sy.hi * W * C + c4 * 4;
+                for (int ix = 0; ix < g.gw; ++ix) {
+                    const Samp sx = axis_sample(g.x1f, g.bw, pw, ix, g.gw, W);
+                    if (sx.lo < 0) continue;
+                    const float w1 = sy.wl * sx.wl, w2 = sy.wl * sx.wh;
+                    const float w3 = sy.wh * sx.wl, w4 = sy.wh * sx.wh;
+                    const float4 f1 = ld4(rl + (size_t)sx.lo * C), f2 = ld4(rl + (size_t)sx.hi * C);
+                    const float4 f3 = ld4(rh + (size_t)sx.lo * C), f4 = ld4(rh + (size_t)sx.hi * C);
+                    // ((w1*f1 + w2*f2) + w3*f3) + w4*f4, no contraction: matches the oracle bit for bit
+                    acc.x += ((w1 * f1.x + w2 * f2.x) + w3 * f3.x) + w4 * f4.x;
+                    acc.y += ((w1 * f1.y + w2 * f2.y) + w3 * f3.y) + w4 * f4.y;
+                    acc.z += ((w1 * f1.z + w2 * f2.z) + w3 * f3.z) + w4 * f4.z;
+                    acc.w += ((w1 * f1.w + w2 * f2.w) + w3 * f3.w) + w4 * f4.w;
+                }
+            }
+        }
+        float4 o = make_float4(acc.x / cnt, acc.y / cnt, acc.z / cnt, acc.w / cnt);
+        *reinterpret_cast<float4 *>(yo + c4 * 4) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward, NHWC, owner-computes tiles.
+// ------------------------------------------------------------------------------------------
+constexpr int TH = 8, TW = 8;     // tile of gradient-map cells owned by one workgroup
+constexpr int SLOTS = 32;         // RoIs whose weight tables are resident in LDS per round
+constexpr int PB = 16;            // max pooled bins per axis on this path (7 and 14 in the model)
+constexpr int LISTCAP = 1024;     // RoIs scanned per segment
+
+__global__ __launch_bounds__(256) void k_roi_align_bwd_nhwc(Levels lv, const float *__restrict__ gy,
+                                                            const float *__restrict__ rois,
+                                                            const int32_t *__restrict__ levels, int R,
+                                                            int N, int C, int PH, int PW, int sr) {
+    __shared__ float sW[SLOTS][2][TH][PB];   // [slot][axis][tile row/col][bin] summed weights
+    __shared__ int sMask[SLOTS];             // bits 0-7: rows with weight, bits 8-15: cols
+    __shared__ int sList[LISTCAP];
+    __shared__ int sWaveCnt[4];
+    __shared__ int sN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int l = 0;
+    while (l + 1 < lv.L && (int)blockIdx.x >= lv.tile_begin[l + 1]) ++l;
+    int t = blockIdx.x - lv.tile_begin[l];
+    const int per_img = lv.tiles_x[l] * lv.tiles_y[l];
+    const int n = t / per_img;
+    t -= n * per_img;
+    const int ty0 = (t / lv.tiles_x[l]) * TH, tx0 = (t % lv.tiles_x[l]) * TW;
+    const int H = lv.H[l], W = lv.W[l];
+    const float scale = lv.scale[l];
+    float *gxb = lv.gx[l] + (size_t)n * H * W * C;
+    const int C4 = C >> 2;
+    const float inv_cnt = 1.0f / (float)(sr * sr);
+    const size_t roi_stride = (size_t)PH * PW * C;
+
+    int round = 0;
+    for (int seg = 0; seg == 0 || seg < R; seg += LISTCAP) {
+        const int seg_end = min(R, seg + LISTCAP);
+        // ---- phase 0: ordered list of RoIs of this (level, image) whose footprint may touch the tile
+        if (tid == 0) sN = 0;
+        __syncthreads();
+        for (int base = seg; base < seg_end; base += 256) {
+            const int i = base + tid;
+            bool f = false;
+            if (i < seg_end) {
+                int li = levels ? levels[i] : 0;
+                li = min(max(li, 0), lv.L - 1);
+                const float *roi = rois + (size_t)i * 5;
+                if (li == l && (int)roi[0] == n) {
+                    const RoiGeom g = roi_geom(roi, scale, PH, PW, sr);
+                    f = (g.y1f - 2.0f < (float)(ty0 + TH)) && (g.y1f + g.rh + 2.0f > (float)ty0) &&
+                        (g.x1f - 2.0f < (float)(tx0 + TW)) && (g.x1f + g.rw + 2.0f > (float)tx0);
+                }
+            }
+            const unsigned long long bal = __ballot(f);
+            if (lane == 0) sWaveCnt[wave] = __popcll(bal);
+            __syncthreads();
+            int off = sN;
+            for (int w = 0; w < wave; ++w) off += sWaveCnt[w];
+            if (f) sList[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            __syncthreads();
+            if (tid == 0) sN += sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
+            __syncthreads();
+        }
+        const int n_list = sN;
+
+        for (int s0 = 0; s0 < n_list || round == 0; s0 += SLOTS) {
+            const int nslots = max(0, min(SLOTS, n_list - s0));
+            // ---- phase 1: per-(slot, axis, row, bin) summed weights, one thread each
+            if (tid < SLOTS) sMask[tid] = 0;
+            __syncthreads();
+            for (int task = tid; task < nslots * 256; task += 256) {
+                const int slot = task >> 8, q = task & 255;
+                const int axis = q >> 7, row = (q >> 4) & 7, bin = q & 15;
+                const RoiGeom g = roi_geom(rois + (size_t)sList[s0 + slot] * 5, scale, PH, PW, sr);
+                const int P = axis ? PW : PH, size = axis ? W : H;
+                const int target = (axis ? tx0 : ty0) + row;
+                const float start = axis ? g.x1f : g.y1f, bsz = axis ? g.bw : g.bh;
+                float wv = 0.0f;
+                if (bin < P) {
+                    for (int i = 0; i < sr; ++i) {
+                        const Samp s = axis_sample(start, bsz, bin, i, sr, size);
+                        if (s.lo == target) wv += s.wl;
+                        if (s.hi == target) wv += s.wh;
+                    }
+                }
+                sW[slot][axis][row][bin] = wv;
+                const unsigned long long nz = __ballot(wv != 0.0f);
+                if ((lane & 15) == 0 && ((nz >> lane) & 0xFFFFull)) atomicOr(&sMask[slot], 1 << (axis * 8 + row));
+            }
+            __syncthreads();
+
+            // ---- phase 2: each wave owns 16 cells (two tile rows); acc lives in registers
+            for (int ci = 0; ci < 16; ++ci) {
+                const int cell = wave * 16 + ci;
+                const int cy = cell >> 3, cx = cell & 7;
+                const int Y = ty0 + cy, X = tx0 + cx;
+                if (Y >= H || X >= W) continue;
+                float *dst = gxb + ((size_t)Y * W + X) * C;
+                const int m = lane < nslots ? sMask[lane] : 0;
+                const unsigned rel = (unsigned)__ballot(((m >> cy) & 1) && ((m >> (8 + cx)) & 1));
+                for (int c4 = lane; c4 < ((C4 + 63) & ~63); c4 += 64) {
+                    const bool act = c4 < C4;
+                    const int c4s = act ? c4 : 0;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (round != 0 && act) acc = ld4(dst + c4s * 4);
+                    unsigned rm = rel;
+                    while (rm) {
+                        const int slot = __builtin_ctz(rm);
+                        rm &= rm - 1;
+                        const int r = sList[s0 + slot];
+                        float wv = 0.0f;
+                        if ((lane & 31) < PB) wv = sW[slot][lane >> 5][(lane >> 5) ? cx : cy][lane & 31];
+                        const unsigned long long nz = __ballot(wv != 0.0f);
+                        unsigned ym = (unsigned)nz;
+                        const unsigned xm = (unsigned)(nz >> 32);
+                        const float *gyr = gy + (size_t)r * roi_stride + c4s * 4;
+                        while (ym) {
+                            const int ph = __builtin_ctz(ym);
+                            ym &= ym - 1;
+                            const float wy = readlane_f(wv, ph) * inv_cnt;
+                            const float *gyp = gyr + (size_t)ph * PW * C;
+                            unsigned xx = xm;
+                            while (xx) {
+                                const int pw = __builtin_ctz(xx);
+                                xx &= xx - 1;
+                                const float coef = wy * readlane_f(wv, 32 + pw);
+                                if (act) {
+                                    const float4 g4 = ld4(gyp + (size_t)pw * C);
+                                    acc.x = fmaf(coef, g4.x, acc.x);
+                                    acc.y = fmaf(coef, g4.y, acc.y);
+                                    acc.z = fmaf(coef, g4.z, acc.z);
+                                    acc.w = fmaf(coef, g4.w, acc.w);
+                                }
+                            }
+                        }
+                    }
+                    if (act) *reinterpret_cast<float4 *>(dst + c4s * 4) = acc;
+                }
+            }
+            ++round;
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic (any layout through strides, any pooled size / sampling): reference-layout fallback.
+// ------------------------------------------------------------------------------------------
+struct Strides4 {
+    long long n, c, h, w;
+};
+
+__global__ __launch_bounds__(256) void k_roi_align_fwd_generic(const float *__restrict__ x, Strides4 xs,
+                                                               const float *__restrict__ rois, int R, int N,
+                                                               int C, int H, int W, int PH, int PW,
+                                                               float scale, int sr, float *__restrict__ y,
+                                                               Strides4 ys, int c_fast) {
+    const long long total = (long long)R * C * PH * PW;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int r, c, ph, pw;
+    long long q = idx;
+    if (c_fast) {  // NHWC order: c fastest
+        c = q % C; q /= C; pw = q % PW; q /= PW; ph = q % PH; r = (int)(q / PH);
+    } else {       // NCHW order: pw fastest
+        pw = q % PW; q /= PW; ph = q % PH; q /= PH; c = q % C; r = (int)(q / C);
+    }
+    const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, PH, PW, sr);
+    float acc = 0.0f;
+    if (g.n >= 0 && g.n < N) {
+        const float *f = x + g.n * xs.n + c * xs.c;
+        for (int iy = 0; iy < g.gh; ++iy) {
+            const Samp sy = axis_sample(g.y1f, g.bh, ph, iy, g.gh, H);
+            if (sy.lo < 0) continue;
+            for (int ix = 0; ix < g.gw; ++ix) {
+                const Samp sx = axis_sample(g.x1f, g.bw, pw, ix, g.gw, W);
+                if (sx.lo < 0) continue;
+                const float w1 = sy.wl * sx.wl, w2 = sy.wl * sx.wh, w3 = sy.wh * sx.wl, w4 = sy.wh * sx.wh;
+                acc += ((w1 * f[sy.lo * xs.h + sx.lo * xs.w] + w2 * f[sy.lo * xs.h + sx.hi * xs.w]) +
+                        w3 * f[sy.hi * xs.h + sx.lo * xs.w]) + w4 * f[sy.hi * xs.h + sx.hi * xs.w];
+            }
+        }
+    }
+    y[r * ys.n + c * ys.c + ph * ys.h + pw * ys.w] = acc / (float)(g.gh * g.gw);
+}
+
+__global__ __launch_bounds__(256) void k_roi_align_bwd_generic(const float *__restrict__ gy, Strides4 ys,
+                                                               const float *__restrict__ rois, int R, int N,
+                                                               int C, int H, int W, int PH, int PW,
+                                                               float scale, int sr, float *__restrict__ gx,
+                                                               Strides4 xs, int c_fast) {
+    const long long total = (long long)R * C * PH * PW;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int r, c, ph, pw;
+    long long q = idx;
+    if (c_fast) {
+        c = q % C; q /= C; pw = q % PW; q /= PW; ph = q % PH; r = (int)(q / PH);
+    } else {
+        pw = q % PW; q /= PW; ph = q % PH; q /= PH; c = q % C; r = (int)(q / C);
+    }
+    const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, PH, PW, sr);
+    if (g.n < 0 || g.n >= N) return;
+    const float gv = gy[r * ys.n + c * ys.c + ph * ys.h + pw * ys.w];
+    const float cnt = (float)(g.gh * g.gw);
+    float *f = gx + g.n * xs.n + c * xs.c;
+    for (int iy = 0; iy < g.gh; ++iy) {
+        const Samp sy = axis_sample(g.y1f, g.bh, ph, iy, g.gh, H);
+        if (sy.lo < 0) continue;
+        for (int ix = 0; ix < g.gw; ++ix) {
+            const Samp sx = axis_sample(g.x1f, g.bw, pw, ix, g.gw, W);
+            if (sx.lo < 0) continue;
+            unsafeAtomicAdd(f + sy.lo * xs.h + sx.lo * xs.w, (gv * (sy.wl * sx.wl)) / cnt);
+            unsafeAtomicAdd(f + sy.lo * xs.h + sx.hi * xs.w, (gv * (sy.wl * sx.wh)) / cnt);
+            unsafeAtomicAdd(f + sy.hi * xs.h + sx.lo * xs.w, (gv * (sy.wh * sx.wl)) / cnt);
+            unsafeAtomicAdd(f + sy.hi * xs.h + sx.hi * xs.w, (gv * (sy.wh * sx.wh)) / cnt);
+        }
+    }
+}
+
+__global__ void k_roi_align_sample_tables(const float *__restrict__ rois, int R, int H, int W, int PH, int PW,
+                                          float scale, int sr, int smax, int32_t *cnt, int32_t *idx,
+                                          float *wgt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * 2 * smax) return;
+    const int k = i % smax, axis = (i / smax) & 1, r = i / (2 * smax);
+    const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, PH, PW, sr);
+    const int grid = axis ? g.gw : g.gh, P = axis ? PW : PH;
+    const int total = P * grid;
+    if (k == 0) cnt[r * 2 + axis] = total;
+    int lo = -2, hi = -2;
+    float wl = 0.f, wh = 0.f;
+    if (k < total) {
+        const Samp s = axis_sample(axis ? g.x1f : g.y1f, axis ? g.bw : g.bh, k / grid, k % grid, grid,
+                                   axis ? W : H);
+        lo = s.lo; hi = s.hi; wl = s.wl; wh = s.wh;
+    }
+    idx[(size_t)i * 2] = lo;
+    idx[(size_t)i * 2 + 1] = hi;
+    wgt[(size_t)i * 2] = wl;
+    wgt[(size_t)i * 2 + 1] = wh;
+}
+
+Strides4 strides_of(int layout, int C, int H, int W) {
+    Strides4 s;
+    if (layout == MRCNN_LAYOUT_NHWC) {
+        s.n = (long long)H * W * C; s.c = 1; s.h = (long long)W * C; s.w = C;
+    } else {
+        s.n = (long long)C * H * W; s.c = (long long)H * W; s.h = W; s.w = 1;
+    }
+    return s;
+}
+
+int check_common(const void *a, const void *rois, const void *b, int layout, int N, int C, int H, int W,
+                 int R, int PH, int PW, int sr) {
+    if (layout != MRCNN_LAYOUT_NCHW && layout != MRCNN_LAYOUT_NHWC)
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align: unknown layout %d", layout);
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || R < 0 || sr < 0)
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align: bad sizes N=%d C=%d H=%d W=%d R=%d PH=%d PW=%d sr=%d",
+                               N, C, H, W, R, PH, PW, sr);
+    if (!a || !b || (R > 0 && !rois)) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align: null pointer");
+    return 0;
+}
+
+bool fast_bwd_ok(int C, int PH, int PW, int sr) { return (C % 4) == 0 && PH <= PB && PW <= PB && sr > 0; }
+
+int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, const int32_t *levels, int R,
+                     int C, int PH, int PW, int sr, hipStream_t st) {
+    int total = 0;
+    for (int l = 0; l < lv.L; ++l) {
+        lv.tiles_x[l] = mrcnn::cdiv(lv.W[l], TW);
+        lv.tiles_y[l] = mrcnn::cdiv(lv.H[l], TH);
+        lv.tile_begin[l] = total;
+        total += lv.tiles_x[l] * lv.tiles_y[l] * N;
+    }
+    lv.tile_begin[lv.L] = total;
+    hipLaunchKernelGGL(k_roi_align_bwd_nhwc, dim3(total), dim3(256), 0, st, lv, gy, rois, levels, R, N, C, PH,
+                       PW, sr);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C, int H, int W,
+                                       const float *rois, int R, int PH, int PW, float spatial_scale,
+                                       int sampling_ratio, float *y, void *stream) {
+    if (int e = check_common(x, rois, y, layout, N, C, H, W, R, PH, PW, sampling_ratio)) return e;
+    if (R == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (layout == MRCNN_LAYOUT_NHWC && (C % 4) == 0) {
+        Levels lv{};
+        lv.L = 1; lv.x[0] = x; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
+        const long long waves = (long long)R * PH * PW;
+        hipLaunchKernelGGL(k_roi_align_fwd_nhwc, dim3(mrcnn::cdiv(waves, 4)), dim3(256), 0, st, lv, rois,
+                           (const int32_t *)nullptr, R, N, C, PH, PW, sampling_ratio, y);
+    } else {
+        const long long total = (long long)R * C * PH * PW;
+        hipLaunchKernelGGL(k_roi_align_fwd_generic, dim3(mrcnn::cdiv(total, 256)), dim3(256), 0, st, x,
+                           strides_of(layout, C, H, W), rois, R, N, C, H, W, PH, PW, spatial_scale,
+                           sampling_ratio, y, strides_of(layout, C, PH, PW), layout == MRCNN_LAYOUT_NHWC);
+    }
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C, int H, int W,
+                                       const float *rois, int R, int PH, int PW, float spatial_scale,
+                                       int sampling_ratio, float *gx, void *stream) {
+    if (int e = check_common(gy, rois, gx, layout, N, C, H, W, R, PH, PW, sampling_ratio)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (layout == MRCNN_LAYOUT_NHWC && fast_bwd_ok(C, PH, PW, sampling_ratio)) {
+        Levels lv{};
+        lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
+        return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, st);
+    }
+    MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * C * H * W, st));
+    if (R == 0) return 0;
+    const long long total = (long long)R * C * PH * PW;
+    hipLaunchKernelGGL(k_roi_align_bwd_generic, dim3(mrcnn::cdiv(total, 256)), dim3(256), 0, st, gy,
+                       strides_of(layout, C, PH, PW), rois, R, N, C, H, W, PH, PW, spatial_scale,
+                       sampling_ratio, gx, strides_of(layout, C, H, W), layout == MRCNN_LAYOUT_NHWC);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int fill_levels(Levels &lv, const float *const *xs, float *const *gxs, const int *Hs, const int *Ws,
+                       const float *scales, int L) {
+    if (L <= 0 || L > MRCNN_MAX_LEVELS) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn: L=%d not in [1,%d]", L, MRCNN_MAX_LEVELS);
+    if (!Hs || !Ws || !scales) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn: null host array");
+    lv.L = L;
+    for (int l = 0; l < L; ++l) {
+        if (Hs[l] <= 0 || Ws[l] <= 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn: bad level %d shape", l);
+        if (xs) { if (!xs[l]) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn: null level pointer"); lv.x[l] = xs[l]; }
+        if (gxs) { if (!gxs[l]) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn: null level pointer"); lv.gx[l] = gxs[l]; }
+        lv.H[l] = Hs[l]; lv.W[l] = Ws[l]; lv.scale[l] = scales[l];
+    }
+    return 0;
+}
+
+extern "C" int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs, const int *Ws,
+                                           const float *scales, int L, int N, int C, const float *rois,
+                                           const int32_t *levels, int R, int PH, int PW,
+                                           int sampling_ratio, float *y, void *stream) {
+    if (!xs || !y || (R > 0 && (!rois || !levels))) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_fwd: null pointer");
+    if (N <= 0 || C <= 0 || (C % 4) || PH <= 0 || PW <= 0 || R < 0 || sampling_ratio < 0)
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_fwd: bad sizes (C must be a multiple of 4)");
+    Levels lv{};
+    if (int e = fill_levels(lv, xs, nullptr, Hs, Ws, scales, L)) return e;
+    if (R == 0) return 0;
+    const long long waves = (long long)R * PH * PW;
+    hipLaunchKernelGGL(k_roi_align_fwd_nhwc, dim3(mrcnn::cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, lv,
+                       rois, levels, R, N, C, PH, PW, sampling_ratio, y);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws,
+                                           const float *scales, int L, int N, int C, const float *rois,
+                                           const int32_t *levels, int R, int PH, int PW,
+                                           int sampling_ratio, void *stream) {
+    if (!gxs || (R > 0 && (!rois || !levels || !gy))) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd: null pointer");
+    if (N <= 0 || C <= 0 || PH <= 0 || PW <= 0 || R < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd: bad sizes");
+    if (!fast_bwd_ok(C, PH, PW, sampling_ratio))
+        return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd: needs C%%4==0, PH,PW<=%d, sampling_ratio>0", PB);
+    Levels lv{};
+    if (int e = fill_levels(lv, nullptr, gxs, Hs, Ws, scales, L)) return e;
+    return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, (hipStream_t)stream);
+}
+
+extern "C" int mrcnn_roi_align_sample_tables(const float *rois, int R, int H, int W, int PH, int PW,
+                                             float spatial_scale, int sampling_ratio, int smax,
+                                             int32_t *cnt, int32_t *idx, float *wgt, void *stream) {
+    if (R < 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || smax <= 0 || sampling_ratio < 0)
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_sample_tables: bad sizes");
+    if (R == 0) return 0;
+    if (!rois || !cnt || !idx || !wgt) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_sample_tables: null pointer");
+    const int total = R * 2 * smax;
+    hipLaunchKernelGGL(k_roi_align_sample_tables, dim3(mrcnn::cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, rois, R, H, W, PH, PW, spatial_scale, sampling_ratio, smax, cnt,
+                       idx, wgt);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}

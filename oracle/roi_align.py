@@ -140,7 +140,7 @@ def roi_align_sample_tables(rois, H, W, outh, outw, spatial_scale, sampling_rati
 
     Returns (cnt (R,2) i32 = [PH*gh, PW*gw], idx (R,2,smax,2) i32, wgt (R,2,smax,2) f32)
     with axis 0 = y, axis 1 = x; idx = (lo, hi) or (-1,-1) for a void sample,
-    (-2,-2) beyond cnt; wgt = (wl, wh), 0 beyond cnt.  This is the "indices
+    (-2,-2) beyond cnt; wgt = (wl, wh), 0 for void samples and beyond cnt.  This is the "indices
     bit-exact" contract of BASELINE.json's north_star.
     """
     rois = np.asarray(rois, dtype=F)
@@ -155,8 +155,8 @@ def roi_align_sample_tables(rois, H, W, outh, outw, spatial_scale, sampling_rati
             m = min(k, smax)
             idx[r, a, :m, 0] = t['lo'][:m]
             idx[r, a, :m, 1] = t['hi'][:m]
-            wgt[r, a, :m, 0] = t['wl'][:m]
-            wgt[r, a, :m, 1] = t['wh'][:m]
+            wgt[r, a, :m, 0] = np.where(t['valid'][:m], t['wl'][:m], F(0))
+            wgt[r, a, :m, 1] = np.where(t['valid'][:m], t['wh'][:m], F(0))
     return cnt, idx, wgt
 
 

@@ -1,0 +1,155 @@
+"""GPU parity tests: HIP ROIAlign (through the C ABI) against the NumPy oracle.
+
+Tolerances: sample indices AND weights bit-exact (integer / same-float-op contract);
+forward values bit-exact on the NHWC and generic kernels (same operation order, no FMA);
+backward values within rtol 1e-5 / atol 1e-5*max|gy| (summation order differs: the tile
+kernel pre-sums weights per bin).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import roi_align as ora
+from tests.util import config2_inputs, rand_rois_xy
+
+pytestmark = pytest.mark.gpu
+
+from chainer_maskrcnn.functions.roi_align.roi_align_2d import roi_align_2d, roi_align_sample_tables  # noqa: E402
+from chainer_maskrcnn.functions.roi_align_2d_yx import _roi_align_2d_yx  # noqa: E402
+from chainer_maskrcnn import _hip  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def _edge_rois(N, H, W, scale):
+    s = 1.0 / scale
+    return np.array([
+        [0, -30 * s, -30 * s, -20 * s, -20 * s],            # fully outside (void samples)
+        [N - 1, 4 * s, 4 * s, 4 * s, 4 * s],                 # zero area
+        [0, 0, 0, W * s, H * s],                             # whole map
+        [0, (W - 1) * s, (H - 1) * s, (W + 3) * s, (H + 3) * s],   # last row/col and beyond
+        [N - 1, -0.9 * s, -0.9 * s, 1.1 * s, 1.3 * s],       # straddles the -1 validity edge
+        [0, 3.5 * s, 2.25 * s, 3.5 * s + 0.5, 2.25 * s + 0.5],     # sub-cell RoI (clamped to 1 cell)
+    ], np.float32)
+
+
+@pytest.mark.parametrize('sr', [1, 2, 0])
+@pytest.mark.parametrize('P', [7, 14])
+def test_sample_indices_and_weights_bit_exact(sr, P):
+    rs = np.random.RandomState(10 + sr)
+    H, W, scale = 50, 68, 0.0625
+    rois = np.concatenate([_edge_rois(2, H, W, scale), rand_rois_xy(rs, 300, 2, H, W, scale)], 0)
+    smax = 64 if sr else 256
+    cnt, idx, wgt = ora.roi_align_sample_tables(rois, H, W, P, P, scale, sr, smax)
+    dcnt, didx, dwgt = roi_align_sample_tables(torch.from_numpy(rois).to(DEV), H, W, P, P, scale, sr, smax)
+    np.testing.assert_array_equal(dcnt.cpu().numpy(), cnt)
+    np.testing.assert_array_equal(didx.cpu().numpy(), idx)
+    np.testing.assert_array_equal(dwgt.cpu().numpy().view(np.uint32), wgt.view(np.uint32))
+
+
+@pytest.mark.parametrize('layout', ['nhwc', 'nchw'])
+@pytest.mark.parametrize('C,P,sr', [(8, 7, 2), (256, 7, 2), (12, 14, 2), (8, 3, 1), (8, 5, 0), (6, 7, 2)])
+def test_forward_matches_oracle(layout, C, P, sr):
+    rs = np.random.RandomState(C + P)
+    N, H, W, scale = 2, 21, 30, 0.125
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = np.concatenate([_edge_rois(N, H, W, scale), rand_rois_xy(rs, 40, N, H, W, scale)], 0)
+    want = ora.roi_align_fwd(x, rois, P, P, scale, sr)
+    xt = torch.from_numpy(x).to(DEV)
+    if layout == 'nhwc':
+        xt = xt.contiguous(memory_format=torch.channels_last)
+    got = roi_align_2d(xt, torch.from_numpy(rois).to(DEV), P, P, scale, sr)
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got.cpu().numpy(), want)      # bit-exact
+
+
+@pytest.mark.parametrize('layout', ['nhwc', 'nchw'])
+@pytest.mark.parametrize('C,P,sr', [(8, 7, 2), (256, 7, 2), (12, 14, 2), (8, 3, 1), (8, 5, 0), (6, 7, 2),
+                                    (260, 7, 2)])
+def test_backward_matches_oracle(layout, C, P, sr):
+    rs = np.random.RandomState(100 + C + P)
+    N, H, W, scale = 2, 21, 30, 0.125
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = np.concatenate([_edge_rois(N, H, W, scale), rand_rois_xy(rs, 40, N, H, W, scale)], 0)
+    gy = rs.standard_normal((rois.shape[0], C, P, P)).astype(np.float32)
+    want = ora.roi_align_bwd(gy, rois, x.shape, scale, sr)
+    xt = torch.from_numpy(x).to(DEV)
+    if layout == 'nhwc':
+        xt = xt.contiguous(memory_format=torch.channels_last)
+    xt.requires_grad_(True)
+    y = roi_align_2d(xt, torch.from_numpy(rois).to(DEV), P, P, scale, sr)
+    y.backward(torch.from_numpy(gy).to(DEV))
+    got = xt.grad.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * np.abs(gy).max() * 4)
+
+
+def test_backward_many_rois_on_one_tile_and_segments():
+    """> SLOTS (32) RoIs on one tile => multi-round read-modify-write; R > LISTCAP (1024) => segments."""
+    rs = np.random.RandomState(7)
+    N, C, H, W, scale, P = 1, 8, 16, 16, 0.25, 7
+    R = 1500
+    c = rs.uniform(10, 30, (R, 2))
+    hw = rs.uniform(2, 20, (R, 2))
+    rois = np.stack([np.zeros(R), c[:, 1] - hw[:, 1], c[:, 0] - hw[:, 0], c[:, 1] + hw[:, 1],
+                     c[:, 0] + hw[:, 0]], 1).astype(np.float32)
+    gy = rs.standard_normal((R, C, P, P)).astype(np.float32)
+    want = ora.roi_align_bwd(gy, rois, (N, C, H, W), scale, 2)
+    gx = torch.empty((N, C, H, W), device=DEV).contiguous(memory_format=torch.channels_last)
+    gyt = torch.from_numpy(gy).to(DEV).contiguous(memory_format=torch.channels_last)
+    _hip.check(_hip.lib().mrcnn_roi_align_bwd_f32(_hip.ptr(gyt), 1, N, C, H, W,
+                                                  _hip.ptr(torch.from_numpy(rois).to(DEV)), R, P, P,
+                                                  scale, 2, _hip.ptr(gx), _hip.stream_ptr()))
+    np.testing.assert_allclose(gx.cpu().numpy(), want, rtol=2e-5, atol=1e-4 * np.abs(want).max())
+
+
+def test_empty_and_error_paths():
+    x = torch.zeros((1, 8, 5, 5), device=DEV).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    y = roi_align_2d(x, torch.zeros((0, 5), device=DEV), 7, 7, 0.25)
+    assert y.shape == (0, 8, 7, 7)
+    y.sum().backward()
+    assert torch.all(x.grad == 0)
+    with pytest.raises(_hip.MrcnnHipError):
+        roi_align_2d(torch.zeros((1, 8, 5, 5)), torch.zeros((1, 5)), 7, 7, 0.25)   # CPU tensor: no fallback
+    with pytest.raises(_hip.MrcnnHipError):
+        _hip.check(_hip.lib().mrcnn_roi_align_fwd_f32(None, 1, 1, 8, 5, 5, None, 1, 7, 7, 0.25, 2, None, None))
+    with pytest.raises(ValueError):
+        roi_align_2d(x, torch.zeros((3, 4), device=DEV), 7, 7, 0.25)
+
+
+def test_yx_shim_column_order():
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((1, 4, 12, 12)).astype(np.float32)
+    yx = np.array([[0, 3, 5, 30, 41], [0, 0, 0, 47, 20]], np.float32)     # (idx,y1,x1,y2,x2)
+    want = ora.roi_align_2d_yx(x, yx, 7, 7, 0.25)
+    got = _roi_align_2d_yx(torch.from_numpy(x).to(DEV), torch.from_numpy(yx).to(DEV), 7, 7, 0.25)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_config2_full_size_properties_and_sampled_parity():
+    """BASELINE configs[1] at full size: adjoint identity <y,gy> == <gx,x>, linearity, run-to-run
+    bit reproducibility of the tile backward, and oracle parity on a 48-RoI subset."""
+    x, yx, gy = config2_inputs()
+    xy = yx[:, [0, 2, 1, 4, 3]]
+    xt = torch.from_numpy(x).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rt = torch.from_numpy(xy).to(DEV)
+    gyt = torch.from_numpy(gy).to(DEV)
+    y = roi_align_2d(xt, rt, 7, 7, 0.25)
+    y.backward(gyt)
+    gx = xt.grad.clone()
+    lhs = torch.sum(y.double() * gyt.double()).item()
+    rhs = torch.sum(gx.double() * xt.detach().double()).item()
+    assert abs(lhs - rhs) <= 1e-6 * abs(lhs) + 1e-3
+    xt.grad = None
+    y2 = roi_align_2d(xt, rt, 7, 7, 0.25)
+    y2.backward(2.0 * gyt)
+    assert torch.equal(xt.grad, 2.0 * gx)                      # linear, and bit-reproducible
+    sub = np.arange(0, 512, 11)[:48]
+    want_y = ora.roi_align_fwd(x, xy[sub], 7, 7, 0.25, 2)
+    np.testing.assert_array_equal(y[torch.from_numpy(sub).to(DEV)].cpu().numpy(), want_y)
+    gsub = torch.zeros_like(gyt)
+    gsub[torch.from_numpy(sub).to(DEV)] = gyt[torch.from_numpy(sub).to(DEV)]
+    xt.grad = None
+    roi_align_2d(xt, rt, 7, 7, 0.25).backward(gsub)
+    want_gx = ora.roi_align_bwd(gy[sub], xy[sub], x.shape, 0.25, 2)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), want_gx, rtol=1e-5, atol=2e-5 * np.abs(gy).max())
