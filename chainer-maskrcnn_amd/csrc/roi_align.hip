@@ -150,22 +150,99 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_nhwc(Levels lv, const flo
 constexpr int TH = 8, TW = 8;     // tile of gradient-map cells owned by one workgroup
 constexpr int SLOTS = 32;         // RoIs whose weight tables are resident in LDS per round
 constexpr int PB = 16;            // max pooled bins per axis on this path (7 and 14 in the model)
-constexpr int LISTCAP = 1024;     // RoIs scanned per segment
+constexpr int LISTCAP = 512;      // RoIs scanned per segment
+constexpr int BWD_THREADS = 512;  // 8 waves, each owning one tile row (8 cells)
+constexpr int BWD_WAVES = BWD_THREADS / 64;
+constexpr int QCAP = 32;          // per-(wave, cell) queue capacity, entries = (gy row, coefficient)
 
-__global__ __launch_bounds__(256) void k_roi_align_bwd_nhwc(Levels lv, const float *__restrict__ gy,
-                                                            const float *__restrict__ rois,
-                                                            const int32_t *__restrict__ levels, int R,
-                                                            int N, int C, int PH, int PW, int sr) {
-    __shared__ float sW[SLOTS][2][TH][PB];   // [slot][axis][tile row/col][bin] summed weights
-    __shared__ int sMask[SLOTS];             // bits 0-7: rows with weight, bits 8-15: cols
+#define MRCNN_FMA4(A, c, g)                \
+    A.x = fmaf(c, g.x, A.x); A.y = fmaf(c, g.y, A.y); \
+    A.z = fmaf(c, g.z, A.z); A.w = fmaf(c, g.w, A.w);
+
+struct Group {       // four queue entries of one cell (padding: coefficient 0 on a live row)
+    int r0, r1, r2, r3;
+    float c0, c1, c2, c3;
+    float4 g0, g1, g2, g3;
+};
+
+// Fetch group j of cell k from the wave's queue and request its four 1-KiB gy rows.
+__device__ __forceinline__ void fetch_group(const int2 *qw, int k, int j, int nk,
+                                            const float *__restrict__ gyc, size_t Cs, bool act, Group &G) {
+    const int4 *p = reinterpret_cast<const int4 *>(qw + k * QCAP + 4 * j);   // wave-uniform address
+    const int4 a = p[0], b = p[1];
+    const int left = nk - 4 * j;      // >= 1
+    G.r0 = a.x;
+    G.c0 = __int_as_float(a.y);
+    G.r1 = left > 1 ? a.z : a.x;
+    G.c1 = left > 1 ? __int_as_float(a.w) : 0.0f;
+    G.r2 = left > 2 ? b.x : a.x;
+    G.c2 = left > 2 ? __int_as_float(b.y) : 0.0f;
+    G.r3 = left > 3 ? b.z : a.x;
+    G.c3 = left > 3 ? __int_as_float(b.w) : 0.0f;
+    if (act) {
+        G.g0 = ld4(gyc + (size_t)G.r0 * Cs);
+        G.g1 = ld4(gyc + (size_t)G.r1 * Cs);
+        G.g2 = ld4(gyc + (size_t)G.r2 * Cs);
+        G.g3 = ld4(gyc + (size_t)G.r3 * Cs);
+    }
+}
+
+// Stream a wave's queues (8 cells): the next group's loads are requested before the current
+// group is consumed, also across cell boundaries => up to 8 independent 1-KiB loads in flight.
+__device__ __forceinline__ void drain_queues(const int2 *qw, int cnt_lane, const float *__restrict__ gyc,
+                                             int C, bool act, float4 (&acc)[TW]) {
+    const size_t Cs = (size_t)C;
+    int k = 0, j = 0, nk = 0;
+    while (k < TW && (nk = __builtin_amdgcn_readlane(cnt_lane, k * 8)) == 0) ++k;
+    if (k == TW) return;
+    Group cur;
+    cur.g0 = cur.g1 = cur.g2 = cur.g3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    fetch_group(qw, k, 0, nk, gyc, Cs, act, cur);
+    while (true) {
+        int k2 = k, j2 = j + 1, nk2 = nk;
+        if (4 * j2 >= nk) {
+            j2 = 0;
+            ++k2;
+            while (k2 < TW && (nk2 = __builtin_amdgcn_readlane(cnt_lane, k2 * 8)) == 0) ++k2;
+        }
+        Group nxt = cur;
+        if (k2 < TW) fetch_group(qw, k2, j2, nk2, gyc, Cs, act, nxt);
+#pragma unroll
+        for (int kk = 0; kk < TW; ++kk) {
+            if (k == kk) {   // wave-uniform
+                MRCNN_FMA4(acc[kk], cur.c0, cur.g0) MRCNN_FMA4(acc[kk], cur.c1, cur.g1)
+                MRCNN_FMA4(acc[kk], cur.c2, cur.g2) MRCNN_FMA4(acc[kk], cur.c3, cur.g3)
+            }
+        }
+        if (k2 >= TW) break;
+        cur = nxt;
+        k = k2; j = j2; nk = nk2;
+    }
+}
+
+template <int PBT>   // bins per axis held in LDS: 8 (7x7 pooling) or 16 (14x14)
+__global__ __launch_bounds__(BWD_THREADS) void k_roi_align_bwd_nhwc(Levels lv, const float *__restrict__ gy,
+                                                                    const float *__restrict__ rois,
+                                                                    const int32_t *__restrict__ levels,
+                                                                    int R, int N, int C, int PH, int PW,
+                                                                    int sr, int chunk) {
+    constexpr int TASKS = 2 * TH * PBT;      // (axis,row,bin) weight cells per slot
+    __shared__ float sW[SLOTS][2][TH][PBT];  // [slot][axis][tile row/col][bin] summed weights
+    __shared__ __attribute__((aligned(16))) int2 sQ[BWD_WAVES][TW * QCAP];
+    __shared__ float4 sGeom[LISTCAP];        // (x1f, y1f, bw, bh) of listed RoIs
     __shared__ int sList[LISTCAP];
-    __shared__ int sWaveCnt[4];
-    __shared__ int sN;
+    __shared__ int sMask[SLOTS];             // bits 0-7: rows with weight, bits 8-15: cols
+    __shared__ int sWaveCnt[BWD_WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so XCD k
+    // takes the contiguous band [k*chunk, (k+1)*chunk) of the row-major tile list: neighbouring
+    // tiles - which read the same RoIs' gy rows - hit the same 4-MiB L2.  Speed only.
+    const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || tile_id >= lv.tile_begin[lv.L]) return;
     int l = 0;
-    while (l + 1 < lv.L && (int)blockIdx.x >= lv.tile_begin[l + 1]) ++l;
-    int t = blockIdx.x - lv.tile_begin[l];
+    while (l + 1 < lv.L && tile_id >= lv.tile_begin[l + 1]) ++l;
+    int t = tile_id - lv.tile_begin[l];
     const int per_img = lv.tiles_x[l] * lv.tiles_y[l];
     const int n = t / per_img;
     t -= n * per_img;
@@ -175,111 +252,129 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_nhwc(Levels lv, const flo
     float *gxb = lv.gx[l] + (size_t)n * H * W * C;
     const int C4 = C >> 2;
     const float inv_cnt = 1.0f / (float)(sr * sr);
-    const size_t roi_stride = (size_t)PH * PW * C;
+    int2 *qw = &sQ[wave][0];
+    const int cxl = lane >> 3, pwl = lane & 7;   // phase-2 lane role: (cell column, bin column)
 
     int round = 0;
     for (int seg = 0; seg == 0 || seg < R; seg += LISTCAP) {
         const int seg_end = min(R, seg + LISTCAP);
-        // ---- phase 0: ordered list of RoIs of this (level, image) whose footprint may touch the tile
-        if (tid == 0) sN = 0;
-        __syncthreads();
-        for (int base = seg; base < seg_end; base += 256) {
-            const int i = base + tid;
-            bool f = false;
-            if (i < seg_end) {
-                int li = levels ? levels[i] : 0;
-                li = min(max(li, 0), lv.L - 1);
-                const float *roi = rois + (size_t)i * 5;
-                if (li == l && (int)roi[0] == n) {
-                    const RoiGeom g = roi_geom(roi, scale, PH, PW, sr);
-                    f = (g.y1f - 2.0f < (float)(ty0 + TH)) && (g.y1f + g.rh + 2.0f > (float)ty0) &&
-                        (g.x1f - 2.0f < (float)(tx0 + TW)) && (g.x1f + g.rw + 2.0f > (float)tx0);
-                }
+        // ---- phase 0: ordered list (+ geometry) of the RoIs of this (level, image) whose
+        //      footprint may touch the tile.  LISTCAP == BWD_THREADS: one RoI per thread.
+        bool f = false;
+        float4 geo = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int i = seg + tid;
+        if (i < seg_end) {
+            int li = levels ? levels[i] : 0;
+            li = min(max(li, 0), lv.L - 1);
+            const float *roi = rois + (size_t)i * 5;
+            if (li == l && (int)roi[0] == n) {
+                const RoiGeom g = roi_geom(roi, scale, PH, PW, sr);
+                f = (g.y1f - 2.0f < (float)(ty0 + TH)) && (g.y1f + g.rh + 2.0f > (float)ty0) &&
+                    (g.x1f - 2.0f < (float)(tx0 + TW)) && (g.x1f + g.rw + 2.0f > (float)tx0);
+                geo = make_float4(g.x1f, g.y1f, g.bw, g.bh);
             }
-            const unsigned long long bal = __ballot(f);
-            if (lane == 0) sWaveCnt[wave] = __popcll(bal);
-            __syncthreads();
-            int off = sN;
-            for (int w = 0; w < wave; ++w) off += sWaveCnt[w];
-            if (f) sList[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-            __syncthreads();
-            if (tid == 0) sN += sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
-            __syncthreads();
         }
-        const int n_list = sN;
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) sWaveCnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, n_list = 0;
+        for (int w = 0; w < BWD_WAVES; ++w) {
+            if (w < wave) off += sWaveCnt[w];
+            n_list += sWaveCnt[w];
+        }
+        if (f) {
+            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            sList[pos] = i;
+            sGeom[pos] = geo;
+        }
+        __syncthreads();
 
         for (int s0 = 0; s0 < n_list || round == 0; s0 += SLOTS) {
             const int nslots = max(0, min(SLOTS, n_list - s0));
             // ---- phase 1: per-(slot, axis, row, bin) summed weights, one thread each
             if (tid < SLOTS) sMask[tid] = 0;
             __syncthreads();
-            for (int task = tid; task < nslots * 256; task += 256) {
-                const int slot = task >> 8, q = task & 255;
-                const int axis = q >> 7, row = (q >> 4) & 7, bin = q & 15;
-                const RoiGeom g = roi_geom(rois + (size_t)sList[s0 + slot] * 5, scale, PH, PW, sr);
+            for (int task = tid; task < nslots * TASKS; task += BWD_THREADS) {
+                const int slot = task / TASKS, q = task % TASKS;
+                const int axis = q / (TH * PBT), row = (q / PBT) % TH, bin = q % PBT;
+                const float4 ge = sGeom[s0 + slot];
                 const int P = axis ? PW : PH, size = axis ? W : H;
                 const int target = (axis ? tx0 : ty0) + row;
-                const float start = axis ? g.x1f : g.y1f, bsz = axis ? g.bw : g.bh;
+                const float start = axis ? ge.x : ge.y, bsz = axis ? ge.z : ge.w;
                 float wv = 0.0f;
                 if (bin < P) {
-                    for (int i = 0; i < sr; ++i) {
-                        const Samp s = axis_sample(start, bsz, bin, i, sr, size);
+                    for (int i2 = 0; i2 < sr; ++i2) {
+                        const Samp s = axis_sample(start, bsz, bin, i2, sr, size);
                         if (s.lo == target) wv += s.wl;
                         if (s.hi == target) wv += s.wh;
                     }
                 }
                 sW[slot][axis][row][bin] = wv;
                 const unsigned long long nz = __ballot(wv != 0.0f);
-                if ((lane & 15) == 0 && ((nz >> lane) & 0xFFFFull)) atomicOr(&sMask[slot], 1 << (axis * 8 + row));
+                if ((lane % PBT) == 0 && ((nz >> lane) & ((1ull << PBT) - 1ull)))
+                    atomicOr(&sMask[slot], 1 << (axis * 8 + row));
             }
             __syncthreads();
 
-            // ---- phase 2: each wave owns 16 cells (two tile rows); acc lives in registers
-            for (int ci = 0; ci < 16; ++ci) {
-                const int cell = wave * 16 + ci;
-                const int cy = cell >> 3, cx = cell & 7;
-                const int Y = ty0 + cy, X = tx0 + cx;
-                if (Y >= H || X >= W) continue;
-                float *dst = gxb + ((size_t)Y * W + X) * C;
+            // ---- phase 2: wave w owns tile row w (8 cells, accumulators in registers).
+            //      2a (lane-parallel): for every listed RoI with weight on this row, lane (cx,pw)
+            //      holds Wx[cx][pw]; for each bin row ph with Wy != 0 the lanes with Wx != 0 append
+            //      (gy row, Wy*Wx/count) to their cell's queue at a ballot-derived rank.
+            //      2b: drain_queues streams the queues.
+            const int cy = wave, Y = ty0 + cy;
+            if (Y < H) {
                 const int m = lane < nslots ? sMask[lane] : 0;
-                const unsigned rel = (unsigned)__ballot(((m >> cy) & 1) && ((m >> (8 + cx)) & 1));
+                const unsigned rowrel = (unsigned)__ballot(((m >> cy) & 1) && (m >> 8));
+                const int roi_of_lane = lane < nslots ? sList[s0 + lane] : 0;
+                const int ncell = min(TW, W - tx0);
+                float *dst = gxb + ((size_t)Y * W + tx0) * C;
                 for (int c4 = lane; c4 < ((C4 + 63) & ~63); c4 += 64) {
                     const bool act = c4 < C4;
                     const int c4s = act ? c4 : 0;
-                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (round != 0 && act) acc = ld4(dst + c4s * 4);
-                    unsigned rm = rel;
+                    const float *gyc = gy + c4s * 4;
+                    float4 acc[TW];
+#pragma unroll
+                    for (int k = 0; k < TW; ++k) {
+                        acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (round != 0 && act && k < ncell) acc[k] = ld4(dst + (size_t)k * C + c4s * 4);
+                    }
+                    int cnt = 0;      // entries queued for this lane's cell (equal across its 8 lanes)
+                    unsigned rm = rowrel;
                     while (rm) {
                         const int slot = __builtin_ctz(rm);
                         rm &= rm - 1;
-                        const int r = sList[s0 + slot];
-                        float wv = 0.0f;
-                        if ((lane & 31) < PB) wv = sW[slot][lane >> 5][(lane >> 5) ? cx : cy][lane & 31];
-                        const unsigned long long nz = __ballot(wv != 0.0f);
-                        unsigned ym = (unsigned)nz;
-                        const unsigned xm = (unsigned)(nz >> 32);
-                        const float *gyr = gy + (size_t)r * roi_stride + c4s * 4;
-                        while (ym) {
-                            const int ph = __builtin_ctz(ym);
-                            ym &= ym - 1;
-                            const float wy = readlane_f(wv, ph) * inv_cnt;
-                            const float *gyp = gyr + (size_t)ph * PW * C;
-                            unsigned xx = xm;
-                            while (xx) {
-                                const int pw = __builtin_ctz(xx);
-                                xx &= xx - 1;
-                                const float coef = wy * readlane_f(wv, 32 + pw);
-                                if (act) {
-                                    const float4 g4 = ld4(gyp + (size_t)pw * C);
-                                    acc.x = fmaf(coef, g4.x, acc.x);
-                                    acc.y = fmaf(coef, g4.y, acc.y);
-                                    acc.z = fmaf(coef, g4.z, acc.z);
-                                    acc.w = fmaf(coef, g4.w, acc.w);
+                        const int r = __builtin_amdgcn_readlane(roi_of_lane, slot);
+                        const float wyl = (lane < PBT) ? sW[slot][0][cy][lane] : 0.0f;
+                        const unsigned ymask = (unsigned)__ballot(wyl != 0.0f);
+                        for (int hx = 0; hx < PBT / 8; ++hx) {
+                            const float wx = sW[slot][1][cxl][hx * 8 + pwl];
+                            const unsigned long long nz = __ballot(wx != 0.0f);
+                            if (!nz) continue;
+                            const unsigned grp = (unsigned)(nz >> (lane & ~7)) & 0xFFu;
+                            const int rank = __popc(grp & ((1u << pwl) - 1u));
+                            const int add = __popc(grp);
+                            unsigned ym = ymask;
+                            while (ym) {
+                                const int ph = __builtin_ctz(ym);
+                                ym &= ym - 1;
+                                const float wy = readlane_f(wyl, ph) * inv_cnt;
+                                if (__ballot(cnt + add > QCAP)) {   // some cell's queue would overflow
+                                    drain_queues(qw, cnt, gyc, C, act, acc);
+                                    cnt = 0;
                                 }
+                                if (wx != 0.0f)
+                                    qw[cxl * QCAP + cnt + rank] =
+                                        make_int2((r * PH + ph) * PW + hx * 8 + pwl, __float_as_int(wy * wx));
+                                cnt += add;
                             }
                         }
                     }
-                    if (act) *reinterpret_cast<float4 *>(dst + c4s * 4) = acc;
+                    drain_queues(qw, cnt, gyc, C, act, acc);
+                    if (act) {
+#pragma unroll
+                        for (int k = 0; k < TW; ++k)
+                            if (k < ncell) *reinterpret_cast<float4 *>(dst + (size_t)k * C + c4s * 4) = acc[k];
+                    }
                 }
             }
             ++round;
@@ -396,18 +491,21 @@ Strides4 strides_of(int layout, int C, int H, int W) {
     return s;
 }
 
-int check_common(const void *a, const void *rois, const void *b, int layout, int N, int C, int H, int W,
+// `map` = the feature-map side pointer (always required); `pooled` = the (R,...) side (may be null when R==0)
+int check_common(const void *pooled, const void *rois, const void *map, int layout, int N, int C, int H, int W,
                  int R, int PH, int PW, int sr) {
     if (layout != MRCNN_LAYOUT_NCHW && layout != MRCNN_LAYOUT_NHWC)
         return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align: unknown layout %d", layout);
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || R < 0 || sr < 0)
         return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align: bad sizes N=%d C=%d H=%d W=%d R=%d PH=%d PW=%d sr=%d",
                                N, C, H, W, R, PH, PW, sr);
-    if (!a || !b || (R > 0 && !rois)) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align: null pointer");
+    if (!map || (R > 0 && (!rois || !pooled))) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align: null pointer");
     return 0;
 }
 
-bool fast_bwd_ok(int C, int PH, int PW, int sr) { return (C % 4) == 0 && PH <= PB && PW <= PB && sr > 0; }
+bool fast_bwd_ok(int C, int PH, int PW, int sr, int R) {
+    return (C % 4) == 0 && PH <= PB && PW <= PB && sr > 0 && (long long)R * PH * PW < (1ll << 31);
+}
 
 int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, const int32_t *levels, int R,
                      int C, int PH, int PW, int sr, hipStream_t st) {
@@ -419,8 +517,13 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
         total += lv.tiles_x[l] * lv.tiles_y[l] * N;
     }
     lv.tile_begin[lv.L] = total;
-    hipLaunchKernelGGL(k_roi_align_bwd_nhwc, dim3(total), dim3(256), 0, st, lv, gy, rois, levels, R, N, C, PH,
-                       PW, sr);
+    const int chunk = mrcnn::cdiv(total, 8);
+    if (PH <= 8 && PW <= 8)
+        hipLaunchKernelGGL(k_roi_align_bwd_nhwc<8>, dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois,
+                           levels, R, N, C, PH, PW, sr, chunk);
+    else
+        hipLaunchKernelGGL(k_roi_align_bwd_nhwc<16>, dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois,
+                           levels, R, N, C, PH, PW, sr, chunk);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -430,7 +533,7 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
 extern "C" int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C, int H, int W,
                                        const float *rois, int R, int PH, int PW, float spatial_scale,
                                        int sampling_ratio, float *y, void *stream) {
-    if (int e = check_common(x, rois, y, layout, N, C, H, W, R, PH, PW, sampling_ratio)) return e;
+    if (int e = check_common(y, rois, x, layout, N, C, H, W, R, PH, PW, sampling_ratio)) return e;
     if (R == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (layout == MRCNN_LAYOUT_NHWC && (C % 4) == 0) {
@@ -454,7 +557,7 @@ extern "C" int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C
                                        int sampling_ratio, float *gx, void *stream) {
     if (int e = check_common(gy, rois, gx, layout, N, C, H, W, R, PH, PW, sampling_ratio)) return e;
     hipStream_t st = (hipStream_t)stream;
-    if (layout == MRCNN_LAYOUT_NHWC && fast_bwd_ok(C, PH, PW, sampling_ratio)) {
+    if (layout == MRCNN_LAYOUT_NHWC && fast_bwd_ok(C, PH, PW, sampling_ratio, R)) {
         Levels lv{};
         lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
         return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, st);
@@ -506,7 +609,7 @@ extern "C" int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, c
                                            int sampling_ratio, void *stream) {
     if (!gxs || (R > 0 && (!rois || !levels || !gy))) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd: null pointer");
     if (N <= 0 || C <= 0 || PH <= 0 || PW <= 0 || R < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd: bad sizes");
-    if (!fast_bwd_ok(C, PH, PW, sampling_ratio))
+    if (!fast_bwd_ok(C, PH, PW, sampling_ratio, R))
         return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd: needs C%%4==0, PH,PW<=%d, sampling_ratio>0", PB);
     Levels lv{};
     if (int e = fill_levels(lv, nullptr, gxs, Hs, Ws, scales, L)) return e;
