@@ -150,85 +150,53 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_nhwc(Levels lv, const flo
 constexpr int TH = 8, TW = 8;     // tile of gradient-map cells owned by one workgroup
 constexpr int SLOTS = 32;         // RoIs whose weight tables are resident in LDS per round
 constexpr int PB = 16;            // max pooled bins per axis on this path (7 and 14 in the model)
-constexpr int LISTCAP = 512;      // RoIs scanned per segment
-constexpr int BWD_THREADS = 512;  // 8 waves, each owning one tile row (8 cells)
+constexpr int BWD_THREADS = 256;  // 4 waves, each owning two tile rows (processed one after the other)
 constexpr int BWD_WAVES = BWD_THREADS / 64;
+constexpr int ROWS_PER_WAVE = TH / BWD_WAVES;
+constexpr int LISTCAP = 512;      // RoIs scanned per segment
 constexpr int QCAP = 32;          // per-(wave, cell) queue capacity, entries = (gy row, coefficient)
+constexpr int CCH = 256;          // channels per pass: lane = (cell column, 32 channels as 8 x float4)
 
 #define MRCNN_FMA4(A, c, g)                \
     A.x = fmaf(c, g.x, A.x); A.y = fmaf(c, g.y, A.y); \
     A.z = fmaf(c, g.z, A.z); A.w = fmaf(c, g.w, A.w);
 
-struct Group {       // four queue entries of one cell (padding: coefficient 0 on a live row)
-    int r0, r1, r2, r3;
-    float c0, c1, c2, c3;
-    float4 g0, g1, g2, g3;
-};
-
-// Fetch group j of cell k from the wave's queue and request its four 1-KiB gy rows.
-__device__ __forceinline__ void fetch_group(const int2 *qw, int k, int j, int nk,
-                                            const float *__restrict__ gyc, size_t Cs, bool act, Group &G) {
-    const int4 *p = reinterpret_cast<const int4 *>(qw + k * QCAP + 4 * j);   // wave-uniform address
-    const int4 a = p[0], b = p[1];
-    const int left = nk - 4 * j;      // >= 1
-    G.r0 = a.x;
-    G.c0 = __int_as_float(a.y);
-    G.r1 = left > 1 ? a.z : a.x;
-    G.c1 = left > 1 ? __int_as_float(a.w) : 0.0f;
-    G.r2 = left > 2 ? b.x : a.x;
-    G.c2 = left > 2 ? __int_as_float(b.y) : 0.0f;
-    G.r3 = left > 3 ? b.z : a.x;
-    G.c3 = left > 3 ? __int_as_float(b.w) : 0.0f;
-    if (act) {
-        G.g0 = ld4(gyc + (size_t)G.r0 * Cs);
-        G.g1 = ld4(gyc + (size_t)G.r1 * Cs);
-        G.g2 = ld4(gyc + (size_t)G.r2 * Cs);
-        G.g3 = ld4(gyc + (size_t)G.r3 * Cs);
-    }
-}
-
-// Stream a wave's queues (8 cells): the next group's loads are requested before the current
-// group is consumed, also across cell boundaries => up to 8 independent 1-KiB loads in flight.
-__device__ __forceinline__ void drain_queues(const int2 *qw, int cnt_lane, const float *__restrict__ gyc,
-                                             int C, bool act, float4 (&acc)[TW]) {
-    const size_t Cs = (size_t)C;
-    int k = 0, j = 0, nk = 0;
-    while (k < TW && (nk = __builtin_amdgcn_readlane(cnt_lane, k * 8)) == 0) ++k;
-    if (k == TW) return;
-    Group cur;
-    cur.g0 = cur.g1 = cur.g2 = cur.g3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    fetch_group(qw, k, 0, nk, gyc, Cs, act, cur);
-    while (true) {
-        int k2 = k, j2 = j + 1, nk2 = nk;
-        if (4 * j2 >= nk) {
-            j2 = 0;
-            ++k2;
-            while (k2 < TW && (nk2 = __builtin_amdgcn_readlane(cnt_lane, k2 * 8)) == 0) ++k2;
-        }
-        Group nxt = cur;
-        if (k2 < TW) fetch_group(qw, k2, j2, nk2, gyc, Cs, act, nxt);
+// Stream the wave's eight per-cell queues.  Lane (cxl = lane>>3, q = lane&7) owns cell cxl and the
+// channels {cb + 4q + 32i .. +3 : i = 0..7}: every lane walks ITS cell's queue (per-lane row
+// offsets, no wave-uniform control flow) and each of the eight loads of an entry touches, for each
+// of the 8 cells, one full 128-B line.
+__device__ __forceinline__ void drain_queues(const int2 *qw, int cnt, const float *__restrict__ gyl, int C,
+                                             float4 (&acc)[8]) {
+    const int cxl = (threadIdx.x & 63) >> 3;
+    const int2 *q = qw + cxl * QCAP;
+#pragma nounroll
+    for (int j = 0; __ballot(j < cnt) != 0ull; ++j) {
+        // Branch-free on the accumulators: lanes past their queue's end add coef 0 * 0.
+        const bool a = j < cnt;
+        const int2 e = q[min(j, QCAP - 1)];
+        const float coef = a ? __int_as_float(e.y) : 0.0f;
+        const float *p = gyl + (size_t)(a ? e.x : 0) * C;
+        float4 g[8];
 #pragma unroll
-        for (int kk = 0; kk < TW; ++kk) {
-            if (k == kk) {   // wave-uniform
-                MRCNN_FMA4(acc[kk], cur.c0, cur.g0) MRCNN_FMA4(acc[kk], cur.c1, cur.g1)
-                MRCNN_FMA4(acc[kk], cur.c2, cur.g2) MRCNN_FMA4(acc[kk], cur.c3, cur.g3)
-            }
+        for (int i = 0; i < 8; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = ld4(p + 32 * i);
         }
-        if (k2 >= TW) break;
-        cur = nxt;
-        k = k2; j = j2; nk = nk2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { MRCNN_FMA4(acc[i], coef, g[i]) }
     }
 }
 
 template <int PBT>   // bins per axis held in LDS: 8 (7x7 pooling) or 16 (14x14)
-__global__ __launch_bounds__(BWD_THREADS) void k_roi_align_bwd_nhwc(Levels lv, const float *__restrict__ gy,
+__global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_nhwc(Levels lv, const float *__restrict__ gy,
                                                                     const float *__restrict__ rois,
                                                                     const int32_t *__restrict__ levels,
                                                                     int R, int N, int C, int PH, int PW,
                                                                     int sr, int chunk) {
     constexpr int TASKS = 2 * TH * PBT;      // (axis,row,bin) weight cells per slot
     __shared__ float sW[SLOTS][2][TH][PBT];  // [slot][axis][tile row/col][bin] summed weights
-    __shared__ __attribute__((aligned(16))) int2 sQ[BWD_WAVES][TW * QCAP];
+    __shared__ int2 sQ[BWD_WAVES][TW * QCAP];
     __shared__ float4 sGeom[LISTCAP];        // (x1f, y1f, bw, bh) of listed RoIs
     __shared__ int sList[LISTCAP];
     __shared__ int sMask[SLOTS];             // bits 0-7: rows with weight, bits 8-15: cols
@@ -250,44 +218,47 @@ __global__ __launch_bounds__(BWD_THREADS) void k_roi_align_bwd_nhwc(Levels lv, c
     const int H = lv.H[l], W = lv.W[l];
     const float scale = lv.scale[l];
     float *gxb = lv.gx[l] + (size_t)n * H * W * C;
-    const int C4 = C >> 2;
     const float inv_cnt = 1.0f / (float)(sr * sr);
     int2 *qw = &sQ[wave][0];
-    const int cxl = lane >> 3, pwl = lane & 7;   // phase-2 lane role: (cell column, bin column)
+    const int cxl = lane >> 3, pwl = lane & 7;   // phase-2 lane role: (cell column, bin column / channel group)
+    const int ncell = min(TW, W - tx0);
 
     int round = 0;
     for (int seg = 0; seg == 0 || seg < R; seg += LISTCAP) {
         const int seg_end = min(R, seg + LISTCAP);
         // ---- phase 0: ordered list (+ geometry) of the RoIs of this (level, image) whose
-        //      footprint may touch the tile.  LISTCAP == BWD_THREADS: one RoI per thread.
-        bool f = false;
-        float4 geo = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int i = seg + tid;
-        if (i < seg_end) {
-            int li = levels ? levels[i] : 0;
-            li = min(max(li, 0), lv.L - 1);
-            const float *roi = rois + (size_t)i * 5;
-            if (li == l && (int)roi[0] == n) {
-                const RoiGeom g = roi_geom(roi, scale, PH, PW, sr);
-                f = (g.y1f - 2.0f < (float)(ty0 + TH)) && (g.y1f + g.rh + 2.0f > (float)ty0) &&
-                    (g.x1f - 2.0f < (float)(tx0 + TW)) && (g.x1f + g.rw + 2.0f > (float)tx0);
-                geo = make_float4(g.x1f, g.y1f, g.bw, g.bh);
+        //      footprint may touch the tile.
+        int n_list = 0;
+        for (int base = seg; base < seg_end; base += BWD_THREADS) {
+            bool f = false;
+            float4 geo = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int i = base + tid;
+            if (i < seg_end) {
+                int li = levels ? levels[i] : 0;
+                li = min(max(li, 0), lv.L - 1);
+                const float *roi = rois + (size_t)i * 5;
+                if (li == l && (int)roi[0] == n) {
+                    const RoiGeom g = roi_geom(roi, scale, PH, PW, sr);
+                    f = (g.y1f - 2.0f < (float)(ty0 + TH)) && (g.y1f + g.rh + 2.0f > (float)ty0) &&
+                        (g.x1f - 2.0f < (float)(tx0 + TW)) && (g.x1f + g.rw + 2.0f > (float)tx0);
+                    geo = make_float4(g.x1f, g.y1f, g.bw, g.bh);
+                }
             }
+            const unsigned long long bal = __ballot(f);
+            if (lane == 0) sWaveCnt[wave] = __popcll(bal);
+            __syncthreads();
+            int off = n_list;
+            for (int w = 0; w < BWD_WAVES; ++w) {
+                if (w < wave) off += sWaveCnt[w];
+                n_list += sWaveCnt[w];
+            }
+            if (f) {
+                const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+                sList[pos] = i;
+                sGeom[pos] = geo;
+            }
+            __syncthreads();
         }
-        const unsigned long long bal = __ballot(f);
-        if (lane == 0) sWaveCnt[wave] = __popcll(bal);
-        __syncthreads();
-        int off = 0, n_list = 0;
-        for (int w = 0; w < BWD_WAVES; ++w) {
-            if (w < wave) off += sWaveCnt[w];
-            n_list += sWaveCnt[w];
-        }
-        if (f) {
-            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-            sList[pos] = i;
-            sGeom[pos] = geo;
-        }
-        __syncthreads();
 
         for (int s0 = 0; s0 < n_list || round == 0; s0 += SLOTS) {
             const int nslots = max(0, min(SLOTS, n_list - s0));
@@ -316,65 +287,68 @@ __global__ __launch_bounds__(BWD_THREADS) void k_roi_align_bwd_nhwc(Levels lv, c
             }
             __syncthreads();
 
-            // ---- phase 2: wave w owns tile row w (8 cells, accumulators in registers).
-            //      2a (lane-parallel): for every listed RoI with weight on this row, lane (cx,pw)
-            //      holds Wx[cx][pw]; for each bin row ph with Wy != 0 the lanes with Wx != 0 append
-            //      (gy row, Wy*Wx/count) to their cell's queue at a ballot-derived rank.
-            //      2b: drain_queues streams the queues.
-            const int cy = wave, Y = ty0 + cy;
-            if (Y < H) {
-                const int m = lane < nslots ? sMask[lane] : 0;
+            // ---- phase 2: a wave owns ROWS_PER_WAVE tile rows and handles them one at a time.
+            //      2a (lane-parallel queue build): for every listed RoI with weight on the row,
+            //      lane (cx,pw) holds Wx[cx][pw]; for each bin row ph with Wy != 0 the lanes with
+            //      Wx != 0 append (gy row, Wy*Wx/count) to their cell's queue at a ballot-derived
+            //      rank (deterministic order).  2b: drain_queues.
+            const int m = lane < nslots ? sMask[lane] : 0;
+            const int roi_of_lane = lane < nslots ? sList[s0 + lane] : 0;
+#pragma nounroll
+            for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+                const int cy = wave * ROWS_PER_WAVE + rr, Y = ty0 + cy;
+                if (Y >= H) break;
                 const unsigned rowrel = (unsigned)__ballot(((m >> cy) & 1) && (m >> 8));
-                const int roi_of_lane = lane < nslots ? sList[s0 + lane] : 0;
-                const int ncell = min(TW, W - tx0);
-                float *dst = gxb + ((size_t)Y * W + tx0) * C;
-                for (int c4 = lane; c4 < ((C4 + 63) & ~63); c4 += 64) {
-                    const bool act = c4 < C4;
-                    const int c4s = act ? c4 : 0;
-                    const float *gyc = gy + c4s * 4;
-                    float4 acc[TW];
-#pragma unroll
-                    for (int k = 0; k < TW; ++k) {
-                        acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (round != 0 && act && k < ncell) acc[k] = ld4(dst + (size_t)k * C + c4s * 4);
-                    }
-                    int cnt = 0;      // entries queued for this lane's cell (equal across its 8 lanes)
-                    unsigned rm = rowrel;
-                    while (rm) {
-                        const int slot = __builtin_ctz(rm);
-                        rm &= rm - 1;
-                        const int r = __builtin_amdgcn_readlane(roi_of_lane, slot);
-                        const float wyl = (lane < PBT) ? sW[slot][0][cy][lane] : 0.0f;
-                        const unsigned ymask = (unsigned)__ballot(wyl != 0.0f);
-                        for (int hx = 0; hx < PBT / 8; ++hx) {
-                            const float wx = sW[slot][1][cxl][hx * 8 + pwl];
-                            const unsigned long long nz = __ballot(wx != 0.0f);
-                            if (!nz) continue;
-                            const unsigned grp = (unsigned)(nz >> (lane & ~7)) & 0xFFu;
-                            const int rank = __popc(grp & ((1u << pwl) - 1u));
-                            const int add = __popc(grp);
-                            unsigned ym = ymask;
-                            while (ym) {
-                                const int ph = __builtin_ctz(ym);
-                                ym &= ym - 1;
-                                const float wy = readlane_f(wyl, ph) * inv_cnt;
-                                if (__ballot(cnt + add > QCAP)) {   // some cell's queue would overflow
-                                    drain_queues(qw, cnt, gyc, C, act, acc);
-                                    cnt = 0;
+                float *dst = gxb + ((size_t)Y * W + tx0 + cxl) * C + pwl * 4;
+#pragma nounroll
+                for (int cb = 0; cb < C; cb += CCH) {
+                    const float *gyl = gy + cb + pwl * 4;
+                    // Passes: pass p drains queue entries [p*QCAP, (p+1)*QCAP) of every cell; one pass
+                    // unless some cell collects more than QCAP entries in this round (then the queue is
+                    // rebuilt with a shifted window and gx is read-modify-written by its owner lane).
+                    int pass = 0, cnt;
+                    do {
+                        cnt = 0;      // entries seen for this lane's cell (equal across its 8 lanes)
+                        const int win = pass * QCAP;
+                        for (unsigned rm = rowrel; rm; rm &= rm - 1) {
+                            const int slot = __builtin_ctz(rm);
+                            const int r = __builtin_amdgcn_readlane(roi_of_lane, slot);
+                            const float wyl = (lane < PBT) ? sW[slot][0][cy][lane] : 0.0f;
+                            const unsigned ymask = (unsigned)__ballot(wyl != 0.0f);
+                            const int ny = __popc(ymask);
+                            for (int hx = 0; hx < PBT / 8; ++hx) {
+                                const float wx = sW[slot][1][cxl][hx * 8 + pwl];
+                                const unsigned long long nz = __ballot(wx != 0.0f);
+                                if (!nz) continue;
+                                const unsigned grp = (unsigned)(nz >> (lane & ~7)) & 0xFFu;
+                                const int rank = __popc(grp & ((1u << pwl) - 1u));
+                                const int add = __popc(grp);
+                                int idx = cnt + rank - win;
+                                for (unsigned ym = ymask; ym; ym &= ym - 1) {
+                                    const int ph = __builtin_ctz(ym);
+                                    const float wy = readlane_f(wyl, ph) * inv_cnt;
+                                    if (wx != 0.0f && (unsigned)idx < (unsigned)QCAP)
+                                        qw[cxl * QCAP + idx] =
+                                            make_int2((r * PH + ph) * PW + hx * 8 + pwl, __float_as_int(wy * wx));
+                                    idx += add;
                                 }
-                                if (wx != 0.0f)
-                                    qw[cxl * QCAP + cnt + rank] =
-                                        make_int2((r * PH + ph) * PW + hx * 8 + pwl, __float_as_int(wy * wx));
-                                cnt += add;
+                                cnt += add * ny;
                             }
                         }
-                    }
-                    drain_queues(qw, cnt, gyc, C, act, acc);
-                    if (act) {
+                        float4 acc[8];
+                        const bool first = (round == 0 && pass == 0);
 #pragma unroll
-                        for (int k = 0; k < TW; ++k)
-                            if (k < ncell) *reinterpret_cast<float4 *>(dst + (size_t)k * C + c4s * 4) = acc[k];
-                    }
+                        for (int i = 0; i < 8; ++i) {
+                            acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (!first && cxl < ncell) acc[i] = ld4(dst + cb + 32 * i);
+                        }
+                        drain_queues(qw, max(0, min(QCAP, cnt - win)), gyl, C, acc);
+                        if (cxl < ncell) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(dst + cb + 32 * i) = acc[i];
+                        }
+                        ++pass;
+                    } while (__ballot(cnt > pass * QCAP) != 0ull);
                 }
             }
             ++round;
@@ -504,7 +478,7 @@ int check_common(const void *pooled, const void *rois, const void *map, int layo
 }
 
 bool fast_bwd_ok(int C, int PH, int PW, int sr, int R) {
-    return (C % 4) == 0 && PH <= PB && PW <= PB && sr > 0 && (long long)R * PH * PW < (1ll << 31);
+    return (C % CCH) == 0 && PH <= PB && PW <= PB && sr > 0 && (long long)R * PH * PW < (1ll << 31);
 }
 
 int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, const int32_t *levels, int R,
@@ -610,7 +584,7 @@ extern "C" int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, c
     if (!gxs || (R > 0 && (!rois || !levels || !gy))) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd: null pointer");
     if (N <= 0 || C <= 0 || PH <= 0 || PW <= 0 || R < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd: bad sizes");
     if (!fast_bwd_ok(C, PH, PW, sampling_ratio, R))
-        return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd: needs C%%4==0, PH,PW<=%d, sampling_ratio>0", PB);
+        return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd: needs C%%256==0, PH,PW<=%d, sampling_ratio>0", PB);
     Levels lv{};
     if (int e = fill_levels(lv, nullptr, gxs, Hs, Ws, scales, L)) return e;
     return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, (hipStream_t)stream);
