@@ -148,55 +148,78 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_nhwc(Levels lv, const flo
 // Backward, NHWC, owner-computes tiles.
 // ------------------------------------------------------------------------------------------
 constexpr int TH = 8, TW = 8;     // tile of gradient-map cells owned by one workgroup
+constexpr int PT = 4;             // a wave owns a PT x PT patch of cells (accumulators in registers)
 constexpr int SLOTS = 32;         // RoIs whose weight tables are resident in LDS per round
 constexpr int PB = 16;            // max pooled bins per axis on this path (7 and 14 in the model)
-constexpr int BWD_THREADS = 256;  // 4 waves, each owning two tile rows (processed one after the other)
+constexpr int BWD_THREADS = 256;  // 4 waves = 2 x 2 patches
 constexpr int BWD_WAVES = BWD_THREADS / 64;
-constexpr int ROWS_PER_WAVE = TH / BWD_WAVES;
 constexpr int LISTCAP = 512;      // RoIs scanned per segment
-constexpr int QCAP = 32;          // per-(wave, cell) queue capacity, entries = (gy row, coefficient)
-constexpr int CCH = 256;          // channels per pass: lane = (cell column, 32 channels as 8 x float4)
+constexpr int QCAP = 64;          // per-wave queue capacity; entry = (gy row, 4 row weights, 4 col weights)
+constexpr int CCH = 256;          // channels per pass: lane = 4 channels
 
 #define MRCNN_FMA4(A, c, g)                \
     A.x = fmaf(c, g.x, A.x); A.y = fmaf(c, g.y, A.y); \
     A.z = fmaf(c, g.z, A.z); A.w = fmaf(c, g.w, A.w);
 
-// Stream the wave's eight per-cell queues.  Lane (cxl = lane>>3, q = lane&7) owns cell cxl and the
-// channels {cb + 4q + 32i .. +3 : i = 0..7}: every lane walks ITS cell's queue (per-lane row
-// offsets, no wave-uniform control flow) and each of the eight loads of an entry touches, for each
-// of the 8 cells, one full 128-B line.
-__device__ __forceinline__ void drain_queues(const int2 *qw, int cnt, const float *__restrict__ gyl, int C,
-                                             float4 (&acc)[8]) {
-    const int cxl = (threadIdx.x & 63) >> 3;
-    const int2 *q = qw + cxl * QCAP;
+struct PatchQueue {     // one per wave, in LDS
+    float4 wy[QCAP];    // weights of the entry's bin row on the patch's 4 map rows (already / count)
+    float4 wx[QCAP];    // weights of the entry's bin column on the patch's 4 map columns
+    int row[QCAP];      // gy row index (r*PH + ph)*PW + pw
+};
+
+// acc[i][k] += wy[i] * wx[k] * g for the 4x4 patch.  Deliberately branch-free: conditional updates of
+// the 64 accumulator registers make hipcc copy them around every branch.
+__device__ __forceinline__ void apply_entry(float4 (&acc)[PT][PT], const float4 wy, const float4 wx,
+                                            const float4 g) {
+    const float4 t0 = make_float4(wx.x * g.x, wx.x * g.y, wx.x * g.z, wx.x * g.w);
+    const float4 t1 = make_float4(wx.y * g.x, wx.y * g.y, wx.y * g.z, wx.y * g.w);
+    const float4 t2 = make_float4(wx.z * g.x, wx.z * g.y, wx.z * g.z, wx.z * g.w);
+    const float4 t3 = make_float4(wx.w * g.x, wx.w * g.y, wx.w * g.z, wx.w * g.w);
+    const float wyv[PT] = {wy.x, wy.y, wy.z, wy.w};
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        MRCNN_FMA4(acc[i][0], wyv[i], t0) MRCNN_FMA4(acc[i][1], wyv[i], t1)
+        MRCNN_FMA4(acc[i][2], wyv[i], t2) MRCNN_FMA4(acc[i][3], wyv[i], t3)
+    }
+}
+
+// Stream the wave's queue: every entry is one coalesced 1-KiB gy row (lane = 4 channels) applied to
+// up to 16 cells.  Entries are handled two at a time and the next two loads are issued before the
+// current two are consumed.  Entries past n get weight 0 on a live row, so the loop is branch-free
+// with respect to the accumulators.  The empty asm statements only stop hipcc from hoisting every
+// LDS weight read to the top of the loop (register pressure).
+__device__ __forceinline__ void drain_queue(const PatchQueue &q, int n, const float *__restrict__ gyl, int C,
+                                            float4 (&acc)[PT][PT]) {
+    if (n <= 0) return;
+    const size_t Cs = (size_t)C;
+    const int r0 = q.row[0];
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a0 = ld4(gyl + (size_t)r0 * Cs);
+    float4 a1 = ld4(gyl + (size_t)(1 < n ? q.row[1] : r0) * Cs);
 #pragma nounroll
-    for (int j = 0; __ballot(j < cnt) != 0ull; ++j) {
-        // Branch-free on the accumulators: lanes past their queue's end add coef 0 * 0.
-        const bool a = j < cnt;
-        const int2 e = q[min(j, QCAP - 1)];
-        const float coef = a ? __int_as_float(e.y) : 0.0f;
-        const float *p = gyl + (size_t)(a ? e.x : 0) * C;
-        float4 g[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) g[i] = ld4(p + 32 * i);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { MRCNN_FMA4(acc[i], coef, g[i]) }
+    for (int j = 0; j < n; j += 2) {
+        const float4 b0 = ld4(gyl + (size_t)(j + 2 < n ? q.row[j + 2] : r0) * Cs);
+        const float4 b1 = ld4(gyl + (size_t)(j + 3 < n ? q.row[j + 3] : r0) * Cs);
+        apply_entry(acc, q.wy[j], q.wx[j], a0);
+        asm volatile("" ::: "memory");
+        apply_entry(acc, j + 1 < n ? q.wy[j + 1] : z, j + 1 < n ? q.wx[j + 1] : z, a1);
+        asm volatile("" ::: "memory");
+        a0 = b0;
+        a1 = b1;
     }
 }
 
 template <int PBT>   // bins per axis held in LDS: 8 (7x7 pooling) or 16 (14x14)
-__global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_nhwc(Levels lv, const float *__restrict__ gy,
-                                                                    const float *__restrict__ rois,
-                                                                    const int32_t *__restrict__ levels,
-                                                                    int R, int N, int C, int PH, int PW,
-                                                                    int sr, int chunk) {
-    constexpr int TASKS = 2 * TH * PBT;      // (axis,row,bin) weight cells per slot
-    __shared__ float sW[SLOTS][2][TH][PBT];  // [slot][axis][tile row/col][bin] summed weights
-    __shared__ int2 sQ[BWD_WAVES][TW * QCAP];
+__global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv, const float *__restrict__ gy,
+                                                                       const float *__restrict__ rois,
+                                                                       const int32_t *__restrict__ levels,
+                                                                       int R, int N, int C, int PH, int PW,
+                                                                       int sr, int chunk) {
+    constexpr int TASKS = 2 * TH * PBT;      // (axis,bin,row) weight cells per slot
+    // sW[slot][axis][bin][tile row/col]: summed weight that bin `bin` of the RoI in `slot` puts on
+    // map row ty0+row (axis 0) / map column tx0+row (axis 1).  4 consecutive rows = one 16-B read.
+    __shared__ __attribute__((aligned(16))) float sW[SLOTS][2][PBT][TH];
+    __shared__ __attribute__((aligned(16))) PatchQueue sQ[BWD_WAVES];
     __shared__ float4 sGeom[LISTCAP];        // (x1f, y1f, bw, bh) of listed RoIs
     __shared__ int sList[LISTCAP];
     __shared__ int sMask[SLOTS];             // bits 0-7: rows with weight, bits 8-15: cols
@@ -219,9 +242,9 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_nhwc(Levels lv
     const float scale = lv.scale[l];
     float *gxb = lv.gx[l] + (size_t)n * H * W * C;
     const float inv_cnt = 1.0f / (float)(sr * sr);
-    int2 *qw = &sQ[wave][0];
-    const int cxl = lane >> 3, pwl = lane & 7;   // phase-2 lane role: (cell column, bin column / channel group)
-    const int ncell = min(TW, W - tx0);
+    PatchQueue &q = sQ[wave];
+    const int cy0 = (wave >> 1) * PT, cx0 = (wave & 1) * PT;      // this wave's patch inside the tile
+    const int nrow = min(PT, H - (ty0 + cy0)), ncol = min(PT, W - (tx0 + cx0));   // may be <= 0
 
     int round = 0;
     for (int seg = 0; seg == 0 || seg < R; seg += LISTCAP) {
@@ -262,12 +285,12 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_nhwc(Levels lv
 
         for (int s0 = 0; s0 < n_list || round == 0; s0 += SLOTS) {
             const int nslots = max(0, min(SLOTS, n_list - s0));
-            // ---- phase 1: per-(slot, axis, row, bin) summed weights, one thread each
+            // ---- phase 1: per-(slot, axis, bin, row) summed weights, one thread each
             if (tid < SLOTS) sMask[tid] = 0;
             __syncthreads();
             for (int task = tid; task < nslots * TASKS; task += BWD_THREADS) {
-                const int slot = task / TASKS, q = task % TASKS;
-                const int axis = q / (TH * PBT), row = (q / PBT) % TH, bin = q % PBT;
+                const int slot = task / TASKS, qq = task % TASKS;
+                const int axis = qq / (TH * PBT), bin = (qq / TH) % PBT, row = qq % TH;
                 const float4 ge = sGeom[s0 + slot];
                 const int P = axis ? PW : PH, size = axis ? W : H;
                 const int target = (axis ? tx0 : ty0) + row;
@@ -280,76 +303,74 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_nhwc(Levels lv
                         if (s.hi == target) wv += s.wh;
                     }
                 }
-                sW[slot][axis][row][bin] = wv;
-                const unsigned long long nz = __ballot(wv != 0.0f);
-                if ((lane % PBT) == 0 && ((nz >> lane) & ((1ull << PBT) - 1ull)))
-                    atomicOr(&sMask[slot], 1 << (axis * 8 + row));
+                sW[slot][axis][bin][row] = wv;
+                if (wv != 0.0f) atomicOr(&sMask[slot], 1 << (axis * 8 + row));
             }
             __syncthreads();
 
-            // ---- phase 2: a wave owns ROWS_PER_WAVE tile rows and handles them one at a time.
-            //      2a (lane-parallel queue build): for every listed RoI with weight on the row,
-            //      lane (cx,pw) holds Wx[cx][pw]; for each bin row ph with Wy != 0 the lanes with
-            //      Wx != 0 append (gy row, Wy*Wx/count) to their cell's queue at a ballot-derived
-            //      rank (deterministic order).  2b: drain_queues.
-            const int m = lane < nslots ? sMask[lane] : 0;
-            const int roi_of_lane = lane < nslots ? sList[s0 + lane] : 0;
-#pragma nounroll
-            for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-                const int cy = wave * ROWS_PER_WAVE + rr, Y = ty0 + cy;
-                if (Y >= H) break;
-                const unsigned rowrel = (unsigned)__ballot(((m >> cy) & 1) && (m >> 8));
-                float *dst = gxb + ((size_t)Y * W + tx0 + cxl) * C + pwl * 4;
-#pragma nounroll
-                for (int cb = 0; cb < C; cb += CCH) {
-                    const float *gyl = gy + cb + pwl * 4;
-                    // Passes: pass p drains queue entries [p*QCAP, (p+1)*QCAP) of every cell; one pass
-                    // unless some cell collects more than QCAP entries in this round (then the queue is
-                    // rebuilt with a shifted window and gx is read-modify-written by its owner lane).
-                    int pass = 0, cnt;
-                    do {
-                        cnt = 0;      // entries seen for this lane's cell (equal across its 8 lanes)
-                        const int win = pass * QCAP;
-                        for (unsigned rm = rowrel; rm; rm &= rm - 1) {
-                            const int slot = __builtin_ctz(rm);
-                            const int r = __builtin_amdgcn_readlane(roi_of_lane, slot);
-                            const float wyl = (lane < PBT) ? sW[slot][0][cy][lane] : 0.0f;
-                            const unsigned ymask = (unsigned)__ballot(wyl != 0.0f);
-                            const int ny = __popc(ymask);
-                            for (int hx = 0; hx < PBT / 8; ++hx) {
-                                const float wx = sW[slot][1][cxl][hx * 8 + pwl];
-                                const unsigned long long nz = __ballot(wx != 0.0f);
-                                if (!nz) continue;
-                                const unsigned grp = (unsigned)(nz >> (lane & ~7)) & 0xFFu;
-                                const int rank = __popc(grp & ((1u << pwl) - 1u));
-                                const int add = __popc(grp);
-                                int idx = cnt + rank - win;
-                                for (unsigned ym = ymask; ym; ym &= ym - 1) {
-                                    const int ph = __builtin_ctz(ym);
-                                    const float wy = readlane_f(wyl, ph) * inv_cnt;
-                                    if (wx != 0.0f && (unsigned)idx < (unsigned)QCAP)
-                                        qw[cxl * QCAP + idx] =
-                                            make_int2((r * PH + ph) * PW + hx * 8 + pwl, __float_as_int(wy * wx));
-                                    idx += add;
-                                }
-                                cnt += add * ny;
+            // ---- phase 2: wave = one 4x4 patch.  2a (lane-parallel queue build): lane = bin (ph,pw)
+            //      of a listed RoI; bins with weight on the patch's rows AND columns append
+            //      (gy row, 4 row weights, 4 column weights) at a ballot-derived rank => deterministic
+            //      order.  2b: drain_queue.  Queue overflow => windowed passes (gx read-modify-write
+            //      by its owner wave).
+            if (nrow > 0 && ncol > 0) {
+                const int m = lane < nslots ? sMask[lane] : 0;
+                const unsigned rel = (unsigned)__ballot(((m >> cy0) & 0xF) && ((m >> (8 + cx0)) & 0xF));
+                const int roi_of_lane = lane < nslots ? sList[s0 + lane] : 0;
+                float *dst = gxb + ((size_t)(ty0 + cy0) * W + tx0 + cx0) * C + lane * 4;
+                int pass = 0, cnt;
+                do {
+                    cnt = 0;      // wave-uniform: entries seen so far
+                    const int win = pass * QCAP;
+                    for (unsigned rm = rel; rm; rm &= rm - 1) {
+                        const int slot = __builtin_ctz(rm);
+                        const int r = __builtin_amdgcn_readlane(roi_of_lane, slot);
+#pragma unroll
+                        for (int ch = 0; ch < (PBT * PBT) / 64; ++ch) {
+                            const int ph = (PBT == 8) ? (lane >> 3) : (ch * 4 + (lane >> 4));
+                            const int pw = (PBT == 8) ? (lane & 7) : (lane & 15);
+                            float4 wy = *reinterpret_cast<const float4 *>(&sW[slot][0][ph][cy0]);
+                            const float4 wx = *reinterpret_cast<const float4 *>(&sW[slot][1][pw][cx0]);
+                            const bool nzl = (wy.x != 0.f || wy.y != 0.f || wy.z != 0.f || wy.w != 0.f) &&
+                                             (wx.x != 0.f || wx.y != 0.f || wx.z != 0.f || wx.w != 0.f);
+                            const unsigned long long bal = __ballot(nzl);
+                            const int idx = cnt + __popcll(bal & ((1ull << lane) - 1ull)) - win;
+                            if (nzl && (unsigned)idx < (unsigned)QCAP) {
+                                wy.x *= inv_cnt; wy.y *= inv_cnt; wy.z *= inv_cnt; wy.w *= inv_cnt;
+                                q.wy[idx] = wy;
+                                q.wx[idx] = wx;
+                                q.row[idx] = (r * PH + ph) * PW + pw;
                             }
+                            cnt += __popcll(bal);
                         }
-                        float4 acc[8];
-                        const bool first = (round == 0 && pass == 0);
+                    }
+                    const bool first = (round == 0 && pass == 0);
+                    const int nq = max(0, min(QCAP, cnt - win));
+#pragma nounroll
+                    for (int cb = 0; cb < C; cb += CCH) {
+                        float4 acc[PT][PT];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (!first && cxl < ncell) acc[i] = ld4(dst + cb + 32 * i);
-                        }
-                        drain_queues(qw, max(0, min(QCAP, cnt - win)), gyl, C, acc);
-                        if (cxl < ncell) {
+                        for (int i = 0; i < PT; ++i)
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(dst + cb + 32 * i) = acc[i];
-                        }
-                        ++pass;
-                    } while (__ballot(cnt > pass * QCAP) != 0ull);
-                }
+                            for (int k = 0; k < PT; ++k) {
+                                acc[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (!first && i < nrow && k < ncol) acc[i][k] = ld4(dst + ((size_t)i * W + k) * C + cb);
+                            }
+                        drain_queue(q, nq, gy + cb + lane * 4, C, acc);
+                        // Opaque zero: keeps hipcc from materialising the 16 store addresses (32
+                        // VGPRs) before the drain loop and holding them live across it.
+                        int opq;
+                        asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
+                        float *dst2 = dst + cb + opq;
+#pragma unroll
+                        for (int i = 0; i < PT; ++i)
+#pragma unroll
+                            for (int k = 0; k < PT; ++k)
+                                if (i < nrow && k < ncol)
+                                    *reinterpret_cast<float4 *>(dst2 + ((size_t)i * W + k) * C) = acc[i][k];
+                    }
+                    ++pass;
+                } while (cnt > pass * QCAP);
             }
             ++round;
             __syncthreads();
