@@ -32,6 +32,11 @@ SIGNATURES = {
                                             c_int, c_int, c_void_p]),
     'mrcnn_roi_align_sample_tables': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                               c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mrcnn_conv2d_fwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    'mrcnn_conv2d_bwd_data_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    'mrcnn_conv2d_bwd_filter_workspace_bytes': (c_size_t, [c_int] * 9),
+    'mrcnn_conv2d_bwd_filter_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 +
+                                    [c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

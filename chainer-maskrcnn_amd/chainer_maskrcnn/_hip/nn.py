@@ -1,0 +1,63 @@
+"""Thin torch-tensor wrappers over the C ABI for the dense layers (NHWC, fp32).
+
+Tensors are only device-memory handles; every FLOP runs in csrc/*.hip.  Functions ending in
+``_raw`` are 1:1 calls; the ``torch.autograd.Function`` classes wire forward/backward pairs so
+the model code can use autograd as the tape (the role Chainer's Variable graph plays in the
+reference).
+"""
+import torch
+
+from chainer_maskrcnn import _hip
+from chainer_maskrcnn._hip import lib, check, ptr, stream_ptr
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (caller-owned workspace of the C ABI)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def conv2d_fwd_raw(x, w, b, stride, pad, relu):
+    _hip.require_cuda(x, w)
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, Cin2 = w.shape
+    assert Cin == Cin2, (x.shape, w.shape)
+    assert x.is_contiguous() and w.is_contiguous()
+    y = torch.empty((N, conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad), Cout),
+                    dtype=torch.float32, device=x.device)
+    check(lib().mrcnn_conv2d_fwd_f32(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cout, KH, KW,
+                                     stride, pad, int(relu), stream_ptr()))
+    return y
+
+
+def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad):
+    N, H, W, Cin = x_shape
+    Cout, KH, KW, _ = w.shape
+    assert gy.is_contiguous()
+    gx = torch.empty(x_shape, dtype=torch.float32, device=gy.device)
+    check(lib().mrcnn_conv2d_bwd_data_f32(ptr(gy), ptr(w), ptr(gx), N, H, W, Cin, Cout, KH, KW,
+                                          stride, pad, stream_ptr()))
+    return gx
+
+
+def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias):
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w_shape
+    assert gy.is_contiguous() and x.is_contiguous()
+    gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    gb = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    nbytes = lib().mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    ws = workspace(nbytes, x.device)
+    check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x), ptr(gy), ptr(gw), ptr(gb), N, H, W, Cin, Cout, KH,
+                                            KW, stride, pad, ptr(ws), ws.numel(), stream_ptr()))
+    return gw, gb

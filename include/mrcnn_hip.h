@@ -97,6 +97,32 @@ int mrcnn_roi_align_sample_tables(const float *rois, int R, int H, int W, int PH
                                   float spatial_scale, int sampling_ratio, int smax,
                                   int32_t *cnt, int32_t *idx, float *wgt, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Convolution (fp32 MFMA implicit GEMM).  Replaces the cuDNN/cuBLAS calls Chainer issues for
+ * L.Convolution2D / L.Linear / L.Deconvolution2D in
+ *   chainer_maskrcnn/model/extractor/feature_pyramid_network.py:22-40,48-68
+ *   chainer_maskrcnn/model/rpn/multilevel_region_proposal_network.py:80-86,131-141
+ *   chainer_maskrcnn/model/head/fpn_roi_mask_head.py:24-49,65-83
+ * and their autograd backward passes.
+ *   x  (N,H,W,Cin) NHWC      w  (Cout,KH,KW,Cin)      y  (N,Ho,Wo,Cout) NHWC
+ *   Ho = (H + 2*pad - KH)/stride + 1.   Cin and Cout must be multiples of 32 (the host layer
+ *   zero-pads channel counts such as 3, 4, 18, 80, 81).  bias (Cout) may be NULL; relu != 0
+ *   fuses max(.,0) into the forward epilogue.  Linear layers are 1x1 convolutions with
+ *   H = W = 1; the 2x2/2 deconvolution is a 1x1 convolution to 4*Cout channels + a host view.
+ * bwd_data supports stride 1 only.  bwd_filter accumulates over pixels with a deterministic
+ * split-K (slabs in the caller's workspace, fixed summation order); gbias may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
+                         int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
+                         void *stream);
+int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, int N, int H, int W, int Cin,
+                              int Cout, int KH, int KW, int stride, int pad, void *stream);
+size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                               int stride, int pad);
+int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, float *gw, float *gbias, int N, int H,
+                                int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void *ws,
+                                size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

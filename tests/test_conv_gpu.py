@@ -1,0 +1,87 @@
+"""GPU tests: MFMA implicit-GEMM convolution against a plain PyTorch fp32 CPU reference
+(floating-point kernel => torch reference, tolerance 1e-3 relative per BASELINE.json north_star;
+observed error is ~1e-6 because the f32 MFMA is an exact fmaf chain)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from chainer_maskrcnn._hip import nn as hnn  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def _ref_conv(x, w, b, stride, pad):
+    # x NHWC, w OHWI -> torch NCHW / OIHW on CPU in float64 for a tight reference
+    y = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(),
+                 None if b is None else b.double(), stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [  # N, H, W, Cin, Cout, K, stride, pad
+    (2, 9, 11, 32, 32, 1, 1, 0),
+    (1, 16, 20, 64, 160, 3, 1, 1),
+    (2, 13, 9, 96, 64, 3, 1, 1),
+    (1, 12, 12, 64, 32, 1, 2, 0),
+    (3, 1, 1, 256, 96, 1, 1, 0),      # linear layer shape
+    (1, 40, 36, 32, 288, 3, 1, 1),    # several M and N tiles
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('relu', [False, True])
+def test_conv_forward(case, relu):
+    N, H, W, Cin, Cout, K, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, H, W, Cin), generator=g)
+    w = torch.randn((Cout, K, K, Cin), generator=g) / (K * K * Cin) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    ref = _ref_conv(x, w, b, s, p)
+    if relu:
+        ref = ref.clamp_min(0)
+    got = hnn.conv2d_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), s, p, relu).cpu().double()
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+    assert err < 1e-5, err
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[6] == 1])
+def test_conv_backward_data_and_filter(case):
+    N, H, W, Cin, Cout, K, s, p = case
+    g = torch.Generator().manual_seed(100 + sum(case))
+    x = torch.randn((N, H, W, Cin), generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn((Cout, K, K, Cin), generator=g, dtype=torch.float64) / (K * K * Cin) ** 0.5).requires_grad_(True)
+    b = torch.randn((Cout,), generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, stride=s, padding=p).permute(0, 2, 3, 1)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    gyd = gy.float().contiguous().to(DEV)
+    gx = hnn.conv2d_bwd_data_raw(gyd, w.detach().float().to(DEV), tuple(x.shape), s, p).cpu().double()
+    gw, gb = hnn.conv2d_bwd_filter_raw(x.detach().float().to(DEV), gyd, tuple(w.shape), s, p, True)
+    for name, got, ref in (('gx', gx, x.grad), ('gw', gw.cpu().double(), w.grad), ('gb', gb.cpu().double(), b.grad)):
+        err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        assert err < 2e-5, (name, err)
+
+
+def test_conv_backward_filter_stride2_and_determinism():
+    N, H, W, Cin, Cout, K, s, p = 1, 24, 24, 64, 32, 1, 2, 0
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((N, H, W, Cin), generator=g, dtype=torch.float64)
+    w = torch.randn((Cout, K, K, Cin), generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, stride=s, padding=p).permute(0, 2, 3, 1)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd, gyd = x.float().to(DEV), gy.float().contiguous().to(DEV)
+    gw1, _ = hnn.conv2d_bwd_filter_raw(xd, gyd, tuple(w.shape), s, p, False)
+    gw2, _ = hnn.conv2d_bwd_filter_raw(xd, gyd, tuple(w.shape), s, p, False)
+    assert torch.equal(gw1, gw2)                     # deterministic split-K
+    err = (gw1.cpu().double() - w.grad).abs().max().item() / w.grad.abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_conv_rejects_unpadded_channels():
+    from chainer_maskrcnn._hip import MrcnnHipError
+    with pytest.raises(MrcnnHipError):
+        hnn.conv2d_fwd_raw(torch.zeros((1, 4, 4, 3), device=DEV), torch.zeros((32, 3, 3, 3), device=DEV), None, 1, 1, False)
