@@ -16,28 +16,49 @@ c_void_p = ctypes.c_void_p
 c_size_t = ctypes.c_size_t
 _P = ctypes.POINTER
 
-# name -> (restype, argtypes); must list every symbol declared in include/mrcnn_hip.h
-SIGNATURES = {
-    'mrcnn_abi_version': (c_int, []),
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', '..', 'include', 'mrcnn_hip.h'))
+
+# Host-array arguments (arrays of device pointers / per-level ints and floats) need typed pointers;
+# every other pointer crosses the boundary as a plain address.
+_MANUAL = {
     'mrcnn_last_error': (ctypes.c_char_p, []),
-    'mrcnn_roi_align_fwd_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
-                                        c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
-    'mrcnn_roi_align_bwd_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
-                                        c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     'mrcnn_roi_align_fpn_fwd_f32': (c_int, [_P(c_void_p), _P(c_int), _P(c_int), _P(c_float), c_int,
                                             c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                             c_int, c_void_p, c_void_p]),
     'mrcnn_roi_align_fpn_bwd_f32': (c_int, [c_void_p, _P(c_void_p), _P(c_int), _P(c_int), _P(c_float),
                                             c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                             c_int, c_int, c_void_p]),
-    'mrcnn_roi_align_sample_tables': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
-                                              c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'mrcnn_conv2d_fwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
-    'mrcnn_conv2d_bwd_data_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
-    'mrcnn_conv2d_bwd_filter_workspace_bytes': (c_size_t, [c_int] * 9),
-    'mrcnn_conv2d_bwd_filter_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 +
-                                    [c_void_p, c_size_t, c_void_p]),
 }
+_CTYPE = {'int': c_int, 'float': c_float, 'size_t': c_size_t, 'long long': ctypes.c_longlong,
+          'int32_t': ctypes.c_int32, 'unsigned': ctypes.c_uint}
+
+
+def _parse_header(path):
+    """name -> (restype, argtypes) for every function declared in include/mrcnn_hip.h."""
+    import re
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r'\b(int|size_t|const char \*)\s*(mrcnn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', src):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        if name in _MANUAL:
+            sigs[name] = _MANUAL[name]
+            continue
+        argtypes = []
+        for a in [x.strip() for x in args.split(',')]:
+            if a in ('void', ''):
+                continue
+            if '*' in a:
+                argtypes.append(c_void_p)
+            else:
+                ty = ' '.join(a.replace('const ', '').split()[:-1])
+                argtypes.append(_CTYPE[ty])
+        sigs[name] = ({'int': c_int, 'size_t': c_size_t}[ret], argtypes)
+    return sigs
+
+
+# name -> (restype, argtypes): every symbol declared in include/mrcnn_hip.h
+SIGNATURES = _parse_header(HEADER_PATH)
 
 _lib = None
 

@@ -40,13 +40,15 @@ def conv2d_fwd_raw(x, w, b, stride, pad, relu):
     return y
 
 
-def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad):
+def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None):
+    """out given => gx is accumulated into it (fan-out points of the graph), else allocated."""
     N, H, W, Cin = x_shape
     Cout, KH, KW, _ = w.shape
     assert gy.is_contiguous()
-    gx = torch.empty(x_shape, dtype=torch.float32, device=gy.device)
+    acc = out is not None
+    gx = out if acc else torch.empty(x_shape, dtype=torch.float32, device=gy.device)
     check(lib().mrcnn_conv2d_bwd_data_f32(ptr(gy), ptr(w), ptr(gx), N, H, W, Cin, Cout, KH, KW,
-                                          stride, pad, stream_ptr()))
+                                          stride, pad, int(acc), stream_ptr()))
     return gx
 
 

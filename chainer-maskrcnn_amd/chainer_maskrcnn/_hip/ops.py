@@ -1,0 +1,302 @@
+"""1:1 torch-tensor wrappers over the C ABI (include/mrcnn_hip.h) for everything except the
+convolutions (``nn.py``) and ROIAlign (``functions/roi_align``).  Tensors are device-memory handles
+only: every function checks the device, allocates outputs with ``torch.empty`` and launches HIP
+kernels on the current stream.  No arithmetic happens in torch.
+"""
+import ctypes
+
+import torch
+
+from chainer_maskrcnn import _hip
+from chainer_maskrcnn._hip import lib, check, ptr, stream_ptr
+from chainer_maskrcnn._hip.nn import workspace
+
+f32 = torch.float32
+i32 = torch.int32
+
+
+def _empty(shape, dev, dtype=f32):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+def _ck(*ts):
+    _hip.require_cuda(*ts)
+    for t in ts:
+        if t is not None and not t.is_contiguous():
+            raise ValueError('non-contiguous tensor passed to a HIP op')
+
+
+# ---- batch norm ---------------------------------------------------------------------------------
+def bn_train_fwd(x, gamma, beta, residual=None, relu=False, running_mean=None, running_var=None,
+                 eps=2e-5, decay=0.9):
+    """x (..., C) NHWC.  Returns (y, save_mean, save_invstd)."""
+    _ck(x, gamma, beta, residual)
+    C = x.shape[-1]
+    P = x.numel() // C
+    y = torch.empty_like(x)
+    mean = _empty((C,), x.device)
+    invstd = _empty((C,), x.device)
+    nb = lib().mrcnn_bn_workspace_bytes(P, C)
+    ws = workspace(nb, x.device)
+    check(lib().mrcnn_bn_train_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean), ptr(invstd),
+                                       ptr(running_mean), ptr(running_var), P, C, eps, decay, int(relu), ptr(ws),
+                                       ws.numel(), stream_ptr()))
+    return y, mean, invstd
+
+
+def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu=False, want_gres=False):
+    _ck(gy, x, y, gamma, mean, invstd)
+    C = x.shape[-1]
+    P = x.numel() // C
+    gx = torch.empty_like(x)
+    gres = torch.empty_like(x) if want_gres else None
+    gg = _empty((C,), x.device)
+    gb = _empty((C,), x.device)
+    ws = workspace(lib().mrcnn_bn_workspace_bytes(P, C), x.device)
+    check(lib().mrcnn_bn_train_bwd_f32(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(gx), ptr(gres),
+                                       ptr(gg), ptr(gb), P, C, int(relu), ptr(ws), ws.numel(), stream_ptr()))
+    return gx, gres, gg, gb
+
+
+def relu_bwd(gy, y, out=None):
+    _ck(gy, y)
+    out = torch.empty_like(gy) if out is None else out
+    check(lib().mrcnn_relu_bwd_f32(ptr(gy), ptr(y), ptr(out), gy.numel(), stream_ptr()))
+    return out
+
+
+def add(a, b, out=None):
+    _ck(a, b)
+    out = torch.empty_like(a) if out is None else out
+    check(lib().mrcnn_add_f32(ptr(a), ptr(b), ptr(out), a.numel(), stream_ptr()))
+    return out
+
+
+def maxpool2x2_fwd(x):
+    _ck(x)
+    N, H, W, C = x.shape
+    y = _empty((N, (H + 1) // 2, (W + 1) // 2, C), x.device)
+    check(lib().mrcnn_maxpool2x2_fwd_f32(ptr(x), ptr(y), N, H, W, C, stream_ptr()))
+    return y
+
+
+def maxpool2x2_bwd(x, gy):
+    _ck(x, gy)
+    N, H, W, C = x.shape
+    gx = torch.empty_like(x)
+    check(lib().mrcnn_maxpool2x2_bwd_f32(ptr(x), ptr(gy), ptr(gx), N, H, W, C, stream_ptr()))
+    return gx
+
+
+def upsample2x_add_fwd(top, lat):
+    _ck(top, lat)
+    N, H, W, C = lat.shape
+    out = torch.empty_like(lat)
+    check(lib().mrcnn_upsample2x_add_fwd_f32(ptr(top), ptr(lat), ptr(out), N, H, W, top.shape[1], top.shape[2], C,
+                                             stream_ptr()))
+    return out
+
+
+def upsample2x_bwd(gout, gtop=None, top_shape=None):
+    """gtop given => accumulate into it; else allocate (top_shape) and overwrite."""
+    _ck(gout, gtop)
+    N, H, W, C = gout.shape
+    acc = gtop is not None
+    if gtop is None:
+        gtop = _empty(top_shape, gout.device)
+    check(lib().mrcnn_upsample2x_bwd_f32(ptr(gout), ptr(gtop), N, H, W, gtop.shape[1], gtop.shape[2], C, int(acc),
+                                         stream_ptr()))
+    return gtop
+
+
+def subsample_bwd(gsub, x_shape, stride, gx=None):
+    _ck(gsub, gx)
+    N, H, W, C = x_shape
+    acc = gx is not None
+    if gx is None:
+        gx = _empty(x_shape, gsub.device)
+    check(lib().mrcnn_subsample_bwd_f32(ptr(gsub), ptr(gx), N, H, W, C, stride, int(acc), stream_ptr()))
+    return gx
+
+
+def pixel_shuffle2x(t, inverse=False):
+    """forward: t (N,H,W,4*C) -> (N,2H,2W,C); inverse: (N,2H,2W,C) -> (N,H,W,4*C)."""
+    _ck(t)
+    if not inverse:
+        N, H, W, C4 = t.shape
+        C = C4 // 4
+        out = _empty((N, 2 * H, 2 * W, C), t.device)
+    else:
+        N, H2, W2, C = t.shape
+        H, W = H2 // 2, W2 // 2
+        out = _empty((N, H, W, 4 * C), t.device)
+    check(lib().mrcnn_pixel_shuffle2x_f32(ptr(t), ptr(out), N, H, W, C, int(inverse), stream_ptr()))
+    return out
+
+
+def sgd_momentum_wd(p, g, v, lr, momentum=0.9, weight_decay=5e-4):
+    _ck(p, g, v)
+    check(lib().mrcnn_sgd_momentum_wd_f32(ptr(p), ptr(g), ptr(v), p.numel(), lr, momentum, weight_decay, stream_ptr()))
+
+
+# ---- losses -------------------------------------------------------------------------------------
+def _loss_ws(dev):
+    return workspace(lib().mrcnn_loss_workspace_bytes(), dev)
+
+
+def softmax_ce(x, t, M, K, xmap, gmap=None, Kfill=0, want_grad=True, gx=None, ignore_label=-1):
+    """x: device tensor holding a logical (M,K) matrix; xmap = (A, gs, rs, es) element map
+    (see include/mrcnn_hip.h).  Returns (loss_out (2,), gx)."""
+    _ck(t)
+    _hip.require_cuda(x)
+    out = _empty((2,), x.device)
+    gmap = gmap or xmap
+    if want_grad and gx is None:
+        gx = torch.empty_like(x)
+    ws = _loss_ws(x.device)
+    check(lib().mrcnn_softmax_ce_f32(ptr(x), xmap[0], xmap[1], xmap[2], xmap[3], ptr(t), M, K, ignore_label, ptr(out),
+                                     ptr(gx) if want_grad else None, gmap[1], gmap[2], gmap[3], Kfill, ptr(ws),
+                                     ws.numel(), stream_ptr()))
+    return out, gx
+
+
+def smooth_l1(x, ldx, t, label, M, sigma, want_grad=True, gfill=0):
+    _ck(x, t, label)
+    out = _empty((2,), x.device)
+    gx = torch.empty_like(x) if want_grad else None
+    ws = _loss_ws(x.device)
+    check(lib().mrcnn_smooth_l1_f32(ptr(x), ldx, ptr(t), ptr(label), M, sigma, ptr(out), ptr(gx), ldx, gfill, ptr(ws),
+                                    ws.numel(), stream_ptr()))
+    return out, gx
+
+
+def mask_bce(x, gt, label, want_grad=True):
+    """x (Rm,H,W,Cm) NHWC logits, gt (Rm,H,W) int32, label (Rm,) int32."""
+    _ck(x, gt, label)
+    Rm, H, W, Cm = x.shape
+    out = _empty((2,), x.device)
+    gx = torch.empty_like(x) if want_grad else None
+    ws = _loss_ws(x.device)
+    check(lib().mrcnn_mask_bce_f32(ptr(x), ptr(gt), ptr(label), Rm, H * W, Cm, ptr(out), ptr(gx), ptr(ws), ws.numel(),
+                                   stream_ptr()))
+    return out, gx
+
+
+# ---- RPN proposal path --------------------------------------------------------------------------
+def rpn_pack(head, A, locs, scores, a_off):
+    _ck(head, locs, scores)
+    N, H, W, Cp = head.shape
+    check(lib().mrcnn_rpn_pack_f32(ptr(head), N, H * W, Cp, A, ptr(locs), ptr(scores), a_off, locs.shape[1],
+                                   stream_ptr()))
+
+
+def rpn_unpack_grad(glocs, gscores, head_shape, A, a_off):
+    _ck(glocs, gscores)
+    N, H, W, Cp = head_shape
+    ghead = _empty(head_shape, glocs.device)
+    check(lib().mrcnn_rpn_unpack_grad_f32(ptr(glocs), ptr(gscores), N, H * W, Cp, A, ptr(ghead), a_off, glocs.shape[1],
+                                          stream_ptr()))
+    return ghead
+
+
+def rpn_proposals(locs, scores, anchors, img_size, min_size, n_pre, n_post, nms_thresh, debug=False):
+    """locs (N,A,4), scores (N,A,2), anchors (A,4).  Returns dict of padded device outputs."""
+    _ck(locs, scores, anchors)
+    N, A, _ = locs.shape
+    dev = locs.device
+    rois = _empty((N * n_post, 4), dev)
+    idx = _empty((N * n_post,), dev, i32)
+    lev = _empty((N * n_post,), dev)
+    cnt = _empty((N,), dev, i32)
+    npre = min(n_pre, A)
+    dbg = [None, None, None]
+    if debug:
+        dbg = [torch.full((N * npre,), -1, dtype=i32, device=dev), _empty((N * n_post,), dev, i32), _empty((N,), dev, i32)]
+    ws = workspace(lib().mrcnn_rpn_proposals_workspace_bytes(N, A, n_pre, n_post), dev)
+    check(lib().mrcnn_rpn_proposals_f32(ptr(locs), ptr(scores), ptr(anchors), N, A, float(img_size[0]),
+                                        float(img_size[1]), float(min_size), n_pre, n_post, float(nms_thresh), ptr(rois),
+                                        ptr(idx), ptr(lev), ptr(cnt), ptr(dbg[0]), ptr(dbg[1]), ptr(dbg[2]), ptr(ws),
+                                        ws.numel(), stream_ptr()))
+    return dict(rois=rois, roi_indices=idx, levels=lev, n_rois=cnt, sorted_anchor=dbg[0], keep=dbg[1], n_pre=dbg[2])
+
+
+def nms(boxes, thresh, max_keep=None):
+    """Greedy NMS in the given order; returns (keep (max_keep,) int32 padded, n_keep (1,) int32)."""
+    _ck(boxes)
+    n = boxes.shape[0]
+    max_keep = max_keep or max(n, 1)
+    keep = torch.full((max_keep,), -1, dtype=i32, device=boxes.device)
+    nk = _empty((1,), boxes.device, i32)
+    ws = workspace(lib().mrcnn_nms_workspace_bytes(n), boxes.device)
+    check(lib().mrcnn_nms_f32(ptr(boxes), n, float(thresh), max_keep, ptr(keep), ptr(nk), ptr(ws), ws.numel(),
+                              stream_ptr()))
+    return keep, nk
+
+
+def map_rois_to_fpn_levels(rois, k_min=0, k_max=4):
+    _ck(rois)
+    lev = _empty((rois.shape[0],), rois.device)
+    check(lib().mrcnn_map_rois_to_fpn_levels_f32(ptr(rois), rois.shape[0], k_min, k_max, ptr(lev), stream_ptr()))
+    return lev
+
+
+# ---- targets ------------------------------------------------------------------------------------
+def proposal_target(rois, roi_levels, n_rois, gt_boxes, gt_labels, n_gt, keys, n_sample=256, pos_ratio=0.25,
+                    pos_iou_thresh=0.5, neg_hi=0.5, neg_lo=0.0, mean=(0., 0., 0., 0.), std=(0.1, 0.1, 0.2, 0.2)):
+    """rois (N*roi_cap,4) padded, gt_boxes (N,gt_cap,4), gt_labels (N,gt_cap) i32, keys (N,roi_cap+gt_cap) u32 (as int32
+    storage).  Returns dict of per-row outputs (N*n_sample rows)."""
+    _ck(rois, roi_levels, n_rois, gt_boxes, gt_labels, n_gt, keys)
+    N, gt_cap = gt_labels.shape
+    roi_cap = rois.shape[0] // N
+    dev = rois.device
+    R = N * n_sample
+    o = dict(sample_roi=_empty((R, 4), dev), rois_xy5=_empty((R, 5), dev), sample_levels=_empty((R,), dev, i32),
+             gt_roi_loc=_empty((R, 4), dev), gt_roi_label=_empty((R,), dev, i32), gt_assign=_empty((R,), dev, i32),
+             sample_src=_empty((R,), dev, i32), n_pos=_empty((N,), dev, i32), n_sampled=_empty((N,), dev, i32))
+    m4 = (ctypes.c_float * 4)(*mean)
+    s4 = (ctypes.c_float * 4)(*std)
+    import numpy as np
+    n_pos_max = int(np.round(n_sample * pos_ratio))
+    check(lib().mrcnn_proposal_target_f32(ptr(rois), ptr(roi_levels), ptr(n_rois), roi_cap, ptr(gt_boxes), ptr(gt_labels),
+                                          ptr(n_gt), gt_cap, ptr(keys), N, n_sample, n_pos_max, pos_iou_thresh, neg_hi,
+                                          neg_lo, ctypes.cast(m4, ctypes.c_void_p), ctypes.cast(s4, ctypes.c_void_p),
+                                          ptr(o['sample_roi']), ptr(o['rois_xy5']), ptr(o['sample_levels']),
+                                          ptr(o['gt_roi_loc']), ptr(o['gt_roi_label']), ptr(o['gt_assign']),
+                                          ptr(o['sample_src']), ptr(o['n_pos']), ptr(o['n_sampled']), stream_ptr()))
+    return o
+
+
+def mask_target(masks, sample_roi, gt_assign, n_pos, n_sample, pos_cap, mask_size):
+    """masks (N,gt_cap,H,W) uint8 -> (N*pos_cap, mask_size, mask_size) int32 (-1 rows for unused slots)."""
+    _ck(masks, sample_roi, gt_assign, n_pos)
+    N, gt_cap, H, W = masks.shape
+    out = _empty((N * pos_cap, mask_size, mask_size), masks.device, i32)
+    check(lib().mrcnn_mask_target_u8(ptr(masks), N, gt_cap, H, W, ptr(sample_roi), ptr(gt_assign), ptr(n_pos), n_sample,
+                                     pos_cap, mask_size, ptr(out), stream_ptr()))
+    return out
+
+
+def keypoint_target(kps, sample_roi, gt_assign, n_pos, n_sample, pos_cap, mask_size):
+    """kps (N,gt_cap,K,3) f32 -> (N*pos_cap, K) int32."""
+    _ck(kps, sample_roi, gt_assign, n_pos)
+    N, gt_cap, K, _ = kps.shape
+    out = _empty((N * pos_cap, K), kps.device, i32)
+    check(lib().mrcnn_keypoint_target_f32(ptr(kps), N, gt_cap, K, ptr(sample_roi), ptr(gt_assign), ptr(n_pos), n_sample,
+                                          pos_cap, mask_size, ptr(out), stream_ptr()))
+    return out
+
+
+def anchor_target(anchors, gt_boxes, n_gt, img_size, keys=None, n_sample=256, pos_iou_thresh=0.7, neg_iou_thresh=0.3,
+                  pos_ratio=0.5):
+    """anchors (A,4), gt_boxes (N,gt_cap,4), keys (N,A) u32 or None (= no subsampling).  Returns (loc (N,A,4), label (N,A))."""
+    _ck(anchors, gt_boxes, n_gt, keys)
+    A = anchors.shape[0]
+    N, gt_cap, _ = gt_boxes.shape
+    dev = anchors.device
+    loc = _empty((N, A, 4), dev)
+    label = _empty((N, A), dev, i32)
+    ws = workspace(lib().mrcnn_anchor_target_workspace_bytes(N, A), dev)
+    check(lib().mrcnn_anchor_target_f32(ptr(anchors), A, ptr(gt_boxes), ptr(n_gt), gt_cap, N, float(img_size[0]),
+                                        float(img_size[1]), ptr(keys), n_sample, pos_iou_thresh, neg_iou_thresh, pos_ratio,
+                                        int(keys is not None), ptr(loc), ptr(label), ptr(ws), ws.numel(), stream_ptr()))
+    return loc, label

@@ -38,3 +38,10 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 }  // namespace mrcnn
 
 constexpr int kWave = 64;  // gfx950 wavefront
+
+namespace mrcnn {
+// Device radix sort of 64-bit keys (sort.hip; rocPRIM device primitive, the only library call in
+// the library).  tmp == nullptr: returns the temporary-storage size in *tmp_bytes.
+int sort_u64(const unsigned long long *in, unsigned long long *out, size_t n, bool descending, void *tmp,
+             size_t *tmp_bytes, hipStream_t st);
+}  // namespace mrcnn

@@ -44,6 +44,8 @@ struct ConvP {
     int Ho, Wo, Cout;     // output tensor (y / gy)
     int KH, KW, stride, pad;
     int relu;
+    int accumulate;       // BWD_DATA: gx += result
+    int smallc;           // Cin == 4: the K axis is (tap, 4 channels) flattened, one 16-B chunk per tap
     int M, Ng;            // GEMM M and N extents
     int ksplit, kchunk;   // BWD_FILTER: number of K splits, pixels per split
 };
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     // K-step bookkeeping
     int nsteps, kbeg = 0, kend = 0;
     const int cin_steps = p.Cin / BK, cout_steps = p.Cout / BK;
-    if (MODE == MODE_FWD) nsteps = p.KH * p.KW * cin_steps;
+    if (MODE == MODE_FWD) nsteps = p.smallc ? (p.KH * p.KW + 7) / 8 : p.KH * p.KW * cin_steps;
     else if (MODE == MODE_BWD_DATA) nsteps = p.KH * p.KW * cout_steps;
     else {
         const int P = p.N * p.Ho * p.Wo;
@@ -148,7 +150,19 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     float4 ra[4], rb[4];
     auto load_step = [&](int s) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE == MODE_FWD) {
+        if (MODE == MODE_FWD && p.smallc) {
+            const int chunk = s * 8 + kc;                 // tap index
+            const bool tv = chunk < p.KH * p.KW;
+            const int kw = chunk % p.KW, kh = chunk / p.KW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hi = gh[i] * p.stride - p.pad + kh, wi = gw[i] * p.stride - p.pad + kw;
+                const bool ok = tv && gvalid[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+                ra[i] = ok ? ldg4(p.a + (((size_t)gn[i] * p.H + hi) * p.W + wi) * 4) : z;
+                const int n = n0 + r0 + 32 * i;
+                rb[i] = (tv && n < p.Ng) ? ldg4(p.b + ((size_t)n * p.KH * p.KW + chunk) * 4) : z;
+            }
+        } else if (MODE == MODE_FWD) {
             const int cs = s % cin_steps, t = s / cin_steps;
             const int kw = t % p.KW, kh = t / p.KW;
 #pragma unroll
@@ -173,7 +187,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             }
         } else {
             // gw[co][kh][kw][ci] = sum_pix gy[pix][co] * x[pix shifted by (kh,kw)][ci]
-            const int kw = tap % p.KW, kh = tap / p.KW;
+            int kw = tap % p.KW, kh = tap / p.KW;
+            int ci = n0 + rc * 4;
+            bool cv = ci < p.Ng;
+            if (p.smallc) {                               // column = (tap, 4 channels)
+                const int tp = ci >> 2;
+                cv = tp < p.KH * p.KW;
+                kw = tp % p.KW; kh = tp / p.KW; ci = 0;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int pix = kbeg + s * BK + k0 + 8 * i;
@@ -184,8 +205,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
                 const int co = m0 + rc * 4;
                 ra[i] = (pv && co < p.M) ? ldg4(p.a + (size_t)pp * p.Cout + co) : z;
                 const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
-                const int ci = n0 + rc * 4;
-                const bool ok = pv && ci < p.Ng && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+                const bool ok = pv && cv && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
                 rb[i] = ok ? ldg4(p.b + (((size_t)n * p.H + hi) * p.W + wi) * p.Cin + ci) : z;
             }
         }
@@ -223,7 +243,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     else if (MODE == MODE_BWD_DATA) { ldc = p.Cin; cbase = p.c; }
     else {
         ldc = (size_t)p.KH * p.KW * p.Cin;
-        cbase = p.c + (size_t)split * p.Cout * ldc + (size_t)tap * p.Cin;
+        cbase = p.c + (size_t)split * p.Cout * ldc + (p.smallc ? 0 : (size_t)tap * p.Cin);
     }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -238,6 +258,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
                 if (m >= p.M) continue;
                 float v = acc[tm][tn][e] + bv;
                 if (MODE == MODE_FWD && p.relu) v = fmaxf(v, 0.0f);
+                if (MODE == MODE_BWD_DATA && p.accumulate) v += cbase[(size_t)m * ldc + n];
                 cbase[(size_t)m * ldc + n] = v;
             }
         }
@@ -285,9 +306,9 @@ int check_conv(const void *a, const void *b, const void *c, int N, int H, int W,
     if (!a || !b || !c) return mrcnn::fail_arg(MRCNN_E_INVALID, "conv2d: null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
         return mrcnn::fail_arg(MRCNN_E_INVALID, "conv2d: bad sizes");
-    if (Cin % BK || Cout % BK)
+    if ((Cin % BK && Cin != 4) || Cout % BK)
         return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED,
-                               "conv2d: Cin (%d) and Cout (%d) must be multiples of %d (the host layer pads)", Cin, Cout, BK);
+                               "conv2d: Cin (%d) must be 4 or a multiple of %d... Cout (%d) a multiple of %d (the host layer pads)", Cin, BK, Cout, BK);
     if (conv_out(H, KH, stride, pad) <= 0 || conv_out(W, KW, stride, pad) <= 0)
         return mrcnn::fail_arg(MRCNN_E_INVALID, "conv2d: empty output");
     return 0;
@@ -299,13 +320,15 @@ ConvP make_p(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
     p.Ho = conv_out(H, KH, stride, pad);
     p.Wo = conv_out(W, KW, stride, pad);
     p.ksplit = 1;
+    p.smallc = (Cin == 4);
     return p;
 }
 
 // split-K plan for backward-filter: enough workgroups to fill 256 CUs a few times over.
 void filter_plan(const ConvP &p, int &ksplit, int &kchunk) {
     const long long P = (long long)p.N * p.Ho * p.Wo;
-    const long long tiles = (long long)mrcnn::cdiv(p.Cout, BM) * mrcnn::cdiv(p.Cin, BN) * p.KH * p.KW;
+    const long long tiles = p.smallc ? (long long)mrcnn::cdiv(p.Cout, BM) * mrcnn::cdiv(p.KH * p.KW * 4, BN)
+                                     : (long long)mrcnn::cdiv(p.Cout, BM) * mrcnn::cdiv(p.Cin, BN) * p.KH * p.KW;
     long long want = (1024 + tiles - 1) / tiles;
     long long maxsplit = (P + 4 * BK - 1) / (4 * BK);     // at least 4 K steps per split
     ksplit = (int)std::max(1ll, std::min(std::min(want, maxsplit), 64ll));
@@ -330,13 +353,14 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
 
 extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, int N, int H, int W,
                                          int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                         void *stream) {
+                                         int accumulate, void *stream) {
     if (int e = check_conv(gy, w, gx, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     if (stride != 1)
         return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: stride %d (only 1; strided 1x1 convs are "
                                                     "handled by the host as a subsample + stride-1 conv)", stride);
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
-    p.a = gy; p.b = w; p.c = gx;
+    if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
+    p.a = gy; p.b = w; p.c = gx; p.accumulate = accumulate;
     p.M = N * H * W; p.Ng = Cin;
     dim3 grid(mrcnn::cdiv(p.M, BM), mrcnn::cdiv(p.Ng, BN), 1);
     hipLaunchKernelGGL(k_conv_igemm<MODE_BWD_DATA>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p);
@@ -370,8 +394,8 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     float *slabs = (float *)ws;
     float *bias_part = (float *)ws + (p.ksplit > 1 ? wcount * p.ksplit : 0);
     p.a = gy; p.b = x; p.c = (p.ksplit > 1) ? slabs : gw;
-    p.M = Cout; p.Ng = Cin;
-    dim3 grid(mrcnn::cdiv(p.M, BM), mrcnn::cdiv(p.Ng, BN), KH * KW * p.ksplit);
+    p.M = Cout; p.Ng = p.smallc ? KH * KW * 4 : Cin;
+    dim3 grid(mrcnn::cdiv(p.M, BM), mrcnn::cdiv(p.Ng, BN), (p.smallc ? 1 : KH * KW) * p.ksplit);
     hipLaunchKernelGGL(k_conv_igemm<MODE_BWD_FILTER>, grid, dim3(CONV_THREADS), 0, st, p);
     MRCNN_LAUNCH_CHECK();
     if (p.ksplit > 1) {

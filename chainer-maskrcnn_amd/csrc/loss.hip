@@ -1,0 +1,253 @@
+// The five training losses of the Mask R-CNN step, forward + gradient, for gfx950.
+//
+// Replaces (chainer_maskrcnn/model/fpn_maskrcnn_train_chain.py:83-85,100-106; train.py:50-58;
+// train_keypoints.py:21-27) the Chainer / ChainerCV functions
+//   F.softmax_cross_entropy (normalize=True, ignore_label=-1)  -> mrcnn_softmax_ce_f32
+//   _fast_rcnn_loc_loss / _smooth_l1_loss                        -> mrcnn_smooth_l1_f32
+//   calc_mask_loss = channel select + F.sigmoid_cross_entropy    -> mrcnn_mask_bce_f32
+// Each entry point writes the scalar loss to device memory (no host sync) and the gradient of
+// the loss w.r.t. the logits (d loss = 1), already normalised.  Reductions are two-stage with a
+// fixed order (bit-reproducible).  All are HBM/latency-bound: bytes = 2 x logits (+ targets).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXB = 1024;     // partial slots
+
+struct RowMap {  // element (r, j) of a logically (M, K) matrix lives at (r/A)*gs + (r%A)*rs + j*es
+    int A;
+    long long gs, rs, es;
+};
+__device__ __forceinline__ size_t rm_off(const RowMap &m, int r, int j) {
+    return (size_t)((long long)(r / m.A) * m.gs + (long long)(r % m.A) * m.rs + (long long)j * m.es);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// block-level deterministic sum of (a, b) -> part[blockIdx.x*2 + {0,1}]
+__device__ __forceinline__ void block_partial(float a, float b, float *part) {
+    __shared__ float sa[NT / 64], sb[NT / 64];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float x = 0.f, y = 0.f;
+        for (int k = 0; k < NT / 64; ++k) { x += sa[k]; y += sb[k]; }
+        part[blockIdx.x * 2] = x;
+        part[blockIdx.x * 2 + 1] = y;
+    }
+}
+
+// out[0] = sum(a)/max(sum(b),1), out[1] = max(sum(b),1)   (single thread, fixed order, double)
+__global__ void k_finalize(const float *__restrict__ part, int nb, float *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nb; ++k) { a += (double)part[2 * k]; b += (double)part[2 * k + 1]; }
+    if (b < 1.0) b = 1.0;
+    out[0] = (float)(a / b);
+    out[1] = (float)b;
+}
+
+// ---- softmax cross entropy -------------------------------------------------------------------
+// Small K (<= 8): one thread per row.
+template <int PHASE>   // 0: loss partials, 1: gradient
+__global__ __launch_bounds__(NT) void k_sce_small(const float *__restrict__ x, RowMap xm, const int32_t *__restrict__ t,
+                                                  int M, int K, int ignore, float *__restrict__ part,
+                                                  const float *__restrict__ norm, float *__restrict__ gx, RowMap gm) {
+    float ls = 0.f, cnt = 0.f;
+    const float inv = PHASE ? 1.0f / norm[1] : 0.f;
+    for (int r = blockIdx.x * NT + threadIdx.x; r < M; r += gridDim.x * NT) {
+        const int tt = t[r];
+        const bool valid = tt != ignore;
+        float v[8], m = -INFINITY;
+        for (int j = 0; j < K; ++j) { v[j] = x[rm_off(xm, r, j)]; m = fmaxf(m, v[j]); }
+        float s = 0.f;
+        for (int j = 0; j < K; ++j) s += expf(v[j] - m);
+        const float lse = logf(s);
+        if (PHASE == 0) {
+            if (valid) { ls += -((v[tt] - m) - lse); cnt += 1.f; }
+        } else {
+            for (int j = 0; j < K; ++j) {
+                float g = 0.f;
+                if (valid) g = (expf((v[j] - m) - lse) - (j == tt ? 1.f : 0.f)) * inv;
+                gx[rm_off(gm, r, j)] = g;
+            }
+        }
+    }
+    if (PHASE == 0) block_partial(ls, cnt, part);
+}
+
+// General K: one wave per row.
+template <int PHASE>
+__global__ __launch_bounds__(NT) void k_sce_wave(const float *__restrict__ x, RowMap xm, const int32_t *__restrict__ t,
+                                                 int M, int K, int Kfill, int ignore, float *__restrict__ part,
+                                                 const float *__restrict__ norm, float *__restrict__ gx, RowMap gm) {
+    const int lane = threadIdx.x & 63;
+    float ls = 0.f, cnt = 0.f;
+    const float inv = PHASE ? 1.0f / norm[1] : 0.f;
+    for (int r = (blockIdx.x * NT + threadIdx.x) >> 6; r < M; r += (gridDim.x * NT) >> 6) {
+        const int tt = t[r];
+        const bool valid = tt != ignore;
+        float m = -INFINITY;
+        for (int j = lane; j < K; j += 64) m = fmaxf(m, x[rm_off(xm, r, j)]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int j = lane; j < K; j += 64) s += expf(x[rm_off(xm, r, j)] - m);
+        s = wave_sum(s);
+        const float lse = logf(s);
+        if (PHASE == 0) {
+            if (valid && lane == 0) { ls += -((x[rm_off(xm, r, tt)] - m) - lse); cnt += 1.f; }
+        } else {
+            for (int j = lane; j < Kfill; j += 64) {
+                float g = 0.f;
+                if (valid && j < K) g = (expf((x[rm_off(xm, r, j)] - m) - lse) - (j == tt ? 1.f : 0.f)) * inv;
+                gx[rm_off(gm, r, j)] = g;
+            }
+        }
+    }
+    if (PHASE == 0) block_partial(ls, cnt, part);
+}
+
+// ---- smooth L1 (Fast R-CNN loc loss) -----------------------------------------------------------
+template <int PHASE>
+__global__ __launch_bounds__(NT) void k_sl1(const float *__restrict__ x, int ldx, const float *__restrict__ t,
+                                            const int32_t *__restrict__ label, int M, float sigma2,
+                                            float *__restrict__ part, const float *__restrict__ norm,
+                                            float *__restrict__ gx, int ldg, int gfill) {
+    float ls = 0.f, cnt = 0.f;
+    const float inv = PHASE ? 1.0f / norm[1] : 0.f;
+    for (int r = blockIdx.x * NT + threadIdx.x; r < M; r += gridDim.x * NT) {
+        const int lb = label[r];
+        const float w = lb > 0 ? 1.f : 0.f;
+        if (PHASE == 0 && lb >= 0) cnt += 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = w * (x[(size_t)r * ldx + j] - t[(size_t)r * 4 + j]);
+            const float ad = fabsf(d);
+            const bool quad = ad < 1.0f / sigma2;
+            if (PHASE == 0) ls += quad ? (sigma2 * 0.5f) * d * d : ad - 0.5f / sigma2;
+            else {
+                const float gd = quad ? sigma2 * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+                gx[(size_t)r * ldg + j] = gd * w * inv;
+            }
+        }
+        if (PHASE == 1)
+            for (int j = 4; j < gfill; ++j) gx[(size_t)r * ldg + j] = 0.f;
+    }
+    if (PHASE == 0) block_partial(ls, cnt, part);
+}
+
+// ---- mask loss: channel label-1 of each row with label > 0, BCE with logits -------------------
+template <int PHASE>
+__global__ __launch_bounds__(NT) void k_mask_bce(const float *__restrict__ x, const int32_t *__restrict__ gt,
+                                                 const int32_t *__restrict__ label, int Rm, int HW, int Cm,
+                                                 float *__restrict__ part, const float *__restrict__ norm,
+                                                 float *__restrict__ gx) {
+    float ls = 0.f, cnt = 0.f;
+    const float inv = PHASE ? 1.0f / norm[1] : 0.f;
+    const long long total = (long long)Rm * HW;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int r = (int)(i / HW);
+        const int lb = label[r];
+        if (lb <= 0) continue;
+        const int tt = gt[i];
+        if (tt == -1) continue;
+        const size_t o = (size_t)i * Cm + (lb - 1);
+        const float v = x[o], tf = (float)tt;
+        if (PHASE == 0) {
+            ls += -(v * (tf - (v >= 0.f ? 1.f : 0.f)) - log1pf(expf(-fabsf(v))));
+            cnt += 1.f;
+        } else {
+            gx[o] = (1.0f / (1.0f + expf(-v)) - tf) * inv;
+        }
+    }
+    if (PHASE == 0) block_partial(ls, cnt, part);
+}
+
+int grid_for(long long work) { return (int)std::max(1ll, std::min<long long>((work + NT - 1) / NT, MAXB)); }
+
+}  // namespace
+
+extern "C" size_t mrcnn_loss_workspace_bytes(void) { return (size_t)MAXB * 2 * sizeof(float) + 16; }
+
+// x: logically (M,K); element (r,j) at (r/A)*gs + (r%A)*rs + j*es floats.  gx uses the same map shape with its own
+// strides; columns K..Kfill-1 of gx are zero-filled (es must be 1 for Kfill > K).  loss_out[0] = loss, [1] = count.
+extern "C" int mrcnn_softmax_ce_f32(const float *x, int A, long long gs, long long rs, long long es, const int32_t *t,
+                                    int M, int K, int ignore_label, float *loss_out, float *gx, long long ggs,
+                                    long long grs, long long ges, int Kfill, void *ws, size_t ws_bytes, void *stream) {
+    if ((M > 0 && (!x || !t)) || !loss_out || !ws || M < 0 || K <= 0 || A <= 0)
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "softmax_ce: bad arguments");
+    if (ws_bytes < mrcnn_loss_workspace_bytes()) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "softmax_ce: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)ws;
+    const RowMap xm{A, gs, rs, es}, gm{A, ggs, grs, ges};
+    if (Kfill < K) Kfill = K;
+    const bool small = K <= 8 && Kfill == K;
+    const int nb = small ? grid_for(M) : grid_for((long long)M * 64);
+    if (small) hipLaunchKernelGGL(k_sce_small<0>, dim3(nb), dim3(NT), 0, st, x, xm, t, M, K, ignore_label, part, nullptr, nullptr, gm);
+    else hipLaunchKernelGGL(k_sce_wave<0>, dim3(nb), dim3(NT), 0, st, x, xm, t, M, K, Kfill, ignore_label, part, nullptr, nullptr, gm);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, part, nb, loss_out);
+    MRCNN_LAUNCH_CHECK();
+    if (gx && M > 0) {
+        if (small) hipLaunchKernelGGL(k_sce_small<1>, dim3(nb), dim3(NT), 0, st, x, xm, t, M, K, ignore_label, part, loss_out, gx, gm);
+        else hipLaunchKernelGGL(k_sce_wave<1>, dim3(nb), dim3(NT), 0, st, x, xm, t, M, K, Kfill, ignore_label, part, loss_out, gx, gm);
+        MRCNN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// x (M, ldx>=4) predictions, t (M,4) targets, label (M,): weight 1 where label>0, normaliser #(label>=0).
+extern "C" int mrcnn_smooth_l1_f32(const float *x, int ldx, const float *t, const int32_t *label, int M, float sigma,
+                                   float *loss_out, float *gx, int ldg, int gfill, void *ws, size_t ws_bytes,
+                                   void *stream) {
+    if ((M > 0 && (!x || !t || !label)) || !loss_out || !ws || M < 0 || ldx < 4)
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "smooth_l1: bad arguments");
+    if (ws_bytes < mrcnn_loss_workspace_bytes()) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "smooth_l1: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)ws;
+    const int nb = grid_for(M);
+    const float s2 = sigma * sigma;
+    hipLaunchKernelGGL(k_sl1<0>, dim3(nb), dim3(NT), 0, st, x, ldx, t, label, M, s2, part, nullptr, nullptr, 0, 0);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, part, nb, loss_out);
+    MRCNN_LAUNCH_CHECK();
+    if (gx && M > 0) {
+        hipLaunchKernelGGL(k_sl1<1>, dim3(nb), dim3(NT), 0, st, x, ldx, t, label, M, s2, part, loss_out, gx, ldg, gfill);
+        MRCNN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// x (Rm, HW, Cm) NHWC mask logits, gt (Rm, HW) int32 in {0,1,-1}, label (Rm,) int32 (class 1..; <=0 = row unused).
+// gx (same shape as x) is zero-filled by the callee and receives the gradient at channel label-1.
+extern "C" int mrcnn_mask_bce_f32(const float *x, const int32_t *gt, const int32_t *label, int Rm, int HW, int Cm,
+                                  float *loss_out, float *gx, void *ws, size_t ws_bytes, void *stream) {
+    if ((Rm > 0 && (!x || !gt || !label)) || !loss_out || !ws || Rm < 0 || HW <= 0 || Cm <= 0)
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "mask_bce: bad arguments");
+    if (ws_bytes < mrcnn_loss_workspace_bytes()) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "mask_bce: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)ws;
+    const int nb = grid_for((long long)Rm * HW);
+    hipLaunchKernelGGL(k_mask_bce<0>, dim3(nb), dim3(NT), 0, st, x, gt, label, Rm, HW, Cm, part, nullptr, nullptr);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, part, nb, loss_out);
+    MRCNN_LAUNCH_CHECK();
+    if (gx && Rm > 0) {
+        MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)Rm * HW * Cm, st));
+        hipLaunchKernelGGL(k_mask_bce<1>, dim3(nb), dim3(NT), 0, st, x, gt, label, Rm, HW, Cm, part, loss_out, gx);
+        MRCNN_LAUNCH_CHECK();
+    }
+    return 0;
+}

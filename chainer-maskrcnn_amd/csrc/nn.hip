@@ -1,0 +1,530 @@
+// HBM-bound layer kernels of the ResNet-50-FPN backbone and heads for gfx950 (NHWC fp32):
+// training-mode BatchNorm (+residual, +ReLU) forward/backward, ReLU backward, add, 2x2/2 max-pool
+// (cover_all), nearest-2x upsample + add, strided-scatter (backward of a subsampling 1x1 conv),
+// pixel-shuffle for the 2x2/2 deconvolution, and the fused MomentumSGD + WeightDecay update.
+//
+// Replaces the cuDNN/CuPy kernels Chainer runs for
+//   chainer_maskrcnn/model/extractor/feature_pyramid_network.py:48-68 (bn/relu/max_pooling_2d/
+//   unpooling_2d/add inside ResNet50Layers and the top-down pathway),
+//   chainer_maskrcnn/model/head/fpn_roi_mask_head.py:65-83 (ReLU, Deconvolution2D data movement),
+//   train.py:107-109 (MomentumSGD + WeightDecay hook).
+//
+// Every kernel streams float4 (16 B/lane), each tensor byte is read/written once per kernel, and
+// all reductions are two-stage with a fixed summation order (bit-reproducible, no float atomics).
+// Roofline: HBM; algorithmic bytes are stated per kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+
+inline int ew_grid(size_t n4) { return (int)std::min<size_t>((n4 + NT - 1) / NT, 256 * 16); }
+
+// ---------------------------------------------------------------------------------------------
+// Channel-wise reductions over a (P, C) row-major matrix.  Thread t owns channel group
+// cg = t % G (G = min(C/4, 256)) and rows t/G, t/G + RPI, ...; a block owns a contiguous chunk of
+// rows.  Partials go to ws[blk][C] (float4 per group), a finalize kernel sums them in order.
+// ---------------------------------------------------------------------------------------------
+struct RedPlan {
+    int G, RPI, nblk, rows_per_blk;
+};
+RedPlan red_plan(int P, int C) {
+    RedPlan r;
+    const int C4 = C / 4;
+    r.G = std::min(C4, NT);
+    r.RPI = NT / r.G;
+    long long want = ((long long)P * C4 + (long long)NT * 16 - 1) / ((long long)NT * 16);
+    r.nblk = (int)std::max(1ll, std::min(want, 1024ll));
+    r.rows_per_blk = (int)(((long long)P + r.nblk - 1) / r.nblk);
+    r.rows_per_blk = (r.rows_per_blk + r.RPI - 1) / r.RPI * r.RPI;
+    r.nblk = (P + r.rows_per_blk - 1) / r.rows_per_blk;
+    return r;
+}
+
+// BN forward statistics: per block, per channel: sum(x - K), sum((x - K)^2) with K = x[0][c]
+// (shifted sums: no catastrophic cancellation when |mean| >> std).
+__global__ __launch_bounds__(NT) void k_bn_stats_partial(const float *__restrict__ x, int P, int C, int G, int RPI,
+                                                         int rows_per_blk, float *__restrict__ part) {
+    __shared__ float4 s1[NT], s2[NT];
+    const int t = threadIdx.x, cg0 = t % G, rr = t / G;
+    const int C4 = C / 4;
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(P, r0 + rows_per_blk);
+    for (int cg = cg0; cg < C4; cg += G) {
+        const float4 K = ld4(x + cg * 4);
+        float4 a = f4(0.f), b = f4(0.f);
+        for (int r = r0 + rr; r < r1; r += RPI) {
+            const float4 v = ld4(x + (size_t)r * C + cg * 4);
+            const float dx = v.x - K.x, dy = v.y - K.y, dz = v.z - K.z, dw = v.w - K.w;
+            a.x += dx; a.y += dy; a.z += dz; a.w += dw;
+            b.x = fmaf(dx, dx, b.x); b.y = fmaf(dy, dy, b.y); b.z = fmaf(dz, dz, b.z); b.w = fmaf(dw, dw, b.w);
+        }
+        s1[t] = a; s2[t] = b;
+        __syncthreads();
+        if (rr == 0) {
+            for (int k = 1; k < RPI; ++k) {
+                const float4 p = s1[k * G + cg0], q = s2[k * G + cg0];
+                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+                b.x += q.x; b.y += q.y; b.z += q.z; b.w += q.w;
+            }
+            st4(part + ((size_t)blockIdx.x * 2 * C) + cg * 4, a);
+            st4(part + ((size_t)blockIdx.x * 2 * C) + C + cg * 4, b);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_bn_stats_final(const float *__restrict__ x, const float *__restrict__ part, int nblk, int P, int C,
+                                 float eps, float decay, float *__restrict__ mean, float *__restrict__ invstd,
+                                 float *__restrict__ run_mean, float *__restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        a += (double)part[(size_t)k * 2 * C + c];
+        b += (double)part[(size_t)k * 2 * C + C + c];
+    }
+    const double ms = a / P;
+    double var = b / P - ms * ms;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)((double)x[c] + ms), v = (float)var;
+    mean[c] = m;
+    invstd[c] = 1.0f / sqrtf(v + eps);
+    if (run_mean) run_mean[c] = decay * run_mean[c] + (1.0f - decay) * m;
+    if (run_var) {
+        const float adj = (float)P / (float)max(P - 1, 1);
+        run_var[c] = decay * run_var[c] + (1.0f - decay) * v * adj;
+    }
+}
+
+// y = gamma*(x-mean)*invstd + beta (+ residual) (ReLU).  Bytes: 4*P*C*(2 or 3).
+__global__ __launch_bounds__(NT) void k_bn_apply(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                 const float *__restrict__ beta, const float *__restrict__ mean,
+                                                 const float *__restrict__ invstd, const float *__restrict__ res,
+                                                 float *__restrict__ y, size_t n4, int C4, int relu) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4) * 4;
+        const float4 v = ld4(x + i * 4), g = ld4(gamma + c), b = ld4(beta + c), m = ld4(mean + c), s = ld4(invstd + c);
+        float4 o;
+        o.x = g.x * ((v.x - m.x) * s.x) + b.x;
+        o.y = g.y * ((v.y - m.y) * s.y) + b.y;
+        o.z = g.z * ((v.z - m.z) * s.z) + b.z;
+        o.w = g.w * ((v.w - m.w) * s.w) + b.w;
+        if (res) {
+            const float4 r = ld4(res + i * 4);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        st4(y + i * 4, o);
+    }
+}
+
+// BN backward reductions: per channel sum(dz), sum(dz*xhat) with dz = relu ? gy*(y>0) : gy.
+__global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__ gy, const float *__restrict__ x,
+                                                       const float *__restrict__ y, const float *__restrict__ mean,
+                                                       const float *__restrict__ invstd, int P, int C, int G, int RPI,
+                                                       int rows_per_blk, int relu, float *__restrict__ part) {
+    __shared__ float4 s1[NT], s2[NT];
+    const int t = threadIdx.x, cg0 = t % G, rr = t / G;
+    const int C4 = C / 4;
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(P, r0 + rows_per_blk);
+    for (int cg = cg0; cg < C4; cg += G) {
+        const float4 m = ld4(mean + cg * 4), s = ld4(invstd + cg * 4);
+        float4 a = f4(0.f), b = f4(0.f);
+        for (int r = r0 + rr; r < r1; r += RPI) {
+            const size_t o = (size_t)r * C + cg * 4;
+            float4 g = ld4(gy + o);
+            const float4 v = ld4(x + o);
+            if (relu) {
+                const float4 yy = ld4(y + o);
+                g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+                g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+            }
+            a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+            b.x = fmaf(g.x, (v.x - m.x) * s.x, b.x); b.y = fmaf(g.y, (v.y - m.y) * s.y, b.y);
+            b.z = fmaf(g.z, (v.z - m.z) * s.z, b.z); b.w = fmaf(g.w, (v.w - m.w) * s.w, b.w);
+        }
+        s1[t] = a; s2[t] = b;
+        __syncthreads();
+        if (rr == 0) {
+            for (int k = 1; k < RPI; ++k) {
+                const float4 p = s1[k * G + cg0], q = s2[k * G + cg0];
+                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+                b.x += q.x; b.y += q.y; b.z += q.z; b.w += q.w;
+            }
+            st4(part + ((size_t)blockIdx.x * 2 * C) + cg * 4, a);
+            st4(part + ((size_t)blockIdx.x * 2 * C) + C + cg * 4, b);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_bn_bwd_final(const float *__restrict__ part, int nblk, int C, float *__restrict__ gbeta,
+                               float *__restrict__ ggamma) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        a += (double)part[(size_t)k * 2 * C + c];
+        b += (double)part[(size_t)k * 2 * C + C + c];
+    }
+    gbeta[c] = (float)a;
+    ggamma[c] = (float)b;
+}
+
+// gx = gamma*invstd*(dz - gbeta/P - xhat*ggamma/P); optionally gres = dz.
+__global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float *__restrict__ gy, const float *__restrict__ x,
+                                                     const float *__restrict__ y, const float *__restrict__ gamma,
+                                                     const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                     const float *__restrict__ gbeta, const float *__restrict__ ggamma,
+                                                     float *__restrict__ gx, float *__restrict__ gres, size_t n4, int C4,
+                                                     float invP, int relu) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4) * 4;
+        float4 g = ld4(gy + i * 4);
+        const float4 v = ld4(x + i * 4);
+        if (relu) {
+            const float4 yy = ld4(y + i * 4);
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        const float4 ga = ld4(gamma + c), m = ld4(mean + c), s = ld4(invstd + c), gb = ld4(gbeta + c), gg = ld4(ggamma + c);
+        float4 o;
+        o.x = ga.x * s.x * (g.x - gb.x * invP - ((v.x - m.x) * s.x) * (gg.x * invP));
+        o.y = ga.y * s.y * (g.y - gb.y * invP - ((v.y - m.y) * s.y) * (gg.y * invP));
+        o.z = ga.z * s.z * (g.z - gb.z * invP - ((v.z - m.z) * s.z) * (gg.z * invP));
+        o.w = ga.w * s.w * (g.w - gb.w * invP - ((v.w - m.w) * s.w) * (gg.w * invP));
+        st4(gx + i * 4, o);
+        if (gres) st4(gres + i * 4, g);
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_relu_bwd(const float *__restrict__ gy, const float *__restrict__ y,
+                                                 float *__restrict__ gx, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        float4 g = ld4(gy + i * 4);
+        const float4 yy = ld4(y + i * 4);
+        g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+        g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        st4(gx + i * 4, g);
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_add(const float *__restrict__ a, const float *__restrict__ b,
+                                            float *__restrict__ o, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const float4 p = ld4(a + i * 4), q = ld4(b + i * 4);
+        st4(o + i * 4, make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w));
+    }
+}
+
+// ---- 2x2 stride-2 max pooling, cover_all (Ho = ceil(H/2)) ------------------------------------
+__global__ __launch_bounds__(NT) void k_maxpool_fwd(const float *__restrict__ x, float *__restrict__ y, int N, int H,
+                                                    int W, int C4, int Ho, int Wo) {
+    const size_t n4 = (size_t)N * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        size_t q = i / C4;
+        const int wo = (int)(q % Wo); q /= Wo;
+        const int ho = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        float4 m = f4(-INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int h = 2 * ho + dy, w = 2 * wo + dx;
+                if (h < H && w < W) {
+                    const float4 v = ld4(x + ((((size_t)n * H + h) * W + w) * C4 + c) * 4);
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+            }
+        st4(y + i * 4, m);
+    }
+}
+
+// gx[cell] = gy[window] if the cell is the FIRST maximum of its window (row-major order), else 0.
+// One thread per window: writes all (<=4) cells of the window => gx fully written, no atomics.
+__global__ __launch_bounds__(NT) void k_maxpool_bwd(const float *__restrict__ x, const float *__restrict__ gy,
+                                                    float *__restrict__ gx, int N, int H, int W, int C4, int Ho, int Wo) {
+    const size_t n4 = (size_t)N * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        size_t q = i / C4;
+        const int wo = (int)(q % Wo); q /= Wo;
+        const int ho = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        const float4 g = ld4(gy + i * 4);
+        float v[4][4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = 2 * ho + (k >> 1), w = 2 * wo + (k & 1);
+            ok[k] = h < H && w < W;
+            float4 t = f4(-INFINITY);
+            if (ok[k]) t = ld4(x + ((((size_t)n * H + h) * W + w) * C4 + c) * 4);
+            v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+        }
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+        float o[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int arg = 0;
+            float best = v[0][e];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k][e] > best) { best = v[k][e]; arg = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][e] = (k == arg) ? gv[e] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = 2 * ho + (k >> 1), w = 2 * wo + (k & 1);
+            if (ok[k]) st4(gx + ((((size_t)n * H + h) * W + w) * C4 + c) * 4, make_float4(o[k][0], o[k][1], o[k][2], o[k][3]));
+        }
+    }
+}
+
+// ---- nearest 2x upsample (F.unpooling_2d ksize 2, cropped to (H,W)) + lateral add --------------
+__global__ __launch_bounds__(NT) void k_upsample_add(const float *__restrict__ top, const float *__restrict__ lat,
+                                                     float *__restrict__ out, int N, int H, int W, int Ht, int Wt, int C4) {
+    const size_t n4 = (size_t)N * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        size_t q = i / C4;
+        const int w = (int)(q % W); q /= W;
+        const int h = (int)(q % H);
+        const int n = (int)(q / H);
+        const float4 a = ld4(top + ((((size_t)n * Ht + (h >> 1)) * Wt + (w >> 1)) * C4 + c) * 4);
+        const float4 b = ld4(lat + i * 4);
+        st4(out + i * 4, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+    }
+}
+
+// gtop[n,ht,wt] (+)= sum of the in-bounds 2x2 block of gout.
+__global__ __launch_bounds__(NT) void k_upsample_bwd(const float *__restrict__ gout, float *__restrict__ gtop, int N,
+                                                     int H, int W, int Ht, int Wt, int C4, int accumulate) {
+    const size_t n4 = (size_t)N * Ht * Wt * C4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        size_t q = i / C4;
+        const int wt = (int)(q % Wt); q /= Wt;
+        const int ht = (int)(q % Ht);
+        const int n = (int)(q / Ht);
+        float4 s = accumulate ? ld4(gtop + i * 4) : f4(0.f);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int h = 2 * ht + dy, w = 2 * wt + dx;
+                if (h < H && w < W) {
+                    const float4 v = ld4(gout + ((((size_t)n * H + h) * W + w) * C4 + c) * 4);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            }
+        st4(gtop + i * 4, s);
+    }
+}
+
+// Backward of y[n,ho,wo] = x[n,ho*s,wo*s]: gx fully written (zeros off the lattice) or accumulated.
+__global__ __launch_bounds__(NT) void k_subsample_bwd(const float *__restrict__ gsub, float *__restrict__ gx, int N,
+                                                      int H, int W, int Ho, int Wo, int C4, int s, int accumulate) {
+    const size_t n4 = (size_t)N * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        size_t q = i / C4;
+        const int w = (int)(q % W); q /= W;
+        const int h = (int)(q % H);
+        const int n = (int)(q / H);
+        const bool on = (h % s == 0) && (w % s == 0) && (h / s < Ho) && (w / s < Wo);
+        if (accumulate) {
+            if (!on) continue;
+            const float4 g = ld4(gsub + ((((size_t)n * Ho + h / s) * Wo + w / s) * C4 + c) * 4);
+            const float4 o = ld4(gx + i * 4);
+            st4(gx + i * 4, make_float4(o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w));
+        } else {
+            float4 g = f4(0.f);
+            if (on) g = ld4(gsub + ((((size_t)n * Ho + h / s) * Wo + w / s) * C4 + c) * 4);
+            st4(gx + i * 4, g);
+        }
+    }
+}
+
+// Pixel shuffle of the 2x2/2 deconvolution: t (P=N*H*W, [a][b][Cout]) <-> y (N, 2H, 2W, Cout).
+// dir 0: y[n,2h+a,2w+b,:] = t[n,h,w,a,b,:];  dir 1: the inverse gather (backward).
+__global__ __launch_bounds__(NT) void k_pixel_shuffle(const float *__restrict__ src, float *__restrict__ dst, int N,
+                                                      int H, int W, int C4, int dir) {
+    const size_t n4 = (size_t)N * H * W * 4 * C4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        // i indexes the (N,2H,2W,C) side
+        const int c = (int)(i % C4);
+        size_t q = i / C4;
+        const int w2 = (int)(q % (2 * W)); q /= (2 * W);
+        const int h2 = (int)(q % (2 * H));
+        const int n = (int)(q / (2 * H));
+        const size_t j = ((((size_t)n * H + (h2 >> 1)) * W + (w2 >> 1)) * 4 + (h2 & 1) * 2 + (w2 & 1)) * C4 + c;
+        if (dir == 0) st4(dst + i * 4, ld4(src + j * 4));
+        else st4(dst + j * 4, ld4(src + i * 4));
+    }
+}
+
+// v = momentum*v - lr*(g + wd*p); p += v   (Chainer WeightDecay hook then MomentumSGD).  20 B/param.
+__global__ __launch_bounds__(NT) void k_sgd(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ v,
+                                            size_t n, float lr, float momentum, float wd) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        float4 pp = ld4(p + i * 4), vv = ld4(v + i * 4);
+        const float4 gg = ld4(g + i * 4);
+        vv.x = momentum * vv.x - lr * (gg.x + wd * pp.x); vv.y = momentum * vv.y - lr * (gg.y + wd * pp.y);
+        vv.z = momentum * vv.z - lr * (gg.z + wd * pp.z); vv.w = momentum * vv.w - lr * (gg.w + wd * pp.w);
+        pp.x += vv.x; pp.y += vv.y; pp.z += vv.z; pp.w += vv.w;
+        st4(p + i * 4, pp);
+        st4(v + i * 4, vv);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        const float nv = momentum * v[i] - lr * (g[i] + wd * p[i]);
+        v[i] = nv;
+        p[i] += nv;
+    }
+}
+
+int chk(bool ok, const char *what) { return ok ? 0 : mrcnn::fail_arg(MRCNN_E_INVALID, "%s", what); }
+
+}  // namespace
+
+extern "C" size_t mrcnn_bn_workspace_bytes(int P, int C) {
+    if (P <= 0 || C <= 0 || (C % 4)) return 0;
+    const RedPlan r = red_plan(P, C);
+    return (size_t)r.nblk * 2 * C * sizeof(float);
+}
+
+extern "C" int mrcnn_bn_train_fwd_f32(const float *x, const float *gamma, const float *beta, const float *residual,
+                                      float *y, float *save_mean, float *save_invstd, float *running_mean,
+                                      float *running_var, int P, int C, float eps, float decay, int relu, void *ws,
+                                      size_t ws_bytes, void *stream) {
+    if (int e = chk(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer")) return e;
+    if (int e = chk(P > 0 && C > 0 && (C % 4) == 0, "bn_train_fwd: need P>0, C%4==0")) return e;
+    if (ws_bytes < mrcnn_bn_workspace_bytes(P, C)) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "bn_train_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan r = red_plan(P, C);
+    hipLaunchKernelGGL(k_bn_stats_partial, dim3(r.nblk), dim3(NT), 0, st, x, P, C, r.G, r.RPI, r.rows_per_blk, (float *)ws);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_stats_final, dim3(mrcnn::cdiv(C, 64)), dim3(64), 0, st, x, (const float *)ws, r.nblk, P, C,
+                       eps, decay, save_mean, save_invstd, running_mean, running_var);
+    MRCNN_LAUNCH_CHECK();
+    const size_t n4 = (size_t)P * C / 4;
+    hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, x, gamma, beta, save_mean, save_invstd, residual, y,
+                       n4, C / 4, relu);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const float *y, const float *gamma,
+                                      const float *save_mean, const float *save_invstd, float *gx, float *gres,
+                                      float *ggamma, float *gbeta, int P, int C, int relu, void *ws, size_t ws_bytes,
+                                      void *stream) {
+    if (int e = chk(gy && x && gamma && save_mean && save_invstd && gx && ggamma && gbeta && ws, "bn_train_bwd: null pointer")) return e;
+    if (int e = chk(!relu || y, "bn_train_bwd: relu needs y")) return e;
+    if (int e = chk(P > 0 && C > 0 && (C % 4) == 0, "bn_train_bwd: need P>0, C%4==0")) return e;
+    if (ws_bytes < mrcnn_bn_workspace_bytes(P, C)) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "bn_train_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan r = red_plan(P, C);
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(r.nblk), dim3(NT), 0, st, gy, x, y, save_mean, save_invstd, P, C, r.G, r.RPI,
+                       r.rows_per_blk, relu, (float *)ws);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(mrcnn::cdiv(C, 64)), dim3(64), 0, st, (const float *)ws, r.nblk, C, gbeta, ggamma);
+    MRCNN_LAUNCH_CHECK();
+    const size_t n4 = (size_t)P * C / 4;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, gy, x, y, gamma, save_mean, save_invstd, gbeta,
+                       ggamma, gx, gres, n4, C / 4, 1.0f / (float)P, relu);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_relu_bwd_f32(const float *gy, const float *y, float *gx, size_t n, void *stream) {
+    if (n == 0) return 0;
+    if (int e = chk(gy && y && gx && (n % 4) == 0, "relu_bwd: null pointer or n%4")) return e;
+    hipLaunchKernelGGL(k_relu_bwd, dim3(ew_grid(n / 4)), dim3(NT), 0, (hipStream_t)stream, gy, y, gx, n / 4);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_add_f32(const float *a, const float *b, float *out, size_t n, void *stream) {
+    if (n == 0) return 0;
+    if (int e = chk(a && b && out && (n % 4) == 0, "add: null pointer or n%4")) return e;
+    hipLaunchKernelGGL(k_add, dim3(ew_grid(n / 4)), dim3(NT), 0, (hipStream_t)stream, a, b, out, n / 4);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_maxpool2x2_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream) {
+    if (int e = chk(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "maxpool2x2_fwd: bad args")) return e;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(ew_grid((size_t)N * Ho * Wo * C / 4)), dim3(NT), 0, (hipStream_t)stream, x, y,
+                       N, H, W, C / 4, Ho, Wo);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_maxpool2x2_bwd_f32(const float *x, const float *gy, float *gx, int N, int H, int W, int C,
+                                        void *stream) {
+    if (int e = chk(x && gy && gx && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "maxpool2x2_bwd: bad args")) return e;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(ew_grid((size_t)N * Ho * Wo * C / 4)), dim3(NT), 0, (hipStream_t)stream, x, gy,
+                       gx, N, H, W, C / 4, Ho, Wo);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_upsample2x_add_fwd_f32(const float *top, const float *lat, float *out, int N, int H, int W, int Ht,
+                                            int Wt, int C, void *stream) {
+    if (int e = chk(top && lat && out && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "upsample2x_add_fwd: bad args")) return e;
+    if (int e = chk(Ht >= (H + 1) / 2 && Wt >= (W + 1) / 2, "upsample2x_add_fwd: top smaller than ceil(out/2)")) return e;
+    hipLaunchKernelGGL(k_upsample_add, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(NT), 0, (hipStream_t)stream, top, lat,
+                       out, N, H, W, Ht, Wt, C / 4);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_upsample2x_bwd_f32(const float *gout, float *gtop, int N, int H, int W, int Ht, int Wt, int C,
+                                        int accumulate, void *stream) {
+    if (int e = chk(gout && gtop && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "upsample2x_bwd: bad args")) return e;
+    if (int e = chk(Ht >= (H + 1) / 2 && Wt >= (W + 1) / 2, "upsample2x_bwd: top smaller than ceil(out/2)")) return e;
+    hipLaunchKernelGGL(k_upsample_bwd, dim3(ew_grid((size_t)N * Ht * Wt * C / 4)), dim3(NT), 0, (hipStream_t)stream, gout,
+                       gtop, N, H, W, Ht, Wt, C / 4, accumulate);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_subsample_bwd_f32(const float *gsub, float *gx, int N, int H, int W, int C, int stride,
+                                       int accumulate, void *stream) {
+    if (int e = chk(gsub && gx && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0 && stride > 0, "subsample_bwd: bad args")) return e;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    hipLaunchKernelGGL(k_subsample_bwd, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(NT), 0, (hipStream_t)stream, gsub, gx,
+                       N, H, W, Ho, Wo, C / 4, stride, accumulate);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_pixel_shuffle2x_f32(const float *src, float *dst, int N, int H, int W, int C, int inverse,
+                                         void *stream) {
+    if (int e = chk(src && dst && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "pixel_shuffle2x: bad args")) return e;
+    hipLaunchKernelGGL(k_pixel_shuffle, dim3(ew_grid((size_t)N * H * W * C)), dim3(NT), 0, (hipStream_t)stream, src, dst, N,
+                       H, W, C / 4, inverse);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_sgd_momentum_wd_f32(float *p, const float *g, float *v, size_t n, float lr, float momentum,
+                                         float weight_decay, void *stream) {
+    if (n == 0) return 0;
+    if (int e = chk(p && g && v, "sgd_momentum_wd: null pointer")) return e;
+    hipLaunchKernelGGL(k_sgd, dim3(ew_grid(std::max<size_t>(n / 4, 1))), dim3(NT), 0, (hipStream_t)stream, p, g, v, n, lr,
+                       momentum, weight_decay);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}

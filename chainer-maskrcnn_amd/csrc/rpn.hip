@@ -1,0 +1,380 @@
+// RPN proposal path on the device for gfx950: head-output packing, anchor decode + clip + min-size
+// filter, top-n_pre selection by score, greedy NMS (bit-mask kernel + in-kernel sequential reduce),
+// FPN level assignment.  No device->host copy anywhere on the path.
+//
+// Replaces, per image (chainer_maskrcnn/model/rpn/multilevel_region_proposal_network.py:133-164):
+//   the transpose/reshape/concat copies (:133-152)                  -> mrcnn_rpn_pack_f32 / _unpack_grad_
+//   ChainerCV ProposalCreator.__call__ (third-party; in-tree mirror utils/proposal_creator.py:108-169)
+//     loc2bbox, clip, min-size filter, argsort()[::-1][:n_pre], non_maximum_suppression, [:n_post]
+//                                                                    -> mrcnn_rpn_proposals_f32
+//   map_rois_to_fpn_levels (:16-31)                                  -> mrcnn_map_rois_to_fpn_levels_f32
+//
+// Float arithmetic is compiled with contraction off and follows oracle/boxes.py and
+// oracle/proposal.py operation for operation.  Sort order is the oracle's pin: (score desc, anchor
+// index desc).  NMS keep lists are bit-exact given identical boxes.  All kernels are latency/HBM
+// bound; sizes at config 3: A = 261,888 anchors, n_pre = 12,000 (18 MB of bit masks), n_post = 2,000.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef unsigned long long u64;
+
+// ---- pack / unpack the RPN head output ---------------------------------------------------------
+// head (N, HW, Cp) NHWC with channels [0,4A) = loc (a*4+k), [4A,6A) = score (a*2+c).
+// locs (N, Atot, 4), scores (N, Atot, 2); this level's anchors start at a_off; anchor index within
+// the level = pos*A + a  (position-major, anchor-minor: multilevel_region_proposal_network.py:133-141).
+__global__ __launch_bounds__(256) void k_rpn_pack(const float *__restrict__ head, int N, int HW, int Cp, int A,
+                                                  float *__restrict__ locs, float *__restrict__ scores, int a_off,
+                                                  int Atot) {
+    const long long total = (long long)N * HW * A;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int a = (int)(i % A);
+        const long long q = i / A;
+        const int pos = (int)(q % HW), n = (int)(q / HW);
+        const float *h = head + ((size_t)n * HW + pos) * Cp;
+        const float4 l = *reinterpret_cast<const float4 *>(h + a * 4);
+        const float2 s = *reinterpret_cast<const float2 *>(h + 4 * A + a * 2);
+        const size_t o = (size_t)n * Atot + a_off + (size_t)pos * A + a;
+        *reinterpret_cast<float4 *>(locs + o * 4) = l;
+        *reinterpret_cast<float2 *>(scores + o * 2) = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rpn_unpack(const float *__restrict__ glocs, const float *__restrict__ gscores,
+                                                    int N, int HW, int Cp, int A, float *__restrict__ ghead, int a_off,
+                                                    int Atot) {
+    const long long total = (long long)N * HW * (Cp / 2);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c2 = (int)(i % (Cp / 2));
+        const long long q = i / (Cp / 2);
+        const int pos = (int)(q % HW), n = (int)(q / HW);
+        const int c = c2 * 2;
+        float2 v = make_float2(0.f, 0.f);
+        const size_t base = (size_t)n * Atot + a_off + (size_t)pos * A;
+        if (c < 4 * A) v = *reinterpret_cast<const float2 *>(glocs + (base + c / 4) * 4 + (c & 3));
+        else if (c < 6 * A) v = *reinterpret_cast<const float2 *>(gscores + (base + (c - 4 * A) / 2) * 2);
+        *reinterpret_cast<float2 *>(ghead + ((size_t)n * HW + pos) * Cp + c) = v;
+    }
+}
+
+// ---- decode + clip + filter + sort key ---------------------------------------------------------
+__device__ __forceinline__ unsigned orderable(float f) {     // monotone float -> uint
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k_decode(const float *__restrict__ locs, const float *__restrict__ scores,
+                                                const float *__restrict__ anchors, int N, int A, float img_h, float img_w,
+                                                float min_size, float *__restrict__ boxes, u64 *__restrict__ keys) {
+    const long long total = (long long)N * A;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int a = (int)(i % A);
+        const float4 an = *reinterpret_cast<const float4 *>(anchors + (size_t)a * 4);
+        const float4 l = *reinterpret_cast<const float4 *>(locs + (size_t)i * 4);
+        const float h = an.z - an.x, w = an.w - an.y;
+        const float cy = an.x + 0.5f * h, cx = an.y + 0.5f * w;
+        const float ncy = l.x * h + cy, ncx = l.y * w + cx;
+        const float nh = expf(l.z) * h, nw = expf(l.w) * w;
+        float y1 = ncy - 0.5f * nh, x1 = ncx - 0.5f * nw, y2 = ncy + 0.5f * nh, x2 = ncx + 0.5f * nw;
+        y1 = fmaxf(fminf(y1, img_h), 0.f); y2 = fmaxf(fminf(y2, img_h), 0.f);
+        x1 = fmaxf(fminf(x1, img_w), 0.f); x2 = fmaxf(fminf(x2, img_w), 0.f);
+        *reinterpret_cast<float4 *>(boxes + (size_t)i * 4) = make_float4(y1, x1, y2, x2);
+        const bool ok = (y2 - y1 >= min_size) && (x2 - x1 >= min_size);
+        const float sc = scores[(size_t)i * 2 + 1];
+        // [63] valid | [62:31] orderable score | [30:0] anchor index: descending sort => (score desc, index desc)
+        keys[i] = ok ? ((1ull << 63) | ((u64)orderable(sc) << 31) | (u64)a) : 0ull;
+    }
+}
+
+// Gather the first n_pre sorted boxes; n_valid[n] = min(n_pre, #valid).
+__global__ __launch_bounds__(256) void k_gather_sorted(const u64 *__restrict__ keys_sorted, const float *__restrict__ boxes,
+                                                       int A, int n_pre, float *__restrict__ sboxes,
+                                                       int32_t *__restrict__ sidx, int32_t *__restrict__ n_valid) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pre || i >= A) return;
+    const u64 *ks = keys_sorted + (size_t)n * A;
+    const u64 k = ks[i];
+    if (k == 0ull) return;
+    const int a = (int)(k & 0x7FFFFFFFull);
+    *reinterpret_cast<float4 *>(sboxes + ((size_t)n * n_pre + i) * 4) =
+        *reinterpret_cast<const float4 *>(boxes + ((size_t)n * A + a) * 4);
+    sidx[(size_t)n * n_pre + i] = a;
+    if (i + 1 == n_pre || i + 1 == A || ks[i + 1] == 0ull) n_valid[n] = i + 1;
+}
+
+// ---- NMS ---------------------------------------------------------------------------------------
+// mask[(n*n_pre + i)*nblk + c] bit j: box i suppresses box c*64+j (j-th box of column block c), only
+// for c*64+j > i.  IoU exactly as ChainerCV's devIoU / oracle.boxes.nms.
+__global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ sboxes, const int32_t *__restrict__ n_valid,
+                                                 int n_pre, int nblk, float thresh, u64 *__restrict__ mask) {
+    const int img = blockIdx.z;
+    const int n = n_valid[img];
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+    __shared__ float4 cbox[64];
+    const float *bx = sboxes + (size_t)img * n_pre * 4;
+    const int cj = cb * 64 + threadIdx.x;
+    cbox[threadIdx.x] = cj < n ? *reinterpret_cast<const float4 *>(bx + (size_t)cj * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int i = rb * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float4 b = *reinterpret_cast<const float4 *>(bx + (size_t)i * 4);
+    const float area_i = (b.z - b.x) * (b.w - b.y);
+    u64 bits = 0ull;
+    const int jmax = min(64, n - cb * 64);
+    for (int j = 0; j < jmax; ++j) {
+        if (cb * 64 + j <= i) continue;
+        const float4 c = cbox[j];
+        const float top = fmaxf(b.x, c.x), left = fmaxf(b.y, c.y);
+        const float bottom = fminf(b.z, c.z), right = fminf(b.w, c.w);
+        const float hgt = fmaxf(bottom - top, 0.f), wid = fmaxf(right - left, 0.f);
+        const float ai = hgt * wid;
+        const float area_j = (c.z - c.x) * (c.w - c.y);
+        const float iou = ai / ((area_i + area_j) - ai);
+        if (iou >= thresh) bits |= 1ull << j;
+    }
+    mask[((size_t)img * n_pre + i) * nblk + cb] = bits;
+}
+
+// One wavefront per image walks the boxes in order, 64 at a time: the intra-chunk dependency is
+// resolved on the diagonal 64x64 block with scalar bit operations; the rows of the boxes kept in the
+// chunk are then OR-ed into the removed set with independent, coalesced loads.
+__global__ __launch_bounds__(64) void k_nms_reduce(const u64 *__restrict__ mask, const int32_t *__restrict__ n_valid,
+                                                   int n_pre, int nblk, int n_post, int32_t *__restrict__ keep,
+                                                   int32_t *__restrict__ n_keep) {
+    constexpr int MAXW = 256;      // up to 16384 boxes
+    __shared__ u64 rem[MAXW];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int n = n_valid[img];
+    const u64 *mk = mask + (size_t)img * n_pre * nblk;
+    int32_t *kp = keep + (size_t)img * n_post;
+    for (int w = lane; w < MAXW; w += 64) rem[w] = 0ull;
+    __syncthreads();
+    int kept = 0;
+    const int nb = (n + 63) / 64;
+    for (int c = 0; c < nb && kept < n_post; ++c) {
+        const int i = c * 64 + lane;
+        const u64 D = i < n ? mk[(size_t)i * nblk + c] : 0ull;
+        const int cnt = min(64, n - c * 64);
+        const u64 remc = rem[c];      // wave-uniform value: make that provable (scalar loop below)
+        u64 alive = ~(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(remc >> 32)) << 32) |
+                      (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)remc));
+        if (cnt < 64) alive &= (1ull << cnt) - 1ull;
+        u64 keepbits = 0ull;
+        const unsigned dlo = (unsigned)D, dhi = (unsigned)(D >> 32);
+        while (alive && kept < n_post) {
+            const int b = __builtin_ctzll(alive);
+            keepbits |= 1ull << b;
+            const u64 Db = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                           (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, b);
+            alive &= ~Db;
+            alive &= ~(1ull << b);
+            if (lane == 0) kp[kept] = c * 64 + b;
+            ++kept;
+        }
+        // OR the kept rows into rem[w] for w > c
+        for (int w0 = c + 1; w0 < nb; w0 += 64) {
+            const int w = w0 + lane;
+            u64 acc0 = 0ull, acc1 = 0ull, acc2 = 0ull, acc3 = 0ull;
+            u64 kb = keepbits;
+            while (kb) {
+                int b0 = __builtin_ctzll(kb); kb &= kb - 1;
+                int b1 = -1, b2 = -1, b3 = -1;
+                if (kb) { b1 = __builtin_ctzll(kb); kb &= kb - 1; }
+                if (kb) { b2 = __builtin_ctzll(kb); kb &= kb - 1; }
+                if (kb) { b3 = __builtin_ctzll(kb); kb &= kb - 1; }
+                if (w < nb) {
+                    acc0 |= mk[(size_t)(c * 64 + b0) * nblk + w];
+                    if (b1 >= 0) acc1 |= mk[(size_t)(c * 64 + b1) * nblk + w];
+                    if (b2 >= 0) acc2 |= mk[(size_t)(c * 64 + b2) * nblk + w];
+                    if (b3 >= 0) acc3 |= mk[(size_t)(c * 64 + b3) * nblk + w];
+                }
+            }
+            if (w < nb) rem[w] |= (acc0 | acc1) | (acc2 | acc3);
+        }
+        __syncthreads();
+    }
+    if (lane == 0) n_keep[img] = kept;
+}
+
+__device__ __forceinline__ float fpn_level(float y1, float x1, float y2, float x2, float k_min, float k_max) {
+    // multilevel_region_proposal_network.py:23-31: floor(4 + log2(sqrt(area)/224 + 1e-6)) clipped
+    const float area = (y2 - y1) * (x2 - x1);
+    const float s = sqrtf(area);
+    const float v = s / 224.0f + 1e-6f;
+    const float lg = (float)log2((double)v);
+    const float t = floorf(4.0f + lg);
+    return fminf(fmaxf(t, k_min), k_max);
+}
+
+// rois (N*n_post, 4) padded with zeros; roi_indices (N*n_post) i32 (-1 padding); levels f32.
+__global__ __launch_bounds__(256) void k_emit_rois(const float *__restrict__ sboxes, const int32_t *__restrict__ keep,
+                                                   const int32_t *__restrict__ n_keep, int n_pre, int n_post,
+                                                   float *__restrict__ rois, int32_t *__restrict__ roi_idx,
+                                                   float *__restrict__ levels) {
+    const int img = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_post) return;
+    const size_t o = (size_t)img * n_post + j;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    int idx = -1;
+    float lv = 0.f;
+    if (j < n_keep[img]) {
+        b = *reinterpret_cast<const float4 *>(sboxes + ((size_t)img * n_pre + keep[o]) * 4);
+        idx = img;
+        lv = fpn_level(b.x, b.y, b.z, b.w, 0.f, 4.f);
+    }
+    *reinterpret_cast<float4 *>(rois + o * 4) = b;
+    roi_idx[o] = idx;
+    levels[o] = lv;
+}
+
+__global__ __launch_bounds__(256) void k_levels(const float *__restrict__ rois, int R, float k_min, float k_max,
+                                                float *__restrict__ levels) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    const float4 b = *reinterpret_cast<const float4 *>(rois + (size_t)i * 4);
+    levels[i] = fpn_level(b.x, b.y, b.z, b.w, k_min, k_max);
+}
+
+__global__ void k_set_i32(int32_t *p, int32_t v) { *p = v; }
+
+struct PropLayout {
+    size_t boxes, keys, keys_sorted, sboxes, sidx, n_valid, mask, keep, sort_tmp, sort_tmp_bytes, total;
+    int nblk;
+};
+size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+PropLayout prop_layout(int N, int A, int n_pre, int n_post) {
+    PropLayout L{};
+    size_t o = 0;
+    L.nblk = (n_pre + 63) / 64;
+    L.boxes = o; o += al((size_t)N * A * 16);
+    L.keys = o; o += al((size_t)N * A * 8);
+    L.keys_sorted = o; o += al((size_t)N * A * 8);
+    L.sboxes = o; o += al((size_t)N * n_pre * 16);
+    L.sidx = o; o += al((size_t)N * n_pre * 4);
+    L.n_valid = o; o += al((size_t)N * 4);
+    L.mask = o; o += al((size_t)N * n_pre * L.nblk * 8);
+    L.keep = o; o += al((size_t)N * n_post * 4);
+    size_t tb = 0;
+    mrcnn::sort_u64(nullptr, nullptr, (size_t)A, true, nullptr, &tb, nullptr);
+    L.sort_tmp_bytes = tb;
+    L.sort_tmp = o; o += al(tb);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int mrcnn_rpn_pack_f32(const float *head, int N, int HW, int Cp, int A, float *locs, float *scores,
+                                  int a_off, int Atot, void *stream) {
+    if (!head || !locs || !scores || N <= 0 || HW <= 0 || A <= 0 || Cp < 6 * A || (Cp % 4))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "rpn_pack: bad arguments");
+    const long long total = (long long)N * HW * A;
+    hipLaunchKernelGGL(k_rpn_pack, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       (hipStream_t)stream, head, N, HW, Cp, A, locs, scores, a_off, Atot);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_rpn_unpack_grad_f32(const float *glocs, const float *gscores, int N, int HW, int Cp, int A,
+                                         float *ghead, int a_off, int Atot, void *stream) {
+    if (!ghead || !glocs || !gscores || N <= 0 || HW <= 0 || A <= 0 || Cp < 6 * A || (Cp % 4))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "rpn_unpack_grad: bad arguments");
+    const long long total = (long long)N * HW * (Cp / 2);
+    hipLaunchKernelGGL(k_rpn_unpack, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       (hipStream_t)stream, glocs, gscores, N, HW, Cp, A, ghead, a_off, Atot);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t mrcnn_rpn_proposals_workspace_bytes(int N, int A, int n_pre, int n_post) {
+    if (N <= 0 || A <= 0 || n_pre <= 0 || n_post <= 0) return 0;
+    return prop_layout(N, A, std::min(n_pre, A), n_post).total;
+}
+
+extern "C" int mrcnn_rpn_proposals_f32(const float *locs, const float *scores, const float *anchors, int N, int A,
+                                       float img_h, float img_w, float min_size, int n_pre, int n_post,
+                                       float nms_thresh, float *rois, int32_t *roi_indices, float *levels,
+                                       int32_t *n_rois, int32_t *dbg_sorted_anchor, int32_t *dbg_keep,
+                                       int32_t *dbg_n_pre, void *ws, size_t ws_bytes, void *stream) {
+    if (!locs || !scores || !anchors || !rois || !roi_indices || !levels || !n_rois || !ws)
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "rpn_proposals: null pointer");
+    if (N <= 0 || A <= 0 || n_pre <= 0 || n_post <= 0 || A >= (1 << 30))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "rpn_proposals: bad sizes");
+    n_pre = std::min(n_pre, A);
+    if (n_pre > 16384) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "rpn_proposals: n_pre %d > 16384", n_pre);
+    const PropLayout L = prop_layout(N, A, n_pre, n_post);
+    if (ws_bytes < L.total) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "rpn_proposals: workspace %zu < %zu", ws_bytes, L.total);
+    hipStream_t st = (hipStream_t)stream;
+    char *w = (char *)ws;
+    float *boxes = (float *)(w + L.boxes);
+    u64 *keys = (u64 *)(w + L.keys), *keys_sorted = (u64 *)(w + L.keys_sorted);
+    float *sboxes = (float *)(w + L.sboxes);
+    int32_t *sidx = (int32_t *)(w + L.sidx), *n_valid = (int32_t *)(w + L.n_valid), *keep = (int32_t *)(w + L.keep);
+    u64 *mask = (u64 *)(w + L.mask);
+    const long long total = (long long)N * A;
+    hipLaunchKernelGGL(k_decode, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, locs, scores,
+                       anchors, N, A, img_h, img_w, min_size, boxes, keys);
+    MRCNN_LAUNCH_CHECK();
+    for (int n = 0; n < N; ++n) {
+        size_t tb = L.sort_tmp_bytes;
+        if (int e = mrcnn::sort_u64(keys + (size_t)n * A, keys_sorted + (size_t)n * A, (size_t)A, true, w + L.sort_tmp, &tb, st)) return e;
+    }
+    MRCNN_HIP_TRY(hipMemsetAsync(n_valid, 0, sizeof(int32_t) * N, st));
+    hipLaunchKernelGGL(k_gather_sorted, dim3(mrcnn::cdiv(n_pre, 256), N), dim3(256), 0, st, keys_sorted, boxes, A, n_pre,
+                       sboxes, sidx, n_valid);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_nms_mask, dim3(L.nblk, L.nblk, N), dim3(64), 0, st, sboxes, n_valid, n_pre, L.nblk, nms_thresh, mask);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_nms_reduce, dim3(N), dim3(64), 0, st, mask, n_valid, n_pre, L.nblk, n_post, keep, n_rois);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_emit_rois, dim3(mrcnn::cdiv(n_post, 256), N), dim3(256), 0, st, sboxes, keep, n_rois, n_pre, n_post,
+                       rois, roi_indices, levels);
+    MRCNN_LAUNCH_CHECK();
+    if (dbg_sorted_anchor) MRCNN_HIP_TRY(hipMemcpyAsync(dbg_sorted_anchor, sidx, sizeof(int32_t) * (size_t)N * n_pre, hipMemcpyDeviceToDevice, st));
+    if (dbg_keep) MRCNN_HIP_TRY(hipMemcpyAsync(dbg_keep, keep, sizeof(int32_t) * (size_t)N * n_post, hipMemcpyDeviceToDevice, st));
+    if (dbg_n_pre) MRCNN_HIP_TRY(hipMemcpyAsync(dbg_n_pre, n_valid, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// Stand-alone greedy NMS on boxes already in priority order (ChainerCV non_maximum_suppression without
+// scores; maskrcnn.py:300 passes score-sorted boxes through the same routine).  boxes (n,4) yx.
+extern "C" size_t mrcnn_nms_workspace_bytes(int n) {
+    if (n <= 0) return 256;
+    const size_t nblk = (n + 63) / 64;
+    return al((size_t)n * nblk * 8) + 256;
+}
+extern "C" int mrcnn_nms_f32(const float *boxes, int n, float thresh, int max_keep, int32_t *keep, int32_t *n_keep,
+                             void *ws, size_t ws_bytes, void *stream) {
+    if (!keep || !n_keep || !ws || n < 0 || max_keep <= 0 || (n > 0 && !boxes))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "nms: bad arguments");
+    if (n > 16384) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "nms: n %d > 16384", n);
+    if (ws_bytes < mrcnn_nms_workspace_bytes(n)) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "nms: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = std::max(1, (n + 63) / 64);
+    int32_t *n_valid = (int32_t *)ws;
+    u64 *mask = (u64 *)((char *)ws + 256);
+    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, n_valid, (int32_t)n);
+    MRCNN_LAUNCH_CHECK();
+    if (n > 0) {
+        hipLaunchKernelGGL(k_nms_mask, dim3(nblk, nblk, 1), dim3(64), 0, st, boxes, n_valid, n, nblk, thresh, mask);
+        MRCNN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_nms_reduce, dim3(1), dim3(64), 0, st, mask, n_valid, std::max(n, 1), nblk, max_keep, keep, n_keep);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_map_rois_to_fpn_levels_f32(const float *rois, int R, int k_min, int k_max, float *levels,
+                                                void *stream) {
+    if (R == 0) return 0;
+    if (!rois || !levels || R < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "map_rois_to_fpn_levels: bad arguments");
+    hipLaunchKernelGGL(k_levels, dim3(mrcnn::cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, rois, R, (float)k_min,
+                       (float)k_max, levels);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}

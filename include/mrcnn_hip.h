@@ -105,23 +105,129 @@ int mrcnn_roi_align_sample_tables(const float *rois, int R, int H, int W, int PH
  *   chainer_maskrcnn/model/head/fpn_roi_mask_head.py:24-49,65-83
  * and their autograd backward passes.
  *   x  (N,H,W,Cin) NHWC      w  (Cout,KH,KW,Cin)      y  (N,Ho,Wo,Cout) NHWC
- *   Ho = (H + 2*pad - KH)/stride + 1.   Cin and Cout must be multiples of 32 (the host layer
- *   zero-pads channel counts such as 3, 4, 18, 80, 81).  bias (Cout) may be NULL; relu != 0
+ *   Ho = (H + 2*pad - KH)/stride + 1.   Cout must be a multiple of 32 and Cin a multiple of 32 or
+ *   exactly 4 (the image layer: K axis = (tap, 4 channels)); the host layer zero-pads channel
+ *   counts such as 3, 18, 80, 81.  bias (Cout) may be NULL; relu != 0
  *   fuses max(.,0) into the forward epilogue.  Linear layers are 1x1 convolutions with
  *   H = W = 1; the 2x2/2 deconvolution is a 1x1 convolution to 4*Cout channels + a host view.
- * bwd_data supports stride 1 only.  bwd_filter accumulates over pixels with a deterministic
+ * bwd_data supports stride 1 only (a strided 1x1 convolution is a stride-1 one on the subsampled
+ * lattice followed by mrcnn_subsample_bwd_f32); accumulate != 0 adds into gx instead of overwriting.  bwd_filter accumulates over pixels with a deterministic
  * split-K (slabs in the caller's workspace, fixed summation order); gbias may be NULL.
  * ---------------------------------------------------------------------------------------- */
 int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                          void *stream);
 int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, int N, int H, int W, int Cin,
-                              int Cout, int KH, int KW, int stride, int pad, void *stream);
+                              int Cout, int KH, int KW, int stride, int pad, int accumulate, void *stream);
 size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                                int stride, int pad);
 int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, float *gw, float *gbias, int N, int H,
                                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void *ws,
                                 size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone / head layer kernels (nn.hip), NHWC fp32, "(P, C)" = P pixels x C channels, C % 4 == 0.
+ * Replace the cuDNN / CuPy kernels behind ResNet50Layers' BatchNormalization + ReLU + residual add,
+ * F.max_pooling_2d(ksize=2) (cover_all), F.unpooling_2d(ksize=2, outsize) + add
+ * (chainer_maskrcnn/model/extractor/feature_pyramid_network.py:48-66), the ReLUs and the
+ * Deconvolution2D data movement of chainer_maskrcnn/model/head/fpn_roi_mask_head.py:65-83, and the
+ * optimizer of train.py:107-109.
+ * ---------------------------------------------------------------------------------------- */
+size_t mrcnn_bn_workspace_bytes(int P, int C);
+/* Training-mode BN: batch statistics over P, y = gamma*(x-mean)*invstd + beta (+ residual) (ReLU if
+ * relu != 0); save_mean / save_invstd (C) are kept for backward; running_* (nullable) are updated with
+ * Chainer's rule (decay, unbiased variance). */
+int mrcnn_bn_train_fwd_f32(const float *x, const float *gamma, const float *beta, const float *residual,
+                           float *y, float *save_mean, float *save_invstd, float *running_mean,
+                           float *running_var, int P, int C, float eps, float decay, int relu, void *ws,
+                           size_t ws_bytes, void *stream);
+/* dz = relu ? gy*(y>0) : gy;  gx = BN backward of dz;  gres (nullable) = dz (gradient of the residual
+ * input);  ggamma, gbeta (C) overwritten. */
+int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const float *y, const float *gamma,
+                           const float *save_mean, const float *save_invstd, float *gx, float *gres,
+                           float *ggamma, float *gbeta, int P, int C, int relu, void *ws, size_t ws_bytes,
+                           void *stream);
+int mrcnn_relu_bwd_f32(const float *gy, const float *y, float *gx, size_t n, void *stream);
+int mrcnn_add_f32(const float *a, const float *b, float *out, size_t n, void *stream);
+int mrcnn_maxpool2x2_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+int mrcnn_maxpool2x2_bwd_f32(const float *x, const float *gy, float *gx, int N, int H, int W, int C, void *stream);
+/* out (N,H,W,C) = nearest-2x(top (N,Ht,Wt,C)) cropped + lat;  backward: gtop (+)= 2x2 block sums of gout. */
+int mrcnn_upsample2x_add_fwd_f32(const float *top, const float *lat, float *out, int N, int H, int W, int Ht,
+                                 int Wt, int C, void *stream);
+int mrcnn_upsample2x_bwd_f32(const float *gout, float *gtop, int N, int H, int W, int Ht, int Wt, int C,
+                             int accumulate, void *stream);
+/* Backward of the lattice subsampling x[:, ::s, ::s] (strided 1x1 convolutions): gx (N,H,W,C). */
+int mrcnn_subsample_bwd_f32(const float *gsub, float *gx, int N, int H, int W, int C, int stride, int accumulate,
+                            void *stream);
+/* 2x2/2 deconvolution data movement: (N,H,W,[2][2][C]) <-> (N,2H,2W,C); inverse != 0 is the backward. */
+int mrcnn_pixel_shuffle2x_f32(const float *src, float *dst, int N, int H, int W, int C, int inverse, void *stream);
+/* g += wd*p; v = momentum*v - lr*g; p += v  over a flat parameter buffer (train.py:107-109). */
+int mrcnn_sgd_momentum_wd_f32(float *p, const float *g, float *v, size_t n, float lr, float momentum,
+                              float weight_decay, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses (loss.hip).  Replace F.softmax_cross_entropy, _fast_rcnn_loc_loss/_smooth_l1_loss and
+ * calc_mask_loss (chainer_maskrcnn/model/fpn_maskrcnn_train_chain.py:83-85,100-106; train.py:50-58;
+ * train_keypoints.py:21-27).  loss_out is 2 floats on the device: [0] = loss, [1] = normaliser.
+ * gx (nullable) receives d loss / d logits.
+ * ---------------------------------------------------------------------------------------- */
+size_t mrcnn_loss_workspace_bytes(void);
+int mrcnn_softmax_ce_f32(const float *x, int A, long long gs, long long rs, long long es, const int32_t *t,
+                         int M, int K, int ignore_label, float *loss_out, float *gx, long long ggs,
+                         long long grs, long long ges, int Kfill, void *ws, size_t ws_bytes, void *stream);
+int mrcnn_smooth_l1_f32(const float *x, int ldx, const float *t, const int32_t *label, int M, float sigma,
+                        float *loss_out, float *gx, int ldg, int gfill, void *ws, size_t ws_bytes, void *stream);
+int mrcnn_mask_bce_f32(const float *x, const int32_t *gt, const int32_t *label, int Rm, int HW, int Cm,
+                       float *loss_out, float *gx, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RPN proposal path (rpn.hip).  Replaces the transposes/concats and the ChainerCV ProposalCreator +
+ * non_maximum_suppression + map_rois_to_fpn_levels calls of
+ * chainer_maskrcnn/model/rpn/multilevel_region_proposal_network.py:16-31,133-164.
+ *   head (N,HW,Cp): channels [0,4A) loc, [4A,6A) score;  locs (N,Atot,4);  scores (N,Atot,2)
+ *   rois (N*n_post,4) yx, zero padded;  roi_indices (N*n_post) = image or -1;  levels f32;  n_rois (N)
+ *   dbg_* (nullable): anchor index of each pre-NMS box in sort order (N*n_pre), NMS keep list
+ *   (N*n_post, indices into the sort order), pre-NMS count (N).
+ * ---------------------------------------------------------------------------------------- */
+int mrcnn_rpn_pack_f32(const float *head, int N, int HW, int Cp, int A, float *locs, float *scores, int a_off,
+                       int Atot, void *stream);
+int mrcnn_rpn_unpack_grad_f32(const float *glocs, const float *gscores, int N, int HW, int Cp, int A,
+                              float *ghead, int a_off, int Atot, void *stream);
+size_t mrcnn_rpn_proposals_workspace_bytes(int N, int A, int n_pre, int n_post);
+int mrcnn_rpn_proposals_f32(const float *locs, const float *scores, const float *anchors, int N, int A,
+                            float img_h, float img_w, float min_size, int n_pre, int n_post, float nms_thresh,
+                            float *rois, int32_t *roi_indices, float *levels, int32_t *n_rois,
+                            int32_t *dbg_sorted_anchor, int32_t *dbg_keep, int32_t *dbg_n_pre, void *ws,
+                            size_t ws_bytes, void *stream);
+size_t mrcnn_nms_workspace_bytes(int n);
+int mrcnn_nms_f32(const float *boxes, int n, float thresh, int max_keep, int32_t *keep, int32_t *n_keep,
+                  void *ws, size_t ws_bytes, void *stream);
+int mrcnn_map_rois_to_fpn_levels_f32(const float *rois, int R, int k_min, int k_max, float *levels, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Target creators (targets.hip).  Replace chainer_maskrcnn/utils/proposal_target_creator.py:26-137
+ * (host NumPy + cv2) and ChainerCV's AnchorTargetCreator (model/fpn_maskrcnn_train_chain.py:81-82).
+ * Per image i the sampler owns rows [i*n_sample, (i+1)*n_sample): positives first, then negatives,
+ * then padding (label -1).  keys: uint32 random numbers, (N, roi_cap + gt_cap) / (N, A).
+ * ---------------------------------------------------------------------------------------- */
+int mrcnn_proposal_target_f32(const float *rois, const float *roi_levels, const int32_t *n_rois, int roi_cap,
+                              const float *gt_boxes, const int32_t *gt_labels, const int32_t *n_gt, int gt_cap,
+                              const uint32_t *keys, int N, int n_sample, int n_pos_max, float pos_iou_thresh,
+                              float neg_iou_thresh_hi, float neg_iou_thresh_lo, const float *loc_mean4,
+                              const float *loc_std4, float *sample_roi, float *rois_xy5, int32_t *sample_levels,
+                              float *gt_roi_loc, int32_t *gt_roi_label, int32_t *gt_assign, int32_t *sample_src,
+                              int32_t *n_pos, int32_t *n_sampled, void *stream);
+int mrcnn_mask_target_u8(const unsigned char *masks, int N, int gt_cap, int H, int W, const float *sample_roi,
+                         const int32_t *gt_assign, const int32_t *n_pos, int n_sample, int pos_cap, int mask_size,
+                         int32_t *gt_roi_mask, void *stream);
+int mrcnn_keypoint_target_f32(const float *keypoints, int N, int gt_cap, int K, const float *sample_roi,
+                              const int32_t *gt_assign, const int32_t *n_pos, int n_sample, int pos_cap,
+                              int mask_size, int32_t *gt_roi_kp, void *stream);
+size_t mrcnn_anchor_target_workspace_bytes(int N, int A);
+int mrcnn_anchor_target_f32(const float *anchors, int A, const float *gt_boxes, const int32_t *n_gt, int gt_cap,
+                            int N, float img_h, float img_w, const uint32_t *keys, int n_sample,
+                            float pos_iou_thresh, float neg_iou_thresh, float pos_ratio, int do_sample,
+                            float *gt_rpn_loc, int32_t *gt_rpn_label, void *ws, size_t ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -82,7 +82,7 @@ class ProposalTargetCreator(object):
 
     def __call__(self, roi, bbox, label, mask, levels,
                  loc_normalize_mean=(0., 0., 0., 0.), loc_normalize_std=(0.1, 0.1, 0.2, 0.2),
-                 mask_size=14, binary_mask=True, rng=None, return_debug=False):
+                 mask_size=14, binary_mask=True, rng=None, return_debug=False, mutate_gt=True):
         rng = rng if rng is not None else np.random
         roi = np.asarray(roi, F)
         bbox = np.asarray(bbox, F)
@@ -125,6 +125,8 @@ class ProposalTargetCreator(object):
             for i, idx in enumerate(gt_assignment[pos_index]):               # :105-127
                 y0, x0, y1, x1 = list(map(int, sample_roi[i, :4]))
                 kp = mask[idx]      # view: mutated IN PLACE like the reference (:112-115)
+                if not mutate_gt:   # the device kernel's deliberate fix: work on a copy
+                    kp = kp.copy()
                 kp[:, :2] = (kp[:, :2] - [y0, x0]) / [max(y1 - y0, 1), max(x1 - x0, 1)] * mask_size
                 keypoint_labels = np.zeros(kp.shape[0], dtype=np.int32)
                 for j, r in enumerate(kp):
@@ -219,3 +221,32 @@ class AnchorTargetCreator(object):
         full_loc = np.zeros((n_anchor, 4), F)
         full_loc[inside] = loc
         return full_loc, full_label
+
+
+def anchor_targets_from_keys(bbox, anchor, img_size, keys, n_sample=256, pos_iou_thresh=0.7,
+                             neg_iou_thresh=0.3, pos_ratio=0.5):
+    """Key-driven AnchorTargetCreator used to pin the DEVICE sampler: identical labels before
+    sampling; the random "disable" draws of the reference are replaced by "keep the k candidates
+    with the smallest (key, anchor index)" for caller-supplied uint32 ``keys`` (one per anchor).
+    Returns (loc (A,4) f32, label (A,) i32)."""
+    atc = AnchorTargetCreator(n_sample, pos_iou_thresh, neg_iou_thresh, pos_ratio)
+    bbox = np.asarray(bbox, F)
+    n_anchor = len(anchor)
+    inside, a, argmax_ious, _, label = atc.labels_before_sampling(bbox, anchor, img_size)
+    comp = (np.asarray(keys, np.uint64)[inside] << np.uint64(31)) | inside.astype(np.uint64)
+
+    def keep_smallest(cand, k):
+        if cand.size > k:
+            order = cand[np.argsort(comp[cand], kind='stable')]
+            label[order[k:]] = -1
+
+    n_pos = int(pos_ratio * n_sample)
+    keep_smallest(np.where(label == 1)[0], n_pos)
+    n_neg = n_sample - int(np.sum(label == 1))
+    keep_smallest(np.where(label == 0)[0], n_neg)
+    loc = bbox2loc(a, bbox[argmax_ious])
+    full_label = np.full((n_anchor,), -1, np.int32)
+    full_label[inside] = label
+    full_loc = np.zeros((n_anchor, 4), F)
+    full_loc[inside] = loc
+    return full_loc, full_label

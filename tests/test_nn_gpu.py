@@ -1,0 +1,149 @@
+"""GPU tests: HBM-bound layer kernels (nn.hip) against plain PyTorch float64 CPU references
+(floating-point kernels => torch reference; tolerance 1e-3 relative per BASELINE.json north_star,
+observed ~1e-6) and the fused SGD update against the NumPy statement of train.py:107-109."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from chainer_maskrcnn._hip import ops  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def _rel(got, ref):
+    return (got.double().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+
+
+@pytest.mark.parametrize('shape', [(2, 9, 7, 64), (1, 5, 6, 256), (2, 3, 3, 2048), (1, 31, 17, 8), (3, 40, 40, 128)])
+@pytest.mark.parametrize('relu,res', [(False, False), (True, False), (True, True)])
+def test_bn_train_fwd_bwd(shape, relu, res):
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[-1]
+    x = (torch.randn(shape, generator=g, dtype=torch.float64) * 2 + 3).requires_grad_(True)   # |mean| > std
+    gamma = torch.rand((C,), generator=g, dtype=torch.float64).add_(0.5).requires_grad_(True)
+    beta = torch.randn((C,), generator=g, dtype=torch.float64).requires_grad_(True)
+    r = torch.randn(shape, generator=g, dtype=torch.float64).requires_grad_(True) if res else None
+    xr = x.reshape(-1, C)
+    mean, var = xr.mean(0), xr.var(0, unbiased=False)
+    y = gamma * (x - mean) / torch.sqrt(var + 2e-5) + beta
+    if res:
+        y = y + r
+    if relu:
+        y = y.clamp_min(0)
+    gy = torch.randn(shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    rm = torch.zeros((C,), device=DEV)
+    rv = torch.ones((C,), device=DEV)
+    xd = x.detach().float().to(DEV)
+    yd, m, s = ops.bn_train_fwd(xd, gamma.detach().float().to(DEV), beta.detach().float().to(DEV),
+                                r.detach().float().to(DEV) if res else None, relu, rm, rv)
+    assert _rel(yd, y.detach()) < 1e-5
+    assert _rel(m, mean.detach()) < 1e-6
+    assert _rel(s, 1 / torch.sqrt(var.detach() + 2e-5)) < 1e-5
+    P = xr.shape[0]
+    assert _rel(rm, 0.1 * mean.detach()) < 1e-5
+    assert _rel(rv, 0.9 + 0.1 * var.detach() * P / max(P - 1, 1)) < 1e-5
+    gx, gres, gg, gb = ops.bn_train_bwd(gy.float().to(DEV), xd, yd, gamma.detach().float().to(DEV), m, s, relu, res)
+    assert _rel(gx, x.grad) < 2e-5
+    assert _rel(gg, gamma.grad) < 2e-5
+    assert _rel(gb, beta.grad) < 2e-5
+    if res:
+        assert _rel(gres, r.grad) < 1e-6
+    # bit-reproducible reductions
+    gx2, _, gg2, _ = ops.bn_train_bwd(gy.float().to(DEV), xd, yd, gamma.detach().float().to(DEV), m, s, relu, res)
+    assert torch.equal(gx, gx2) and torch.equal(gg, gg2)
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 8, 16), (1, 9, 7, 64), (2, 5, 5, 8), (1, 1, 1, 4)])
+def test_maxpool_cover_all(shape):
+    g = torch.Generator().manual_seed(1 + sum(shape))
+    x = torch.randn(shape, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.max_pool2d(x.permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd = x.detach().float().to(DEV)
+    yd = ops.maxpool2x2_fwd(xd)
+    assert yd.shape == y.shape
+    assert torch.equal(yd.cpu(), y.detach().float())
+    gx = ops.maxpool2x2_bwd(xd, gy.float().contiguous().to(DEV))
+    assert torch.equal(gx.cpu(), x.grad.float())
+
+
+def test_maxpool_tie_goes_to_first_cell():
+    x = torch.zeros((1, 2, 2, 4), device=DEV)
+    gy = torch.ones((1, 1, 1, 4), device=DEV)
+    gx = ops.maxpool2x2_bwd(x, gy).cpu()
+    assert torch.equal(gx[0, 0, 0], torch.ones(4)) and gx.sum().item() == 4
+
+
+@pytest.mark.parametrize('H,W', [(8, 8), (7, 9), (13, 25)])
+def test_upsample_add_and_backward(H, W):
+    g = torch.Generator().manual_seed(H * W)
+    N, C = 2, 16
+    Ht, Wt = (H + 1) // 2, (W + 1) // 2
+    top = torch.randn((N, Ht, Wt, C), generator=g, dtype=torch.float64, requires_grad=True)
+    lat = torch.randn((N, H, W, C), generator=g, dtype=torch.float64)
+    up = top.repeat_interleave(2, 1).repeat_interleave(2, 2)[:, :H, :W]
+    out = up + lat
+    gout = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(gout)
+    od = ops.upsample2x_add_fwd(top.detach().float().to(DEV), lat.float().to(DEV))
+    assert torch.equal(od.cpu(), (up.detach().float() + lat.float()))
+    gt = ops.upsample2x_bwd(gout.float().to(DEV), top_shape=tuple(top.shape))
+    assert _rel(gt, top.grad) < 1e-6
+    base = torch.randn(top.shape, generator=g).to(DEV)
+    gt2 = ops.upsample2x_bwd(gout.float().to(DEV), gtop=base.clone())
+    assert _rel(gt2, top.grad + base.cpu().double()) < 1e-6
+
+
+@pytest.mark.parametrize('H,W,s', [(8, 8, 2), (7, 9, 2), (5, 5, 1)])
+def test_subsample_bwd(H, W, s):
+    g = torch.Generator().manual_seed(3)
+    N, C = 2, 8
+    x = torch.randn((N, H, W, C), generator=g, dtype=torch.float64, requires_grad=True)
+    y = x[:, ::s, ::s]
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    gx = ops.subsample_bwd(gy.float().contiguous().to(DEV), tuple(x.shape), s)
+    assert torch.equal(gx.cpu(), x.grad.float())
+    base = torch.randn(x.shape, generator=g).to(DEV)
+    gx2 = ops.subsample_bwd(gy.float().contiguous().to(DEV), tuple(x.shape), s, gx=base.clone())
+    assert _rel(gx2, x.grad + base.cpu().double()) < 1e-6
+
+
+def test_pixel_shuffle_roundtrip_matches_deconv_layout():
+    g = torch.Generator().manual_seed(4)
+    N, H, W, C = 2, 3, 5, 8
+    t = torch.randn((N, H, W, 4 * C), generator=g)
+    want = t.reshape(N, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * H, 2 * W, C)
+    got = ops.pixel_shuffle2x(t.to(DEV))
+    assert torch.equal(got.cpu(), want)
+    back = ops.pixel_shuffle2x(got, inverse=True)
+    assert torch.equal(back.cpu(), t)
+
+
+def test_relu_bwd_and_add():
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn((1000,), generator=g).clamp_min(0)
+    gy = torch.randn((1000,), generator=g)
+    got = ops.relu_bwd(gy.to(DEV), y.to(DEV))
+    assert torch.equal(got.cpu(), gy * (y > 0))
+    a, b = torch.randn((4096,), generator=g), torch.randn((4096,), generator=g)
+    assert torch.equal(ops.add(a.to(DEV), b.to(DEV)).cpu(), a + b)
+
+
+@pytest.mark.parametrize('n', [4096, 1000003])
+def test_sgd_momentum_weight_decay(n):
+    rs = np.random.RandomState(n)
+    p, g, v = (rs.standard_normal(n).astype(np.float32) for _ in range(3))
+    lr, mom, wd = np.float32(1e-3), np.float32(0.9), np.float32(5e-4)
+    gg = g + wd * p                       # WeightDecay hook (train.py:109)
+    v2 = mom * v - lr * gg                # MomentumSGD (train.py:107)
+    p2 = p + v2
+    pd, gd, vd = (torch.from_numpy(t).to(DEV) for t in (p, g, v))
+    ops.sgd_momentum_wd(pd, gd, vd, float(lr), float(mom), float(wd))
+    np.testing.assert_allclose(vd.cpu().numpy(), v2, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(pd.cpu().numpy(), p2, rtol=1e-6, atol=1e-9)

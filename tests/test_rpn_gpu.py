@@ -1,0 +1,136 @@
+"""GPU parity tests: device proposal path (rpn.hip) against the NumPy oracle (oracle/boxes.py,
+oracle/proposal.py).  Integer outputs (sort order, NMS keep lists, FPN levels) are bit-exact given
+identical float inputs; decoded boxes involve exp() and are compared to 2 ulp-level tolerance, so
+the end-to-end bit-exact case uses dh = dw = 0 (exp(0) == 1 on both sides)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as ob
+from oracle.proposal import ProposalCreator
+
+pytestmark = pytest.mark.gpu
+
+from chainer_maskrcnn._hip import ops  # noqa: E402
+
+DEV = 'cuda:0'
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _rand_boxes(rs, n, size=400.0):
+    c = rs.uniform(0, size, (n, 2))
+    hw = np.exp(rs.uniform(np.log(8), np.log(200), (n, 2)))
+    return np.concatenate([c - hw / 2, c + hw / 2], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize('n,thresh', [(1, 0.7), (63, 0.7), (64, 0.5), (65, 0.3), (1000, 0.7), (5000, 0.7)])
+def test_nms_keep_list_bit_exact(n, thresh):
+    rs = np.random.RandomState(n)
+    b = _rand_boxes(rs, n)
+    if n > 100:      # duplicates and threshold-equal pairs
+        b[10] = b[3]
+        b[11] = [0, 0, 10, 10]
+        b[12] = [0, 0, 10, 7]        # IoU exactly 0.7 with box 11
+    want = ob.nms(b, thresh)
+    keep, nk = ops.nms(torch.from_numpy(b).to(DEV), thresh)
+    nk = int(nk.item())
+    assert nk == len(want)
+    np.testing.assert_array_equal(keep.cpu().numpy()[:nk], want)
+
+
+def test_nms_max_keep_and_empty():
+    rs = np.random.RandomState(2)
+    b = _rand_boxes(rs, 500)
+    want = ob.nms(b, 0.7)[:50]
+    keep, nk = ops.nms(torch.from_numpy(b).to(DEV), 0.7, max_keep=50)
+    assert int(nk.item()) == 50
+    np.testing.assert_array_equal(keep.cpu().numpy(), want)
+    keep, nk = ops.nms(torch.zeros((0, 4), device=DEV), 0.7)
+    assert int(nk.item()) == 0
+
+
+def test_fpn_levels_match_reference_golden():
+    """tests/golden/levels_reference.npz was produced by the REFERENCE function
+    (model/rpn/multilevel_region_proposal_network.py:16-31) in the build container."""
+    z = np.load(os.path.join(GOLDEN, 'levels_reference.npz'))
+    rois, want = z['rois'], z['levels']
+    got = ops.map_rois_to_fpn_levels(torch.from_numpy(np.ascontiguousarray(rois, np.float32)).to(DEV)).cpu().numpy()
+    np.testing.assert_array_equal(got, want.astype(np.float32))
+    rs = np.random.RandomState(0)
+    b = _rand_boxes(rs, 5000, 1000.0)
+    np.testing.assert_array_equal(ops.map_rois_to_fpn_levels(torch.from_numpy(b).to(DEV)).cpu().numpy(),
+                                  ob.map_rois_to_fpn_levels(b))
+
+
+def _rpn_case(seed, N, feat_shapes, exact):
+    rs = np.random.RandomState(seed)
+    anchors = ob.fpn_anchors(feat_shapes)
+    A = anchors.shape[0]
+    locs = (rs.standard_normal((N, A, 4)) * 0.3).astype(np.float32)
+    if exact:
+        locs[:, :, 2:] = 0
+    scores = rs.standard_normal((N, A, 2)).astype(np.float32)
+    scores[:, 5:40, 1] = scores[0, 5, 1]          # tied scores: order must follow the (score desc, index desc) pin
+    return anchors, locs, scores
+
+
+@pytest.mark.parametrize('n_pre,n_post', [(12000, 2000), (600, 100)])
+def test_proposals_end_to_end_bit_exact(n_pre, n_post):
+    N = 2
+    feat = [(40, 48), (20, 24), (10, 12), (5, 6), (3, 3)]
+    anchors, locs, scores = _rpn_case(1, N, feat, exact=True)
+    img_size = (160, 192)
+    o = ops.rpn_proposals(torch.from_numpy(locs).to(DEV), torch.from_numpy(scores).to(DEV), torch.from_numpy(anchors).to(DEV),
+                          img_size, 16.0, n_pre, n_post, 0.7, debug=True)
+    pc = ProposalCreator(n_train_pre_nms=n_pre, n_train_post_nms=n_post)
+    for i in range(N):
+        want, dbg = pc(locs[i], scores[i, :, 1], anchors, img_size, return_debug=True)
+        npre = int(o['n_pre'][i].item())
+        assert npre == len(dbg['pre_nms_index'])
+        np.testing.assert_array_equal(o['sorted_anchor'].cpu().numpy().reshape(N, -1)[i, :npre], dbg['pre_nms_index'])
+        nk = int(o['n_rois'][i].item())
+        assert nk == len(want)
+        np.testing.assert_array_equal(o['keep'].cpu().numpy().reshape(N, -1)[i, :nk], dbg['nms_keep'])
+        got = o['rois'].cpu().numpy().reshape(N, n_post, 4)[i]
+        np.testing.assert_array_equal(got[:nk], want)
+        assert np.all(got[nk:] == 0)
+        idx = o['roi_indices'].cpu().numpy().reshape(N, n_post)[i]
+        assert np.all(idx[:nk] == i) and np.all(idx[nk:] == -1)
+        np.testing.assert_array_equal(o['levels'].cpu().numpy().reshape(N, n_post)[i, :nk], ob.map_rois_to_fpn_levels(want))
+
+
+def test_proposals_random_scales_decode_tolerance():
+    """exp() differs by <= 2 ulp between NumPy and the device: boxes compared with tolerance."""
+    N = 1
+    feat = [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]
+    anchors, locs, scores = _rpn_case(2, N, feat, exact=False)
+    img_size = (128, 128)
+    o = ops.rpn_proposals(torch.from_numpy(locs).to(DEV), torch.from_numpy(scores).to(DEV), torch.from_numpy(anchors).to(DEV),
+                          img_size, 16.0, 3000, 300, 0.7, debug=True)
+    want, dbg = ProposalCreator(n_train_pre_nms=3000, n_train_post_nms=300)(locs[0], scores[0, :, 1], anchors, img_size,
+                                                                            return_debug=True)
+    nk = int(o['n_rois'][0].item())
+    got = o['rois'].cpu().numpy()[:nk]
+    m = min(nk, len(want), 50)          # the head of the list is stable under ulp-level box differences
+    np.testing.assert_allclose(got[:m], want[:m], rtol=1e-5, atol=1e-4)
+    assert abs(nk - len(want)) <= 3
+
+
+def test_pack_unpack_roundtrip():
+    rs = np.random.RandomState(5)
+    N, H, W, Cp, A = 2, 5, 7, 32, 3
+    head = rs.standard_normal((N, H, W, Cp)).astype(np.float32)
+    Atot = H * W * A + 11
+    locs = torch.zeros((N, Atot, 4), device=DEV)
+    scores = torch.zeros((N, Atot, 2), device=DEV)
+    ops.rpn_pack(torch.from_numpy(head).to(DEV), A, locs, scores, 11)
+    # reference semantics: NCHW conv output -> transpose(0,2,3,1).reshape(n,-1,4)  (multilevel_rpn.py:133-141)
+    want_l = head[..., :12].reshape(N, H * W * A, 4)
+    want_s = head[..., 12:18].reshape(N, H * W * A, 2)
+    np.testing.assert_array_equal(locs.cpu().numpy()[:, 11:], want_l)
+    np.testing.assert_array_equal(scores.cpu().numpy()[:, 11:], want_s)
+    gh = ops.rpn_unpack_grad(locs, scores, (N, H, W, Cp), A, 11).cpu().numpy()
+    np.testing.assert_array_equal(gh[..., :18], head[..., :18])
+    assert np.all(gh[..., 18:] == 0)
