@@ -30,7 +30,7 @@ _MANUAL = {
                                             c_int, c_int, c_void_p]),
 }
 _CTYPE = {'int': c_int, 'float': c_float, 'size_t': c_size_t, 'long long': ctypes.c_longlong,
-          'int32_t': ctypes.c_int32, 'unsigned': ctypes.c_uint}
+          'int32_t': ctypes.c_int32, 'unsigned': ctypes.c_uint, 'unsigned long long': ctypes.c_ulonglong}
 
 
 def _parse_header(path):

@@ -52,14 +52,17 @@ def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None):
     return gx
 
 
-def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias):
+def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias, gw=None, gb=None):
+    """gw / gb given => gradients are ACCUMULATED into them (shared layers); else allocated."""
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w_shape
     assert gy.is_contiguous() and x.is_contiguous()
-    gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
-    gb = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    acc = gw is not None
+    if gw is None:
+        gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+        gb = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     nbytes = lib().mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     ws = workspace(nbytes, x.device)
-    check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x), ptr(gy), ptr(gw), ptr(gb), N, H, W, Cin, Cout, KH,
-                                            KW, stride, pad, ptr(ws), ws.numel(), stream_ptr()))
+    check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x), ptr(gy), ptr(gw), ptr(gb) if want_bias else None, N, H, W, Cin,
+                                            Cout, KH, KW, stride, pad, int(acc), ptr(ws), ws.numel(), stream_ptr()))
     return gw, gb

@@ -119,9 +119,9 @@ def subsample_bwd(gsub, x_shape, stride, gx=None):
     return gx
 
 
-def pixel_shuffle2x(t, inverse=False):
-    """forward: t (N,H,W,4*C) -> (N,2H,2W,C); inverse: (N,2H,2W,C) -> (N,H,W,4*C)."""
-    _ck(t)
+def pixel_shuffle2x(t, bias=None, inverse=False):
+    """forward: t (N,H,W,4*C) [+ bias (C)] -> (N,2H,2W,C); inverse: (N,2H,2W,C) -> (N,H,W,4*C)."""
+    _ck(t, bias)
     if not inverse:
         N, H, W, C4 = t.shape
         C = C4 // 4
@@ -130,7 +130,24 @@ def pixel_shuffle2x(t, inverse=False):
         N, H2, W2, C = t.shape
         H, W = H2 // 2, W2 // 2
         out = _empty((N, H, W, 4 * C), t.device)
-    check(lib().mrcnn_pixel_shuffle2x_f32(ptr(t), ptr(out), N, H, W, C, int(inverse), stream_ptr()))
+    check(lib().mrcnn_pixel_shuffle2x_f32(ptr(t), ptr(bias), ptr(out), N, H, W, C, int(inverse), stream_ptr()))
+    return out
+
+
+def image_nchw3_to_nhwc4(x):
+    _ck(x)
+    N, C, H, W = x.shape
+    if C != 3:
+        raise ValueError('expected (N,3,H,W) images')
+    y = _empty((N, H, W, 4), x.device)
+    check(lib().mrcnn_image_nchw3_to_nhwc4_f32(ptr(x), ptr(y), N, H, W, stream_ptr()))
+    return y
+
+
+def random_keys(shape, seed, device):
+    """uint32 sampler keys stored in an int32 tensor."""
+    out = _empty(shape, device, i32)
+    check(lib().mrcnn_random_keys_u32(ptr(out), out.numel(), int(seed) & (2 ** 64 - 1), stream_ptr()))
     return out
 
 
@@ -144,12 +161,12 @@ def _loss_ws(dev):
     return workspace(lib().mrcnn_loss_workspace_bytes(), dev)
 
 
-def softmax_ce(x, t, M, K, xmap, gmap=None, Kfill=0, want_grad=True, gx=None, ignore_label=-1):
+def softmax_ce(x, t, M, K, xmap, gmap=None, Kfill=0, want_grad=True, gx=None, ignore_label=-1, out=None):
     """x: device tensor holding a logical (M,K) matrix; xmap = (A, gs, rs, es) element map
     (see include/mrcnn_hip.h).  Returns (loss_out (2,), gx)."""
     _ck(t)
     _hip.require_cuda(x)
-    out = _empty((2,), x.device)
+    out = _empty((2,), x.device) if out is None else out
     gmap = gmap or xmap
     if want_grad and gx is None:
         gx = torch.empty_like(x)
@@ -160,26 +177,39 @@ def softmax_ce(x, t, M, K, xmap, gmap=None, Kfill=0, want_grad=True, gx=None, ig
     return out, gx
 
 
-def smooth_l1(x, ldx, t, label, M, sigma, want_grad=True, gfill=0):
-    _ck(x, t, label)
-    out = _empty((2,), x.device)
-    gx = torch.empty_like(x) if want_grad else None
+def smooth_l1(x, ldx, t, label, M, sigma, want_grad=True, gfill=0, col0=0, gx=None, out=None):
+    """x: (M, ldx) buffer; the 4 predictions of row r start at column col0.  gx (same buffer shape) receives
+    columns [col0, col0+max(4,gfill))."""
+    _ck(x, t, label, gx)
+    out = _empty((2,), x.device) if out is None else out
+    if want_grad and gx is None:
+        gx = torch.empty_like(x)
     ws = _loss_ws(x.device)
-    check(lib().mrcnn_smooth_l1_f32(ptr(x), ldx, ptr(t), ptr(label), M, sigma, ptr(out), ptr(gx), ldx, gfill, ptr(ws),
+    xp = ctypes.c_void_p(x.data_ptr() + 4 * col0)
+    gp = ctypes.c_void_p(gx.data_ptr() + 4 * col0) if want_grad else None
+    check(lib().mrcnn_smooth_l1_f32(xp, ldx, ptr(t), ptr(label), M, sigma, ptr(out), gp, ldx, gfill, ptr(ws),
                                     ws.numel(), stream_ptr()))
     return out, gx
 
 
-def mask_bce(x, gt, label, want_grad=True):
+def mask_bce(x, gt, label, want_grad=True, out=None):
     """x (Rm,H,W,Cm) NHWC logits, gt (Rm,H,W) int32, label (Rm,) int32."""
     _ck(x, gt, label)
     Rm, H, W, Cm = x.shape
-    out = _empty((2,), x.device)
+    out = _empty((2,), x.device) if out is None else out
     gx = torch.empty_like(x) if want_grad else None
     ws = _loss_ws(x.device)
     check(lib().mrcnn_mask_bce_f32(ptr(x), ptr(gt), ptr(label), Rm, H * W, Cm, ptr(out), ptr(gx), ptr(ws), ws.numel(),
                                    stream_ptr()))
     return out, gx
+
+
+def loss_total(losses):
+    """losses (n,2) device pairs -> (1,) total."""
+    _ck(losses)
+    out = _empty((1,), losses.device)
+    check(lib().mrcnn_loss_total_f32(ptr(losses), losses.shape[0], ptr(out), stream_ptr()))
+    return out
 
 
 # ---- RPN proposal path --------------------------------------------------------------------------

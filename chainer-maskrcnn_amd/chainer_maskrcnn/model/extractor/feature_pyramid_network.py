@@ -1,0 +1,104 @@
+"""ResNet-50 + FPN feature extractor on gfx950 kernels.
+
+Mirror of chainer_maskrcnn/model/extractor/feature_pyramid_network.py:9-71 (class attributes :9-16,
+layers :22-40, forward :46-71) with the bottom-up network of Chainer's ``ResNet50Layers`` (SURVEY.md
+Appendix A-8) spelled out.  Quirks kept on purpose (SURVEY.md Appendix B-1,2,4): 2x2/2 cover_all
+max-pool after conv1, BatchNorm in training mode, no 3x3 smoothing on P5, P6 = 1x1 stride-2 conv of P5.
+Tensors are NHWC; the image enters as (N,H,W,4) with a zero 4th channel.
+"""
+from chainer_maskrcnn.nn.core import Conv, BatchNorm, Bottleneck, ParamStore
+from chainer_maskrcnn._hip import ops
+
+
+class FeaturePyramidNetwork(object):
+    feat_strides = [4, 8, 16, 32, 64]
+    spatial_scales = list(map(lambda x: 1. / x, feat_strides))
+    anchor_base = 16
+    anchor_sizes = [32, 64, 128, 256, 512]
+    anchor_scales = list(map(lambda x: x / 16., anchor_sizes))
+
+    STAGES = (('res2', 3, 64, 64, 256, 1), ('res3', 4, 256, 128, 512, 2),
+              ('res4', 6, 512, 256, 1024, 2), ('res5', 3, 1024, 512, 2048, 2))
+
+    def __init__(self, ps=None, prefix='extractor', stages=None, width_div=1):
+        """``stages`` / ``width_div`` shrink the network for tests (blocks per stage, channel divisor);
+        the defaults are the reference's ResNet-50."""
+        self.ps = ps if ps is not None else ParamStore()
+        p = prefix + '/'
+        d = width_div
+        self.conv1 = Conv(self.ps, p + 'resnet/conv1', 3, 64 // d, 7, 2, 3, bias=True)
+        self.bn1 = BatchNorm(self.ps, p + 'resnet/bn1', 64 // d)
+        self.stages = []
+        for si, (name, n, cin, mid, cout, stride) in enumerate(self.STAGES):
+            n = n if stages is None else stages[si]
+            cin, mid, cout = cin // d, mid // d, cout // d
+            blocks = [Bottleneck(self.ps, p + 'resnet/%s/a' % name, cin, mid, cout, stride, True)]
+            for i in range(1, n):
+                blocks.append(Bottleneck(self.ps, p + 'resnet/%s/b%d' % (name, i), cout, mid, cout, 1, False))
+            self.stages.append(blocks)
+        fc = 256 // d
+        self.out_channels = fc
+        self.toplayer = Conv(self.ps, p + 'toplayer', 2048 // d, fc, 1)
+        self.conv_p4 = Conv(self.ps, p + 'conv_p4', fc, fc, 3, 1, 1)
+        self.conv_p3 = Conv(self.ps, p + 'conv_p3', fc, fc, 3, 1, 1)
+        self.conv_p2 = Conv(self.ps, p + 'conv_p2', fc, fc, 3, 1, 1)
+        self.conv_p6 = Conv(self.ps, p + 'conv_p6', fc, fc, 1, 2, 0)
+        self.lat_p4 = Conv(self.ps, p + 'lat_p4', 1024 // d, fc, 1)
+        self.lat_p3 = Conv(self.ps, p + 'lat_p3', 512 // d, fc, 1)
+        self.lat_p2 = Conv(self.ps, p + 'lat_p2', 256 // d, fc, 1)
+        self.anchor_scales = list(map(lambda x: x / float(self.anchor_base), self.anchor_sizes))
+
+    def __call__(self, x):
+        """x (N,H,W,4) NHWC.  Returns (p2, p3, p4, p5, p6) NHWC and keeps the tape for backward()."""
+        t = {}
+        h, t['conv1'] = self.conv1.fwd(x)
+        h, t['bn1'] = self.bn1.fwd(h, relu=True)
+        t['pool_in'] = h
+        h = ops.maxpool2x2_fwd(h)
+        cs = []
+        t['blocks'] = []
+        for blocks in self.stages:
+            for b in blocks:
+                h, ctx = b.fwd(h)
+                t['blocks'].append((b, ctx))
+            cs.append(h)
+        c2, c3, c4, c5 = cs
+        p5, t['top'] = self.toplayer.fwd(c5)
+        l4, t['lat4'] = self.lat_p4.fwd(c4)
+        m4 = ops.upsample2x_add_fwd(p5, l4)
+        p4, t['p4'] = self.conv_p4.fwd(m4)
+        l3, t['lat3'] = self.lat_p3.fwd(c3)
+        m3 = ops.upsample2x_add_fwd(p4, l3)
+        p3, t['p3'] = self.conv_p3.fwd(m3)
+        l2, t['lat2'] = self.lat_p2.fwd(c2)
+        m2 = ops.upsample2x_add_fwd(p3, l2)
+        p2, t['p2'] = self.conv_p2.fwd(m2)
+        p6, t['p6'] = self.conv_p6.fwd(p5)
+        self.tape = t
+        return p2, p3, p4, p5, p6
+
+    def backward(self, grads):
+        """grads: [g_p2, g_p3, g_p4, g_p5, g_p6]; consumed (accumulated into in place)."""
+        t = self.tape
+        g_p2, g_p3, g_p4, g_p5, g_p6 = grads
+        self.conv_p6.bwd(t['p6'], g_p6, gx_acc=g_p5)
+        g_m2 = self.conv_p2.bwd(t['p2'], g_p2)
+        ops.upsample2x_bwd(g_m2, gtop=g_p3)
+        g_c2 = self.lat_p2.bwd(t['lat2'], g_m2)
+        g_m3 = self.conv_p3.bwd(t['p3'], g_p3)
+        ops.upsample2x_bwd(g_m3, gtop=g_p4)
+        g_c3 = self.lat_p3.bwd(t['lat3'], g_m3)
+        g_m4 = self.conv_p4.bwd(t['p4'], g_p4)
+        ops.upsample2x_bwd(g_m4, gtop=g_p5)
+        g_c4 = self.lat_p4.bwd(t['lat4'], g_m4)
+        g_c5 = self.toplayer.bwd(t['top'], g_p5)
+        # The gradient of c2..c4 is (lateral gradient) + (input gradient of the next stage): the next
+        # stage's first block accumulates its input gradient into the lateral one (gx_acc).
+        acc_for = {id(self.stages[k][0]): g for k, g in ((1, g_c2), (2, g_c3), (3, g_c4))}
+        g = g_c5
+        for b, ctx in reversed(t['blocks']):
+            g = b.bwd(ctx, g, gx_acc=acc_for.get(id(b)))
+        g = ops.maxpool2x2_bwd(t['pool_in'], g)
+        g, _ = self.bn1.bwd(t['bn1'], g)
+        self.conv1.bwd(t['conv1'], g, need_gx=False)
+        self.tape = None

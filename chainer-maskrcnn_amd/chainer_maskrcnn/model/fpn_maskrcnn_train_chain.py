@@ -1,0 +1,196 @@
+"""The FPN Mask R-CNN training step on gfx950 kernels.
+
+Mirror of chainer_maskrcnn/model/fpn_maskrcnn_train_chain.py:14-117: same constructor arguments,
+``__call__(imgs, bboxes, labels, masks, scale) -> loss``, five un-weighted losses (:106), the same
+report keys (:108-115; kept in ``self.observation`` as device scalars).  As in the reference the
+``rpn_sigma`` / ``roi_sigma`` / ``anchor_target_creator`` arguments are accepted and the base-class
+defaults (3, 1, default AnchorTargetCreator) apply (:19-26).
+
+What is different in mechanism:
+  * no host round trip: proposals, both target creators, the mask crop+resize and all losses run on
+    the device; per-image counts stay on the device (padded rows carry label -1);
+  * batch size > 1 (the reference raises for n != 1, :37-40; ``strict_batch1=True`` restores that):
+    every image samples its own RoIs / anchors, the rows are concatenated and each loss is
+    normalised over the concatenated batch (hard part 8);
+  * the backward pass is an explicit tape walk (``backward()``); ``loss.backward()`` on the returned
+    tensor triggers it, so reference-style ``loss = model(*batch); loss.backward()`` works;
+  * the mask branch runs on the (<= 64 per image) positive rows only by default - identical loss and
+    gradients; ``mask_rows='all'`` evaluates all sampled rows like the reference.
+"""
+import torch
+
+from chainer_maskrcnn._hip import ops
+from chainer_maskrcnn.utils.proposal_target_creator import ProposalTargetCreator
+
+
+class AnchorTargetCreator(object):
+    """Parameters of ChainerCV's AnchorTargetCreator; the work is ops.anchor_target."""
+
+    def __init__(self, n_sample=256, pos_iou_thresh=0.7, neg_iou_thresh=0.3, pos_ratio=0.5):
+        self.n_sample, self.pos_iou_thresh, self.neg_iou_thresh, self.pos_ratio = n_sample, pos_iou_thresh, neg_iou_thresh, pos_ratio
+        self.seed = 1 << 32
+
+    def __call__(self, bbox, anchor, img_size, n_gt=None, keys=None):
+        """bbox (N,G,4) (or (G,4)), anchor (A,4) -> (loc (N,A,4), label (N,A))."""
+        if bbox.dim() == 2:
+            bbox = bbox[None]
+        N, G, _ = bbox.shape
+        if n_gt is None:
+            n_gt = torch.full((N,), G, dtype=torch.int32, device=bbox.device)
+        if keys is None:
+            self.seed += 1
+            keys = ops.random_keys((N, anchor.shape[0]), self.seed, bbox.device)
+        return ops.anchor_target(anchor, bbox.contiguous(), n_gt, img_size, keys, self.n_sample, self.pos_iou_thresh,
+                                 self.neg_iou_thresh, self.pos_ratio)
+
+
+class _LossHandle(torch.autograd.Function):
+    """Makes ``loss.backward()`` on the returned scalar run the chain's explicit backward pass."""
+
+    @staticmethod
+    def forward(ctx, anchor, chain, value):
+        ctx.chain = chain
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.chain.backward()
+        return None, None, None
+
+
+def calc_mask_loss(roi_cls_mask, gt_roi_mask, xp, gt_roi_label):
+    """train.py:50-58 (channel gt_label-1 of the first n_pos rows, sigmoid cross entropy).  On this path the
+    selection, the loss and its gradient are ONE fused kernel (``mrcnn_mask_bce_f32``); the function object is
+    only the tag the train chain dispatches on."""
+    raise RuntimeError('calc_mask_loss is evaluated inside FPNMaskRCNNTrainChain by mrcnn_mask_bce_f32')
+
+
+calc_mask_loss.fused_kind = 'mask_bce'
+
+
+def calc_keypoint_loss(roi_cls_mask, gt_roi_mask, xp, gt_roi_label):
+    """train_keypoints.py:21-27 (softmax cross entropy over the 56*56 positions of each keypoint)."""
+    raise RuntimeError('calc_keypoint_loss is evaluated inside FPNMaskRCNNTrainChain by mrcnn_softmax_ce_f32')
+
+
+calc_keypoint_loss.fused_kind = 'keypoint_ce'
+
+
+class FPNMaskRCNNTrainChain(object):
+    def __init__(self, faster_rcnn, mask_loss_fun=calc_mask_loss, binary_mask=True, rpn_sigma=3., roi_sigma=1.,
+                 anchor_target_creator=None, strict_batch1=False, mask_rows='positives'):
+        self.faster_rcnn = faster_rcnn
+        self.proposal_target_creator = ProposalTargetCreator(faster_rcnn.extractor.anchor_sizes)
+        self.anchor_target_creator = AnchorTargetCreator()      # the argument is ignored, as in the reference
+        self.rpn_sigma, self.roi_sigma = 3., 1.                  # base-class defaults apply (:25-26)
+        self.loc_normalize_mean = faster_rcnn.loc_normalize_mean
+        self.loc_normalize_std = faster_rcnn.loc_normalize_std
+        kind = getattr(mask_loss_fun, 'fused_kind', None)
+        if kind not in ('mask_bce', 'keypoint_ce'):
+            raise TypeError('mask_loss_fun must be chainer_maskrcnn...calc_mask_loss / calc_keypoint_loss '
+                            '(the loss runs as a fused HIP kernel)')
+        self.mask_loss_kind = kind
+        self.binary_mask = binary_mask
+        self.strict_batch1 = strict_batch1
+        self.mask_rows = mask_rows
+        self.observation = {}
+        self.grad_ready_hook = None         # called with the lowest finished parameter offset during backward (DP overlap)
+        self.sampler_keys = None            # (proposal keys, anchor keys) override for parity tests
+
+    # ------------------------------------------------------------------------------------------
+    def __call__(self, imgs, bboxes, labels, masks, scale, n_gt=None):
+        m = self.faster_rcnn
+        n = bboxes.shape[0]
+        if self.strict_batch1 and n != 1:
+            raise ValueError('Currently only batch size 1 is supported. n={}'.format(n))
+        if torch.is_tensor(scale):
+            scale = float(scale.reshape(-1)[0].item())
+        dev = imgs.device
+        _, _, H, W = imgs.shape
+        img_size = (H, W)
+        i32 = torch.int32
+        G = bboxes.shape[1]
+        if n_gt is None:
+            n_gt = torch.full((n,), G, dtype=i32, device=dev)
+        bboxes = bboxes.contiguous()
+        labels = labels.to(i32).contiguous()
+
+        features = m.extractor(m.to_nhwc4(imgs))
+        m.rpn.train = True
+        r = m.rpn.forward_padded(features, img_size, scale)
+
+        pk, ak = self.sampler_keys if self.sampler_keys is not None else (None, None)
+        t = self.proposal_target_creator.sample_batch(
+            r['rois'], r['levels'], r['n_rois'], bboxes, labels, n_gt,
+            masks=masks.contiguous() if self.binary_mask else None,
+            keypoints=None if self.binary_mask else masks.contiguous(),
+            loc_normalize_mean=self.loc_normalize_mean, loc_normalize_std=self.loc_normalize_std,
+            mask_size=m.head.mask_size, keys=pk, mask_rows=self.mask_rows)
+        gt_rpn_loc, gt_rpn_label = self.anchor_target_creator(bboxes, r['anchors'], img_size, n_gt=n_gt, keys=ak)
+
+        losses = torch.empty((5, 2), dtype=torch.float32, device=dev)
+        A = r['anchors'].shape[0]
+        # RPN losses (:81-85)
+        _, g_locs = ops.smooth_l1(r['locs'].view(n * A, 4), 4, gt_rpn_loc.view(n * A, 4), gt_rpn_label.view(-1), n * A,
+                                  self.rpn_sigma, out=losses[0])
+        _, g_scores = ops.softmax_ce(r['scores'].view(n * A, 2), gt_rpn_label.view(-1), n * A, 2, (1, 2, 0, 1), out=losses[1])
+
+        # head (:88-89) on the n*n_sample sampled rows (padding rows have label -1 and get zero gradient)
+        head = m.head
+        S = self.proposal_target_creator.n_sample
+        R = n * S
+        scales = m.extractor.spatial_scales
+        box = head.box_branch(features, t['rois_xy5'], t['sample_levels'], scales)
+        ld = head.out_p
+        g_box = torch.empty_like(box)
+        ops.softmax_ce(box, t['gt_roi_label'], R, head.n_class, (1, ld, 0, 1), Kfill=head.LOC0, gx=g_box, out=losses[3])
+        ops.smooth_l1(box, ld, t['gt_roi_loc'], t['gt_roi_label'], R, self.roi_sigma, gfill=ld - head.LOC0,
+                      col0=head.LOC0, gx=g_box, out=losses[2])
+
+        rows = t['mask_rows']
+        if rows == S:
+            m_rois, m_levels, m_label = t['rois_xy5'], t['sample_levels'], t['gt_roi_label']
+        else:   # the first `rows` rows of every image block (positives come first)
+            m_rois = t['rois_xy5'].view(n, S, 5)[:, :rows].reshape(n * rows, 5)
+            m_levels = t['sample_levels'].view(n, S)[:, :rows].reshape(n * rows)
+            m_label = t['gt_roi_label'].view(n, S)[:, :rows].reshape(n * rows)
+        mask_out = head.mask_branch(features, m_rois, m_levels, scales)
+        if self.mask_loss_kind == 'mask_bce':
+            _, g_mask = ops.mask_bce(mask_out, t['gt_roi_mask'], m_label, out=losses[4])
+        else:
+            Rm, Hm, Wm, Cm = mask_out.shape
+            K = head.n_keypoints
+            g_mask = torch.zeros_like(mask_out)
+            ops.softmax_ce(mask_out, t['gt_roi_mask'].view(-1), Rm * K, Hm * Wm, (K, Hm * Wm * Cm, 1, Cm), gx=g_mask,
+                           out=losses[4])
+
+        total = ops.loss_total(losses)
+        self.observation = {'rpn_loc_loss': losses[0, 0], 'rpn_cls_loss': losses[1, 0], 'roi_loc_loss': losses[2, 0],
+                            'roi_cls_loss': losses[3, 0], 'mask_loss': losses[4, 0], 'loss': total[0]}
+        self._bwd = (features, g_locs.view(n, A, 4), g_scores.view(n, A, 2), g_box, g_mask)
+        self.targets = t
+        self.rpn_out = r
+        self._anchor = torch.zeros((), device=dev, requires_grad=True)
+        return _LossHandle.apply(self._anchor, self, total[0])
+
+    # ------------------------------------------------------------------------------------------
+    def backward(self):
+        """Explicit backward pass: fills the flat gradient buffer of ``faster_rcnn.ps``."""
+        m = self.faster_rcnn
+        features, g_locs, g_scores, g_box, g_mask = self._bwd
+        hook = self.grad_ready_hook
+        g_feats = [torch.empty_like(f) for f in features]
+        m.head.backward(g_box, g_mask, g_feats)
+        if hook:
+            hook(self._offset_of('head/'))
+        m.rpn.backward(g_locs, g_scores, g_feats)
+        if hook:
+            hook(self._offset_of('rpn/'))
+        m.extractor.backward(g_feats)
+        if hook:
+            hook(0)
+        self._bwd = None
+
+    def _offset_of(self, prefix):
+        ps = self.faster_rcnn.ps
+        return min(o for name, (o, _) in ps.offsets.items() if name.startswith(prefix))

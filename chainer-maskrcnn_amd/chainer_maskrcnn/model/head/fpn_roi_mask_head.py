@@ -1,0 +1,156 @@
+"""Box + mask head over FPN levels on gfx950 kernels.
+
+Mirror of chainer_maskrcnn/model/head/fpn_roi_mask_head.py:11-102 (layers :24-49, forward :55-88,
+predict_mask :90-102).  Kept: conv3x3 BEFORE the two FCs in the box branch (:65), class-agnostic
+4-vector regressor (:28), no ReLU between deconv and the final 1x1 conv (:83).
+Mechanism differences (results identical):
+  * the two per-RoI Python loops (:59-61, :75-77) are ONE batched multi-level ROIAlign launch each;
+  * ``cls_loc`` (4) and ``score`` (n_class) are one fused linear layer: output columns [0,n_class) =
+    score, [LOC0, LOC0+4) = loc;
+  * the 2x2/2 deconvolution is a 1x1 convolution to 4*256 channels + a pixel shuffle that adds the bias.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from chainer_maskrcnn import _hip
+from chainer_maskrcnn._hip import lib, check, ptr, stream_ptr, ops
+from chainer_maskrcnn.nn.core import Conv, ParamStore, normal, pad_to
+
+
+def _level_args(xs, scales):
+    L = len(xs)
+    arr_p = (ctypes.c_void_p * L)(*[x.data_ptr() for x in xs])
+    Hs = (ctypes.c_int * L)(*[x.shape[1] for x in xs])
+    Ws = (ctypes.c_int * L)(*[x.shape[2] for x in xs])
+    sc = (ctypes.c_float * L)(*[float(s) for s in scales])
+    return L, arr_p, Hs, Ws, sc
+
+
+def roi_align_fpn_fwd(xs, rois_xy5, levels, out_size, scales, sampling_ratio=2):
+    """xs: NHWC levels (N,H_l,W_l,C); rois_xy5 (R,5) (idx,x1,y1,x2,y2); levels (R,) int32 -> (R,P,P,C)."""
+    _hip.require_cuda(rois_xy5, levels, *xs)
+    L, arr_p, Hs, Ws, sc = _level_args(xs, scales)
+    N, C = xs[0].shape[0], xs[0].shape[3]
+    R = rois_xy5.shape[0]
+    y = torch.empty((R, out_size, out_size, C), dtype=torch.float32, device=rois_xy5.device)
+    check(lib().mrcnn_roi_align_fpn_fwd_f32(arr_p, Hs, Ws, sc, L, N, C, ptr(rois_xy5), ptr(levels), R, out_size,
+                                            out_size, sampling_ratio, ptr(y), stream_ptr()))
+    return y
+
+
+def roi_align_fpn_bwd(gy, gxs, rois_xy5, levels, out_size, scales, accumulate, sampling_ratio=2):
+    L, arr_p, Hs, Ws, sc = _level_args(gxs, scales)
+    N, C = gxs[0].shape[0], gxs[0].shape[3]
+    check(lib().mrcnn_roi_align_fpn_bwd_f32(ptr(gy), arr_p, Hs, Ws, sc, L, N, C, ptr(rois_xy5), ptr(levels),
+                                            rois_xy5.shape[0], out_size, out_size, sampling_ratio, int(accumulate),
+                                            stream_ptr()))
+
+
+class FPNRoIMaskHead(object):
+    mask_size = 28
+
+    def __init__(self, n_class, roi_size_box, roi_size_mask, loc_initialW=None, score_initialW=None,
+                 mask_initialW=None, ps=None, prefix='head', in_channels=256, fc_channels=1024):
+        self.ps = ps if ps is not None else ParamStore()
+        self.n_class, self.roi_size_box, self.roi_size_mask = n_class, roi_size_box, roi_size_mask
+        c = in_channels
+        p = prefix + '/'
+        self.conv1 = Conv(self.ps, p + 'conv1', c, c, 3, 1, 1, relu=True)
+        self.fc1 = Conv(self.ps, p + 'fc1', c * roi_size_box * roi_size_box, fc_channels, relu=True)
+        self.fc2 = Conv(self.ps, p + 'fc2', fc_channels, fc_channels, relu=True)
+        # fused [score | loc] linear layer
+        self.LOC0 = pad_to(n_class, 8)
+        self.out_p = pad_to(self.LOC0 + 4, 32)
+        li = normal(0.001 if loc_initialW is None else loc_initialW)((4, 1, 1, fc_channels))
+        si = normal(0.01 if score_initialW is None else score_initialW)((n_class, 1, 1, fc_channels))
+        self.box_out = Conv(self.ps, p + 'score_cls_loc', fc_channels, n_class + 4, 1, cout_p=self.out_p,
+                            cout_index=list(range(n_class)) + list(range(self.LOC0, self.LOC0 + 4)),
+                            init=lambda shape: (lambda rs: np.concatenate([si(rs), li(rs)], 0)))
+        mi = 0.01 if mask_initialW is None else mask_initialW
+        self.mask_convs = [Conv(self.ps, p + 'mask%d' % (i + 1), c, c, 3, 1, 1, relu=True) for i in range(4)]
+        # deconv1: W (Cin, Cout, 2, 2) in Chainer == 1x1 conv weight ((a*2+b)*Cout + o, Cin); bias added by the shuffle
+        self.deconv1 = Conv(self.ps, p + 'deconv1', c, 4 * c, 1, bias=False, init=normal(mi))
+        self.ps.register(p + 'deconv1/b', (c,), lambda rs: np.zeros((c,), np.float32))
+        self.deconv_b = p + 'deconv1/b'
+        self.conv2 = Conv(self.ps, p + 'conv2', c, n_class - 1, 1, init=normal(mi))
+        self.channels = c
+
+    # ---- forward --------------------------------------------------------------------------------
+    def box_branch(self, xs, rois_xy5, levels, spatial_scales):
+        pool = roi_align_fpn_fwd(xs, rois_xy5, levels, self.roi_size_box, spatial_scales)
+        h, t1 = self.conv1.fwd(pool)
+        R = h.shape[0]
+        h, t2 = self.fc1.fwd(h.view(R, 1, 1, -1))
+        h, t3 = self.fc2.fwd(h)
+        o, t4 = self.box_out.fwd(h)
+        self.box_tape = (t1, t2, t3, t4, tuple(pool.shape), rois_xy5, levels, spatial_scales)
+        return o.view(R, self.out_p)          # [:, :n_class] scores, [:, LOC0:LOC0+4] loc
+
+    def mask_branch(self, xs, rois_xy5, levels, spatial_scales):
+        pool = roi_align_fpn_fwd(xs, rois_xy5, levels, self.roi_size_mask, spatial_scales)
+        h, tapes = pool, []
+        for cv in self.mask_convs:
+            h, t = cv.fwd(h)
+            tapes.append(t)
+        d, td = self.deconv1.fwd(h)
+        up = ops.pixel_shuffle2x(d, bias=self.ps.p(self.deconv_b))
+        m, t2 = self.conv2.fwd(up)
+        self.mask_tape = (tapes, td, t2, rois_xy5, levels, spatial_scales)
+        return m                               # (Rm, 28, 28, pad32(n_class-1)) NHWC
+
+    def __call__(self, x, indices_and_rois, levels, spatial_scales, train=True):
+        """Reference signature (:55): x = pyramid levels, indices_and_rois (R,5) (idx,y1,x1,y2,x2),
+        levels (R,).  Returns (roi_cls_locs (R,4), roi_scores (R,n_class), mask (R,n_class-1,28,28) NCHW view)."""
+        xy5 = indices_and_rois[:, [0, 2, 1, 4, 3]].contiguous()
+        lv = levels.to(torch.int32).contiguous()
+        o = self.box_branch(x, xy5, lv, spatial_scales)
+        locs, scores = o[:, self.LOC0:self.LOC0 + 4], o[:, :self.n_class]
+        if not train:
+            self.x = x
+            return locs, scores
+        m = self.mask_branch(x, xy5, lv, spatial_scales)
+        return locs, scores, m[..., :self.n_class - 1].permute(0, 3, 1, 2)
+
+    def predict_mask(self, levels, indices_and_rois, spatial_scales):
+        xy5 = indices_and_rois[:, [0, 2, 1, 4, 3]].contiguous()
+        m = self.mask_branch(self.x, xy5, levels.to(torch.int32).contiguous(), spatial_scales)
+        return m[..., :self.n_class - 1].permute(0, 3, 1, 2)
+
+    # ---- backward -------------------------------------------------------------------------------
+    def backward(self, g_box_out, g_mask, g_feats):
+        """g_box_out (R, out_p), g_mask (Rm,28,28,Cm) or None; g_feats: per-level gradient buffers, fully
+        overwritten by the first ROIAlign backward and accumulated into by the second."""
+        t1, t2, t3, t4, pool_shape, rois, levels, scales = self.box_tape
+        R = g_box_out.shape[0]
+        g = self.box_out.bwd(t4, g_box_out.view(R, 1, 1, -1))
+        g = self.fc2.bwd(t3, g)
+        g = self.fc1.bwd(t2, g)
+        g = self.conv1.bwd(t1, g.view(pool_shape))
+        roi_align_fpn_bwd(g, g_feats, rois, levels, self.roi_size_box, scales, accumulate=False)
+        if g_mask is not None:
+            tapes, td, tc2, rois, levels, scales = self.mask_tape
+            g = self.conv2.bwd(tc2, g_mask)
+            # deconv bias gradient = column sums of g (over all output pixels): take it from a filter-gradient
+            # call of the shuffled tensor below (gb4 of length 4*C, summed over the 4 sub-pixel copies)
+            g4 = ops.pixel_shuffle2x(g, inverse=True)
+            C = self.channels
+            gb4 = torch.empty((4 * C,), dtype=torch.float32, device=g.device)
+            gw = self.ps.g(self.deconv1.name + '/W')
+            x_in = td[0]
+            N_, H_, W_, Cin = x_in.shape
+            nbytes = lib().mrcnn_conv2d_bwd_filter_workspace_bytes(N_, H_, W_, Cin, 4 * C, 1, 1, 1, 0)
+            from chainer_maskrcnn._hip import nn as hnn
+            ws = hnn.workspace(nbytes, g.device)
+            check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x_in), ptr(g4), ptr(gw), ptr(gb4), N_, H_, W_, Cin, 4 * C, 1, 1,
+                                                    1, 0, 0, ptr(ws), ws.numel(), stream_ptr()))
+            gb = self.ps.g(self.deconv_b)
+            ops.add(gb4[0:C], gb4[C:2 * C], out=gb)
+            ops.add(gb, gb4[2 * C:3 * C], out=gb)
+            ops.add(gb, gb4[3 * C:4 * C], out=gb)
+            g = hnn.conv2d_bwd_data_raw(g4, self.deconv1.W, tuple(x_in.shape), 1, 0)
+            for cv, t in zip(reversed(self.mask_convs), reversed(tapes)):
+                g = cv.bwd(t, g)
+            roi_align_fpn_bwd(g, g_feats, rois, levels, self.roi_size_mask, scales, accumulate=True)
+        self.box_tape = self.mask_tape = None

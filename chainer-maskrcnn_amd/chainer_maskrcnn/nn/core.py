@@ -1,0 +1,247 @@
+"""Parameter store and layer objects with hand-written backward passes.
+
+Role in the mirror of the reference: this is what Chainer's ``Link``/``Variable`` graph does for
+chainer_maskrcnn/model/* - here as an explicit tape: ``y, ctx = layer.fwd(x)`` /
+``gx = layer.bwd(ctx, gy)``.  All arithmetic is in csrc/*.hip; tensors are NHWC fp32 device
+buffers.
+
+MI355X-first choices
+  * ONE flat fp32 buffer for all parameters, one for gradients, one for momentum: the optimiser is
+    a single fused kernel and the data-parallel all-reduce runs over contiguous slices of the
+    gradient buffer, launched bucket by bucket as backward produces them (parameters are registered
+    in forward order, so backward fills the buffer from the end towards the start).
+  * Fan-out points of the graph accumulate in place through the ``accumulate`` flags of the
+    backward kernels instead of separate add passes.
+"""
+import math
+
+import numpy as np
+import torch
+
+from chainer_maskrcnn._hip import nn as hnn
+from chainer_maskrcnn._hip import ops
+
+
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+class ParamStore(object):
+    """Registers named parameters, then materialises them as views of flat device buffers."""
+
+    ALIGN = 64          # floats (256 B): every view is 16-B aligned for the float4 kernels
+
+    def __init__(self):
+        self._specs = []        # (name, shape, init(np.RandomState) -> ndarray, trainable)
+        self.offsets = {}
+        self.params = self.grads = self.momentum = None
+        self.size = 0
+        self.buffers = {}       # non-trainable state (BN running statistics)
+
+    def register(self, name, shape, init, trainable=True):
+        if name in self.offsets:
+            raise KeyError('duplicate parameter %s' % name)
+        n = int(np.prod(shape))
+        if trainable:
+            self.offsets[name] = (self.size, tuple(shape))
+            self.size += pad_to(n, self.ALIGN)
+        self._specs.append((name, tuple(shape), init, trainable))
+
+    def materialise(self, device, seed=1234):
+        rs = np.random.RandomState(seed)
+        host = np.zeros((self.size,), np.float32)
+        for name, shape, init, trainable in self._specs:
+            v = np.asarray(init(rs), np.float32).reshape(shape)
+            if trainable:
+                o = self.offsets[name][0]
+                host[o:o + v.size] = v.ravel()
+            else:
+                self.buffers[name] = torch.from_numpy(v.copy()).to(device)
+        self.params = torch.from_numpy(host).to(device)
+        self.grads = torch.zeros_like(self.params)
+        self.momentum = torch.zeros_like(self.params)
+        return self
+
+    def _view(self, flat, name):
+        o, shape = self.offsets[name]
+        return flat[o:o + int(np.prod(shape))].view(shape)
+
+    def p(self, name):
+        return self._view(self.params, name)
+
+    def g(self, name):
+        return self._view(self.grads, name)
+
+    def names(self):
+        return list(self.offsets)
+
+    def n_params(self):
+        return sum(int(np.prod(s)) for _, s in self.offsets.values())
+
+
+def lecun_normal(fan_in):
+    return lambda shape: (lambda rs: rs.standard_normal(shape) * (1.0 / math.sqrt(fan_in)))
+
+
+def normal(std):
+    return lambda shape: (lambda rs: rs.standard_normal(shape) * std)
+
+
+class Conv(object):
+    """Convolution2D / Linear / (as 1x1 to 4*Cout) Deconvolution2D on NHWC tensors.
+
+    Logical channel counts (cin, cout) are zero-padded to what the MFMA kernel wants (cin: multiple
+    of 32, or 4 for the image layer; cout: multiple of 32).  ``cout_map`` optionally places logical
+    output channels at chosen padded positions (fused heads).
+    """
+
+    def __init__(self, ps, name, cin, cout, k=1, stride=1, pad=0, bias=True, relu=False, init=None,
+                 cin_p=None, cout_p=None, cout_index=None):
+        self.ps, self.name = ps, name
+        self.cin, self.cout, self.k, self.stride, self.pad, self.relu = cin, cout, k, stride, pad, relu
+        self.cin_p = cin_p or (4 if cin <= 4 else pad_to(cin, 32))
+        self.cout_p = cout_p or pad_to(cout, 32)
+        self.has_bias = bias
+        idx = np.arange(cout) if cout_index is None else np.asarray(cout_index)
+        fan_in = cin * k * k
+        gen = (init or lecun_normal(fan_in))((cout, k, k, cin))
+
+        def w_init(rs):
+            w = np.zeros((self.cout_p, k, k, self.cin_p), np.float32)
+            w[idx, :, :, :cin] = gen(rs)
+            return w
+        ps.register(name + '/W', (self.cout_p, k, k, self.cin_p), w_init)
+        if bias:
+            ps.register(name + '/b', (self.cout_p,), lambda rs: np.zeros((self.cout_p,), np.float32))
+
+    @property
+    def W(self):
+        return self.ps.p(self.name + '/W')
+
+    @property
+    def b(self):
+        return self.ps.p(self.name + '/b') if self.has_bias else None
+
+    def fwd(self, x, relu=None):
+        relu = self.relu if relu is None else relu
+        y = hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu)
+        return y, (x, y if relu else None)
+
+    def bwd(self, ctx, gy, need_gx=True, gx_acc=None, accumulate_params=False):
+        """gy: gradient w.r.t. the (post-ReLU) output.  gx_acc: tensor to accumulate gx into.
+        accumulate_params: add into the parameter gradients (layer applied several times)."""
+        x, y = ctx
+        if y is not None:
+            gy = ops.relu_bwd(gy, y)
+        gw = self.ps.g(self.name + '/W')
+        gb = self.ps.g(self.name + '/b') if self.has_bias else None
+        if accumulate_params:
+            hnn.conv2d_bwd_filter_raw(x, gy, tuple(gw.shape), self.stride, self.pad, self.has_bias, gw=gw, gb=gb)
+        else:
+            self._filter_overwrite(x, gy, gw, gb)
+        if not need_gx:
+            return None
+        if self.stride == 1:
+            return hnn.conv2d_bwd_data_raw(gy, self.W, tuple(x.shape), 1, self.pad, out=gx_acc)
+        assert self.k == 1 and self.pad == 0, 'strided backward-data only for 1x1 convolutions'
+        g_sub = self.bwd_data_sub(gy)
+        return ops.subsample_bwd(g_sub, tuple(x.shape), self.stride, gx=gx_acc)
+
+    def _filter_overwrite(self, x, gy, gw, gb):
+        from chainer_maskrcnn._hip import lib, check, ptr, stream_ptr
+        N, H, W, Cin = x.shape
+        Cout, KH, KW, _ = gw.shape
+        nbytes = lib().mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, self.stride, self.pad)
+        ws = hnn.workspace(nbytes, x.device)
+        check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x), ptr(gy), ptr(gw), ptr(gb), N, H, W, Cin, Cout, KH, KW,
+                                                self.stride, self.pad, 0, ptr(ws), ws.numel(), stream_ptr()))
+
+    def bwd_data_sub(self, gy, out=None):
+        """Data gradient of a strided 1x1 convolution on the subsampled lattice (N,Ho,Wo,Cin)."""
+        N, Ho, Wo, _ = gy.shape
+        return hnn.conv2d_bwd_data_raw(gy, self.W, (N, Ho, Wo, self.cin_p), 1, 0, out=out)
+
+
+class BatchNorm(object):
+    """Training-mode BatchNormalization (batch statistics; eps 2e-5, decay 0.9 as in Chainer)."""
+
+    def __init__(self, ps, name, c):
+        self.ps, self.name, self.c = ps, name, c
+        ps.register(name + '/gamma', (c,), lambda rs: np.ones((c,), np.float32))
+        ps.register(name + '/beta', (c,), lambda rs: np.zeros((c,), np.float32))
+        ps.register(name + '/avg_mean', (c,), lambda rs: np.zeros((c,), np.float32), trainable=False)
+        ps.register(name + '/avg_var', (c,), lambda rs: np.ones((c,), np.float32), trainable=False)
+
+    def fwd(self, x, relu=False, residual=None):
+        gamma, beta = self.ps.p(self.name + '/gamma'), self.ps.p(self.name + '/beta')
+        y, mean, invstd = ops.bn_train_fwd(x, gamma, beta, residual, relu, self.ps.buffers[self.name + '/avg_mean'],
+                                           self.ps.buffers[self.name + '/avg_var'])
+        return y, (x, y, mean, invstd, relu)
+
+    def bwd(self, ctx, gy, want_gres=False):
+        x, y, mean, invstd, relu = ctx
+        from chainer_maskrcnn._hip import lib, check, ptr, stream_ptr
+        C = self.c
+        P = x.numel() // C
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if want_gres else None
+        ws = hnn.workspace(lib().mrcnn_bn_workspace_bytes(P, C), x.device)
+        check(lib().mrcnn_bn_train_bwd_f32(ptr(gy), ptr(x), ptr(y), ptr(self.ps.p(self.name + '/gamma')), ptr(mean),
+                                           ptr(invstd), ptr(gx), ptr(gres), ptr(self.ps.g(self.name + '/gamma')),
+                                           ptr(self.ps.g(self.name + '/beta')), P, C, int(relu), ptr(ws), ws.numel(),
+                                           stream_ptr()))
+        return gx, gres
+
+
+class Bottleneck(object):
+    """ResNet bottleneck (Chainer BottleneckA when ``project`` else BottleneckB):
+    relu(bn3(conv3(relu(bn2(conv2 3x3(relu(bn1(conv1 1x1/s))))))) + shortcut), stride on the first 1x1."""
+
+    def __init__(self, ps, name, cin, mid, cout, stride, project):
+        self.project, self.stride = project, stride
+        he = lambda fan_in: (lambda shape: (lambda rs: rs.standard_normal(shape) * math.sqrt(2.0 / fan_in)))
+        self.conv1 = Conv(ps, name + '/conv1', cin, mid, 1, stride, 0, bias=False, init=he(cin))
+        self.bn1 = BatchNorm(ps, name + '/bn1', mid)
+        self.conv2 = Conv(ps, name + '/conv2', mid, mid, 3, 1, 1, bias=False, init=he(mid * 9))
+        self.bn2 = BatchNorm(ps, name + '/bn2', mid)
+        self.conv3 = Conv(ps, name + '/conv3', mid, cout, 1, 1, 0, bias=False, init=he(mid))
+        self.bn3 = BatchNorm(ps, name + '/bn3', cout)
+        if project:
+            self.conv4 = Conv(ps, name + '/conv4', cin, cout, 1, stride, 0, bias=False, init=he(cin))
+            self.bn4 = BatchNorm(ps, name + '/bn4', cout)
+
+    def fwd(self, x):
+        h1, c1 = self.conv1.fwd(x)
+        a1, b1 = self.bn1.fwd(h1, relu=True)
+        h2, c2 = self.conv2.fwd(a1)
+        a2, b2 = self.bn2.fwd(h2, relu=True)
+        h3, c3 = self.conv3.fwd(a2)
+        if self.project:
+            h4, c4 = self.conv4.fwd(x)
+            r, b4 = self.bn4.fwd(h4)
+        else:
+            r, c4, b4 = x, None, None
+        y, b3 = self.bn3.fwd(h3, relu=True, residual=r)
+        return y, (c1, b1, c2, b2, c3, b3, c4, b4)
+
+    def bwd(self, ctx, gy, gx_acc=None):
+        c1, b1, c2, b2, c3, b3, c4, b4 = ctx
+        g_h3, g_r = self.bn3.bwd(b3, gy, want_gres=True)
+        g_a2 = self.conv3.bwd(c3, g_h3)
+        g_h2, _ = self.bn2.bwd(b2, g_a2)
+        g_a1 = self.conv2.bwd(c2, g_h2)
+        g_h1, _ = self.bn1.bwd(b1, g_a1)
+        if not self.project:
+            if gx_acc is not None:
+                g_r = ops.add(g_r, gx_acc, out=gx_acc)
+            return self.conv1.bwd(c1, g_h1, gx_acc=g_r)
+        g_h4, _ = self.bn4.bwd(b4, g_r)
+        if self.stride == 1:
+            gx = self.conv1.bwd(c1, g_h1, gx_acc=gx_acc)
+            return self.conv4.bwd(c4, g_h4, gx_acc=gx)
+        # both strided 1x1 convolutions read the same lattice: sum on the lattice, scatter once
+        self.conv1.bwd(c1, g_h1, need_gx=False)
+        self.conv4.bwd(c4, g_h4, need_gx=False)
+        g_sub = self.conv1.bwd_data_sub(g_h1)
+        self.conv4.bwd_data_sub(g_h4, out=g_sub)
+        return ops.subsample_bwd(g_sub, tuple(c1[0].shape), self.stride, gx=gx_acc)

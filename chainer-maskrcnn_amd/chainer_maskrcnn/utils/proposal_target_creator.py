@@ -1,0 +1,72 @@
+"""ProposalTargetCreator on the device.
+
+Mirror of chainer_maskrcnn/utils/proposal_target_creator.py:12-137 (constructor :12-24, __call__
+:26-137): same arguments and outputs; the NumPy/OpenCV body (5 D2H + 5 H2D copies, <=64 cv2.resize
+calls) is replaced by ``mrcnn_proposal_target_f32`` + ``mrcnn_mask_target_u8`` /
+``mrcnn_keypoint_target_f32``.  Random subsets: smallest-key selection with keys from
+``mrcnn_random_keys_u32`` (``seed`` attribute, advanced per call) or caller-provided ``keys``;
+sampled rows come out positives first in ascending candidate order (the reference: random order).
+"""
+import numpy as np
+import torch
+
+from chainer_maskrcnn._hip import ops
+
+
+class ProposalTargetCreator(object):
+    def __init__(self, sizes=[16], n_sample=256, pos_ratio=0.25, pos_iou_thresh=0.5, neg_iou_thresh_hi=0.5,
+                 neg_iou_thresh_lo=0.0):
+        self.sizes = sizes                      # stored, never used - as in the reference (:19)
+        self.n_sample = n_sample
+        self.pos_ratio = pos_ratio
+        self.pos_iou_thresh = pos_iou_thresh
+        self.neg_iou_thresh_hi = neg_iou_thresh_hi
+        self.neg_iou_thresh_lo = neg_iou_thresh_lo
+        self.seed = 0
+
+    @property
+    def pos_cap(self):
+        return int(np.round(self.n_sample * self.pos_ratio))
+
+    def sample_batch(self, rois, roi_levels, n_rois, gt_boxes, gt_labels, n_gt, masks=None, keypoints=None,
+                     loc_normalize_mean=(0., 0., 0., 0.), loc_normalize_std=(0.1, 0.1, 0.2, 0.2), mask_size=14,
+                     keys=None, mask_rows='positives'):
+        """Batched, sync-free form used by the train chain.  rois (N*roi_cap,4) padded, gt_boxes (N,G,4),
+        gt_labels (N,G) i32, masks (N,G,H,W) u8 or keypoints (N,G,K,3) f32.  Returns the dict of
+        ops.proposal_target plus 'gt_roi_mask' ((N*rows, S, S) or (N*rows, K) int32, -1 = unused) where
+        rows = pos_cap ('positives') or n_sample ('all')."""
+        N, G = gt_labels.shape
+        roi_cap = rois.shape[0] // N
+        if keys is None:
+            self.seed += 1
+            keys = ops.random_keys((N, roi_cap + G), self.seed, rois.device)
+        o = ops.proposal_target(rois, roi_levels, n_rois, gt_boxes, gt_labels, n_gt, keys, self.n_sample,
+                                self.pos_ratio, self.pos_iou_thresh, self.neg_iou_thresh_hi, self.neg_iou_thresh_lo,
+                                loc_normalize_mean, loc_normalize_std)
+        rows = self.pos_cap if mask_rows == 'positives' else self.n_sample
+        if masks is not None:
+            o['gt_roi_mask'] = ops.mask_target(masks, o['sample_roi'], o['gt_assign'], o['n_pos'], self.n_sample, rows,
+                                               mask_size)
+        elif keypoints is not None:
+            o['gt_roi_mask'] = ops.keypoint_target(keypoints, o['sample_roi'], o['gt_assign'], o['n_pos'], self.n_sample,
+                                                   rows, mask_size)
+        o['mask_rows'] = rows
+        return o
+
+    def __call__(self, roi, bbox, label, mask, levels, loc_normalize_mean=(0., 0., 0., 0.),
+                 loc_normalize_std=(0.1, 0.1, 0.2, 0.2), mask_size=14, binary_mask=True, keys=None):
+        """Reference signature (single image): returns (sample_roi, sample_levels, gt_roi_loc, gt_roi_label,
+        gt_roi_mask) with exact sizes (one host sync for the counts)."""
+        dev = roi.device
+        R, G = roi.shape[0], bbox.shape[0]
+        i32 = torch.int32
+        o = self.sample_batch(roi.contiguous(), levels.to(torch.float32).contiguous(),
+                              torch.tensor([R], dtype=i32, device=dev), bbox[None].contiguous(),
+                              label[None].to(i32).contiguous(), torch.tensor([G], dtype=i32, device=dev),
+                              masks=mask[None].contiguous() if binary_mask else None,
+                              keypoints=None if binary_mask else mask[None].contiguous(),
+                              loc_normalize_mean=loc_normalize_mean, loc_normalize_std=loc_normalize_std,
+                              mask_size=mask_size, keys=keys)
+        S, n_pos = int(o['n_sampled'][0].item()), int(o['n_pos'][0].item())
+        return (o['sample_roi'][:S], o['sample_levels'][:S].to(torch.float32), o['gt_roi_loc'][:S],
+                o['gt_roi_label'][:S], o['gt_roi_mask'][:n_pos])

@@ -264,13 +264,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         }
 }
 
-// Sum split-K slabs: out[i] = sum_s slab[s][i]  (deterministic order).
+// Sum split-K slabs: out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]  (deterministic order).
 __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ slabs, float *__restrict__ out,
-                                                   size_t n4, int ksplit) {
+                                                   size_t n4, int ksplit, int accumulate) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    float4 s = ldg4(slabs + i * 4);
-    for (int k = 1; k < ksplit; ++k) {
+    float4 s = accumulate ? ldg4(out + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < ksplit; ++k) {
         const float4 v = ldg4(slabs + ((size_t)k * n4 + i) * 4);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -291,10 +291,10 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
     __syncthreads();
     if (sub == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int nb, int C) {
+__global__ void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int nb, int C, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s = 0.0f;
+    float s = accumulate ? out[c] : 0.0f;
     for (int b = 0; b < nb; ++b) s += part[(size_t)b * C + c];
     out[c] = s;
 }
@@ -378,12 +378,12 @@ extern "C" size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, i
     const size_t wsz = (size_t)Cout * KH * KW * Cin * sizeof(float);
     const size_t P = (size_t)N * p.Ho * p.Wo;
     const size_t bias_part = (size_t)mrcnn::cdiv(P, 1024) * Cout * sizeof(float);
-    return (ksplit > 1 ? wsz * ksplit : 0) + bias_part + 256;
+    return wsz * ksplit + bias_part + 256;     // slabs are also used for ksplit == 1 when accumulating
 }
 
 extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, float *gw, float *gbias, int N,
                                            int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                           void *ws, size_t ws_bytes, void *stream) {
+                                           int accumulate, void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_conv(x, gy, gw, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     const size_t need = mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (!ws || ws_bytes < need) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "conv2d_bwd_filter: workspace %zu < %zu", ws_bytes, need);
@@ -392,15 +392,16 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     filter_plan(p, p.ksplit, p.kchunk);
     const size_t wcount = (size_t)Cout * KH * KW * Cin;
     float *slabs = (float *)ws;
-    float *bias_part = (float *)ws + (p.ksplit > 1 ? wcount * p.ksplit : 0);
-    p.a = gy; p.b = x; p.c = (p.ksplit > 1) ? slabs : gw;
+    float *bias_part = (float *)ws + wcount * p.ksplit;
+    const bool use_slabs = p.ksplit > 1 || accumulate;
+    p.a = gy; p.b = x; p.c = use_slabs ? slabs : gw;
     p.M = Cout; p.Ng = p.smallc ? KH * KW * 4 : Cin;
     dim3 grid(mrcnn::cdiv(p.M, BM), mrcnn::cdiv(p.Ng, BN), (p.smallc ? 1 : KH * KW) * p.ksplit);
     hipLaunchKernelGGL(k_conv_igemm<MODE_BWD_FILTER>, grid, dim3(CONV_THREADS), 0, st, p);
     MRCNN_LAUNCH_CHECK();
-    if (p.ksplit > 1) {
+    if (use_slabs) {
         const size_t n4 = wcount / 4;
-        hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, gw, n4, p.ksplit);
+        hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, gw, n4, p.ksplit, accumulate);
         MRCNN_LAUNCH_CHECK();
     }
     if (gbias) {
@@ -408,7 +409,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
         const int nb = mrcnn::cdiv(P, 1024);
         hipLaunchKernelGGL(k_colsum_partial, dim3(mrcnn::cdiv(Cout, 64), nb), dim3(256), 0, st, gy, bias_part, P, Cout, 1024);
         MRCNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, 256)), dim3(256), 0, st, bias_part, gbias, nb, Cout);
+        hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, 256)), dim3(256), 0, st, bias_part, gbias, nb, Cout, accumulate);
         MRCNN_LAUNCH_CHECK();
     }
     return 0;

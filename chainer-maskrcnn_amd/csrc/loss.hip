@@ -175,6 +175,14 @@ __global__ __launch_bounds__(NT) void k_mask_bce(const float *__restrict__ x, co
     if (PHASE == 0) block_partial(ls, cnt, part);
 }
 
+// out[0] = sum_i losses[2*i]   (the un-weighted sum of fpn_maskrcnn_train_chain.py:106)
+__global__ void k_loss_total(const float *__restrict__ losses, int n, float *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += losses[2 * i];
+    out[0] = s;
+}
+
 int grid_for(long long work) { return (int)std::max(1ll, std::min<long long>((work + NT - 1) / NT, MAXB)); }
 
 }  // namespace
@@ -249,5 +257,13 @@ extern "C" int mrcnn_mask_bce_f32(const float *x, const int32_t *gt, const int32
         hipLaunchKernelGGL(k_mask_bce<1>, dim3(nb), dim3(NT), 0, st, x, gt, label, Rm, HW, Cm, part, loss_out, gx);
         MRCNN_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// losses: n pairs (loss, normaliser) as written by the entry points above; out[0] = sum of the n losses.
+extern "C" int mrcnn_loss_total_f32(const float *losses, int n, float *out, void *stream) {
+    if (!losses || !out || n <= 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "loss_total: bad arguments");
+    hipLaunchKernelGGL(k_loss_total, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, n, out);
+    MRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -355,8 +355,8 @@ __global__ __launch_bounds__(NT) void k_subsample_bwd(const float *__restrict__ 
 
 // Pixel shuffle of the 2x2/2 deconvolution: t (P=N*H*W, [a][b][Cout]) <-> y (N, 2H, 2W, Cout).
 // dir 0: y[n,2h+a,2w+b,:] = t[n,h,w,a,b,:];  dir 1: the inverse gather (backward).
-__global__ __launch_bounds__(NT) void k_pixel_shuffle(const float *__restrict__ src, float *__restrict__ dst, int N,
-                                                      int H, int W, int C4, int dir) {
+__global__ __launch_bounds__(NT) void k_pixel_shuffle(const float *__restrict__ src, const float *__restrict__ bias,
+                                                      float *__restrict__ dst, int N, int H, int W, int C4, int dir) {
     const size_t n4 = (size_t)N * H * W * 4 * C4;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
         // i indexes the (N,2H,2W,C) side
@@ -366,8 +366,11 @@ __global__ __launch_bounds__(NT) void k_pixel_shuffle(const float *__restrict__ 
         const int h2 = (int)(q % (2 * H));
         const int n = (int)(q / (2 * H));
         const size_t j = ((((size_t)n * H + (h2 >> 1)) * W + (w2 >> 1)) * 4 + (h2 & 1) * 2 + (w2 & 1)) * C4 + c;
-        if (dir == 0) st4(dst + i * 4, ld4(src + j * 4));
-        else st4(dst + j * 4, ld4(src + i * 4));
+        if (dir == 0) {
+            float4 v = ld4(src + j * 4);
+            if (bias) { const float4 b = ld4(bias + c * 4); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            st4(dst + i * 4, v);
+        } else st4(dst + j * 4, ld4(src + i * 4));
     }
 }
 
@@ -389,6 +392,25 @@ __global__ __launch_bounds__(NT) void k_sgd(float *__restrict__ p, const float *
         const float nv = momentum * v[i] - lr * (g[i] + wd * p[i]);
         v[i] = nv;
         p[i] += nv;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_img_nhwc4(const float *__restrict__ x, float *__restrict__ y, int N, size_t HW) {
+    const size_t total = (size_t)N * HW;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
+        const size_t n = i / HW, p = i % HW;
+        const float *b = x + n * 3 * HW + p;
+        st4(y + i * 4, make_float4(b[0], b[HW], b[2 * HW], 0.f));
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_random_keys(uint32_t *__restrict__ out, size_t n, unsigned long long seed) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (i + 1);      // splitmix64
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        out[i] = (uint32_t)(z >> 32);
     }
 }
 
@@ -510,10 +532,10 @@ extern "C" int mrcnn_subsample_bwd_f32(const float *gsub, float *gx, int N, int 
     return 0;
 }
 
-extern "C" int mrcnn_pixel_shuffle2x_f32(const float *src, float *dst, int N, int H, int W, int C, int inverse,
-                                         void *stream) {
+extern "C" int mrcnn_pixel_shuffle2x_f32(const float *src, const float *bias, float *dst, int N, int H, int W, int C,
+                                         int inverse, void *stream) {
     if (int e = chk(src && dst && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "pixel_shuffle2x: bad args")) return e;
-    hipLaunchKernelGGL(k_pixel_shuffle, dim3(ew_grid((size_t)N * H * W * C)), dim3(NT), 0, (hipStream_t)stream, src, dst, N,
+    hipLaunchKernelGGL(k_pixel_shuffle, dim3(ew_grid((size_t)N * H * W * C)), dim3(NT), 0, (hipStream_t)stream, src, inverse ? nullptr : bias, dst, N,
                        H, W, C / 4, inverse);
     MRCNN_LAUNCH_CHECK();
     return 0;
@@ -525,6 +547,21 @@ extern "C" int mrcnn_sgd_momentum_wd_f32(float *p, const float *g, float *v, siz
     if (int e = chk(p && g && v, "sgd_momentum_wd: null pointer")) return e;
     hipLaunchKernelGGL(k_sgd, dim3(ew_grid(std::max<size_t>(n / 4, 1))), dim3(NT), 0, (hipStream_t)stream, p, g, v, n, lr,
                        momentum, weight_decay);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_image_nchw3_to_nhwc4_f32(const float *x, float *y, int N, int H, int W, void *stream) {
+    if (int e = chk(x && y && N > 0 && H > 0 && W > 0, "image_nchw3_to_nhwc4: bad args")) return e;
+    hipLaunchKernelGGL(k_img_nhwc4, dim3(ew_grid((size_t)N * H * W)), dim3(NT), 0, (hipStream_t)stream, x, y, N, (size_t)H * W);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_random_keys_u32(uint32_t *out, size_t n, unsigned long long seed, void *stream) {
+    if (n == 0) return 0;
+    if (int e = chk(out != nullptr, "random_keys: null pointer")) return e;
+    hipLaunchKernelGGL(k_random_keys, dim3(ew_grid(n)), dim3(NT), 0, (hipStream_t)stream, out, n, seed);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

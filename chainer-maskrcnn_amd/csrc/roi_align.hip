@@ -214,7 +214,7 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
                                                                        const float *__restrict__ rois,
                                                                        const int32_t *__restrict__ levels,
                                                                        int R, int N, int C, int PH, int PW,
-                                                                       int sr, int chunk) {
+                                                                       int sr, int chunk, int accumulate) {
     constexpr int TASKS = 2 * TH * PBT;      // (axis,bin,row) weight cells per slot
     // sW[slot][axis][bin][tile row/col]: summed weight that bin `bin` of the RoI in `slot` puts on
     // map row ty0+row (axis 0) / map column tx0+row (axis 1).  4 consecutive rows = one 16-B read.
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
                 const int m = lane < nslots ? sMask[lane] : 0;
                 const unsigned rel = (unsigned)__ballot(((m >> cy0) & 0xF) && ((m >> (8 + cx0)) & 0xF));
                 const int roi_of_lane = lane < nslots ? sList[s0 + lane] : 0;
-                float *dst = gxb + ((size_t)(ty0 + cy0) * W + tx0 + cx0) * C + lane * 4;
+                float *dst = gxb + ((size_t)(ty0 + cy0) * W + tx0 + cx0) * C;
                 int pass = 0, cnt;
                 do {
                     cnt = 0;      // wave-uniform: entries seen so far
@@ -344,29 +344,31 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
                             cnt += __popcll(bal);
                         }
                     }
-                    const bool first = (round == 0 && pass == 0);
+                    const bool first = (round == 0 && pass == 0) && !accumulate;
                     const int nq = max(0, min(QCAP, cnt - win));
 #pragma nounroll
                     for (int cb = 0; cb < C; cb += CCH) {
+                        const bool act = cb + lane * 4 < C;          // C < 256 (or a tail): idle lanes
+                        const int lo = act ? cb + lane * 4 : 0;
                         float4 acc[PT][PT];
 #pragma unroll
                         for (int i = 0; i < PT; ++i)
 #pragma unroll
                             for (int k = 0; k < PT; ++k) {
                                 acc[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                                if (!first && i < nrow && k < ncol) acc[i][k] = ld4(dst + ((size_t)i * W + k) * C + cb);
+                                if (!first && act && i < nrow && k < ncol) acc[i][k] = ld4(dst + ((size_t)i * W + k) * C + lo);
                             }
-                        drain_queue(q, nq, gy + cb + lane * 4, C, acc);
+                        drain_queue(q, nq, gy + lo, C, acc);
                         // Opaque zero: keeps hipcc from materialising the 16 store addresses (32
                         // VGPRs) before the drain loop and holding them live across it.
                         int opq;
                         asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
-                        float *dst2 = dst + cb + opq;
+                        float *dst2 = dst + lo + opq;
 #pragma unroll
                         for (int i = 0; i < PT; ++i)
 #pragma unroll
                             for (int k = 0; k < PT; ++k)
-                                if (i < nrow && k < ncol)
+                                if (act && i < nrow && k < ncol)
                                     *reinterpret_cast<float4 *>(dst2 + ((size_t)i * W + k) * C) = acc[i][k];
                     }
                     ++pass;
@@ -499,11 +501,11 @@ int check_common(const void *pooled, const void *rois, const void *map, int layo
 }
 
 bool fast_bwd_ok(int C, int PH, int PW, int sr, int R) {
-    return (C % CCH) == 0 && PH <= PB && PW <= PB && sr > 0 && (long long)R * PH * PW < (1ll << 31);
+    return (C % 4) == 0 && PH <= PB && PW <= PB && sr > 0 && (long long)R * PH * PW < (1ll << 31);
 }
 
 int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, const int32_t *levels, int R,
-                     int C, int PH, int PW, int sr, hipStream_t st) {
+                     int C, int PH, int PW, int sr, int accumulate, hipStream_t st) {
     int total = 0;
     for (int l = 0; l < lv.L; ++l) {
         lv.tiles_x[l] = mrcnn::cdiv(lv.W[l], TW);
@@ -515,10 +517,10 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
     const int chunk = mrcnn::cdiv(total, 8);
     if (PH <= 8 && PW <= 8)
         hipLaunchKernelGGL(k_roi_align_bwd_nhwc<8>, dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois,
-                           levels, R, N, C, PH, PW, sr, chunk);
+                           levels, R, N, C, PH, PW, sr, chunk, accumulate);
     else
         hipLaunchKernelGGL(k_roi_align_bwd_nhwc<16>, dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois,
-                           levels, R, N, C, PH, PW, sr, chunk);
+                           levels, R, N, C, PH, PW, sr, chunk, accumulate);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -555,7 +557,7 @@ extern "C" int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C
     if (layout == MRCNN_LAYOUT_NHWC && fast_bwd_ok(C, PH, PW, sampling_ratio, R)) {
         Levels lv{};
         lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
-        return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, st);
+        return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, st);
     }
     MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * C * H * W, st));
     if (R == 0) return 0;
@@ -601,14 +603,14 @@ extern "C" int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs
 extern "C" int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws,
                                            const float *scales, int L, int N, int C, const float *rois,
                                            const int32_t *levels, int R, int PH, int PW,
-                                           int sampling_ratio, void *stream) {
+                                           int sampling_ratio, int accumulate, void *stream) {
     if (!gxs || (R > 0 && (!rois || !levels || !gy))) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd: null pointer");
     if (N <= 0 || C <= 0 || PH <= 0 || PW <= 0 || R < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd: bad sizes");
     if (!fast_bwd_ok(C, PH, PW, sampling_ratio, R))
-        return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd: needs C%%256==0, PH,PW<=%d, sampling_ratio>0", PB);
+        return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd: needs C%%4==0, PH,PW<=%d, sampling_ratio>0", PB);
     Levels lv{};
     if (int e = fill_levels(lv, nullptr, gxs, Hs, Ws, scales, L)) return e;
-    return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, (hipStream_t)stream);
+    return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, accumulate, (hipStream_t)stream);
 }
 
 extern "C" int mrcnn_roi_align_sample_tables(const float *rois, int R, int H, int W, int PH, int PW,

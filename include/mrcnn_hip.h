@@ -79,6 +79,8 @@ int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C, int H, in
  *   levels          (R,) int32 device, level of each RoI (already clipped to [0,L))
  *   rois            (R,5) f32 device (batch_idx,x1,y1,x2,y2)
  *   y / gy          (R,PH,PW,C) f32
+ *   accumulate      backward: 0 = every gxs[l] is overwritten (zero where no RoI lands),
+ *                   1 = gradients are added to gxs[l] (second pooled size over the same pyramid)
  * Only MRCNN_LAYOUT_NHWC with C%4==0 is supported. */
 int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs, const int *Ws,
                                 const float *scales, int L, int N, int C, const float *rois,
@@ -87,7 +89,7 @@ int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs, const int
 int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws,
                                 const float *scales, int L, int N, int C, const float *rois,
                                 const int32_t *levels, int R, int PH, int PW,
-                                int sampling_ratio, void *stream);
+                                int sampling_ratio, int accumulate, void *stream);
 
 /* Verification hook for the "ROIAlign indices bit-exact" contract: dumps, for every RoI and
  * both axes, the integer corner cells and float weights of every sample exactly as the
@@ -112,7 +114,8 @@ int mrcnn_roi_align_sample_tables(const float *rois, int R, int H, int W, int PH
  *   H = W = 1; the 2x2/2 deconvolution is a 1x1 convolution to 4*Cout channels + a host view.
  * bwd_data supports stride 1 only (a strided 1x1 convolution is a stride-1 one on the subsampled
  * lattice followed by mrcnn_subsample_bwd_f32); accumulate != 0 adds into gx instead of overwriting.  bwd_filter accumulates over pixels with a deterministic
- * split-K (slabs in the caller's workspace, fixed summation order); gbias may be NULL.
+ * split-K (slabs in the caller's workspace, fixed summation order); gbias may be NULL; accumulate != 0
+ * adds into gw / gbias (layers shared by several inputs, e.g. the RPN head over 5 pyramid levels).
  * ---------------------------------------------------------------------------------------- */
 int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
@@ -122,8 +125,8 @@ int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, int N,
 size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                                int stride, int pad);
 int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, float *gw, float *gbias, int N, int H,
-                                int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void *ws,
-                                size_t ws_bytes, void *stream);
+                                int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,
+                                void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Backbone / head layer kernels (nn.hip), NHWC fp32, "(P, C)" = P pixels x C channels, C % 4 == 0.
@@ -160,7 +163,12 @@ int mrcnn_upsample2x_bwd_f32(const float *gout, float *gtop, int N, int H, int W
 int mrcnn_subsample_bwd_f32(const float *gsub, float *gx, int N, int H, int W, int C, int stride, int accumulate,
                             void *stream);
 /* 2x2/2 deconvolution data movement: (N,H,W,[2][2][C]) <-> (N,2H,2W,C); inverse != 0 is the backward. */
-int mrcnn_pixel_shuffle2x_f32(const float *src, float *dst, int N, int H, int W, int C, int inverse, void *stream);
+int mrcnn_pixel_shuffle2x_f32(const float *src, const float *bias, float *dst, int N, int H, int W, int C, int inverse,
+                              void *stream);      /* bias (C, nullable) is added in the forward direction */
+/* x (N,3,H,W) NCHW -> y (N,H,W,4) NHWC with a zero 4th channel (the image layer's operand layout). */
+int mrcnn_image_nchw3_to_nhwc4_f32(const float *x, float *y, int N, int H, int W, void *stream);
+/* n uint32 sampler keys from a counter-based hash of (seed, index). */
+int mrcnn_random_keys_u32(uint32_t *out, size_t n, unsigned long long seed, void *stream);
 /* g += wd*p; v = momentum*v - lr*g; p += v  over a flat parameter buffer (train.py:107-109). */
 int mrcnn_sgd_momentum_wd_f32(float *p, const float *g, float *v, size_t n, float lr, float momentum,
                               float weight_decay, void *stream);
@@ -179,6 +187,8 @@ int mrcnn_smooth_l1_f32(const float *x, int ldx, const float *t, const int32_t *
                         float *loss_out, float *gx, int ldg, int gfill, void *ws, size_t ws_bytes, void *stream);
 int mrcnn_mask_bce_f32(const float *x, const int32_t *gt, const int32_t *label, int Rm, int HW, int Cm,
                        float *loss_out, float *gx, void *ws, size_t ws_bytes, void *stream);
+/* out[0] = sum of n (loss, normaliser) pairs' losses: the un-weighted total of fpn_maskrcnn_train_chain.py:106 */
+int mrcnn_loss_total_f32(const float *losses, int n, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * RPN proposal path (rpn.hip).  Replaces the transposes/concats and the ChainerCV ProposalCreator +

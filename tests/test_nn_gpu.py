@@ -123,6 +123,20 @@ def test_pixel_shuffle_roundtrip_matches_deconv_layout():
     assert torch.equal(got.cpu(), want)
     back = ops.pixel_shuffle2x(got, inverse=True)
     assert torch.equal(back.cpu(), t)
+    b = torch.randn((C,), generator=g)
+    assert torch.equal(ops.pixel_shuffle2x(t.to(DEV), bias=b.to(DEV)).cpu(), want + b)
+
+
+def test_image_layout_and_random_keys():
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand((2, 3, 5, 7), generator=g)
+    y = ops.image_nchw3_to_nhwc4(x.to(DEV)).cpu()
+    assert torch.equal(y[..., :3], x.permute(0, 2, 3, 1)) and torch.all(y[..., 3] == 0)
+    k1 = ops.random_keys((2, 5000), 123, torch.device(DEV)).cpu().numpy().view(np.uint32)
+    k2 = ops.random_keys((2, 5000), 123, torch.device(DEV)).cpu().numpy().view(np.uint32)
+    k3 = ops.random_keys((2, 5000), 124, torch.device(DEV)).cpu().numpy().view(np.uint32)
+    assert np.array_equal(k1, k2) and not np.array_equal(k1, k3)
+    assert len(np.unique(k1)) > 9990 and abs(k1.mean() / 2 ** 32 - 0.5) < 0.02
 
 
 def test_relu_bwd_and_add():
