@@ -141,6 +141,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--workload', default='auto', choices=['auto', 'roialign', 'step'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mask-rows', default='positives', choices=['positives', 'all'])
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
@@ -163,6 +164,7 @@ def main():
         from chainer_maskrcnn.bench_step import bench_step
         args.steps = args.steps or 20
         args.warmup = 3 if args.warmup is None else args.warmup
+        args.mask_rows = args.mask_rows
         out = bench_step(args, rank, world)
     else:
         args.steps = args.steps or 200

@@ -7,3 +7,8 @@ Keeps the module paths and call signatures of katotetsuro/chainer-maskrcnn
 gfx950 HIP kernels from ``csrc/`` behind the C ABI of ``include/mrcnn_hip.h``;
 there is no CPU or eager-PyTorch fallback - a missing library raises.
 """
+
+
+def train_step_available():
+    """bench.py switches to the full training-step workload (BASELINE.json configs[2]) when this is True."""
+    return True

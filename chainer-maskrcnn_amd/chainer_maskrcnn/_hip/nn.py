@@ -12,6 +12,31 @@ from chainer_maskrcnn._hip import lib, check, ptr, stream_ptr
 
 _ws_cache = {}
 
+# bench.py instrumentation: when PROFILE is a list, every convolution launch is bracketed by HIP events on the
+# launch stream and recorded as (kind, algorithmic MACs, start, end).  LOGICAL = (cin, cout) un-padded channel
+# counts of the layer being run (set by nn.core.Conv), so padded channels do not count as work.
+PROFILE = None
+LOGICAL = None
+
+
+class _prof(object):
+    def __init__(self, kind, n_out_pix, KH, KW, cin, cout):
+        self.on = PROFILE is not None
+        if self.on:
+            if LOGICAL is not None:
+                cin, cout = LOGICAL
+            self.rec = [kind, n_out_pix * KH * KW * cin * cout, torch.cuda.Event(enable_timing=True),
+                        torch.cuda.Event(enable_timing=True)]
+
+    def __enter__(self):
+        if self.on:
+            self.rec[2].record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.rec[3].record()
+            PROFILE.append(tuple(self.rec))
+
 
 def workspace(nbytes, device):
     """Grow-only per-device scratch buffer (caller-owned workspace of the C ABI)."""
@@ -35,8 +60,9 @@ def conv2d_fwd_raw(x, w, b, stride, pad, relu):
     assert x.is_contiguous() and w.is_contiguous()
     y = torch.empty((N, conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad), Cout),
                     dtype=torch.float32, device=x.device)
-    check(lib().mrcnn_conv2d_fwd_f32(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cout, KH, KW,
-                                     stride, pad, int(relu), stream_ptr()))
+    with _prof('fwd', N * y.shape[1] * y.shape[2], KH, KW, Cin, Cout):
+        check(lib().mrcnn_conv2d_fwd_f32(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cout, KH, KW,
+                                         stride, pad, int(relu), stream_ptr()))
     return y
 
 
@@ -47,22 +73,24 @@ def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None):
     assert gy.is_contiguous()
     acc = out is not None
     gx = out if acc else torch.empty(x_shape, dtype=torch.float32, device=gy.device)
-    check(lib().mrcnn_conv2d_bwd_data_f32(ptr(gy), ptr(w), ptr(gx), N, H, W, Cin, Cout, KH, KW,
-                                          stride, pad, int(acc), stream_ptr()))
+    with _prof('bwd_data', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout):
+        check(lib().mrcnn_conv2d_bwd_data_f32(ptr(gy), ptr(w), ptr(gx), N, H, W, Cin, Cout, KH, KW,
+                                              stride, pad, int(acc), stream_ptr()))
     return gx
 
 
-def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias, gw=None, gb=None):
-    """gw / gb given => gradients are ACCUMULATED into them (shared layers); else allocated."""
+def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias, gw=None, gb=None, accumulate=None):
+    """gw / gb given: written in place (accumulate=True adds - layers applied several times); else allocated."""
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w_shape
     assert gy.is_contiguous() and x.is_contiguous()
-    acc = gw is not None
+    acc = (gw is not None) if accumulate is None else bool(accumulate)
     if gw is None:
         gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
         gb = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     nbytes = lib().mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     ws = workspace(nbytes, x.device)
-    check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x), ptr(gy), ptr(gw), ptr(gb) if want_bias else None, N, H, W, Cin,
-                                            Cout, KH, KW, stride, pad, int(acc), ptr(ws), ws.numel(), stream_ptr()))
+    with _prof('bwd_filter', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout):
+        check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x), ptr(gy), ptr(gw), ptr(gb) if want_bias else None, N, H, W, Cin,
+                                                Cout, KH, KW, stride, pad, int(acc), ptr(ws), ws.numel(), stream_ptr()))
     return gw, gb

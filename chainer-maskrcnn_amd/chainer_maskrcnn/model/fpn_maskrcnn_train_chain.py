@@ -169,6 +169,8 @@ class FPNMaskRCNNTrainChain(object):
                             'roi_cls_loss': losses[3, 0], 'mask_loss': losses[4, 0], 'loss': total[0]}
         self._bwd = (features, g_locs.view(n, A, 4), g_scores.view(n, A, 2), g_box, g_mask)
         self.targets = t
+        self.rpn_targets = (gt_rpn_loc, gt_rpn_label)
+        self.mask_inputs = (m_rois, m_levels, m_label)
         self.rpn_out = r
         self._anchor = torch.zeros((), device=dev, requires_grad=True)
         return _LossHandle.apply(self._anchor, self, total[0])

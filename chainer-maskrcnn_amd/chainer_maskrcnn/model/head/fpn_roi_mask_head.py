@@ -139,12 +139,8 @@ class FPNRoIMaskHead(object):
             gb4 = torch.empty((4 * C,), dtype=torch.float32, device=g.device)
             gw = self.ps.g(self.deconv1.name + '/W')
             x_in = td[0]
-            N_, H_, W_, Cin = x_in.shape
-            nbytes = lib().mrcnn_conv2d_bwd_filter_workspace_bytes(N_, H_, W_, Cin, 4 * C, 1, 1, 1, 0)
             from chainer_maskrcnn._hip import nn as hnn
-            ws = hnn.workspace(nbytes, g.device)
-            check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x_in), ptr(g4), ptr(gw), ptr(gb4), N_, H_, W_, Cin, 4 * C, 1, 1,
-                                                    1, 0, 0, ptr(ws), ws.numel(), stream_ptr()))
+            hnn.conv2d_bwd_filter_raw(x_in, g4, tuple(gw.shape), 1, 0, True, gw=gw, gb=gb4, accumulate=False)
             gb = self.ps.g(self.deconv_b)
             ops.add(gb4[0:C], gb4[C:2 * C], out=gb)
             ops.add(gb, gb4[2 * C:3 * C], out=gb)

@@ -124,7 +124,9 @@ class Conv(object):
 
     def fwd(self, x, relu=None):
         relu = self.relu if relu is None else relu
+        hnn.LOGICAL = (self.cin, self.cout)
         y = hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu)
+        hnn.LOGICAL = None
         return y, (x, y if relu else None)
 
     def bwd(self, ctx, gy, need_gx=True, gx_acc=None, accumulate_params=False):
@@ -135,31 +137,28 @@ class Conv(object):
             gy = ops.relu_bwd(gy, y)
         gw = self.ps.g(self.name + '/W')
         gb = self.ps.g(self.name + '/b') if self.has_bias else None
-        if accumulate_params:
-            hnn.conv2d_bwd_filter_raw(x, gy, tuple(gw.shape), self.stride, self.pad, self.has_bias, gw=gw, gb=gb)
-        else:
-            self._filter_overwrite(x, gy, gw, gb)
-        if not need_gx:
-            return None
-        if self.stride == 1:
-            return hnn.conv2d_bwd_data_raw(gy, self.W, tuple(x.shape), 1, self.pad, out=gx_acc)
-        assert self.k == 1 and self.pad == 0, 'strided backward-data only for 1x1 convolutions'
-        g_sub = self.bwd_data_sub(gy)
+        hnn.LOGICAL = (self.cin, self.cout)
+        try:
+            hnn.conv2d_bwd_filter_raw(x, gy, tuple(gw.shape), self.stride, self.pad, self.has_bias, gw=gw, gb=gb,
+                                      accumulate=accumulate_params)
+            if not need_gx:
+                return None
+            if self.stride == 1:
+                return hnn.conv2d_bwd_data_raw(gy, self.W, tuple(x.shape), 1, self.pad, out=gx_acc)
+            assert self.k == 1 and self.pad == 0, 'strided backward-data only for 1x1 convolutions'
+            g_sub = self.bwd_data_sub(gy)
+        finally:
+            hnn.LOGICAL = None
         return ops.subsample_bwd(g_sub, tuple(x.shape), self.stride, gx=gx_acc)
-
-    def _filter_overwrite(self, x, gy, gw, gb):
-        from chainer_maskrcnn._hip import lib, check, ptr, stream_ptr
-        N, H, W, Cin = x.shape
-        Cout, KH, KW, _ = gw.shape
-        nbytes = lib().mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, self.stride, self.pad)
-        ws = hnn.workspace(nbytes, x.device)
-        check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x), ptr(gy), ptr(gw), ptr(gb), N, H, W, Cin, Cout, KH, KW,
-                                                self.stride, self.pad, 0, ptr(ws), ws.numel(), stream_ptr()))
 
     def bwd_data_sub(self, gy, out=None):
         """Data gradient of a strided 1x1 convolution on the subsampled lattice (N,Ho,Wo,Cin)."""
         N, Ho, Wo, _ = gy.shape
-        return hnn.conv2d_bwd_data_raw(gy, self.W, (N, Ho, Wo, self.cin_p), 1, 0, out=out)
+        keep = hnn.LOGICAL
+        hnn.LOGICAL = (self.cin, self.cout)
+        g = hnn.conv2d_bwd_data_raw(gy, self.W, (N, Ho, Wo, self.cin_p), 1, 0, out=out)
+        hnn.LOGICAL = keep
+        return g
 
 
 class BatchNorm(object):
