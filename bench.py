@@ -141,7 +141,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--workload', default='auto', choices=['auto', 'roialign', 'step'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--mask-rows', default='positives', choices=['positives', 'all'])
+    ap.add_argument('--mask-rows', default='all', choices=['positives', 'all'])
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))

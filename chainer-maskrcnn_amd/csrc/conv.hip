@@ -28,9 +28,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDK = BK + 4;    // KC tile row stride (floats): 144 B, keeps b128 alignment, spreads banks
-constexpr int LDR = BM + 4;    // RC tile row stride
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;    // KC tile row stride (floats): 144 B, keeps b128 alignment, conflict-free b128 reads
 constexpr int CONV_THREADS = 256;
 
 enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_FILTER = 2 };
@@ -53,70 +52,83 @@ struct ConvP {
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 // ---- MFMA over one staged K step -----------------------------------------------------------
-template <bool A_KC, bool B_KC>
+// The workgroup tile is BM_ x BN_ (128 or 64 each), 2x2 waves, a wave owns (BM_/2) x (BN_/2) = TM x TN MFMA tiles.
+template <bool A_KC, bool B_KC, int BM_, int BN_>
 __device__ __forceinline__ void mma_step(const float *__restrict__ sA, const float *__restrict__ sB,
-                                         f32x16 (&acc)[2][2], int wm, int wn, int lane) {
+                                         f32x16 (&acc)[BM_ / 64][BN_ / 64], int wm, int wn, int lane) {
+    constexpr int TM = BM_ / 64, TN = BN_ / 64;
+    constexpr int LDA = BM_ + 4, LDB = BN_ + 4;     // RC tile row strides
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
-        float af[2][4], bf[2][4];
+        float af[TM][4], bf[TN][4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = wm * 64 + t * 32 + r;
+        for (int t = 0; t < TM; ++t) {
+            const int row = wm * (BM_ / 2) + t * 32 + r;
             if (A_KC) {
                 const float4 v = *reinterpret_cast<const float4 *>(&sA[row * LDK + kg * 8 + 4 * h]);
                 af[t][0] = v.x; af[t][1] = v.y; af[t][2] = v.z; af[t][3] = v.w;
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[t][i] = sA[(kg * 8 + 4 * h + i) * LDR + row];
+                for (int i = 0; i < 4; ++i) af[t][i] = sA[(kg * 8 + 4 * h + i) * LDA + row];
             }
-            const int col = wn * 64 + t * 32 + r;
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int col = wn * (BN_ / 2) + t * 32 + r;
             if (B_KC) {
                 const float4 v = *reinterpret_cast<const float4 *>(&sB[col * LDK + kg * 8 + 4 * h]);
                 bf[t][0] = v.x; bf[t][1] = v.y; bf[t][2] = v.z; bf[t][3] = v.w;
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bf[t][i] = sB[(kg * 8 + 4 * h + i) * LDR + col];
+                for (int i = 0; i < 4; ++i) bf[t][i] = sB[(kg * 8 + 4 * h + i) * LDB + col];
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][i], bf[tn][i], acc[tm][tn], 0, 0, 0);
     }
 }
 
 // ---- the kernel ----------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int BM_, int BN_>
 __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     constexpr bool A_KC = (MODE != MODE_BWD_FILTER);
     constexpr bool B_KC = (MODE == MODE_FWD);
-    constexpr int A_ELEMS = A_KC ? BM * LDK : BK * LDR;
-    constexpr int B_ELEMS = B_KC ? BN * LDK : BK * LDR;
+    constexpr int TM = BM_ / 64, TN = BN_ / 64;
+    constexpr int LDA = BM_ + 4, LDB = BN_ + 4;
+    constexpr int A_ELEMS = A_KC ? BM_ * LDK : BK * LDA;
+    constexpr int B_ELEMS = B_KC ? BN_ * LDK : BK * LDB;
+    constexpr int NA = BM_ / 32, NB = BN_ / 32;          // float4 loads per thread per K step
+    // RC loader geometry: a k-row of width Wd floats is covered by Wd/4 threads; 256/(Wd/4) k-rows per pass
+    constexpr int A_TPR = BM_ / 4, A_KPP = CONV_THREADS / A_TPR;
+    constexpr int B_TPR = BN_ / 4, B_KPP = CONV_THREADS / B_TPR;
     __shared__ __attribute__((aligned(16))) float sA[A_ELEMS];
     __shared__ __attribute__((aligned(16))) float sB[B_ELEMS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // blockIdx.x walks M tiles fastest so that neighbouring workgroups share the B (weight) panel.
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM_, n0 = blockIdx.y * BN_;
     const int split = (MODE == MODE_BWD_FILTER) ? (int)(blockIdx.z % p.ksplit) : 0;
     const int tap = (MODE == MODE_BWD_FILTER) ? (int)(blockIdx.z / p.ksplit) : 0;   // kh*KW+kw
 
-    // KC loader role: 16-B chunk kc of rows r0+32i.   RC loader role: rows 4*rc.. of k index k0+8i.
+    // KC loader role: 16-B chunk kc of rows r0+32i.   RC loader role: columns 4*rc.. of k index k0 + KPP*i.
     const int kc = tid & 7, r0 = tid >> 3;
-    const int rc = tid & 31, k0 = tid >> 5;
+    const int rcA = tid % A_TPR, k0A = tid / A_TPR;
+    const int rcB = tid % B_TPR, k0B = tid / B_TPR;
 
-    // Pixel decomposition of the 4 gathered rows this thread stages (FWD / BWD_DATA: A rows).
-    int gn[4], gh[4], gw[4];
-    bool gvalid[4];
+    // Pixel decomposition of the gathered rows this thread stages (FWD / BWD_DATA: A rows).
+    int gn[NA], gh[NA], gw[NA];
+    bool gvalid[NA];
     if (MODE != MODE_BWD_FILTER) {
         const int PW_ = (MODE == MODE_FWD) ? p.Wo : p.W, PH_ = (MODE == MODE_FWD) ? p.Ho : p.H;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int m = m0 + r0 + 32 * i;
             gvalid[i] = m < p.M;
             const int mm = gvalid[i] ? m : 0;
@@ -127,11 +139,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         }
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         nsteps = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
     }
 
-    float4 ra[4], rb[4];
+    float4 ra[NA], rb[NB];
     auto load_step = [&](int s) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE == MODE_FWD && p.smallc) {
@@ -155,10 +167,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             const bool tv = chunk < p.KH * p.KW;
             const int kw = chunk % p.KW, kh = chunk / p.KW;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 const int hi = gh[i] * p.stride - p.pad + kh, wi = gw[i] * p.stride - p.pad + kw;
                 const bool ok = tv && gvalid[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
                 ra[i] = ok ? ldg4(p.a + (((size_t)gn[i] * p.H + hi) * p.W + wi) * 4) : z;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
                 const int n = n0 + r0 + 32 * i;
                 rb[i] = (tv && n < p.Ng) ? ldg4(p.b + ((size_t)n * p.KH * p.KW + chunk) * 4) : z;
             }
@@ -166,10 +181,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             const int cs = s % cin_steps, t = s / cin_steps;
             const int kw = t % p.KW, kh = t / p.KW;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 const int hi = gh[i] * p.stride - p.pad + kh, wi = gw[i] * p.stride - p.pad + kw;
                 const bool ok = gvalid[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
                 ra[i] = ok ? ldg4(p.a + (((size_t)gn[i] * p.H + hi) * p.W + wi) * p.Cin + cs * BK + kc * 4) : z;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
                 const int n = n0 + r0 + 32 * i;
                 rb[i] = (n < p.Ng) ? ldg4(p.b + (((size_t)n * p.KH + kh) * p.KW + kw) * p.Cin + cs * BK + kc * 4) : z;
             }
@@ -178,17 +196,20 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             const int cs = s % cout_steps, t = s / cout_steps;
             const int kw = t % p.KW, kh = t / p.KW;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 const int ho = gh[i] + p.pad - kh, wo = gw[i] + p.pad - kw;
                 const bool ok = gvalid[i] && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo;
                 ra[i] = ok ? ldg4(p.a + (((size_t)gn[i] * p.Ho + ho) * p.Wo + wo) * p.Cout + cs * BK + kc * 4) : z;
-                const int co = cs * BK + k0 + 8 * i, ci = n0 + rc * 4;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int co = cs * BK + k0B + B_KPP * i, ci = n0 + rcB * 4;
                 rb[i] = (ci < p.Ng) ? ldg4(p.b + (((size_t)co * p.KH + kh) * p.KW + kw) * p.Cin + ci) : z;
             }
         } else {
             // gw[co][kh][kw][ci] = sum_pix gy[pix][co] * x[pix shifted by (kh,kw)][ci]
             int kw = tap % p.KW, kh = tap / p.KW;
-            int ci = n0 + rc * 4;
+            int ci = n0 + rcB * 4;
             bool cv = ci < p.Ng;
             if (p.smallc) {                               // column = (tap, 4 channels)
                 const int tp = ci >> 2;
@@ -196,14 +217,18 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
                 kw = tp % p.KW; kh = tp / p.KW; ci = 0;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int pix = kbeg + s * BK + k0 + 8 * i;
+            for (int i = 0; i < NA; ++i) {
+                const int pix = kbeg + s * BK + k0A + A_KPP * i;
+                const int co = m0 + rcA * 4;
+                ra[i] = (pix < kend && co < p.M) ? ldg4(p.a + (size_t)pix * p.Cout + co) : z;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int pix = kbeg + s * BK + k0B + B_KPP * i;
                 const bool pv = pix < kend;
                 const int pp = pv ? pix : 0;
                 const int wo = pp % p.Wo, q = pp / p.Wo;
                 const int ho = q % p.Ho, n = q / p.Ho;
-                const int co = m0 + rc * 4;
-                ra[i] = (pv && co < p.M) ? ldg4(p.a + (size_t)pp * p.Cout + co) : z;
                 const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
                 const bool ok = pv && cv && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
                 rb[i] = ok ? ldg4(p.b + (((size_t)n * p.H + hi) * p.W + wi) * p.Cin + ci) : z;
@@ -212,11 +237,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     };
     auto store_step = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             if (A_KC) *reinterpret_cast<float4 *>(&sA[(r0 + 32 * i) * LDK + kc * 4]) = ra[i];
-            else *reinterpret_cast<float4 *>(&sA[(k0 + 8 * i) * LDR + rc * 4]) = ra[i];
+            else *reinterpret_cast<float4 *>(&sA[(k0A + A_KPP * i) * LDA + rcA * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
             if (B_KC) *reinterpret_cast<float4 *>(&sB[(r0 + 32 * i) * LDK + kc * 4]) = rb[i];
-            else *reinterpret_cast<float4 *>(&sB[(k0 + 8 * i) * LDR + rc * 4]) = rb[i];
+            else *reinterpret_cast<float4 *>(&sB[(k0B + B_KPP * i) * LDB + rcB * 4]) = rb[i];
         }
     };
 
@@ -226,7 +254,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
             if (s + 1 < nsteps) load_step(s + 1);
-            mma_step<A_KC, B_KC>(sA, sB, acc, wm, wn, lane);
+            mma_step<A_KC, B_KC, BM_, BN_>(sA, sB, acc, wm, wn, lane);
             __syncthreads();
             if (s + 1 < nsteps) {
                 store_step();
@@ -246,15 +274,15 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         cbase = p.c + (size_t)split * p.Cout * ldc + (p.smallc ? 0 : (size_t)tap * p.Cin);
     }
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int n = n0 + wn * 64 + tn * 32 + r;
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn * (BN_ / 2) + tn * 32 + r;
             if (n >= p.Ng) continue;
             const float bv = (MODE == MODE_FWD && p.bias) ? p.bias[n] : 0.0f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int m = m0 + wm * (BM_ / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m >= p.M) continue;
                 float v = acc[tm][tn][e] + bv;
                 if (MODE == MODE_FWD && p.relu) v = fmaxf(v, 0.0f);
@@ -262,6 +290,28 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
                 cbase[(size_t)m * ldc + n] = v;
             }
         }
+}
+
+// Tile choice: the largest tile that still yields >= 2 workgroups per CU (512 on 256 CUs); narrow N -> 64-wide tiles.
+struct TileChoice { int bm, bn; };
+TileChoice choose_tile(long long M, long long Ng, long long z) {
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Ng + bn - 1) / bn) * z; };
+    const bool narrow_n = Ng <= 64, narrow_m = M <= 64;
+    if (!narrow_n && !narrow_m && tiles(128, 128) >= 512) return {128, 128};
+    if (!narrow_m && tiles(128, 64) >= 512) return {128, 64};
+    if (!narrow_n && !narrow_m && tiles(128, 128) >= 384) return {128, 128};
+    if (narrow_m && !narrow_n) return {64, 128};
+    if (!narrow_m && narrow_n) return {128, 64};
+    return {64, 64};
+}
+
+template <int MODE>
+void launch_conv(const ConvP &p, dim3 grid_z1, TileChoice t, hipStream_t st) {
+    const dim3 grid(mrcnn::cdiv(p.M, t.bm), mrcnn::cdiv(p.Ng, t.bn), grid_z1.z);
+    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 128>), grid, dim3(CONV_THREADS), 0, st, p);
+    else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64>), grid, dim3(CONV_THREADS), 0, st, p);
+    else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 128>), grid, dim3(CONV_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 64>), grid, dim3(CONV_THREADS), 0, st, p);
 }
 
 // Sum split-K slabs: out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]  (deterministic order).
@@ -325,10 +375,17 @@ ConvP make_p(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
 }
 
 // split-K plan for backward-filter: enough workgroups to fill 256 CUs a few times over.
+TileChoice filter_tile(const ConvP &p) {
+    TileChoice t;
+    t.bm = p.Cout <= 64 ? 64 : 128;
+    t.bn = (p.smallc ? p.KH * p.KW * 4 : p.Cin) <= 64 ? 64 : 128;
+    return t;
+}
 void filter_plan(const ConvP &p, int &ksplit, int &kchunk) {
     const long long P = (long long)p.N * p.Ho * p.Wo;
-    const long long tiles = p.smallc ? (long long)mrcnn::cdiv(p.Cout, BM) * mrcnn::cdiv(p.KH * p.KW * 4, BN)
-                                     : (long long)mrcnn::cdiv(p.Cout, BM) * mrcnn::cdiv(p.Cin, BN) * p.KH * p.KW;
+    const TileChoice t = filter_tile(p);
+    const long long tiles = p.smallc ? (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.KH * p.KW * 4, t.bn)
+                                     : (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.Cin, t.bn) * p.KH * p.KW;
     long long want = (1024 + tiles - 1) / tiles;
     long long maxsplit = (P + 4 * BK - 1) / (4 * BK);     // at least 4 K steps per split
     ksplit = (int)std::max(1ll, std::min(std::min(want, maxsplit), 64ll));
@@ -345,8 +402,7 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     p.a = x; p.b = w; p.c = y; p.bias = bias; p.relu = relu;
     p.M = N * p.Ho * p.Wo; p.Ng = Cout;
-    dim3 grid(mrcnn::cdiv(p.M, BM), mrcnn::cdiv(p.Ng, BN), 1);
-    hipLaunchKernelGGL(k_conv_igemm<MODE_FWD>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p);
+    launch_conv<MODE_FWD>(p, dim3(1, 1, 1), choose_tile(p.M, p.Ng, 1), (hipStream_t)stream);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -362,8 +418,7 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
     if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
     p.a = gy; p.b = w; p.c = gx; p.accumulate = accumulate;
     p.M = N * H * W; p.Ng = Cin;
-    dim3 grid(mrcnn::cdiv(p.M, BM), mrcnn::cdiv(p.Ng, BN), 1);
-    hipLaunchKernelGGL(k_conv_igemm<MODE_BWD_DATA>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p);
+    launch_conv<MODE_BWD_DATA>(p, dim3(1, 1, 1), choose_tile(p.M, p.Ng, 1), (hipStream_t)stream);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -396,8 +451,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     const bool use_slabs = p.ksplit > 1 || accumulate;
     p.a = gy; p.b = x; p.c = use_slabs ? slabs : gw;
     p.M = Cout; p.Ng = p.smallc ? KH * KW * 4 : Cin;
-    dim3 grid(mrcnn::cdiv(p.M, BM), mrcnn::cdiv(p.Ng, BN), (p.smallc ? 1 : KH * KW) * p.ksplit);
-    hipLaunchKernelGGL(k_conv_igemm<MODE_BWD_FILTER>, grid, dim3(CONV_THREADS), 0, st, p);
+    launch_conv<MODE_BWD_FILTER>(p, dim3(1, 1, (p.smallc ? 1 : KH * KW) * p.ksplit), filter_tile(p), st);
     MRCNN_LAUNCH_CHECK();
     if (use_slabs) {
         const size_t n4 = wcount / 4;

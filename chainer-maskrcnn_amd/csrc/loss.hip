@@ -49,14 +49,18 @@ __device__ __forceinline__ void block_partial(float a, float b, float *part) {
     }
 }
 
-// out[0] = sum(a)/max(sum(b),1), out[1] = max(sum(b),1)   (single thread, fixed order, double)
-__global__ void k_finalize(const float *__restrict__ part, int nb, float *__restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// out[0] = sum(a)/max(sum(b),1), out[1] = max(sum(b),1): one wave, lane l adds partials l, l+64, ... in double,
+// then a fixed xor-shuffle tree (bit-reproducible).
+__global__ __launch_bounds__(64) void k_finalize(const float *__restrict__ part, int nb, float *__restrict__ out) {
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nb; ++k) { a += (double)part[2 * k]; b += (double)part[2 * k + 1]; }
-    if (b < 1.0) b = 1.0;
-    out[0] = (float)(a / b);
-    out[1] = (float)b;
+    for (int k = threadIdx.x; k < nb; k += 64) { a += (double)part[2 * k]; b += (double)part[2 * k + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (threadIdx.x == 0) {
+        if (b < 1.0) b = 1.0;
+        out[0] = (float)(a / b);
+        out[1] = (float)b;
+    }
 }
 
 // ---- softmax cross entropy -------------------------------------------------------------------

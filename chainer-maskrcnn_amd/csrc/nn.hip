@@ -77,16 +77,34 @@ __global__ __launch_bounds__(NT) void k_bn_stats_partial(const float *__restrict
     }
 }
 
-__global__ void k_bn_stats_final(const float *__restrict__ x, const float *__restrict__ part, int nblk, int P, int C,
-                                 float eps, float decay, float *__restrict__ mean, float *__restrict__ invstd,
-                                 float *__restrict__ run_mean, float *__restrict__ run_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-        a += (double)part[(size_t)k * 2 * C + c];
-        b += (double)part[(size_t)k * 2 * C + C + c];
+// Sum of the per-block partials of 64 channels by a 1024-thread block: thread (slice s, channel c) adds partials
+// s, s+16, ... in double, the 16 slice sums are then added in slice order (fixed order => bit-reproducible).
+constexpr int FIN_SLICES = 16;
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int nblk, int C, int c, int slice,
+                                                double (*sa)[64], double (*sb)[64], double &a, double &b) {
+    a = 0.0; b = 0.0;
+    if (c < C)
+        for (int k = slice; k < nblk; k += FIN_SLICES) {
+            a += (double)part[(size_t)k * 2 * C + c];
+            b += (double)part[(size_t)k * 2 * C + C + c];
+        }
+    sa[slice][threadIdx.x & 63] = a;
+    sb[slice][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (slice == 0) {
+        for (int k = 1; k < FIN_SLICES; ++k) { a += sa[k][threadIdx.x & 63]; b += sb[k][threadIdx.x & 63]; }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_bn_stats_final(const float *__restrict__ x, const float *__restrict__ part,
+                                                         int nblk, int P, int C, float eps, float decay,
+                                                         float *__restrict__ mean, float *__restrict__ invstd,
+                                                         float *__restrict__ run_mean, float *__restrict__ run_var) {
+    __shared__ double sa[FIN_SLICES][64], sb[FIN_SLICES][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    double a, b;
+    reduce_partials(part, nblk, C, c, slice, sa, sb, a, b);
+    if (slice != 0 || c >= C) return;
     const double ms = a / P;
     double var = b / P - ms * ms;
     if (var < 0.0) var = 0.0;
@@ -162,15 +180,13 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__
     }
 }
 
-__global__ void k_bn_bwd_final(const float *__restrict__ part, int nblk, int C, float *__restrict__ gbeta,
-                               float *__restrict__ ggamma) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-        a += (double)part[(size_t)k * 2 * C + c];
-        b += (double)part[(size_t)k * 2 * C + C + c];
-    }
+__global__ __launch_bounds__(1024) void k_bn_bwd_final(const float *__restrict__ part, int nblk, int C,
+                                                       float *__restrict__ gbeta, float *__restrict__ ggamma) {
+    __shared__ double sa[FIN_SLICES][64], sb[FIN_SLICES][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    double a, b;
+    reduce_partials(part, nblk, C, c, slice, sa, sb, a, b);
+    if (slice != 0 || c >= C) return;
     gbeta[c] = (float)a;
     ggamma[c] = (float)b;
 }
@@ -435,7 +451,7 @@ extern "C" int mrcnn_bn_train_fwd_f32(const float *x, const float *gamma, const 
     const RedPlan r = red_plan(P, C);
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(r.nblk), dim3(NT), 0, st, x, P, C, r.G, r.RPI, r.rows_per_blk, (float *)ws);
     MRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_stats_final, dim3(mrcnn::cdiv(C, 64)), dim3(64), 0, st, x, (const float *)ws, r.nblk, P, C,
+    hipLaunchKernelGGL(k_bn_stats_final, dim3(mrcnn::cdiv(C, 64)), dim3(1024), 0, st, x, (const float *)ws, r.nblk, P, C,
                        eps, decay, save_mean, save_invstd, running_mean, running_var);
     MRCNN_LAUNCH_CHECK();
     const size_t n4 = (size_t)P * C / 4;
@@ -458,7 +474,7 @@ extern "C" int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const flo
     hipLaunchKernelGGL(k_bn_bwd_partial, dim3(r.nblk), dim3(NT), 0, st, gy, x, y, save_mean, save_invstd, P, C, r.G, r.RPI,
                        r.rows_per_blk, relu, (float *)ws);
     MRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(mrcnn::cdiv(C, 64)), dim3(64), 0, st, (const float *)ws, r.nblk, C, gbeta, ggamma);
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(mrcnn::cdiv(C, 64)), dim3(1024), 0, st, (const float *)ws, r.nblk, C, gbeta, ggamma);
     MRCNN_LAUNCH_CHECK();
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, gy, x, y, gamma, save_mean, save_invstd, gbeta,

@@ -260,18 +260,24 @@ __global__ __launch_bounds__(256) void k_at_iou(const float *__restrict__ anchor
     for (int g = threadIdx.x; g < G; g += 256) sg[g] = *reinterpret_cast<const float4 *>(gt_boxes + ((size_t)img * gt_cap + g) * 4);
     __syncthreads();
     const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= A) return;
-    const float4 an = *reinterpret_cast<const float4 *>(anchors + (size_t)a * 4);
+    const bool live = a < A;
+    const float4 an = live ? *reinterpret_cast<const float4 *>(anchors + (size_t)a * 4) : make_float4(-1.f, -1.f, -1.f, -1.f);
     float best = 0.f;
     int arg = 0;
-    const bool in = anchor_inside(an, img_h, img_w);
-    if (in) {
-        for (int g = 0; g < G; ++g) {
-            const float v = box_iou(an, sg[g]);
+    const bool in = live && anchor_inside(an, img_h, img_w);
+    for (int g = 0; g < G; ++g) {
+        float v = 0.f;
+        if (in) {
+            v = box_iou(an, sg[g]);
             if (g == 0 || v > best) { best = v; arg = g; }
-            atomicMax(&gt_max_bits[(size_t)img * AT_GCAP + g], __float_as_int(v));   // IoU >= 0: int order == float order
         }
+        // per-gt maximum over the inside anchors: wave reduction first, one atomic per wave (IoU >= 0: int order == float order)
+        int vb = in ? __float_as_int(v) : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vb = max(vb, __shfl_xor(vb, o));
+        if ((threadIdx.x & 63) == 0 && vb > 0) atomicMax(&gt_max_bits[(size_t)img * AT_GCAP + g], vb);
     }
+    if (!live) return;
     max_iou[(size_t)img * A + a] = best;
     argmax[(size_t)img * A + a] = in ? arg : -1;
 }

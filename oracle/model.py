@@ -23,6 +23,12 @@ from . import roi_align as ora
 D = torch.float64
 
 
+def set_dtype(dt):
+    """float64 for parity checks (default); float32 when timed as the CPU baseline (the reference computes in fp32)."""
+    global D
+    D = dt
+
+
 def conv(x, w, b=None, stride=1, pad=0):
     """x (N,H,W,Cin) NHWC, w (Cout,KH,KW,Cin) -> (N,Ho,Wo,Cout)."""
     y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, stride=stride, padding=pad)
@@ -54,13 +60,13 @@ class _RoIAlignNp(torch.autograd.Function):
         xn = x.detach().permute(0, 3, 1, 2).numpy().astype(np.float32)
         y = ora.roi_align_fwd(xn, rois, P, P, scale, 2)
         ctx.meta = (rois, tuple(xn.shape), scale)
-        return torch.from_numpy(y.astype(np.float64)).permute(0, 2, 3, 1)
+        return torch.from_numpy(y).to(D).permute(0, 2, 3, 1)
 
     @staticmethod
     def backward(ctx, gy):
         rois, shape, scale = ctx.meta
         g = ora.roi_align_bwd(gy.permute(0, 3, 1, 2).numpy().astype(np.float32), rois, shape, scale, 2)
-        return torch.from_numpy(g.astype(np.float64)).permute(0, 2, 3, 1), None, None, None
+        return torch.from_numpy(g).to(D).permute(0, 2, 3, 1), None, None, None
 
 
 def roi_align_fpn(feats, rois_xy5, levels, P, scales):
