@@ -38,9 +38,21 @@ class _prof(object):
             PROFILE.append(tuple(self.rec))
 
 
-def workspace(nbytes, device):
-    """Grow-only per-device scratch buffer (caller-owned workspace of the C ABI)."""
+_side = {}
+
+
+def side_stream(device):
+    """Second HIP stream per device: weight-gradient GEMMs run here, concurrently with the data-gradient chain on
+    the main stream (they fill each other's tail waves; both only read gy)."""
     key = (device.type, device.index)
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, current stream): the caller-owned workspace of the C ABI."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -189,6 +189,8 @@ class FPNMaskRCNNTrainChain(object):
         if hook:
             hook(self._offset_of('rpn/'))
         m.extractor.backward(g_feats)
+        from chainer_maskrcnn.nn import core
+        core.join_side_stream(features[0].device)
         if hook:
             hook(0)
         self._bwd = None

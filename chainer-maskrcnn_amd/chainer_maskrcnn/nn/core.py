@@ -22,6 +22,14 @@ from chainer_maskrcnn._hip import nn as hnn
 from chainer_maskrcnn._hip import ops
 
 
+# Weight-gradient GEMMs on a second stream (joined by join_side_stream() at the end of backward).
+FILTER_GRAD_ON_SIDE_STREAM = True
+
+
+def join_side_stream(device):
+    torch.cuda.current_stream(device).wait_stream(hnn.side_stream(device))
+
+
 def pad_to(n, m):
     return (n + m - 1) // m * m
 
@@ -139,8 +147,18 @@ class Conv(object):
         gb = self.ps.g(self.name + '/b') if self.has_bias else None
         hnn.LOGICAL = (self.cin, self.cout)
         try:
-            hnn.conv2d_bwd_filter_raw(x, gy, tuple(gw.shape), self.stride, self.pad, self.has_bias, gw=gw, gb=gb,
-                                      accumulate=accumulate_params)
+            if FILTER_GRAD_ON_SIDE_STREAM and hnn.PROFILE is None:
+                main = torch.cuda.current_stream(gy.device)
+                side = hnn.side_stream(gy.device)
+                side.wait_stream(main)                      # gy (and x) are complete on the main stream
+                with torch.cuda.stream(side):
+                    hnn.conv2d_bwd_filter_raw(x, gy, tuple(gw.shape), self.stride, self.pad, self.has_bias, gw=gw, gb=gb,
+                                              accumulate=accumulate_params)
+                gy.record_stream(side)                      # allocator: do not recycle gy before the side kernel is done
+                x.record_stream(side)
+            else:
+                hnn.conv2d_bwd_filter_raw(x, gy, tuple(gw.shape), self.stride, self.pad, self.has_bias, gw=gw, gb=gb,
+                                          accumulate=accumulate_params)
             if not need_gx:
                 return None
             if self.stride == 1:

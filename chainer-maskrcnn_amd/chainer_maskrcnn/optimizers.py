@@ -50,7 +50,9 @@ class GradientSynchronizer(object):
     def _reduce(self, start, end):
         sl = self.grads[start:end]
         if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream())      # the bucket's producers have been enqueued
+            self.stream.wait_stream(torch.cuda.current_stream())      # the bucket's producers have been enqueued ...
+            from chainer_maskrcnn._hip import nn as hnn
+            self.stream.wait_stream(hnn.side_stream(self.grads.device))   # ... on the main and on the weight-gradient stream
             with torch.cuda.stream(self.stream):
                 torch.distributed.all_reduce(sl, op=torch.distributed.ReduceOp.SUM, group=self.group)
         else:
