@@ -50,6 +50,14 @@ struct ConvP {
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// Predicated 16-B loads WITHOUT a branch: the load is always issued (from the tensor base when the predicate is
+// false) and the zero-select is applied when the value is written to LDS (store_step), AFTER the MFMAs of the current
+// step, so the load stays in flight across them.  A conditional load makes hipcc branch around it and wait vmcnt(0)
+// at the join, which serialises the staging pipeline (cdna_hip_programming.md section 5, "Three .s-level traps" (c)).
+__device__ __forceinline__ float4 zero_unless(unsigned mask, int bit, float4 v) {
+    const bool ok = (mask >> bit) & 1u;
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
 
 // ---- MFMA over one staged K step -----------------------------------------------------------
 // The workgroup tile is BM_ x BN_ (128 or 64 each), 2x2 waves, a wave owns (BM_/2) x (BN_/2) = TM x TN MFMA tiles.
@@ -59,18 +67,17 @@ __device__ __forceinline__ void mma_step(const float *__restrict__ sA, const flo
     constexpr int TM = BM_ / 64, TN = BN_ / 64;
     constexpr int LDA = BM_ + 4, LDB = BN_ + 4;     // RC tile row strides
     const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
-        float af[TM][4], bf[TN][4];
+    float af[2][TM][4], bf[2][TN][4];
+    auto load_frag = [&](int kg, float (&a)[TM][4], float (&b)[TN][4]) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int row = wm * (BM_ / 2) + t * 32 + r;
             if (A_KC) {
                 const float4 v = *reinterpret_cast<const float4 *>(&sA[row * LDK + kg * 8 + 4 * h]);
-                af[t][0] = v.x; af[t][1] = v.y; af[t][2] = v.z; af[t][3] = v.w;
+                a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[t][i] = sA[(kg * 8 + 4 * h + i) * LDA + row];
+                for (int i = 0; i < 4; ++i) a[t][i] = sA[(kg * 8 + 4 * h + i) * LDA + row];
             }
         }
 #pragma unroll
@@ -78,24 +85,40 @@ __device__ __forceinline__ void mma_step(const float *__restrict__ sA, const flo
             const int col = wn * (BN_ / 2) + t * 32 + r;
             if (B_KC) {
                 const float4 v = *reinterpret_cast<const float4 *>(&sB[col * LDK + kg * 8 + 4 * h]);
-                bf[t][0] = v.x; bf[t][1] = v.y; bf[t][2] = v.z; bf[t][3] = v.w;
+                b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bf[t][i] = sB[(kg * 8 + 4 * h + i) * LDB + col];
+                for (int i = 0; i < 4; ++i) b[t][i] = sB[(kg * 8 + 4 * h + i) * LDB + col];
             }
         }
+    };
+    // operands of k-group kg+1 are fetched from LDS before the 16/8/4 MFMAs of k-group kg are issued
+    load_frag(0, af[0], bf[0]);
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+        if (kg + 1 < BK / 8) load_frag(kg + 1, af[(kg + 1) & 1], bf[(kg + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][i], bf[tn][i], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg & 1][tm][i], bf[kg & 1][tn][i], acc[tm][tn], 0, 0, 0);
     }
 }
 
 // ---- the kernel ----------------------------------------------------------------------------
-template <int MODE, int BM_, int BN_>
+// All tensor offsets are 32-bit element indices (the host checks every tensor has < 2^31 elements); the per-row
+// part of every gather address is computed once, a K step only adds a wave-uniform tap/channel offset.
+__device__ __forceinline__ void divmod_small(int v, int d, float inv, int &q, int &r) {
+    // exact for 0 <= v < 2^24: float estimate + one correction step each way
+    q = (int)((float)v * inv);
+    r = v - q * d;
+    if (r >= d) { r -= d; ++q; }
+    if (r < 0) { r += d; --q; }
+}
+
+template <int MODE, int BM_, int BN_, bool SMALLC>
 __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     constexpr bool A_KC = (MODE != MODE_BWD_FILTER);
     constexpr bool B_KC = (MODE == MODE_FWD);
@@ -121,21 +144,41 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     const int kc = tid & 7, r0 = tid >> 3;
     const int rcA = tid % A_TPR, k0A = tid / A_TPR;
     const int rcB = tid % B_TPR, k0B = tid / B_TPR;
+    const int taps = p.KH * p.KW;
 
-    // Pixel decomposition of the gathered rows this thread stages (FWD / BWD_DATA: A rows).
-    int gn[NA], gh[NA], gw[NA];
-    bool gvalid[NA];
+    // ---- per-thread row state ----------------------------------------------------------------
+    // FWD / BWD_DATA: gathered A rows (output pixels m): rowoff = element offset of (n, h0, w0, 0) in the source
+    // tensor, (h0, w0) = top-left source coordinate of tap (0,0); rowmask bit i = row exists.
+    int a_off[NA], a_h0[NA], a_w0[NA];
+    unsigned rowmask = 0;
+    // weights (FWD: row n of B; BWD_DATA: handled per step);  BWD_FILTER: pixel walk state of the B loads
+    int b_off[NB];
+    unsigned colmask = 0;
     if (MODE != MODE_BWD_FILTER) {
         const int PW_ = (MODE == MODE_FWD) ? p.Wo : p.W, PH_ = (MODE == MODE_FWD) ? p.Ho : p.H;
+        const float invW = 1.0f / (float)PW_, invH = 1.0f / (float)PH_;
+        const int srcH = (MODE == MODE_FWD) ? p.H : p.Ho, srcW = (MODE == MODE_FWD) ? p.W : p.Wo;
+        const int srcC = (MODE == MODE_FWD) ? (SMALLC ? 4 : p.Cin) : p.Cout;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = m0 + r0 + 32 * i;
-            gvalid[i] = m < p.M;
-            const int mm = gvalid[i] ? m : 0;
-            gw[i] = mm % PW_;
-            const int q = mm / PW_;
-            gh[i] = q % PH_;
-            gn[i] = q / PH_;
+            const bool v = m < p.M;
+            rowmask |= v ? (1u << i) : 0u;
+            int q, w_, n_, h_;
+            divmod_small(v ? m : 0, PW_, invW, q, w_);
+            divmod_small(q, PH_, invH, n_, h_);
+            a_h0[i] = (MODE == MODE_FWD) ? h_ * p.stride - p.pad : h_ + p.pad;
+            a_w0[i] = (MODE == MODE_FWD) ? w_ * p.stride - p.pad : w_ + p.pad;
+            a_off[i] = ((n_ * srcH + a_h0[i]) * srcW + a_w0[i]) * srcC;
+        }
+    }
+    if (MODE == MODE_FWD) {
+        const int krow = SMALLC ? taps * 4 : taps * p.Cin;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = n0 + r0 + 32 * i;
+            colmask |= (n < p.Ng) ? (1u << i) : 0u;
+            b_off[i] = (n < p.Ng ? n : 0) * krow;
         }
     }
 
@@ -150,101 +193,117 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     // K-step bookkeeping
     int nsteps, kbeg = 0, kend = 0;
     const int cin_steps = p.Cin / BK, cout_steps = p.Cout / BK;
-    if (MODE == MODE_FWD) nsteps = p.smallc ? (p.KH * p.KW + 7) / 8 : p.KH * p.KW * cin_steps;
-    else if (MODE == MODE_BWD_DATA) nsteps = p.KH * p.KW * cout_steps;
+    if (MODE == MODE_FWD) nsteps = SMALLC ? (taps + 7) / 8 : taps * cin_steps;
+    else if (MODE == MODE_BWD_DATA) nsteps = taps * cout_steps;
     else {
         const int P = p.N * p.Ho * p.Wo;
         kbeg = split * p.kchunk;
         kend = min(P, kbeg + p.kchunk);
         nsteps = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
     }
+    // BWD_FILTER constants
+    int f_kh = 0, f_kw = 0, f_ci = 0;
+    bool f_cv = false;
+    float f_invW = 0.f, f_invH = 0.f;
+    if (MODE == MODE_BWD_FILTER) {
+        f_kw = tap % p.KW; f_kh = tap / p.KW;
+        f_ci = n0 + rcB * 4;
+        f_cv = f_ci < p.Ng;
+        if (SMALLC) {                               // column = (tap, 4 channels)
+            const int tp = f_ci >> 2;
+            f_cv = tp < taps;
+            f_kw = tp % p.KW; f_kh = tp / p.KW; f_ci = 0;
+        }
+        f_invW = 1.0f / (float)p.Wo; f_invH = 1.0f / (float)p.Ho;
+    }
 
     float4 ra[NA], rb[NB];
+    unsigned okmask = 0;      // bit i: ra[i] is real data, bit 8+i: rb[i]; applied when the values go to LDS
+    auto ld = [&](bool ok, const float *base, int off, int bit) -> float4 {
+        okmask |= ok ? (1u << bit) : 0u;
+        return ldg4(base + (ok ? off : 0));
+    };
     auto load_step = [&](int s) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE == MODE_FWD && p.smallc) {
-            const int chunk = s * 8 + kc;                 // tap index
-            const bool tv = chunk < p.KH * p.KW;
+        okmask = 0;
+        if (MODE == MODE_FWD && SMALLC) {
+            const int chunk = s * 8 + kc;                 // tap index of this thread's 16-B chunk
+            const bool tv = chunk < taps;
             const int kw = chunk % p.KW, kh = chunk / p.KW;
+            const int toff = (kh * p.W + kw) * 4;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int hi = gh[i] * p.stride - p.pad + kh, wi = gw[i] * p.stride - p.pad + kw;
-                const bool ok = tv && gvalid[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-                ra[i] = ok ? ldg4(p.a + (((size_t)gn[i] * p.H + hi) * p.W + wi) * 4) : z;
+                const int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
+                const bool ok = tv & (bool)((rowmask >> i) & 1u) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+                ra[i] = ld(ok, p.a, a_off[i] + toff, i);
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int n = n0 + r0 + 32 * i;
-                rb[i] = (tv && n < p.Ng) ? ldg4(p.b + ((size_t)n * p.KH * p.KW + chunk) * 4) : z;
-            }
+            for (int i = 0; i < NB; ++i) rb[i] = ld(tv && ((colmask >> i) & 1u), p.b, b_off[i] + chunk * 4, 8 + i);
         } else if (MODE == MODE_FWD) {
-            const int cs = s % cin_steps, t = s / cin_steps;
+            const int cs = s % cin_steps, t = s / cin_steps;     // wave-uniform
             const int kw = t % p.KW, kh = t / p.KW;
+            const int toff = (kh * p.W + kw) * p.Cin + cs * BK + kc * 4;
+            const int woff = t * p.Cin + cs * BK + kc * 4;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int hi = gh[i] * p.stride - p.pad + kh, wi = gw[i] * p.stride - p.pad + kw;
-                const bool ok = gvalid[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-                ra[i] = ok ? ldg4(p.a + (((size_t)gn[i] * p.H + hi) * p.W + wi) * p.Cin + cs * BK + kc * 4) : z;
+                const int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
+                const bool ok = (bool)((rowmask >> i) & 1u) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+                ra[i] = ld(ok, p.a, a_off[i] + toff, i);
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int n = n0 + r0 + 32 * i;
-                rb[i] = (n < p.Ng) ? ldg4(p.b + (((size_t)n * p.KH + kh) * p.KW + kw) * p.Cin + cs * BK + kc * 4) : z;
-            }
+            for (int i = 0; i < NB; ++i) rb[i] = ld((colmask >> i) & 1u, p.b, b_off[i] + woff, 8 + i);
         } else if (MODE == MODE_BWD_DATA) {
             // gx[n,hi,wi,ci] = sum_{kh,kw,co} gy[n, hi+pad-kh, wi+pad-kw, co] * w[co][kh][kw][ci]   (stride 1)
             const int cs = s % cout_steps, t = s / cout_steps;
             const int kw = t % p.KW, kh = t / p.KW;
+            const int toff = -(kh * p.Wo + kw) * p.Cout + cs * BK + kc * 4;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int ho = gh[i] + p.pad - kh, wo = gw[i] + p.pad - kw;
-                const bool ok = gvalid[i] && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo;
-                ra[i] = ok ? ldg4(p.a + (((size_t)gn[i] * p.Ho + ho) * p.Wo + wo) * p.Cout + cs * BK + kc * 4) : z;
+                const int ho = a_h0[i] - kh, wo = a_w0[i] - kw;
+                const bool ok = (bool)((rowmask >> i) & 1u) & ((unsigned)ho < (unsigned)p.Ho) & ((unsigned)wo < (unsigned)p.Wo);
+                ra[i] = ld(ok, p.a, a_off[i] + toff, i);
             }
+            const int ci = n0 + rcB * 4;
+            const int wbase = t * p.Cin + ci;
+            const int krow = taps * p.Cin;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int co = cs * BK + k0B + B_KPP * i, ci = n0 + rcB * 4;
-                rb[i] = (ci < p.Ng) ? ldg4(p.b + (((size_t)co * p.KH + kh) * p.KW + kw) * p.Cin + ci) : z;
+                const int co = cs * BK + k0B + B_KPP * i;
+                rb[i] = ld(ci < p.Ng, p.b, co * krow + wbase, 8 + i);
             }
         } else {
             // gw[co][kh][kw][ci] = sum_pix gy[pix][co] * x[pix shifted by (kh,kw)][ci]
-            int kw = tap % p.KW, kh = tap / p.KW;
-            int ci = n0 + rcB * 4;
-            bool cv = ci < p.Ng;
-            if (p.smallc) {                               // column = (tap, 4 channels)
-                const int tp = ci >> 2;
-                cv = tp < p.KH * p.KW;
-                kw = tp % p.KW; kh = tp / p.KW; ci = 0;
-            }
+            const int co = m0 + rcA * 4;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int pix = kbeg + s * BK + k0A + A_KPP * i;
-                const int co = m0 + rcA * 4;
-                ra[i] = (pix < kend && co < p.M) ? ldg4(p.a + (size_t)pix * p.Cout + co) : z;
+                ra[i] = ld(pix < kend && co < p.M, p.a, pix * p.Cout + co, i);
             }
+            const int xc = SMALLC ? 4 : p.Cin;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int pix = kbeg + s * BK + k0B + B_KPP * i;
                 const bool pv = pix < kend;
-                const int pp = pv ? pix : 0;
-                const int wo = pp % p.Wo, q = pp / p.Wo;
-                const int ho = q % p.Ho, n = q / p.Ho;
-                const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
-                const bool ok = pv && cv && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-                rb[i] = ok ? ldg4(p.b + (((size_t)n * p.H + hi) * p.W + wi) * p.Cin + ci) : z;
+                int q, wo, n, ho;
+                divmod_small(pv ? pix : 0, p.Wo, f_invW, q, wo);
+                divmod_small(q, p.Ho, f_invH, n, ho);
+                const int hi = ho * p.stride - p.pad + f_kh, wi = wo * p.stride - p.pad + f_kw;
+                const bool ok = pv & f_cv & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+                rb[i] = ld(ok, p.b, ((n * p.H + hi) * p.W + wi) * xc + f_ci, 8 + i);
             }
         }
     };
     auto store_step = [&]() {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            if (A_KC) *reinterpret_cast<float4 *>(&sA[(r0 + 32 * i) * LDK + kc * 4]) = ra[i];
-            else *reinterpret_cast<float4 *>(&sA[(k0A + A_KPP * i) * LDA + rcA * 4]) = ra[i];
+            const float4 v = zero_unless(okmask, i, ra[i]);
+            if (A_KC) *reinterpret_cast<float4 *>(&sA[(r0 + 32 * i) * LDK + kc * 4]) = v;
+            else *reinterpret_cast<float4 *>(&sA[(k0A + A_KPP * i) * LDA + rcA * 4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            if (B_KC) *reinterpret_cast<float4 *>(&sB[(r0 + 32 * i) * LDK + kc * 4]) = rb[i];
-            else *reinterpret_cast<float4 *>(&sB[(k0B + B_KPP * i) * LDB + rcB * 4]) = rb[i];
+            const float4 v = zero_unless(okmask, 8 + i, rb[i]);
+            if (B_KC) *reinterpret_cast<float4 *>(&sB[(r0 + 32 * i) * LDK + kc * 4]) = v;
+            else *reinterpret_cast<float4 *>(&sB[(k0B + B_KPP * i) * LDB + rcB * 4]) = v;
         }
     };
 
@@ -253,7 +312,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         store_step();
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
-            if (s + 1 < nsteps) load_step(s + 1);
+            if (s + 1 < nsteps) load_step(s + 1);          // global -> registers: in flight during the MFMAs below
             mma_step<A_KC, B_KC, BM_, BN_>(sA, sB, acc, wm, wn, lane);
             __syncthreads();
             if (s + 1 < nsteps) {
@@ -270,20 +329,21 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     if (MODE == MODE_FWD) { ldc = p.Cout; cbase = p.c; }
     else if (MODE == MODE_BWD_DATA) { ldc = p.Cin; cbase = p.c; }
     else {
-        ldc = (size_t)p.KH * p.KW * p.Cin;
-        cbase = p.c + (size_t)split * p.Cout * ldc + (p.smallc ? 0 : (size_t)tap * p.Cin);
+        ldc = (size_t)taps * (SMALLC ? 4 : p.Cin);
+        cbase = p.c + (size_t)split * p.Cout * ldc + (SMALLC ? 0 : (size_t)tap * p.Cin);
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int n = n0 + wn * (BN_ / 2) + tn * 32 + r;
-            if (n >= p.Ng) continue;
-            const float bv = (MODE == MODE_FWD && p.bias) ? p.bias[n] : 0.0f;
+            const bool nv = n < p.Ng;
+            float bv = 0.0f;
+            if (MODE == MODE_FWD) bv = p.bias ? p.bias[nv ? n : 0] : 0.0f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * (BM_ / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m >= p.M) continue;
+                if (!nv || m >= p.M) continue;
                 float v = acc[tm][tn][e] + bv;
                 if (MODE == MODE_FWD && p.relu) v = fmaxf(v, 0.0f);
                 if (MODE == MODE_BWD_DATA && p.accumulate) v += cbase[(size_t)m * ldc + n];
@@ -307,11 +367,21 @@ TileChoice choose_tile(long long M, long long Ng, long long z) {
 
 template <int MODE>
 void launch_conv(const ConvP &p, dim3 grid_z1, TileChoice t, hipStream_t st) {
+    if (p.smallc) {      // image layer: fixed tiles (fwd: Cout = 64 wide; filter gradient: Cout = 64 x 196 columns)
+        if (MODE == MODE_FWD) {
+            const dim3 grid(mrcnn::cdiv(p.M, 128), mrcnn::cdiv(p.Ng, 64), grid_z1.z);
+            hipLaunchKernelGGL((k_conv_igemm<MODE_FWD, 128, 64, true>), grid, dim3(CONV_THREADS), 0, st, p);
+        } else {
+            const dim3 grid(mrcnn::cdiv(p.M, 64), mrcnn::cdiv(p.Ng, 128), grid_z1.z);
+            hipLaunchKernelGGL((k_conv_igemm<MODE_BWD_FILTER, 64, 128, true>), grid, dim3(CONV_THREADS), 0, st, p);
+        }
+        return;
+    }
     const dim3 grid(mrcnn::cdiv(p.M, t.bm), mrcnn::cdiv(p.Ng, t.bn), grid_z1.z);
-    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 128>), grid, dim3(CONV_THREADS), 0, st, p);
-    else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64>), grid, dim3(CONV_THREADS), 0, st, p);
-    else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 128>), grid, dim3(CONV_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 64>), grid, dim3(CONV_THREADS), 0, st, p);
+    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 128, false>), grid, dim3(CONV_THREADS), 0, st, p);
+    else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64, false>), grid, dim3(CONV_THREADS), 0, st, p);
+    else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 128, false>), grid, dim3(CONV_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 64, false>), grid, dim3(CONV_THREADS), 0, st, p);
 }
 
 // Sum split-K slabs: out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]  (deterministic order).
@@ -361,6 +431,11 @@ int check_conv(const void *a, const void *b, const void *c, int N, int H, int W,
                                "conv2d: Cin (%d) must be 4 or a multiple of %d... Cout (%d) a multiple of %d (the host layer pads)", Cin, BK, Cout, BK);
     if (conv_out(H, KH, stride, pad) <= 0 || conv_out(W, KW, stride, pad) <= 0)
         return mrcnn::fail_arg(MRCNN_E_INVALID, "conv2d: empty output");
+    const long long lim = (1ll << 31) - 1;
+    const long long Ho_ = conv_out(H, KH, stride, pad), Wo_ = conv_out(W, KW, stride, pad);
+    if ((long long)N * H * W * Cin > lim || (long long)N * Ho_ * Wo_ * Cout > lim || (long long)Cout * KH * KW * Cin > lim ||
+        (long long)N * std::max<long long>(H * W, Ho_ * Wo_) >= (1ll << 24))
+        return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d: tensor too large for 32-bit offsets / 24-bit pixel indices");
     return 0;
 }
 
@@ -377,6 +452,7 @@ ConvP make_p(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
 // split-K plan for backward-filter: enough workgroups to fill 256 CUs a few times over.
 TileChoice filter_tile(const ConvP &p) {
     TileChoice t;
+    if (p.smallc) return {64, 128};
     t.bm = p.Cout <= 64 ? 64 : 128;
     t.bn = (p.smallc ? p.KH * p.KW * 4 : p.Cin) <= 64 ? 64 : 128;
     return t;
