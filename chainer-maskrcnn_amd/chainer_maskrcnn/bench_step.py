@@ -93,51 +93,9 @@ def bench_step(args, rank, world):
                                      'ms': round(a[2] / n_prof * 1e3, 3)} for k, a in agg.items()},
                      'note': 'HIP events around every conv launch on %d instrumented steps right after the timed region' % n_prof},
     }
-    if world == 1 and rank == 0 and not getattr(args, 'no_cpu_baseline', False):
-        out['cpu_baseline'] = cpu_baseline_step(model, dev)
     if alt is not None:
         out['config']['images_per_sec_mask_branch_on_positive_rows_only'] = round(alt, 3)
-    return out
-
-
-def cpu_baseline_step(model, dev):
-    """The CPU restatement (oracle/model.py, kind 'port') of ONE training step on ONE 1024x1024 image (the
-    reference's own batch size), float32, timed on this box's host cores: forward + backward of the whole network with
-    the sampled targets of a device step on the same image.  Checker code is timed here, never shipped."""
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    if root not in sys.path:
-        sys.path.insert(0, root)
-    from oracle import model as om
-    from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss
-    from chainer_maskrcnn.utils.synthetic import make_batch
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
-    b = make_batch(7, 1, 1024, 1024, G=8)
-    chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows='all')
-    imgs, bb, lab, masks = (torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'masks'))
-    chain(imgs, bb, lab, masks, 1.0)
-    t = {k: v.cpu().numpy() for k, v in chain.targets.items() if torch.is_tensor(v)}
-    t['gt_rpn_loc'], t['gt_rpn_label'] = (x.cpu().numpy() for x in chain.rpn_targets)
-    t['mask_rois_xy5'], t['mask_levels'], t['mask_label'] = (x.cpu().numpy() for x in chain.mask_inputs)
-    om.set_dtype(torch.float32)
-    try:
-        ps = model.ps
-        params = {n: ps.p(n).detach().cpu().requires_grad_(True) for n in ps.names()}
-        oracle = om.OracleStep(params, tuple(len(s) for s in model.extractor.stages), model.head.n_class, model.head.LOC0)
-        img4 = torch.cat([torch.from_numpy(b['imgs']).permute(0, 2, 3, 1), torch.zeros((1, 1024, 1024, 1))], -1)
-        t0 = time.perf_counter()
-        out = oracle.losses(img4, t)
-        t1 = time.perf_counter()
-        sum(out[k] for k in ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')).backward()
-        t2 = time.perf_counter()
-    finally:
-        om.set_dtype(torch.float64)
-    return {'value': round(1.0 / (t2 - t0), 4), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': 'one full training step (fwd %.1f s + bwd %.1f s) on ONE 1024x1024 image, 256 sampled RoIs, fp32: '
-                      'torch-CPU convolutions on %d threads + single-thread NumPy ROIAlign oracle; targets taken from a '
-                      'device step (samplers not timed)' % (t1 - t0, t2 - t1, threads),
-            'host_cpus': os.cpu_count()}
+    return out, model, dev
 
 
 def _sync(world):

@@ -352,17 +352,59 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         }
 }
 
-// Tile choice: the largest tile that still yields >= 2 workgroups per CU (512 on 256 CUs); narrow N -> 64-wide tiles.
+// ---- launch planning -------------------------------------------------------------------------------------
+// Workgroup slots of the chip for one kernel instantiation = resident workgroups per CU (runtime occupancy query,
+// cached) x CUs.  Tiles and split-K factors are chosen so that the grid is a whole number of slot "rounds": a grid of
+// 1.02 rounds costs 2.
+int g_cus() {
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+template <int MODE, int BM_, int BN_, bool SMALLC>
+int slots_of() {
+    static int slots = 0;
+    if (!slots) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(&k_conv_igemm<MODE, BM_, BN_, SMALLC>),
+                                                         CONV_THREADS, 0) != hipSuccess || occ <= 0)
+            occ = 2;
+        (void)hipGetLastError();
+        slots = occ * g_cus();
+    }
+    return slots;
+}
+template <int MODE>
+int slots_for(int bm, int bn) {
+    if (bm == 128 && bn == 128) return slots_of<MODE, 128, 128, false>();
+    if (bm == 128 && bn == 64) return slots_of<MODE, 128, 64, false>();
+    if (bm == 64 && bn == 128) return slots_of<MODE, 64, 128, false>();
+    return slots_of<MODE, 64, 64, false>();
+}
+
 struct TileChoice { int bm, bn; };
+// Smallest estimated time = rounds x (workgroups sharing a CU) x tile area / relative efficiency of the tile shape
+// (the `occ` resident workgroups of a CU share its MFMA pipes, so a round of small tiles is not faster per tile).
+template <int MODE>
 TileChoice choose_tile(long long M, long long Ng, long long z) {
-    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Ng + bn - 1) / bn) * z; };
-    const bool narrow_n = Ng <= 64, narrow_m = M <= 64;
-    if (!narrow_n && !narrow_m && tiles(128, 128) >= 512) return {128, 128};
-    if (!narrow_m && tiles(128, 64) >= 512) return {128, 64};
-    if (!narrow_n && !narrow_m && tiles(128, 128) >= 384) return {128, 128};
-    if (narrow_m && !narrow_n) return {64, 128};
-    if (!narrow_m && narrow_n) return {128, 64};
-    return {64, 64};
+    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    static const double eff[4] = {1.0, 0.90, 0.90, 0.78};
+    TileChoice best{64, 64};
+    double best_t = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        const int bm = cand[c][0], bn = cand[c][1];
+        if ((bm == 128 && M <= 64) || (bn == 128 && Ng <= 64)) continue;
+        const long long tiles = ((M + bm - 1) / bm) * ((Ng + bn - 1) / bn) * z;
+        const long long slots = slots_for<MODE>(bm, bn);
+        const double t = (double)((tiles + slots - 1) / slots) * (double)(slots / g_cus()) * bm * bn / eff[c];
+        if (t < best_t) { best_t = t; best = {bm, bn}; }
+    }
+    return best;
 }
 
 template <int MODE>
@@ -457,14 +499,19 @@ TileChoice filter_tile(const ConvP &p) {
     t.bn = (p.smallc ? p.KH * p.KW * 4 : p.Cin) <= 64 ? 64 : 128;
     return t;
 }
+// split-K plan for backward-filter: the number of splits that fills a whole number of slot rounds (1 or 2), with at
+// least 8 K steps per split.
 void filter_plan(const ConvP &p, int &ksplit, int &kchunk) {
     const long long P = (long long)p.N * p.Ho * p.Wo;
     const TileChoice t = filter_tile(p);
     const long long tiles = p.smallc ? (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.KH * p.KW * 4, t.bn)
                                      : (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.Cin, t.bn) * p.KH * p.KW;
-    long long want = (1024 + tiles - 1) / tiles;
-    long long maxsplit = (P + 4 * BK - 1) / (4 * BK);     // at least 4 K steps per split
-    ksplit = (int)std::max(1ll, std::min(std::min(want, maxsplit), 64ll));
+    const long long slots = p.smallc ? slots_of<MODE_BWD_FILTER, 64, 128, true>() : slots_for<MODE_BWD_FILTER>(t.bm, t.bn);
+    const long long maxsplit = std::max(1ll, P / (8 * BK));
+    long long want = slots / tiles;                               // one full round
+    if (want < 1) want = 1;
+    if (want * 4 <= maxsplit && tiles * want * 2 <= 4096) want = (2 * slots) / tiles;   // long K: two rounds, shorter tails
+    ksplit = (int)std::max(1ll, std::min(std::min(want, maxsplit), 256ll));
     kchunk = (int)(((P + ksplit - 1) / ksplit + BK - 1) / BK * BK);
     ksplit = (int)((P + kchunk - 1) / kchunk);
 }
@@ -478,7 +525,7 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     p.a = x; p.b = w; p.c = y; p.bias = bias; p.relu = relu;
     p.M = N * p.Ho * p.Wo; p.Ng = Cout;
-    launch_conv<MODE_FWD>(p, dim3(1, 1, 1), choose_tile(p.M, p.Ng, 1), (hipStream_t)stream);
+    launch_conv<MODE_FWD>(p, dim3(1, 1, 1), choose_tile<MODE_FWD>(p.M, p.Ng, 1), (hipStream_t)stream);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -494,7 +541,7 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
     if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
     p.a = gy; p.b = w; p.c = gx; p.accumulate = accumulate;
     p.M = N * H * W; p.Ng = Cin;
-    launch_conv<MODE_BWD_DATA>(p, dim3(1, 1, 1), choose_tile(p.M, p.Ng, 1), (hipStream_t)stream);
+    launch_conv<MODE_BWD_DATA>(p, dim3(1, 1, 1), choose_tile<MODE_BWD_DATA>(p.M, p.Ng, 1), (hipStream_t)stream);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }
