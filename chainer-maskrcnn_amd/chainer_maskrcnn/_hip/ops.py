@@ -134,6 +134,22 @@ def pixel_shuffle2x(t, bias=None, inverse=False):
     return out
 
 
+def bilinear2x_fwd(x):
+    _ck(x)
+    N, H, W, C = x.shape
+    y = _empty((N, 2 * H, 2 * W, C), x.device)
+    check(lib().mrcnn_bilinear2x_fwd_f32(ptr(x), ptr(y), N, H, W, C, stream_ptr()))
+    return y
+
+
+def bilinear2x_bwd(gy):
+    _ck(gy)
+    N, OH, OW, C = gy.shape
+    gx = _empty((N, OH // 2, OW // 2, C), gy.device)
+    check(lib().mrcnn_bilinear2x_bwd_f32(ptr(gy), ptr(gx), N, OH // 2, OW // 2, C, stream_ptr()))
+    return gx
+
+
 def image_nchw3_to_nhwc4(x):
     _ck(x)
     N, C, H, W = x.shape

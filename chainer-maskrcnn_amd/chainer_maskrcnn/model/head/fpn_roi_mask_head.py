@@ -52,7 +52,8 @@ class FPNRoIMaskHead(object):
     mask_size = 28
 
     def __init__(self, n_class, roi_size_box, roi_size_mask, loc_initialW=None, score_initialW=None,
-                 mask_initialW=None, ps=None, prefix='head', in_channels=256, fc_channels=1024):
+                 mask_initialW=None, ps=None, prefix='head', in_channels=256, fc_channels=1024,
+                 n_mask_convs=4, mask_out_channels=None, upsample2x=False, mask_conv_names=None):
         self.ps = ps if ps is not None else ParamStore()
         self.n_class, self.roi_size_box, self.roi_size_mask = n_class, roi_size_box, roi_size_mask
         c = in_channels
@@ -69,12 +70,15 @@ class FPNRoIMaskHead(object):
                             cout_index=list(range(n_class)) + list(range(self.LOC0, self.LOC0 + 4)),
                             init=lambda shape: (lambda rs: np.concatenate([si(rs), li(rs)], 0)))
         mi = 0.01 if mask_initialW is None else mask_initialW
-        self.mask_convs = [Conv(self.ps, p + 'mask%d' % (i + 1), c, c, 3, 1, 1, relu=True) for i in range(4)]
+        names = mask_conv_names or ['mask%d' % (i + 1) for i in range(n_mask_convs)]
+        self.mask_convs = [Conv(self.ps, p + nm, c, c, 3, 1, 1, relu=True) for nm in names]
+        self.mask_out_channels = (n_class - 1) if mask_out_channels is None else mask_out_channels
+        self.upsample2x = upsample2x
         # deconv1: W (Cin, Cout, 2, 2) in Chainer == 1x1 conv weight ((a*2+b)*Cout + o, Cin); bias added by the shuffle
         self.deconv1 = Conv(self.ps, p + 'deconv1', c, 4 * c, 1, bias=False, init=normal(mi))
         self.ps.register(p + 'deconv1/b', (c,), lambda rs: np.zeros((c,), np.float32))
         self.deconv_b = p + 'deconv1/b'
-        self.conv2 = Conv(self.ps, p + 'conv2', c, n_class - 1, 1, init=normal(mi))
+        self.conv2 = Conv(self.ps, p + 'conv2', c, self.mask_out_channels, 1, init=normal(mi))
         self.channels = c
 
     # ---- forward --------------------------------------------------------------------------------
@@ -97,8 +101,10 @@ class FPNRoIMaskHead(object):
         d, td = self.deconv1.fwd(h)
         up = ops.pixel_shuffle2x(d, bias=self.ps.p(self.deconv_b))
         m, t2 = self.conv2.fwd(up)
+        if self.upsample2x:                    # keypoint head: F.resize_images x2 (fpn_roi_keypoint_head.py:80-81)
+            m = ops.bilinear2x_fwd(m)
         self.mask_tape = (tapes, td, t2, rois_xy5, levels, spatial_scales)
-        return m                               # (Rm, 28, 28, pad32(n_class-1)) NHWC
+        return m                               # (Rm, mask_size, mask_size, pad32(mask_out_channels)) NHWC
 
     def __call__(self, x, indices_and_rois, levels, spatial_scales, train=True):
         """Reference signature (:55): x = pyramid levels, indices_and_rois (R,5) (idx,y1,x1,y2,x2),
@@ -111,12 +117,12 @@ class FPNRoIMaskHead(object):
             self.x = x
             return locs, scores
         m = self.mask_branch(x, xy5, lv, spatial_scales)
-        return locs, scores, m[..., :self.n_class - 1].permute(0, 3, 1, 2)
+        return locs, scores, m[..., :self.mask_out_channels].permute(0, 3, 1, 2)
 
     def predict_mask(self, levels, indices_and_rois, spatial_scales):
         xy5 = indices_and_rois[:, [0, 2, 1, 4, 3]].contiguous()
         m = self.mask_branch(self.x, xy5, levels.to(torch.int32).contiguous(), spatial_scales)
-        return m[..., :self.n_class - 1].permute(0, 3, 1, 2)
+        return m[..., :self.mask_out_channels].permute(0, 3, 1, 2)
 
     # ---- backward -------------------------------------------------------------------------------
     def backward(self, g_box_out, g_mask, g_feats):
@@ -131,6 +137,8 @@ class FPNRoIMaskHead(object):
         roi_align_fpn_bwd(g, g_feats, rois, levels, self.roi_size_box, scales, accumulate=False)
         if g_mask is not None:
             tapes, td, tc2, rois, levels, scales = self.mask_tape
+            if self.upsample2x:
+                g_mask = ops.bilinear2x_bwd(g_mask)
             g = self.conv2.bwd(tc2, g_mask)
             # deconv bias gradient = column sums of g (over all output pixels): take it from a filter-gradient
             # call of the shuffled tensor below (gb4 of length 4*C, summed over the 4 sub-pixel copies)

@@ -411,6 +411,80 @@ __global__ __launch_bounds__(NT) void k_sgd(float *__restrict__ p, const float *
     }
 }
 
+// ---- bilinear x2 with corner alignment (Chainer F.resize_images, fpn_roi_keypoint_head.py:80-81,109) ----------
+// u = i*(H-1)/(OH-1) (float64 like numpy.linspace), u0 = clip(floor(u), 0, H-2), u1 = u0+1, weights (u1-u), (u-u0).
+struct Lin { int i0; float w0, w1; };
+__device__ __forceinline__ Lin lin_coord(int o, int in, int out) {
+    Lin l;
+    if (in < 2) { l.i0 = 0; l.w0 = 1.f; l.w1 = 0.f; return l; }
+    const double u = (double)o * (double)(in - 1) / (double)(out - 1);
+    int i0 = (int)floor(u);
+    i0 = min(max(i0, 0), in - 2);
+    l.i0 = i0;
+    l.w0 = (float)((double)(i0 + 1) - u);
+    l.w1 = (float)(u - (double)i0);
+    return l;
+}
+
+__global__ __launch_bounds__(NT) void k_bilinear2x_fwd(const float *__restrict__ x, float *__restrict__ y, int N, int H,
+                                                       int W, int C4) {
+    const int OH = 2 * H, OW = 2 * W;
+    const size_t n4 = (size_t)N * OH * OW * C4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        size_t q = i / C4;
+        const int ow = (int)(q % OW); q /= OW;
+        const int oh = (int)(q % OH);
+        const int n = (int)(q / OH);
+        const Lin ly = lin_coord(oh, H, OH), lx = lin_coord(ow, W, OW);
+        const int y1 = min(ly.i0 + 1, H - 1), x1 = min(lx.i0 + 1, W - 1);
+        const float *b = x + (size_t)n * H * W * C4 * 4 + c * 4;
+        const float4 a00 = ld4(b + ((size_t)ly.i0 * W + lx.i0) * C4 * 4), a01 = ld4(b + ((size_t)ly.i0 * W + x1) * C4 * 4);
+        const float4 a10 = ld4(b + ((size_t)y1 * W + lx.i0) * C4 * 4), a11 = ld4(b + ((size_t)y1 * W + x1) * C4 * 4);
+        const float w1 = lx.w0 * ly.w0, w2 = lx.w1 * ly.w0, w3 = lx.w0 * ly.w1, w4 = lx.w1 * ly.w1;
+        float4 o;
+        o.x = w1 * a00.x + w2 * a01.x + w3 * a10.x + w4 * a11.x;
+        o.y = w1 * a00.y + w2 * a01.y + w3 * a10.y + w4 * a11.y;
+        o.z = w1 * a00.z + w2 * a01.z + w3 * a10.z + w4 * a11.z;
+        o.w = w1 * a00.w + w2 * a01.w + w3 * a10.w + w4 * a11.w;
+        st4(y + i * 4, o);
+    }
+}
+
+// Adjoint, owner-computes: every input cell gathers the (<= 3x3) output cells that interpolate from it.
+__global__ __launch_bounds__(NT) void k_bilinear2x_bwd(const float *__restrict__ gy, float *__restrict__ gx, int N, int H,
+                                                       int W, int C4) {
+    const int OH = 2 * H, OW = 2 * W;
+    const size_t n4 = (size_t)N * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        size_t q = i / C4;
+        const int w = (int)(q % W); q /= W;
+        const int h = (int)(q % H);
+        const int n = (int)(q / H);
+        // output rows whose u lies in (h-1, h+1): o in ((h-1)(OH-1)/(H-1), (h+1)(OH-1)/(H-1))
+        const int oy0 = H > 1 ? max(0, (int)(((long long)(h - 1) * (OH - 1)) / (H - 1))) : 0;
+        const int oy1 = H > 1 ? min(OH - 1, (int)(((long long)(h + 1) * (OH - 1) + (H - 2)) / (H - 1))) : OH - 1;
+        const int ox0 = W > 1 ? max(0, (int)(((long long)(w - 1) * (OW - 1)) / (W - 1))) : 0;
+        const int ox1 = W > 1 ? min(OW - 1, (int)(((long long)(w + 1) * (OW - 1) + (W - 2)) / (W - 1))) : OW - 1;
+        float4 s = f4(0.f);
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            const Lin ly = lin_coord(oy, H, OH);
+            const float wy = (ly.i0 == h ? ly.w0 : 0.f) + (min(ly.i0 + 1, H - 1) == h ? ly.w1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const Lin lx = lin_coord(ox, W, OW);
+                const float wx = (lx.i0 == w ? lx.w0 : 0.f) + (min(lx.i0 + 1, W - 1) == w ? lx.w1 : 0.f);
+                if (wx == 0.f) continue;
+                const float4 g = ld4(gy + ((((size_t)n * OH + oy) * OW + ox) * C4 + c) * 4);
+                const float ww = wx * wy;
+                s.x = fmaf(ww, g.x, s.x); s.y = fmaf(ww, g.y, s.y); s.z = fmaf(ww, g.z, s.z); s.w = fmaf(ww, g.w, s.w);
+            }
+        }
+        st4(gx + i * 4, s);
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_img_nhwc4(const float *__restrict__ x, float *__restrict__ y, int N, size_t HW) {
     const size_t total = (size_t)N * HW;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
@@ -578,6 +652,20 @@ extern "C" int mrcnn_random_keys_u32(uint32_t *out, size_t n, unsigned long long
     if (n == 0) return 0;
     if (int e = chk(out != nullptr, "random_keys: null pointer")) return e;
     hipLaunchKernelGGL(k_random_keys, dim3(ew_grid(n)), dim3(NT), 0, (hipStream_t)stream, out, n, seed);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_bilinear2x_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream) {
+    if (int e = chk(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "bilinear2x_fwd: bad args")) return e;
+    hipLaunchKernelGGL(k_bilinear2x_fwd, dim3(ew_grid((size_t)N * H * W * C)), dim3(NT), 0, (hipStream_t)stream, x, y, N, H, W, C / 4);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_bilinear2x_bwd_f32(const float *gy, float *gx, int N, int H, int W, int C, void *stream) {
+    if (int e = chk(gy && gx && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "bilinear2x_bwd: bad args")) return e;
+    hipLaunchKernelGGL(k_bilinear2x_bwd, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(NT), 0, (hipStream_t)stream, gy, gx, N, H, W, C / 4);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -165,6 +165,10 @@ int mrcnn_subsample_bwd_f32(const float *gsub, float *gx, int N, int H, int W, i
 /* 2x2/2 deconvolution data movement: (N,H,W,[2][2][C]) <-> (N,2H,2W,C); inverse != 0 is the backward. */
 int mrcnn_pixel_shuffle2x_f32(const float *src, const float *bias, float *dst, int N, int H, int W, int C, int inverse,
                               void *stream);      /* bias (C, nullable) is added in the forward direction */
+/* Bilinear x2 with corner alignment (Chainer F.resize_images, chainer_maskrcnn/model/head/fpn_roi_keypoint_head.py:
+ * 80-81,109): x (N,H,W,C) -> y (N,2H,2W,C); bwd is the exact adjoint (owner-computes, no atomics). */
+int mrcnn_bilinear2x_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+int mrcnn_bilinear2x_bwd_f32(const float *gy, float *gx, int N, int H, int W, int C, void *stream);
 /* x (N,3,H,W) NCHW -> y (N,H,W,4) NHWC with a zero 4th channel (the image layer's operand layout). */
 int mrcnn_image_nchw3_to_nhwc4_f32(const float *x, float *y, int N, int H, int W, void *stream);
 /* n uint32 sampler keys from a counter-based hash of (seed, index). */

@@ -52,6 +52,22 @@ def upsample_add(top, lat):
     return top.repeat_interleave(2, 1).repeat_interleave(2, 2)[:, :H, :W] + lat
 
 
+def resize_images_x2(x):
+    """Chainer F.resize_images to twice the size [3P-RECALL, SURVEY.md App. A-8]: corner-aligned bilinear,
+    u = linspace(0, H-1, 2H), u0 = clip(floor(u), 0, H-2), u1 = u0+1, weights (u1-u), (u-u0).  x NHWC."""
+    N, H, W, C = x.shape
+
+    def axis(n):
+        u = np.linspace(0, n - 1, 2 * n)
+        u0 = np.clip(np.floor(u).astype(np.int64), 0, max(n - 2, 0))
+        u1 = np.minimum(u0 + 1, n - 1)
+        return torch.from_numpy(u0), torch.from_numpy(u1), torch.from_numpy(u0 + 1 - u).to(x.dtype), torch.from_numpy(u - u0).to(x.dtype)
+    y0, y1, wy0, wy1 = axis(H)
+    x0, x1, wx0, wx1 = axis(W)
+    rows = x[:, y0] * wy0[None, :, None, None] + x[:, y1] * wy1[None, :, None, None]
+    return rows[:, :, x0] * wx0[None, None, :, None] + rows[:, :, x1] * wx1[None, None, :, None]
+
+
 class _RoIAlignNp(torch.autograd.Function):
     """oracle.roi_align on one level (NCHW NumPy, float32 arithmetic as specified) inside autograd."""
 
@@ -102,8 +118,10 @@ def softmax_ce(x, t):
 class OracleStep(object):
     """params: dict name -> float64 torch tensor (requires_grad) in the product's storage convention."""
 
-    def __init__(self, params, stage_blocks, n_class, loc0, feat_strides=(4, 8, 16, 32, 64), n_anchor=3):
+    def __init__(self, params, stage_blocks, n_class, loc0, feat_strides=(4, 8, 16, 32, 64), n_anchor=3,
+                 mask_conv_names=('mask1', 'mask2', 'mask3', 'mask4'), n_keypoints=None):
         self.p = params
+        self.mask_conv_names, self.n_keypoints = mask_conv_names, n_keypoints
         self.stage_blocks = stage_blocks
         self.n_class, self.loc0, self.n_anchor = n_class, loc0, n_anchor
         self.scales = [1.0 / s for s in feat_strides]
@@ -164,13 +182,14 @@ class OracleStep(object):
     def head_mask(self, feats, rois_xy5, levels):
         p = self.p
         h = roi_align_fpn(feats, rois_xy5, levels, 14, self.scales)
-        for i in range(4):
-            h = F.relu(conv(h, p['head/mask%d/W' % (i + 1)], p['head/mask%d/b' % (i + 1)], 1, 1))
+        for nm in self.mask_conv_names:
+            h = F.relu(conv(h, p['head/%s/W' % nm], p['head/%s/b' % nm], 1, 1))
         d = conv(h, p['head/deconv1/W'])
         N, H, W, C4 = d.shape
         C = C4 // 4
         up = d.reshape(N, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * H, 2 * W, C) + p['head/deconv1/b']
-        return conv(up, p['head/conv2/W'], p['head/conv2/b'])
+        m = conv(up, p['head/conv2/W'], p['head/conv2/b'])
+        return resize_images_x2(m) if self.n_keypoints else m
 
     def losses(self, img4, t):
         """t: dict of NumPy targets taken from the device step (see tests/test_step_gpu.py)."""
@@ -188,6 +207,12 @@ class OracleStep(object):
         ml = t['mask_label']
         gt = t['gt_roi_mask']
         rows = np.nonzero(ml > 0)[0]
+        if self.n_keypoints:           # train_keypoints.py:21-27: softmax CE over the H*W positions of each (RoI, keypoint)
+            K = self.n_keypoints
+            x = m[torch.from_numpy(rows)][..., :K].permute(0, 3, 1, 2).reshape(len(rows) * K, -1)
+            l_mask = softmax_ce(x, torch.from_numpy(gt[rows].reshape(-1)))
+            return dict(rpn_loc_loss=l_rpn_loc, rpn_cls_loss=l_rpn_cls, roi_loc_loss=l_roi_loc, roi_cls_loss=l_roi_cls,
+                        mask_loss=l_mask, feats=feats, locs=locs, scores=scores, box=box, mask=m)
         sel = m[torch.from_numpy(rows), :, :, torch.from_numpy(ml[rows] - 1)]        # calc_mask_loss: channel label-1
         tt = torch.from_numpy(gt[rows]).to(D)
         valid = torch.from_numpy(gt[rows] != -1)

@@ -139,6 +139,24 @@ def test_image_layout_and_random_keys():
     assert len(np.unique(k1)) > 9990 and abs(k1.mean() / 2 ** 32 - 0.5) < 0.02
 
 
+@pytest.mark.parametrize('shape', [(2, 7, 5, 8), (1, 28, 28, 32), (3, 1, 4, 4)])
+def test_bilinear2x_matches_resize_images_and_adjoint(shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g, dtype=torch.float64, requires_grad=True)
+    N, H, W, C = shape
+    if H > 1 and W > 1:
+        y = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
+    else:
+        from oracle.model import resize_images_x2
+        y = resize_images_x2(x)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    yd = ops.bilinear2x_fwd(x.detach().float().to(DEV))
+    assert _rel(yd, y.detach()) < 1e-6
+    gx = ops.bilinear2x_bwd(gy.float().contiguous().to(DEV))
+    assert _rel(gx, x.grad) < 1e-6
+
+
 def test_relu_bwd_and_add():
     g = torch.Generator().manual_seed(5)
     y = torch.randn((1000,), generator=g).clamp_min(0)

@@ -11,7 +11,7 @@ from oracle.model import OracleStep, D
 pytestmark = pytest.mark.gpu
 
 from chainer_maskrcnn.model.maskrcnn import MaskRCNN  # noqa: E402
-from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss  # noqa: E402
+from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss, calc_keypoint_loss  # noqa: E402
 from chainer_maskrcnn.optimizers import MomentumSGD, WeightDecay  # noqa: E402
 from chainer_maskrcnn.utils.synthetic import make_batch  # noqa: E402
 
@@ -51,7 +51,8 @@ def test_step_losses_and_gradients_match_oracle(mask_rows):
     out = oracle.losses(img4, t)
     names = ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
     for k in names:
-        assert abs(obs[k] - float(out[k])) <= 1e-4 * max(abs(float(out[k])), 1e-3), (k, obs[k], float(out[k]))
+        ok_ = float(out[k].detach())
+        assert abs(obs[k] - ok_) <= 1e-4 * max(abs(ok_), 1e-3), (k, obs[k], ok_)
     sum(out[k] for k in names).backward()
     worst = 0.0
     gmax = max(float(params[n].grad.abs().max()) for n in ps.names() if params[n].grad is not None)
@@ -65,6 +66,54 @@ def test_step_losses_and_gradients_match_oracle(mask_rows):
         worst = max(worst, err)
         assert err < 1e-3, (n, err, scale)
     print('worst relative gradient error', worst)
+
+
+def test_keypoint_step_matches_oracle():
+    """BASELINE config 5 head (train_keypoints.py): 17 keypoints, 56x56 heat maps, softmax CE over positions."""
+    K, NMC = 17, 2
+    m = MaskRCNN(n_fg_class=1, n_keypoints=K, n_mask_convs=NMC, head_arch='fpn_keypoint', device=DEV, seed=11,
+                 _test_shrink=dict(stages=(1, 1, 1, 1), width_div=2))
+    chain = FPNMaskRCNNTrainChain(m, mask_loss_fun=calc_keypoint_loss, binary_mask=False)
+    b = make_batch(5, 2, 128, 160, G=3, n_fg_class=1, n_keypoints=K)
+    b['bboxes'][:, :, 2:] = np.minimum(b['bboxes'][:, :, 2:], [128, 160])
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
+    loss = chain(b['imgs'], b['bboxes'], b['labels'], b['keypoints'], 1.0)
+    loss.backward()
+    obs = {k: float(v) for k, v in chain.observation.items()}
+    assert m.head.mask_size == 56 and chain.targets['gt_roi_mask'].shape[1] == K
+    ps = m.ps
+    params = {n: ps.p(n).detach().cpu().to(D).requires_grad_(True) for n in ps.names()}
+    t = {k: v.cpu().numpy() for k, v in chain.targets.items() if torch.is_tensor(v)}
+    t['gt_rpn_loc'], t['gt_rpn_label'] = (x.cpu().numpy() for x in chain.rpn_targets)
+    t['mask_rois_xy5'], t['mask_levels'], t['mask_label'] = (x.cpu().numpy() for x in chain.mask_inputs)
+    assert (t['gt_roi_mask'] >= 0).sum() > 10
+    oracle = OracleStep(params, (1, 1, 1, 1), m.head.n_class, m.head.LOC0,
+                        mask_conv_names=['mask_convs/%d' % i for i in range(NMC)], n_keypoints=K)
+    img4 = torch.cat([b['imgs'].cpu().permute(0, 2, 3, 1), torch.zeros((2, 128, 160, 1))], -1).to(D)
+    out = oracle.losses(img4, t)
+    names = ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
+    for k in names:
+        assert abs(obs[k] - float(out[k].detach())) <= 1e-4 * max(abs(float(out[k].detach())), 1e-3), (k, obs[k], float(out[k].detach()))
+    sum(out[k] for k in names).backward()
+    # fp32 noise floor of this (tiny-batch BatchNorm) network: the same oracle evaluated in float32
+    from oracle import model as om
+    om.set_dtype(torch.float32)
+    try:
+        p32 = {n: ps.p(n).detach().cpu().requires_grad_(True) for n in ps.names()}
+        o32 = OracleStep(p32, (1, 1, 1, 1), m.head.n_class, m.head.LOC0,
+                         mask_conv_names=['mask_convs/%d' % i for i in range(NMC)], n_keypoints=K)
+        out32 = o32.losses(img4.float(), t)
+        sum(out32[k] for k in names).backward()
+    finally:
+        om.set_dtype(torch.float64)
+    gmax = max(float(params[n].grad.abs().max()) for n in ps.names() if params[n].grad is not None)
+    for n in ps.names():
+        want = params[n].grad if params[n].grad is not None else torch.zeros_like(params[n])
+        w32 = p32[n].grad if p32[n].grad is not None else torch.zeros_like(p32[n])
+        scale = max(float(want.abs().max()), 1e-3 * gmax)
+        err = float((ps.g(n).cpu().to(D) - want).abs().max()) / scale
+        floor = float((w32.to(D) - want).abs().max()) / scale
+        assert err < max(1e-3, 3 * floor), (n, err, floor)
 
 
 def test_step_is_bit_reproducible_and_sgd_updates():
