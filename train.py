@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Training entry point with the flags, constants and log keys of the reference's train.py (:62-74 flags, :95-98
+model, :107-109 optimizer, :117-132 updater wiring, :134-161 snapshot / LR shift / log), on the MI355X-native path.
+
+The reference's train.py imports chainer / chainercv / chainerui / cv2 / pycocotools (train.py:1-8), none of which
+exist on the target machine, so this is the repo's own counterpart: same CLI, synthetic COCO-shaped data
+(--synthetic, the default; the COCO loader is a SURVEY.md section 8f "next" row), JSON-lines log in --out.
+Multi GPU: launch with `python -m torch.distributed.run --nproc-per-node N train.py --multi-gpu 1 ...`
+(one process per GPU, RCCL all-reduce of the flat gradient buffer; the reference forks 8 workers itself).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'chainer-maskrcnn_amd'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def build_parser(keypoints=False):
+    parser = argparse.ArgumentParser(description='Mask R-CNN')
+    parser.add_argument('--gpu', '-g', type=int, default=0)
+    parser.add_argument('--lr', '-l', type=float, default=1e-3)
+    parser.add_argument('--out', '-o', default='result', help='Output directory')
+    parser.add_argument('--iteration', '-i', type=int, default=200000)
+    parser.add_argument('--weight', '-w', type=str, default='')
+    if keypoints:   # train_keypoints.py spells its flags with underscores (train_keypoints.py:73-89)
+        parser.add_argument('--backbone', type=str, default='fpn')
+        parser.add_argument('--head_arch', '-a', type=str, default='fpn_keypoint')
+        parser.add_argument('--multi_gpu', '-m', type=int, default=0)
+        parser.add_argument('--batch_size', '-b', type=int, default=1)
+    else:
+        parser.add_argument('--label_file', '-f', type=str, default='data/label_coco.txt')
+        parser.add_argument('--backbone', type=str, default='fpn')
+        parser.add_argument('--head-arch', '-a', type=str, default='fpn')
+        parser.add_argument('--multi-gpu', '-m', type=int, default=0)
+        parser.add_argument('--batch-size', '-b', type=int, default=1)
+    parser.add_argument('--synthetic', type=int, default=1, help='synthetic COCO-shaped batches (only data source on this path)')
+    parser.add_argument('--image-size', type=int, nargs=2, default=[800, 800])
+    parser.add_argument('--log-interval', type=int, default=100)
+    parser.add_argument('--snapshot-interval', type=int, default=5000)
+    parser.add_argument('--lr-shift-interval', type=int, default=0, help='iterations between lr x0.1 (reference: 2 epochs)')
+    return parser
+
+
+def run(args, keypoints=False):
+    from chainer_maskrcnn.model.maskrcnn import MaskRCNN
+    from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss, calc_keypoint_loss
+    from chainer_maskrcnn.optimizers import MomentumSGD, WeightDecay
+    from chainer_maskrcnn.utils.synthetic import make_batch
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', args.gpu))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl')
+    if keypoints:
+        n_fg, K = 1, 17
+        faster_rcnn = MaskRCNN(n_fg_class=n_fg, n_keypoints=K, backbone=args.backbone, head_arch=args.head_arch, device=dev)
+        model = FPNMaskRCNNTrainChain(faster_rcnn, mask_loss_fun=calc_keypoint_loss, binary_mask=False)
+    else:
+        n_fg, K = 80, None
+        if os.path.exists(args.label_file):
+            with open(args.label_file) as f:
+                n_fg = len(f.read().strip().split('\n'))
+        faster_rcnn = MaskRCNN(n_fg_class=n_fg, backbone=args.backbone, head_arch=args.head_arch, device=dev)
+        model = FPNMaskRCNNTrainChain(faster_rcnn, mask_loss_fun=calc_mask_loss)
+    faster_rcnn.use_preset('evaluate')
+    if args.weight and os.path.exists(args.weight):
+        load_npz(args.weight, faster_rcnn)
+    optimizer = MomentumSGD(lr=args.lr, momentum=0.9)
+    optimizer.setup(model)
+    optimizer.add_hook(WeightDecay(rate=0.0005))
+    if world > 1:
+        optimizer.enable_data_parallel()
+    bs = args.batch_size
+    H, W = args.image_size
+    os.makedirs(args.out, exist_ok=True)
+    log = open(os.path.join(args.out, 'log'), 'a') if rank == 0 else None
+    keys = ('loss', 'rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
+    acc = {k: 0.0 for k in keys}
+    t0 = time.time()
+    for it in range(1, args.iteration + 1):
+        b = make_batch(it * world + rank, bs, H, W, G=8, n_fg_class=n_fg, n_keypoints=K)
+        batch = [torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')]
+        optimizer.update(model, *batch, 1.0)
+        if it % args.log_interval == 0 or it == args.iteration:       # one device->host sync per log interval
+            obs = {k: float(v) for k, v in model.observation.items()}
+            if any(not np.isfinite(v) for v in obs.values()):
+                raise FloatingPointError('non-finite loss at iteration %d: %r' % (it, obs))
+            entry = {'iteration': it, 'lr': optimizer.lr, 'elapsed_time': time.time() - t0,
+                     'images/sec': it * bs * world / (time.time() - t0)}
+            entry.update({'main/' + k: v for k, v in obs.items()})
+            if rank == 0:
+                log.write(json.dumps(entry) + '\n')
+                log.flush()
+                print(entry)
+        if args.lr_shift_interval and it % args.lr_shift_interval == 0:
+            optimizer.lr *= 0.1                                       # ExponentialShift('lr', 0.1), train.py:139-140
+        if rank == 0 and it % args.snapshot_interval == 0:
+            save_npz(os.path.join(args.out, 'model_%d.npz' % it), faster_rcnn)      # snapshot_object, train.py:134-137
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def save_npz(path, faster_rcnn):
+    ps = faster_rcnn.ps
+    d = {n: ps.p(n).detach().cpu().numpy() for n in ps.names()}
+    d.update({n: v.cpu().numpy() for n, v in ps.buffers.items()})
+    np.savez(path, **d)
+
+
+def load_npz(path, faster_rcnn):
+    """strict=False like train.py:99-101: parameters present in the file with the right shape are loaded."""
+    z = np.load(path)
+    ps = faster_rcnn.ps
+    for n in ps.names():
+        if n in z.files and tuple(z[n].shape) == tuple(ps.p(n).shape):
+            ps.p(n).copy_(torch.from_numpy(z[n]))
+    for n, v in ps.buffers.items():
+        if n in z.files and tuple(z[n].shape) == tuple(v.shape):
+            v.copy_(torch.from_numpy(z[n]))
+
+
+def main():
+    args = build_parser().parse_args()
+    print('lr:{}'.format(args.lr))
+    print('output:{}'.format(args.out))
+    print('iteration::{}'.format(args.iteration))
+    print('backbone architecture:{}'.format(args.backbone))
+    print('head architecture:{}'.format(args.head_arch))
+    run(args)
+
+
+if __name__ == '__main__':
+    main()
