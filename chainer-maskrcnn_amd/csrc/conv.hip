@@ -440,25 +440,58 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ sla
 }
 
 // Column sums of a (P, C) matrix (bias gradient): out[c] = sum_p g[p][c]; two-stage, deterministic.
-__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ g, float *__restrict__ part,
-                                                        int P, int C, int rows_per_block) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sub = threadIdx.x >> 6;
-    const int pbeg = blockIdx.y * rows_per_block, pend = min(P, pbeg + rows_per_block);
-    float s = 0.0f;
-    if (c < C)
-        for (int pix = pbeg + sub; pix < pend; pix += 4) s += g[(size_t)pix * C + c];
-    __shared__ float red[4][64];
-    red[sub][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (sub == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+// Stage 1: thread = (channel group of 4, row lane), float4 streaming loads, a block owns a contiguous chunk of rows.
+// Stage 2: 64 channels x 16 slices per 1024-thread block, slices added in order.
+struct ColPlan { int G, RPI, nblk, rows_per_blk; };
+ColPlan col_plan(int P, int C) {
+    ColPlan r;
+    const int C4 = C / 4;
+    r.G = std::min(C4, 256);
+    r.RPI = 256 / r.G;
+    long long want = ((long long)P * C4 + 256ll * 16 - 1) / (256ll * 16);
+    r.nblk = (int)std::max(1ll, std::min(want, 1024ll));
+    r.rows_per_blk = (int)(((long long)P + r.nblk - 1) / r.nblk);
+    r.rows_per_blk = (r.rows_per_blk + r.RPI - 1) / r.RPI * r.RPI;
+    r.nblk = (P + r.rows_per_blk - 1) / r.rows_per_blk;
+    return r;
 }
-__global__ void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int nb, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = accumulate ? out[c] : 0.0f;
-    for (int b = 0; b < nb; ++b) s += part[(size_t)b * C + c];
-    out[c] = s;
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ g, float *__restrict__ part, int P, int C,
+                                                        int G, int RPI, int rows_per_blk) {
+    __shared__ float4 s1[256];
+    const int t = threadIdx.x, cg0 = t % G, rr = t / G;
+    const int C4 = C / 4;
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(P, r0 + rows_per_blk);
+    for (int cg = cg0; cg < C4; cg += G) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = r0 + rr; r < r1; r += RPI) {
+            const float4 v = ldg4(g + (size_t)r * C + cg * 4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        s1[t] = a;
+        __syncthreads();
+        if (rr == 0) {
+            for (int k = 1; k < RPI; ++k) {
+                const float4 q = s1[k * G + cg0];
+                a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+            }
+            *reinterpret_cast<float4 *>(part + (size_t)blockIdx.x * C + cg * 4) = a;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int nb, int C,
+                                                       int accumulate) {
+    __shared__ double sa[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    double a = 0.0;
+    if (c < C)
+        for (int k = slice; k < nb; k += 16) a += (double)part[(size_t)k * C + c];
+    sa[slice][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        for (int k = 1; k < 16; ++k) a += sa[k][threadIdx.x & 63];
+        out[c] = (float)a + (accumulate ? out[c] : 0.0f);
+    }
 }
 
 int conv_out(int in, int k, int s, int pad) { return (in + 2 * pad - k) / s + 1; }
@@ -555,7 +588,7 @@ extern "C" size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, i
     filter_plan(p, ksplit, kchunk);
     const size_t wsz = (size_t)Cout * KH * KW * Cin * sizeof(float);
     const size_t P = (size_t)N * p.Ho * p.Wo;
-    const size_t bias_part = (size_t)mrcnn::cdiv(P, 1024) * Cout * sizeof(float);
+    const size_t bias_part = (size_t)col_plan((int)P, Cout).nblk * Cout * sizeof(float);
     return wsz * ksplit + bias_part + 256;     // slabs are also used for ksplit == 1 when accumulating
 }
 
@@ -583,10 +616,10 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     }
     if (gbias) {
         const int P = N * p.Ho * p.Wo;
-        const int nb = mrcnn::cdiv(P, 1024);
-        hipLaunchKernelGGL(k_colsum_partial, dim3(mrcnn::cdiv(Cout, 64), nb), dim3(256), 0, st, gy, bias_part, P, Cout, 1024);
+        const ColPlan cp = col_plan(P, Cout);
+        hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, gy, bias_part, P, Cout, cp.G, cp.RPI, cp.rows_per_blk);
         MRCNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, 256)), dim3(256), 0, st, bias_part, gbias, nb, Cout, accumulate);
+        hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, 64)), dim3(1024), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
         MRCNN_LAUNCH_CHECK();
     }
     return 0;

@@ -139,65 +139,64 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ sboxe
     mask[((size_t)img * n_pre + i) * nblk + cb] = bits;
 }
 
-// One wavefront per image walks the boxes in order, 64 at a time: the intra-chunk dependency is
-// resolved on the diagonal 64x64 block with scalar bit operations; the rows of the boxes kept in the
-// chunk are then OR-ed into the removed set with independent, coalesced loads.
-__global__ __launch_bounds__(64) void k_nms_reduce(const u64 *__restrict__ mask, const int32_t *__restrict__ n_valid,
-                                                   int n_pre, int nblk, int n_post, int32_t *__restrict__ keep,
-                                                   int32_t *__restrict__ n_keep) {
+// One 1024-thread workgroup per image walks the boxes in order, 64 at a time.  Wave 0 resolves the intra-chunk
+// dependency on the diagonal 64x64 block with scalar bit operations (the next chunk's diagonal words are already in
+// flight); then ALL threads OR the mask rows of the boxes kept in the chunk into the removed set with independent,
+// coalesced loads (one round of memory latency per chunk instead of one per kept box).
+constexpr int NMS_RED_THREADS = 1024;
+__global__ __launch_bounds__(NMS_RED_THREADS) void k_nms_reduce(const u64 *__restrict__ mask, const int32_t *__restrict__ n_valid,
+                                                                int n_pre, int nblk, int n_post, int32_t *__restrict__ keep,
+                                                                int32_t *__restrict__ n_keep) {
     constexpr int MAXW = 256;      // up to 16384 boxes
     __shared__ u64 rem[MAXW];
-    const int img = blockIdx.x, lane = threadIdx.x;
+    __shared__ int s_list[64];
+    __shared__ int s_cnt, s_kept;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = n_valid[img];
     const u64 *mk = mask + (size_t)img * n_pre * nblk;
     int32_t *kp = keep + (size_t)img * n_post;
-    for (int w = lane; w < MAXW; w += 64) rem[w] = 0ull;
+    for (int w = tid; w < MAXW; w += NMS_RED_THREADS) rem[w] = 0ull;
+    if (tid == 0) { s_kept = 0; s_cnt = 0; }
     __syncthreads();
-    int kept = 0;
     const int nb = (n + 63) / 64;
-    for (int c = 0; c < nb && kept < n_post; ++c) {
-        const int i = c * 64 + lane;
-        const u64 D = i < n ? mk[(size_t)i * nblk + c] : 0ull;
-        const int cnt = min(64, n - c * 64);
-        const u64 remc = rem[c];      // wave-uniform value: make that provable (scalar loop below)
-        u64 alive = ~(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(remc >> 32)) << 32) |
-                      (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)remc));
-        if (cnt < 64) alive &= (1ull << cnt) - 1ull;
-        u64 keepbits = 0ull;
-        const unsigned dlo = (unsigned)D, dhi = (unsigned)(D >> 32);
-        while (alive && kept < n_post) {
-            const int b = __builtin_ctzll(alive);
-            keepbits |= 1ull << b;
-            const u64 Db = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
-                           (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, b);
-            alive &= ~Db;
-            alive &= ~(1ull << b);
-            if (lane == 0) kp[kept] = c * 64 + b;
-            ++kept;
-        }
-        // OR the kept rows into rem[w] for w > c
-        for (int w0 = c + 1; w0 < nb; w0 += 64) {
-            const int w = w0 + lane;
-            u64 acc0 = 0ull, acc1 = 0ull, acc2 = 0ull, acc3 = 0ull;
-            u64 kb = keepbits;
-            while (kb) {
-                int b0 = __builtin_ctzll(kb); kb &= kb - 1;
-                int b1 = -1, b2 = -1, b3 = -1;
-                if (kb) { b1 = __builtin_ctzll(kb); kb &= kb - 1; }
-                if (kb) { b2 = __builtin_ctzll(kb); kb &= kb - 1; }
-                if (kb) { b3 = __builtin_ctzll(kb); kb &= kb - 1; }
-                if (w < nb) {
-                    acc0 |= mk[(size_t)(c * 64 + b0) * nblk + w];
-                    if (b1 >= 0) acc1 |= mk[(size_t)(c * 64 + b1) * nblk + w];
-                    if (b2 >= 0) acc2 |= mk[(size_t)(c * 64 + b2) * nblk + w];
-                    if (b3 >= 0) acc3 |= mk[(size_t)(c * 64 + b3) * nblk + w];
-                }
+    u64 Dn = (wave == 0 && lane < n) ? mk[(size_t)lane * nblk] : 0ull;       // diagonal word of chunk 0
+    for (int c = 0; c < nb; ++c) {
+        int kept = s_kept;
+        if (kept >= n_post) break;
+        if (wave == 0) {
+            const u64 D = Dn;
+            const int inext = (c + 1) * 64 + lane;
+            Dn = (c + 1 < nb && inext < n) ? mk[(size_t)inext * nblk + (c + 1)] : 0ull;   // prefetch
+            const int cnt = min(64, n - c * 64);
+            const u64 remc = rem[c];      // wave-uniform value: make that provable (scalar loop below)
+            u64 alive = ~(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(remc >> 32)) << 32) |
+                          (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)remc));
+            if (cnt < 64) alive &= (1ull << cnt) - 1ull;
+            const unsigned dlo = (unsigned)D, dhi = (unsigned)(D >> 32);
+            int k = 0;
+            while (alive && kept < n_post) {
+                const int b = __builtin_ctzll(alive);
+                const u64 Db = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                               (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, b);
+                alive &= ~Db;
+                alive &= ~(1ull << b);
+                if (lane == 0) { kp[kept] = c * 64 + b; s_list[k] = b; }
+                ++kept; ++k;
             }
-            if (w < nb) rem[w] |= (acc0 | acc1) | (acc2 | acc3);
+            if (lane == 0) { s_cnt = k; s_kept = kept; }
+        }
+        __syncthreads();
+        const int K = s_cnt, Wd = nb - c - 1;
+        if (K > 0 && Wd > 0 && s_kept < n_post) {
+            for (int idx = tid; idx < K * Wd; idx += NMS_RED_THREADS) {
+                const int b = s_list[idx / Wd], w = c + 1 + idx % Wd;
+                const u64 v = mk[(size_t)(c * 64 + b) * nblk + w];
+                if (v) atomicOr(&rem[w], v);
+            }
         }
         __syncthreads();
     }
-    if (lane == 0) n_keep[img] = kept;
+    if (tid == 0) n_keep[img] = s_kept;
 }
 
 __device__ __forceinline__ float fpn_level(float y1, float x1, float y2, float x2, float k_min, float k_max) {
@@ -330,7 +329,7 @@ extern "C" int mrcnn_rpn_proposals_f32(const float *locs, const float *scores, c
     MRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_nms_mask, dim3(L.nblk, L.nblk, N), dim3(64), 0, st, sboxes, n_valid, n_pre, L.nblk, nms_thresh, mask);
     MRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_reduce, dim3(N), dim3(64), 0, st, mask, n_valid, n_pre, L.nblk, n_post, keep, n_rois);
+    hipLaunchKernelGGL(k_nms_reduce, dim3(N), dim3(NMS_RED_THREADS), 0, st, mask, n_valid, n_pre, L.nblk, n_post, keep, n_rois);
     MRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_emit_rois, dim3(mrcnn::cdiv(n_post, 256), N), dim3(256), 0, st, sboxes, keep, n_rois, n_pre, n_post,
                        rois, roi_indices, levels);
@@ -364,7 +363,7 @@ extern "C" int mrcnn_nms_f32(const float *boxes, int n, float thresh, int max_ke
         hipLaunchKernelGGL(k_nms_mask, dim3(nblk, nblk, 1), dim3(64), 0, st, boxes, n_valid, n, nblk, thresh, mask);
         MRCNN_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_nms_reduce, dim3(1), dim3(64), 0, st, mask, n_valid, std::max(n, 1), nblk, max_keep, keep, n_keep);
+    hipLaunchKernelGGL(k_nms_reduce, dim3(1), dim3(NMS_RED_THREADS), 0, st, mask, n_valid, std::max(n, 1), nblk, max_keep, keep, n_keep);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }
