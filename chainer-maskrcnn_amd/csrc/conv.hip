@@ -388,23 +388,20 @@ int slots_for(int bm, int bn) {
 }
 
 struct TileChoice { int bm, bn; };
-// Smallest estimated time = rounds x (workgroups sharing a CU) x tile area / relative efficiency of the tile shape
-// (the `occ` resident workgroups of a CU share its MFMA pipes, so a round of small tiles is not faster per tile).
+// The largest tile that still gives every CU at least two workgroups (measured on gfx950: 128x128 ~118 TF, 128x64 ~103,
+// 64x64 ~80 on large layers, so a smaller tile only pays when the big one cannot fill the chip); narrow GEMM sides
+// (<= 64) take the 64-wide tile.
 template <int MODE>
 TileChoice choose_tile(long long M, long long Ng, long long z) {
-    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    static const double eff[4] = {1.0, 0.90, 0.90, 0.78};
-    TileChoice best{64, 64};
-    double best_t = 1e300;
-    for (int c = 0; c < 4; ++c) {
-        const int bm = cand[c][0], bn = cand[c][1];
-        if ((bm == 128 && M <= 64) || (bn == 128 && Ng <= 64)) continue;
-        const long long tiles = ((M + bm - 1) / bm) * ((Ng + bn - 1) / bn) * z;
-        const long long slots = slots_for<MODE>(bm, bn);
-        const double t = (double)((tiles + slots - 1) / slots) * (double)(slots / g_cus()) * bm * bn / eff[c];
-        if (t < best_t) { best_t = t; best = {bm, bn}; }
-    }
-    return best;
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Ng + bn - 1) / bn) * z; };
+    const long long fill = 2ll * g_cus();
+    const bool narrow_n = Ng <= 64, narrow_m = M <= 64;
+    if (!narrow_n && !narrow_m && tiles(128, 128) >= fill) return {128, 128};
+    if (!narrow_m && tiles(128, 64) >= fill) return {128, 64};
+    if (!narrow_n && !narrow_m && tiles(128, 128) >= fill * 3 / 4) return {128, 128};
+    if (narrow_m && !narrow_n) return {64, 128};
+    if (!narrow_m && narrow_n) return {128, 64};
+    return {64, 64};
 }
 
 template <int MODE>
@@ -532,8 +529,8 @@ TileChoice filter_tile(const ConvP &p) {
     t.bn = (p.smallc ? p.KH * p.KW * 4 : p.Cin) <= 64 ? 64 : 128;
     return t;
 }
-// split-K plan for backward-filter: the number of splits that fills a whole number of slot rounds (1 or 2), with at
-// least 8 K steps per split.
+// split-K plan for backward-filter: the number of splits that fills exactly one round of workgroup slots (slab traffic
+// grows with the split count), with at least 8 K steps per split.
 void filter_plan(const ConvP &p, int &ksplit, int &kchunk) {
     const long long P = (long long)p.N * p.Ho * p.Wo;
     const TileChoice t = filter_tile(p);
@@ -543,7 +540,6 @@ void filter_plan(const ConvP &p, int &ksplit, int &kchunk) {
     const long long maxsplit = std::max(1ll, P / (8 * BK));
     long long want = slots / tiles;                               // one full round
     if (want < 1) want = 1;
-    if (want * 4 <= maxsplit && tiles * want * 2 <= 4096) want = (2 * slots) / tiles;   // long K: two rounds, shorter tails
     ksplit = (int)std::max(1ll, std::min(std::min(want, maxsplit), 256ll));
     kchunk = (int)(((P + ksplit - 1) / ksplit + BK - 1) / BK * BK);
     ksplit = (int)((P + kchunk - 1) / kchunk);
