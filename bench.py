@@ -42,6 +42,15 @@ def roialign_inputs(seed_shift=0):
     return x, yx, gy
 
 
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_roialign_pmc_traffic.json')))
+        return d[kernel]['hbm_bytes']
+    except Exception:
+        return None
+
+
 def bench_roialign(args, rank, world):
     from chainer_maskrcnn.functions.roi_align_2d_yx import _roi_align_2d_yx
     from chainer_maskrcnn.functions.roi_align.roi_align_2d import roi_align_2d
@@ -92,7 +101,7 @@ def bench_roialign(args, rank, world):
                    'parallelism': 'independent batch per rank, no collective'},
         'roofline': {'bound': 'hbm', 'kernel': 'k_roi_align_bwd_nhwc', 'achieved': round(bwd_gbps, 2),
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(bwd_gbps / HBM_PEAK_GBPS, 4),
-                     'traffic': None, 'algorithmic_bytes_per_launch': algo_bytes,
+                     'traffic': _pmc_traffic('k_roi_align_bwd_nhwc'), 'algorithmic_bytes_per_launch': algo_bytes,
                      'avg_launch_us': round(bwd_avg_s * 1e6, 3), 'median_launch_us': round(float(np.median(bwd_ms)) * 1e3, 3)},
         'roi_align_fwd': {'avg_launch_us': round(fwd_avg_s * 1e6, 3),
                           'achieved_GBps': round(algo_bytes / fwd_avg_s / 1e9, 2),
@@ -204,6 +213,10 @@ def main():
         out, model, dev = bench_step(args, rank, world)
         if world == 1 and rank == 0 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_step(model, dev)
+        if rank == 0:       # second half of BASELINE.json's metric: ROIAlign backward HBM GB/s on configs[1]
+            ra = argparse.Namespace(steps=100, warmup=10, no_cpu_baseline=True)
+            r = bench_roialign(ra, 0, 1)
+            out['roi_align_microbench'] = {'workload': r['config']['workload'], 'bwd': r['roofline'], 'fwd': r['roi_align_fwd']}
     else:
         args.steps = args.steps or 200
         args.warmup = 20 if args.warmup is None else args.warmup
