@@ -55,7 +55,7 @@ def bench_roialign(args, rank, world):
     from chainer_maskrcnn.functions.roi_align_2d_yx import _roi_align_2d_yx
     from chainer_maskrcnn.functions.roi_align.roi_align_2d import roi_align_2d
     from chainer_maskrcnn import _hip
-    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    dev = torch.device('cuda', _local_device())
     torch.cuda.set_device(dev)
     x, yx, gy = roialign_inputs(rank)
     N, C, H, W = x.shape
@@ -164,6 +164,11 @@ def cpu_baseline_step(model, dev):
             'host_cpus': os.cpu_count()}
 
 
+def _local_device():
+    """LOCAL_RANK, or 0 for every rank when MRCNN_BENCH_SINGLE_DEVICE=1 (functional check on a 1-GPU box)."""
+    return 0 if os.environ.get('MRCNN_BENCH_SINGLE_DEVICE') == '1' else int(os.environ.get('LOCAL_RANK', 0))
+
+
 def sync_all(world):
     torch.cuda.synchronize()
     if world > 1:
@@ -187,13 +192,15 @@ def main():
     ap.add_argument('--workload', default='auto', choices=['auto', 'roialign', 'step'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mask-rows', default='all', choices=['positives', 'all'])
+    ap.add_argument('--graph', type=int, default=0, help='capture the step into a HIP graph (single GPU; measured slower than eager multi-stream launches on ROCm 7.2, so off by default)')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
-        torch.distributed.init_process_group('nccl')
+        torch.cuda.set_device(_local_device())
+        # RCCL over xGMI; MRCNN_BENCH_BACKEND=gloo only for the 1-GPU functional check of the multi-process path
+        torch.distributed.init_process_group(os.environ.get('MRCNN_BENCH_BACKEND', 'nccl'))
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
     workload = args.workload

@@ -167,6 +167,18 @@ def random_keys(shape, seed, device):
     return out
 
 
+def seed_state(seed, device):
+    """Device-resident sampler seed (int64 tensor of one element)."""
+    return torch.tensor([int(seed) & (2 ** 63 - 1)], dtype=torch.int64, device=device)
+
+
+def random_keys_dev(shape, state):
+    """uint32 keys from the device seed state; advances the state (graph-replay safe)."""
+    out = _empty(shape, state.device, i32)
+    check(lib().mrcnn_random_keys_dev_u32(ptr(out), out.numel(), ptr(state), stream_ptr()))
+    return out
+
+
 def sgd_momentum_wd(p, g, v, lr, momentum=0.9, weight_decay=5e-4):
     _ck(p, g, v)
     check(lib().mrcnn_sgd_momentum_wd_f32(ptr(p), ptr(g), ptr(v), p.numel(), lr, momentum, weight_decay, stream_ptr()))

@@ -16,7 +16,7 @@ def bench_step(args, rank, world):
     from chainer_maskrcnn.optimizers import MomentumSGD, WeightDecay
     from chainer_maskrcnn.utils.synthetic import make_batch
     from chainer_maskrcnn._hip import nn as hnn
-    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    dev = torch.device('cuda', 0 if os.environ.get('MRCNN_BENCH_SINGLE_DEVICE') == '1' else int(os.environ.get('LOCAL_RANK', 0)))
     torch.cuda.set_device(dev)
     N, H, W = 2, 1024, 1024
     mask_rows = getattr(args, 'mask_rows', 'all')
@@ -29,7 +29,21 @@ def bench_step(args, rank, world):
     b = make_batch(100 + rank, N, H, W, G=8)
     imgs, bb, lab, masks = (torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'masks'))
 
+    graphed = None
+    mode = 'eager launches'
+    if world == 1 and getattr(args, 'graph', 0):
+        try:
+            from chainer_maskrcnn.optimizers import GraphedStep
+            graphed = GraphedStep(opt, chain, [imgs, bb, lab, masks], 1.0)
+            mode = 'one HIP graph per step (forward + backward + SGD captured once, replayed)'
+        except Exception as e:      # capture is an optimisation: report and measure the eager path instead
+            graphed = None
+            mode = 'eager launches (graph capture failed: %s)' % str(e).split('\n')[0][:120]
+            torch.cuda.synchronize()
+
     def step():
+        if graphed is not None:
+            return graphed(imgs, bb, lab, masks)
         return opt.update(chain, imgs, bb, lab, masks, 1.0)
 
     for _ in range(args.warmup):
@@ -49,11 +63,11 @@ def bench_step(args, rank, world):
     if mask_rows == 'all' and world == 1:
         chain.mask_rows = 'positives'
         for _ in range(2):
-            step()
+            opt.update(chain, imgs, bb, lab, masks, 1.0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(5):
-            step()
+            opt.update(chain, imgs, bb, lab, masks, 1.0)
         torch.cuda.synchronize()
         alt = N * 5 / (time.perf_counter() - t1)
         chain.mask_rows = 'all'
@@ -62,7 +76,7 @@ def bench_step(args, rank, world):
     hnn.PROFILE = []
     n_prof = 2
     for _ in range(n_prof):
-        step()
+        opt.update(chain, imgs, bb, lab, masks, 1.0)      # eager, single stream: every launch bracketed by events
     torch.cuda.synchronize()
     recs, hnn.PROFILE = hnn.PROFILE, None
     agg = {}
@@ -83,7 +97,7 @@ def bench_step(args, rank, world):
         'config': {'workload': 'configs[2] ResNet50-FPN Mask R-CNN full fwd+bwd+SGD step, batch 2/GPU, 1024x1024, fp32, '
                                '8 gt boxes/image, 2000 proposals -> 256 sampled RoIs/image, mask branch on %s rows'
                                % ('the <=64 positive' if mask_rows == 'positives' else 'all 256 sampled'),
-                   'global_batch': N * world, 'parallelism': 'dp%d: RCCL all-reduce of the flat gradient buffer in 25 MB '
+                   'global_batch': N * world, 'launch_mode': mode, 'parallelism': 'dp%d: RCCL all-reduce of the flat gradient buffer in 25 MB '
                    'buckets on a side stream' % world if world > 1 else 'single GPU', 'final_loss': round(loss, 4)},
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm<fwd|bwd_data|bwd_filter> (all %d launches of a step)' % launches,
                      'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',

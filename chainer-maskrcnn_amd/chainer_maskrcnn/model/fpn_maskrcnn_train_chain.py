@@ -29,6 +29,11 @@ class AnchorTargetCreator(object):
     def __init__(self, n_sample=256, pos_iou_thresh=0.7, neg_iou_thresh=0.3, pos_ratio=0.5):
         self.n_sample, self.pos_iou_thresh, self.neg_iou_thresh, self.pos_ratio = n_sample, pos_iou_thresh, neg_iou_thresh, pos_ratio
         self.seed = 1 << 32
+        self._state = None
+
+    def set_seed(self, seed):
+        self.seed = seed
+        self._state = None
 
     def __call__(self, bbox, anchor, img_size, n_gt=None, keys=None):
         """bbox (N,G,4) (or (G,4)), anchor (A,4) -> (loc (N,A,4), label (N,A))."""
@@ -38,8 +43,9 @@ class AnchorTargetCreator(object):
         if n_gt is None:
             n_gt = torch.full((N,), G, dtype=torch.int32, device=bbox.device)
         if keys is None:
-            self.seed += 1
-            keys = ops.random_keys((N, anchor.shape[0]), self.seed, bbox.device)
+            if self._state is None or self._state.device != bbox.device:
+                self._state = ops.seed_state(self.seed, bbox.device)
+            keys = ops.random_keys_dev((N, anchor.shape[0]), self._state)
         return ops.anchor_target(anchor, bbox.contiguous(), n_gt, img_size, keys, self.n_sample, self.pos_iou_thresh,
                                  self.neg_iou_thresh, self.pos_ratio)
 

@@ -113,3 +113,39 @@ class MomentumSGD(object):
         ops.sgd_momentum_wd(self.ps.params, self.ps.grads, self.ps.momentum, self.lr, self.momentum, self.weight_decay)
         self.t += 1
         return loss
+
+
+class GraphedStep(object):
+    """One whole training step (forward, backward, SGD update) captured into a HIP graph and replayed.
+
+    The step has no device->host copy and static shapes (padded RoI / sample rows, device-resident counts and
+    sampler seeds), so the ~800 kernel launches of a step can be recorded once; a replay costs one host call and
+    removes the launch gaps (MI355X_MICROARCH.md price list, rows 'boundary' / 'graph-replay-floor').
+    Inputs are copied into static buffers; ``chain.observation`` tensors are rewritten by every replay.
+    Single-GPU only (the data-parallel path issues its RCCL collectives eagerly).
+    """
+
+    def __init__(self, optimizer, chain, example_batch, scale=1.0, warmup=3):
+        if optimizer.sync is not None:
+            raise RuntimeError('GraphedStep: data-parallel steps run eagerly')
+        self.optimizer, self.chain, self.scale = optimizer, chain, scale
+        self.static = [t.clone() for t in example_batch]
+        cur = torch.cuda.current_stream()
+        s = torch.cuda.Stream()
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                optimizer.update(chain, *self.static, scale)
+        cur.wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            optimizer.update(chain, *self.static, scale)
+
+    def __call__(self, *batch):
+        for dst, src in zip(self.static, batch):
+            if src is not dst:
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        self.optimizer.t += 1
+        return self.chain.observation['loss']

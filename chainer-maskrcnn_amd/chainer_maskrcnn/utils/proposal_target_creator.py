@@ -23,6 +23,16 @@ class ProposalTargetCreator(object):
         self.neg_iou_thresh_hi = neg_iou_thresh_hi
         self.neg_iou_thresh_lo = neg_iou_thresh_lo
         self.seed = 0
+        self._state = None           # device-resident seed (created lazily; see set_seed)
+
+    def set_seed(self, seed, device=None):
+        self.seed = seed
+        self._state = None if device is None else ops.seed_state(seed, device)
+
+    def _keys(self, shape, device):
+        if self._state is None or self._state.device != device:
+            self._state = ops.seed_state(self.seed, device)
+        return ops.random_keys_dev(shape, self._state)
 
     @property
     def pos_cap(self):
@@ -38,8 +48,7 @@ class ProposalTargetCreator(object):
         N, G = gt_labels.shape
         roi_cap = rois.shape[0] // N
         if keys is None:
-            self.seed += 1
-            keys = ops.random_keys((N, roi_cap + G), self.seed, rois.device)
+            keys = self._keys((N, roi_cap + G), rois.device)
         o = ops.proposal_target(rois, roi_levels, n_rois, gt_boxes, gt_labels, n_gt, keys, self.n_sample,
                                 self.pos_ratio, self.pos_iou_thresh, self.neg_iou_thresh_hi, self.neg_iou_thresh_lo,
                                 loc_normalize_mean, loc_normalize_std)

@@ -504,6 +504,21 @@ __global__ __launch_bounds__(NT) void k_random_keys(uint32_t *__restrict__ out, 
     }
 }
 
+// Device-resident seed: keys = hash(state[0], index); state[0] is advanced by a second launch, so a captured HIP
+// graph draws fresh keys on every replay (a by-value seed would be frozen into the graph).
+__global__ __launch_bounds__(NT) void k_random_keys_dev(uint32_t *__restrict__ out, size_t n,
+                                                        const unsigned long long *__restrict__ state) {
+    const unsigned long long seed = state[0];
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        out[i] = (uint32_t)(z >> 32);
+    }
+}
+__global__ void k_advance_seed(unsigned long long *state) { state[0] += 0xD1B54A32D192ED03ull; }
+
 int chk(bool ok, const char *what) { return ok ? 0 : mrcnn::fail_arg(MRCNN_E_INVALID, "%s", what); }
 
 }  // namespace
@@ -666,6 +681,17 @@ extern "C" int mrcnn_bilinear2x_fwd_f32(const float *x, float *y, int N, int H, 
 extern "C" int mrcnn_bilinear2x_bwd_f32(const float *gy, float *gx, int N, int H, int W, int C, void *stream) {
     if (int e = chk(gy && gx && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "bilinear2x_bwd: bad args")) return e;
     hipLaunchKernelGGL(k_bilinear2x_bwd, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(NT), 0, (hipStream_t)stream, gy, gx, N, H, W, C / 4);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_random_keys_dev_u32(uint32_t *out, size_t n, unsigned long long *state, void *stream) {
+    if (int e = chk(out != nullptr && state != nullptr, "random_keys_dev: null pointer")) return e;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_random_keys_dev, dim3(ew_grid(n)), dim3(NT), 0, (hipStream_t)stream, out, n, state);
+        MRCNN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_advance_seed, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -173,6 +173,9 @@ int mrcnn_bilinear2x_bwd_f32(const float *gy, float *gx, int N, int H, int W, in
 int mrcnn_image_nchw3_to_nhwc4_f32(const float *x, float *y, int N, int H, int W, void *stream);
 /* n uint32 sampler keys from a counter-based hash of (seed, index). */
 int mrcnn_random_keys_u32(uint32_t *out, size_t n, unsigned long long seed, void *stream);
+/* Same with the seed in device memory (state[0]); the call also advances the state, so a replayed HIP graph draws
+ * fresh keys every time. */
+int mrcnn_random_keys_dev_u32(uint32_t *out, size_t n, unsigned long long *state, void *stream);
 /* g += wd*p; v = momentum*v - lr*g; p += v  over a flat parameter buffer (train.py:107-109). */
 int mrcnn_sgd_momentum_wd_f32(float *p, const float *g, float *v, size_t n, float lr, float momentum,
                               float weight_decay, void *stream);

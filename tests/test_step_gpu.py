@@ -120,13 +120,13 @@ def test_step_is_bit_reproducible_and_sgd_updates():
     m, chain = _build('positives')
     b = _batch()
     chain.sampler_keys = None
-    chain.proposal_target_creator.seed = 5
-    chain.anchor_target_creator.seed = 9
+    chain.proposal_target_creator.set_seed(5)
+    chain.anchor_target_creator.set_seed(9)
     chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0).backward()
     g1 = m.ps.grads.clone()
     l1 = float(chain.observation['loss'])
-    chain.proposal_target_creator.seed = 5
-    chain.anchor_target_creator.seed = 9
+    chain.proposal_target_creator.set_seed(5)
+    chain.anchor_target_creator.set_seed(9)
     chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0).backward()
     assert float(chain.observation['loss']) == l1
     assert torch.equal(g1, m.ps.grads)                      # no atomics anywhere on the path
