@@ -72,9 +72,11 @@ def conv2d_fwd_raw(x, w, b, stride, pad, relu):
     assert x.is_contiguous() and w.is_contiguous()
     y = torch.empty((N, conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad), Cout),
                     dtype=torch.float32, device=x.device)
+    nb = lib().mrcnn_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    ws = workspace(nb, x.device) if nb else None
     with _prof('fwd', N * y.shape[1] * y.shape[2], KH, KW, Cin, Cout):
         check(lib().mrcnn_conv2d_fwd_f32(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cout, KH, KW,
-                                         stride, pad, int(relu), stream_ptr()))
+                                         stride, pad, int(relu), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()))
     return y
 
 
@@ -85,9 +87,12 @@ def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None):
     assert gy.is_contiguous()
     acc = out is not None
     gx = out if acc else torch.empty(x_shape, dtype=torch.float32, device=gy.device)
+    nb = lib().mrcnn_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    ws = workspace(nb, gy.device) if nb else None
     with _prof('bwd_data', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout):
         check(lib().mrcnn_conv2d_bwd_data_f32(ptr(gy), ptr(w), ptr(gx), N, H, W, Cin, Cout, KH, KW,
-                                              stride, pad, int(acc), stream_ptr()))
+                                              stride, pad, int(acc), ptr(ws), ws.numel() if ws is not None else 0,
+                                              stream_ptr()))
     return gx
 
 

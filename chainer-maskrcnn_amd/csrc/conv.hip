@@ -46,7 +46,8 @@ struct ConvP {
     int accumulate;       // BWD_DATA: gx += result
     int smallc;           // Cin == 4: the K axis is (tap, 4 channels) flattened, one 16-B chunk per tap
     int M, Ng;            // GEMM M and N extents
-    int ksplit, kchunk;   // BWD_FILTER: number of K splits, pixels per split
+    int ksplit, kchunk;   // BWD_FILTER: number of K splits, pixels per split;  FWD / BWD_DATA: splits, K steps per split
+    float *slab;          // FWD / BWD_DATA split-K: (ksplit, M, ldc) partial sums
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     const int wm = wave >> 1, wn = wave & 1;
     // blockIdx.x walks M tiles fastest so that neighbouring workgroups share the B (weight) panel.
     const int m0 = blockIdx.x * BM_, n0 = blockIdx.y * BN_;
-    const int split = (MODE == MODE_BWD_FILTER) ? (int)(blockIdx.z % p.ksplit) : 0;
+    const int split = (MODE == MODE_BWD_FILTER) ? (int)(blockIdx.z % p.ksplit) : (int)blockIdx.z;
     const int tap = (MODE == MODE_BWD_FILTER) ? (int)(blockIdx.z / p.ksplit) : 0;   // kh*KW+kw
 
     // KC loader role: 16-B chunk kc of rows r0+32i.   RC loader role: columns 4*rc.. of k index k0 + KPP*i.
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     // K-step bookkeeping
     int nsteps, kbeg = 0, kend = 0;
     const int cin_steps = p.Cin / BK, cout_steps = p.Cout / BK;
+    int sbeg = 0;             // FWD / BWD_DATA split-K: this workgroup's K steps are [sbeg, sbeg + nsteps)
     if (MODE == MODE_FWD) nsteps = SMALLC ? (taps + 7) / 8 : taps * cin_steps;
     else if (MODE == MODE_BWD_DATA) nsteps = taps * cout_steps;
     else {
@@ -200,6 +202,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         kbeg = split * p.kchunk;
         kend = min(P, kbeg + p.kchunk);
         nsteps = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    }
+    if (MODE != MODE_BWD_FILTER && p.ksplit > 1) {
+        sbeg = split * p.kchunk;
+        nsteps = max(0, min(nsteps, sbeg + p.kchunk) - sbeg);
     }
     // BWD_FILTER constants
     int f_kh = 0, f_kw = 0, f_ci = 0;
@@ -308,11 +314,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     };
 
     if (nsteps > 0) {
-        load_step(0);
+        load_step(sbeg);
         store_step();
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
-            if (s + 1 < nsteps) load_step(s + 1);          // global -> registers: in flight during the MFMAs below
+            if (s + 1 < nsteps) load_step(sbeg + s + 1);   // global -> registers: in flight during the MFMAs below
             mma_step<A_KC, B_KC, BM_, BN_>(sA, sB, acc, wm, wn, lane);
             __syncthreads();
             if (s + 1 < nsteps) {
@@ -326,8 +332,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     const int r = lane & 31, h = lane >> 5;
     size_t ldc;
     float *cbase;
-    if (MODE == MODE_FWD) { ldc = p.Cout; cbase = p.c; }
-    else if (MODE == MODE_BWD_DATA) { ldc = p.Cin; cbase = p.c; }
+    const bool partial = (MODE != MODE_BWD_FILTER) && p.ksplit > 1;     // raw partial sums go to slab `split`
+    if (MODE == MODE_FWD) { ldc = p.Cout; cbase = partial ? p.slab + (size_t)split * p.M * ldc : p.c; }
+    else if (MODE == MODE_BWD_DATA) { ldc = p.Cin; cbase = partial ? p.slab + (size_t)split * p.M * ldc : p.c; }
     else {
         ldc = (size_t)taps * (SMALLC ? 4 : p.Cin);
         cbase = p.c + (size_t)split * p.Cout * ldc + (SMALLC ? 0 : (size_t)tap * p.Cin);
@@ -339,14 +346,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             const int n = n0 + wn * (BN_ / 2) + tn * 32 + r;
             const bool nv = n < p.Ng;
             float bv = 0.0f;
-            if (MODE == MODE_FWD) bv = p.bias ? p.bias[nv ? n : 0] : 0.0f;
+            if (MODE == MODE_FWD && !partial) bv = p.bias ? p.bias[nv ? n : 0] : 0.0f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * (BM_ / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (!nv || m >= p.M) continue;
                 float v = acc[tm][tn][e] + bv;
-                if (MODE == MODE_FWD && p.relu) v = fmaxf(v, 0.0f);
-                if (MODE == MODE_BWD_DATA && p.accumulate) v += cbase[(size_t)m * ldc + n];
+                if (MODE == MODE_FWD && p.relu && !partial) v = fmaxf(v, 0.0f);
+                if (MODE == MODE_BWD_DATA && p.accumulate && !partial) v += cbase[(size_t)m * ldc + n];
                 cbase[(size_t)m * ldc + n] = v;
             }
         }
@@ -433,6 +440,25 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ sla
         const float4 v = ldg4(slabs + ((size_t)k * n4 + i) * 4);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+    *reinterpret_cast<float4 *>(out + i * 4) = s;
+}
+
+// FWD / BWD_DATA split-K epilogue: out[m][n] = (accumulate ? out : 0) + sum_s slab[s][m][n] + bias[n], optional ReLU.
+__global__ __launch_bounds__(256) void k_sum_slabs_ep(const float *__restrict__ slabs, float *__restrict__ out, size_t n4,
+                                                      int ksplit, int ldc4, const float *__restrict__ bias, int relu,
+                                                      int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = accumulate ? ldg4(out + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < ksplit; ++k) {
+        const float4 v = ldg4(slabs + ((size_t)k * n4 + i) * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+        const float4 b = ldg4(bias + (i % ldc4) * 4);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
     *reinterpret_cast<float4 *>(out + i * 4) = s;
 }
 
@@ -545,23 +571,74 @@ void filter_plan(const ConvP &p, int &ksplit, int &kchunk) {
     ksplit = (int)((P + kchunk - 1) / kchunk);
 }
 
+// FWD / BWD_DATA split-K: when even the smallest useful tile leaves CUs idle (deep layers: few pixels, long K) the K
+// steps are split over `ksplit` workgroups per tile; partial tiles go to slabs and are summed in fixed order.
+template <int MODE>
+void data_plan(ConvP &p, TileChoice &t, int nsteps) {
+    t = choose_tile<MODE>(p.M, p.Ng, 1);
+    const long long tiles = (long long)mrcnn::cdiv(p.M, t.bm) * mrcnn::cdiv(p.Ng, t.bn);
+    const long long fill = 2ll * g_cus();
+    p.ksplit = 1;
+    p.kchunk = nsteps;
+    if (p.smallc || tiles >= fill || nsteps < 16) return;
+    long long ks = std::min<long long>(std::min<long long>(fill / tiles, nsteps / 8), 16);
+    if (ks < 2) return;
+    p.kchunk = (int)((nsteps + ks - 1) / ks);
+    p.ksplit = (nsteps + p.kchunk - 1) / p.kchunk;
+}
+size_t data_ws_bytes(const ConvP &p, long long ldc) { return p.ksplit > 1 ? (size_t)p.ksplit * p.M * ldc * sizeof(float) : 0; }
+
+template <int MODE>
+int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes, hipStream_t st) {
+    TileChoice t;
+    data_plan<MODE>(p, t, nsteps);
+    if (p.ksplit > 1) {
+        if (!ws || ws_bytes < data_ws_bytes(p, ldc)) { p.ksplit = 1; p.kchunk = nsteps; }      // no workspace: unsplit
+        else p.slab = (float *)ws;
+    }
+    launch_conv<MODE>(p, dim3(1, 1, p.ksplit), t, st);
+    MRCNN_LAUNCH_CHECK();
+    if (p.ksplit > 1) {
+        const size_t n4 = (size_t)p.M * ldc / 4;
+        hipLaunchKernelGGL(k_sum_slabs_ep, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, p.slab, p.c, n4, p.ksplit, (int)(ldc / 4),
+                           MODE == MODE_FWD ? p.bias : nullptr, MODE == MODE_FWD ? p.relu : 0,
+                           MODE == MODE_BWD_DATA ? p.accumulate : 0);
+        MRCNN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 }  // namespace
+
+extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    // upper bound for both the forward and the backward-data split-K slabs (16 splits of the larger output)
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
+    const long long Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
+    if (Ho <= 0 || Wo <= 0) return 0;
+    const long long a = (long long)N * Ho * Wo * Cout, b = (long long)N * H * W * Cin;
+    const long long fill = 2ll * g_cus();
+    // split-K only engages when the 64x64 tiling has fewer than `fill` tiles: M*Ng < fill*4096
+    const long long cap = fill * 8192;
+    long long need = 0;
+    if (a < cap) need = std::max(need, a);
+    if (b < cap) need = std::max(need, b);
+    return (size_t)need * 16 * sizeof(float);
+}
 
 extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                                     int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
-                                    void *stream) {
+                                    void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     p.a = x; p.b = w; p.c = y; p.bias = bias; p.relu = relu;
     p.M = N * p.Ho * p.Wo; p.Ng = Cout;
-    launch_conv<MODE_FWD>(p, dim3(1, 1, 1), choose_tile<MODE_FWD>(p.M, p.Ng, 1), (hipStream_t)stream);
-    MRCNN_LAUNCH_CHECK();
-    return 0;
+    const int nsteps = p.smallc ? (KH * KW + 7) / 8 : KH * KW * (Cin / BK);
+    return run_data_conv<MODE_FWD>(p, nsteps, Cout, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, int N, int H, int W,
                                          int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                         int accumulate, void *stream) {
+                                         int accumulate, void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_conv(gy, w, gx, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     if (stride != 1)
         return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: stride %d (only 1; strided 1x1 convs are "
@@ -570,9 +647,7 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
     if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
     p.a = gy; p.b = w; p.c = gx; p.accumulate = accumulate;
     p.M = N * H * W; p.Ng = Cin;
-    launch_conv<MODE_BWD_DATA>(p, dim3(1, 1, 1), choose_tile<MODE_BWD_DATA>(p.M, p.Ng, 1), (hipStream_t)stream);
-    MRCNN_LAUNCH_CHECK();
-    return 0;
+    return run_data_conv<MODE_BWD_DATA>(p, KH * KW * (Cout / BK), Cin, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW,

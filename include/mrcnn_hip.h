@@ -112,16 +112,20 @@ int mrcnn_roi_align_sample_tables(const float *rois, int R, int H, int W, int PH
  *   counts such as 3, 18, 80, 81.  bias (Cout) may be NULL; relu != 0
  *   fuses max(.,0) into the forward epilogue.  Linear layers are 1x1 convolutions with
  *   H = W = 1; the 2x2/2 deconvolution is a 1x1 convolution to 4*Cout channels + a host view.
+ * fwd / bwd_data take an optional workspace (mrcnn_conv2d_workspace_bytes; may be NULL/0): deep layers with few
+ * pixels and a long K axis are split over K into slabs summed in fixed order (deterministic), so all CUs work.
  * bwd_data supports stride 1 only (a strided 1x1 convolution is a stride-1 one on the subsampled
  * lattice followed by mrcnn_subsample_bwd_f32); accumulate != 0 adds into gx instead of overwriting.  bwd_filter accumulates over pixels with a deterministic
  * split-K (slabs in the caller's workspace, fixed summation order); gbias may be NULL; accumulate != 0
  * adds into gw / gbias (layers shared by several inputs, e.g. the RPN head over 5 pyramid levels).
  * ---------------------------------------------------------------------------------------- */
+size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
-                         void *stream);
+                         void *ws, size_t ws_bytes, void *stream);
 int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, int N, int H, int W, int Cin,
-                              int Cout, int KH, int KW, int stride, int pad, int accumulate, void *stream);
+                              int Cout, int KH, int KW, int stride, int pad, int accumulate, void *ws,
+                              size_t ws_bytes, void *stream);
 size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                                int stride, int pad);
 int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, float *gw, float *gbias, int N, int H,
