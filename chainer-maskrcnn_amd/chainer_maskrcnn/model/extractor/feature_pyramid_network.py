@@ -77,8 +77,9 @@ class FeaturePyramidNetwork(object):
         self.tape = t
         return p2, p3, p4, p5, p6
 
-    def backward(self, grads):
-        """grads: [g_p2, g_p3, g_p4, g_p5, g_p6]; consumed (accumulated into in place)."""
+    def backward(self, grads, progress=None):
+        """grads: [g_p2, g_p3, g_p4, g_p5, g_p6]; consumed (accumulated into in place).  ``progress(prefix)`` is
+        called when every parameter registered at or after ``prefix`` has its final gradient (data-parallel overlap)."""
         t = self.tape
         g_p2, g_p3, g_p4, g_p5, g_p6 = grads
         self.conv_p6.bwd(t['p6'], g_p6, gx_acc=g_p5)
@@ -92,12 +93,16 @@ class FeaturePyramidNetwork(object):
         ops.upsample2x_bwd(g_m4, gtop=g_p5)
         g_c4 = self.lat_p4.bwd(t['lat4'], g_m4)
         g_c5 = self.toplayer.bwd(t['top'], g_p5)
+        if progress:
+            progress(self.toplayer.name)        # the FPN layers are registered after the ResNet
         # The gradient of c2..c4 is (lateral gradient) + (input gradient of the next stage): the next
         # stage's first block accumulates its input gradient into the lateral one (gx_acc).
         acc_for = {id(self.stages[k][0]): g for k, g in ((1, g_c2), (2, g_c3), (3, g_c4))}
         g = g_c5
         for b, ctx in reversed(t['blocks']):
             g = b.bwd(ctx, g, gx_acc=acc_for.get(id(b)))
+            if progress:
+                progress(b.conv1.name)
         g = ops.maxpool2x2_bwd(t['pool_in'], g)
         g, _ = self.bn1.bwd(t['bn1'], g)
         self.conv1.bwd(t['conv1'], g, need_gx=False)

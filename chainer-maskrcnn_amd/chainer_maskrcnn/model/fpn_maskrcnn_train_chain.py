@@ -194,7 +194,7 @@ class FPNMaskRCNNTrainChain(object):
         m.rpn.backward(g_locs, g_scores, g_feats)
         if hook:
             hook(self._offset_of('rpn/'))
-        m.extractor.backward(g_feats)
+        m.extractor.backward(g_feats, progress=(lambda prefix: hook(self._offset_of(prefix))) if hook else None)
         from chainer_maskrcnn.nn import core
         core.join_side_stream(features[0].device)
         if hook:
@@ -202,5 +202,8 @@ class FPNMaskRCNNTrainChain(object):
         self._bwd = None
 
     def _offset_of(self, prefix):
-        ps = self.faster_rcnn.ps
-        return min(o for name, (o, _) in ps.offsets.items() if name.startswith(prefix))
+        cache = self.__dict__.setdefault('_offset_cache', {})
+        if prefix not in cache:
+            ps = self.faster_rcnn.ps
+            cache[prefix] = min(o for name, (o, _) in ps.offsets.items() if name.startswith(prefix))
+        return cache[prefix]
