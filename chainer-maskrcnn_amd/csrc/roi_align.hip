@@ -215,7 +215,6 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
                                                                        const int32_t *__restrict__ levels,
                                                                        int R, int N, int C, int PH, int PW,
                                                                        int sr, int chunk, int accumulate) {
-    constexpr int TASKS = 2 * TH * PBT;      // (axis,bin,row) weight cells per slot
     // sW[slot][axis][bin][tile row/col]: summed weight that bin `bin` of the RoI in `slot` puts on
     // map row ty0+row (axis 0) / map column tx0+row (axis 1).  4 consecutive rows = one 16-B read.
     __shared__ __attribute__((aligned(16))) float sW[SLOTS][2][PBT][TH];
@@ -288,23 +287,29 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
             // ---- phase 1: per-(slot, axis, bin, row) summed weights, one thread each
             if (tid < SLOTS) sMask[tid] = 0;
             __syncthreads();
-            for (int task = tid; task < nslots * TASKS; task += BWD_THREADS) {
-                const int slot = task / TASKS, qq = task % TASKS;
-                const int axis = qq / (TH * PBT), bin = (qq / TH) % PBT, row = qq % TH;
+            // one thread per (slot, axis, bin): the bin's `sr` samples are evaluated once and their weights summed
+            // into the bin's 8 tile rows (the thread owns that LDS row: no atomics, fixed order)
+            for (int task = tid; task < nslots * 2 * PBT; task += BWD_THREADS) {
+                const int slot = task / (2 * PBT), qq = task % (2 * PBT);
+                const int axis = qq / PBT, bin = qq % PBT;
                 const float4 ge = sGeom[s0 + slot];
-                const int P = axis ? PW : PH, size = axis ? W : H;
-                const int target = (axis ? tx0 : ty0) + row;
+                const int P = axis ? PW : PH, size = axis ? W : H, t0 = axis ? tx0 : ty0;
                 const float start = axis ? ge.x : ge.y, bsz = axis ? ge.z : ge.w;
-                float wv = 0.0f;
+                float *tab = &sW[slot][axis][bin][0];
+#pragma unroll
+                for (int j = 0; j < TH; ++j) tab[j] = 0.0f;
+                int bits = 0;
                 if (bin < P) {
                     for (int i2 = 0; i2 < sr; ++i2) {
-                        const Samp s = axis_sample(start, bsz, bin, i2, sr, size);
-                        if (s.lo == target) wv += s.wl;
-                        if (s.hi == target) wv += s.wh;
+                        const Samp sp = axis_sample(start, bsz, bin, i2, sr, size);
+                        const unsigned dl = (unsigned)(sp.lo - t0), dh = (unsigned)(sp.hi - t0);
+                        if (sp.lo >= 0 && dl < (unsigned)TH) tab[dl] += sp.wl;
+                        if (sp.hi >= 0 && dh < (unsigned)TH) tab[dh] += sp.wh;
                     }
+#pragma unroll
+                    for (int j = 0; j < TH; ++j) bits |= (tab[j] != 0.0f) ? (1 << j) : 0;
                 }
-                sW[slot][axis][bin][row] = wv;
-                if (wv != 0.0f) atomicOr(&sMask[slot], 1 << (axis * 8 + row));
+                if (bits) atomicOr(&sMask[slot], bits << (axis * 8));
             }
             __syncthreads();
 
