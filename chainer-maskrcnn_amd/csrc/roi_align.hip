@@ -154,17 +154,19 @@ constexpr int PB = 16;            // max pooled bins per axis on this path (7 an
 constexpr int BWD_THREADS = 256;  // 4 waves = 2 x 2 patches
 constexpr int BWD_WAVES = BWD_THREADS / 64;
 constexpr int LISTCAP = 512;      // RoIs scanned per segment
-constexpr int QCAP = 64;          // per-wave queue capacity; entry = (gy row, 4 row weights, 4 col weights)
+constexpr int QCAP_MAX = 256;     // per-wave queue capacity (template QC): 64 entries for 7x7 pooling, 256 for 14x14
+                                  // (a full window is rebuilt per pass; entry = (gy row, 4 row weights, 4 col weights))
 constexpr int CCH = 256;          // channels per pass: lane = 4 channels
 
 #define MRCNN_FMA4(A, c, g)                \
     A.x = fmaf(c, g.x, A.x); A.y = fmaf(c, g.y, A.y); \
     A.z = fmaf(c, g.z, A.z); A.w = fmaf(c, g.w, A.w);
 
+template <int QC>
 struct PatchQueue {     // one per wave, in LDS
-    float4 wy[QCAP];    // weights of the entry's bin row on the patch's 4 map rows (already / count)
-    float4 wx[QCAP];    // weights of the entry's bin column on the patch's 4 map columns
-    int row[QCAP];      // gy row index (r*PH + ph)*PW + pw
+    float4 wy[QC];      // weights of the entry's bin row on the patch's 4 map rows (already / count)
+    float4 wx[QC];      // weights of the entry's bin column on the patch's 4 map columns
+    int row[QC];        // gy row index (r*PH + ph)*PW + pw
 };
 
 // acc[i][k] += wy[i] * wx[k] * g for the 4x4 patch.  Deliberately branch-free: conditional updates of
@@ -188,7 +190,8 @@ __device__ __forceinline__ void apply_entry(float4 (&acc)[PT][PT], const float4 
 // current two are consumed.  Entries past n get weight 0 on a live row, so the loop is branch-free
 // with respect to the accumulators.  The empty asm statements only stop hipcc from hoisting every
 // LDS weight read to the top of the loop (register pressure).
-__device__ __forceinline__ void drain_queue(const PatchQueue &q, int n, const float *__restrict__ gyl, int C,
+template <int QC>
+__device__ __forceinline__ void drain_queue(const PatchQueue<QC> &q, int n, const float *__restrict__ gyl, int C,
                                             float4 (&acc)[PT][PT]) {
     if (n <= 0) return;
     const size_t Cs = (size_t)C;
@@ -217,8 +220,9 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
                                                                        int sr, int chunk, int accumulate) {
     // sW[slot][axis][bin][tile row/col]: summed weight that bin `bin` of the RoI in `slot` puts on
     // map row ty0+row (axis 0) / map column tx0+row (axis 1).  4 consecutive rows = one 16-B read.
+    constexpr int QCAP = PBT == 8 ? 64 : QCAP_MAX;
     __shared__ __attribute__((aligned(16))) float sW[SLOTS][2][PBT][TH];
-    __shared__ __attribute__((aligned(16))) PatchQueue sQ[BWD_WAVES];
+    __shared__ __attribute__((aligned(16))) PatchQueue<QCAP> sQ[BWD_WAVES];
     __shared__ float4 sGeom[LISTCAP];        // (x1f, y1f, bw, bh) of listed RoIs
     __shared__ int sList[LISTCAP];
     __shared__ int sMask[SLOTS];             // bits 0-7: rows with weight, bits 8-15: cols
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
     const float scale = lv.scale[l];
     float *gxb = lv.gx[l] + (size_t)n * H * W * C;
     const float inv_cnt = 1.0f / (float)(sr * sr);
-    PatchQueue &q = sQ[wave];
+    PatchQueue<QCAP> &q = sQ[wave];
     const int cy0 = (wave >> 1) * PT, cx0 = (wave & 1) * PT;      // this wave's patch inside the tile
     const int nrow = min(PT, H - (ty0 + cy0)), ncol = min(PT, W - (tx0 + cx0));   // may be <= 0
 
