@@ -436,7 +436,15 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ sla
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     float4 s = accumulate ? ldg4(out + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < ksplit; ++k) {
+    int k = 0;
+    for (; k + 8 <= ksplit; k += 8) {            // 8 independent loads in flight, added in slab order
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ldg4(slabs + ((size_t)(k + j) * n4 + i) * 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+    }
+    for (; k < ksplit; ++k) {
         const float4 v = ldg4(slabs + ((size_t)k * n4 + i) * 4);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -507,8 +515,15 @@ __global__ __launch_bounds__(1024) void k_colsum_final(const float *__restrict__
     __shared__ double sa[16][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     double a = 0.0;
-    if (c < C)
-        for (int k = slice; k < nb; k += 16) a += (double)part[(size_t)k * C + c];
+    if (c < C) {
+        int k = slice;
+        for (; k + 48 < nb; k += 64) {           // 4 independent loads in flight, added in order
+            const float v0 = part[(size_t)k * C + c], v1 = part[(size_t)(k + 16) * C + c];
+            const float v2 = part[(size_t)(k + 32) * C + c], v3 = part[(size_t)(k + 48) * C + c];
+            a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
+        }
+        for (; k < nb; k += 16) a += (double)part[(size_t)k * C + c];
+    }
     sa[slice][threadIdx.x & 63] = a;
     __syncthreads();
     if (slice == 0 && c < C) {

@@ -83,11 +83,23 @@ constexpr int FIN_SLICES = 16;
 __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int nblk, int C, int c, int slice,
                                                 double (*sa)[64], double (*sb)[64], double &a, double &b) {
     a = 0.0; b = 0.0;
-    if (c < C)
-        for (int k = slice; k < nblk; k += FIN_SLICES) {
+    if (c < C) {
+        int k = slice;
+        for (; k + 3 * FIN_SLICES < nblk; k += 4 * FIN_SLICES) {      // 8 independent loads in flight, added in order
+            float va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                va[j] = part[(size_t)(k + j * FIN_SLICES) * 2 * C + c];
+                vb[j] = part[(size_t)(k + j * FIN_SLICES) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a += (double)va[j]; b += (double)vb[j]; }
+        }
+        for (; k < nblk; k += FIN_SLICES) {
             a += (double)part[(size_t)k * 2 * C + c];
             b += (double)part[(size_t)k * 2 * C + C + c];
         }
+    }
     sa[slice][threadIdx.x & 63] = a;
     sb[slice][threadIdx.x & 63] = b;
     __syncthreads();
