@@ -102,6 +102,14 @@ class FPNMaskRCNNTrainChain(object):
         self.observation = {}
         self.grad_ready_hook = None         # called with the lowest finished parameter offset during backward (DP overlap)
         self.sampler_keys = None            # (proposal keys, anchor keys) override for parity tests
+        self.use_aux_stream = True          # independent branches (RPN losses, box head) on a second compute stream
+        self._aux = {}
+
+    def _aux_stream(self, dev):
+        key = (dev.type, dev.index)
+        if key not in self._aux:
+            self._aux[key] = torch.cuda.Stream(device=dev)
+        return self._aux[key]
 
     # ------------------------------------------------------------------------------------------
     def __call__(self, imgs, bboxes, labels, masks, scale, n_gt=None):
@@ -126,32 +134,40 @@ class FPNMaskRCNNTrainChain(object):
         r = m.rpn.forward_padded(features, img_size, scale)
 
         pk, ak = self.sampler_keys if self.sampler_keys is not None else (None, None)
+        losses = torch.empty((5, 2), dtype=torch.float32, device=dev)
+        A = r['anchors'].shape[0]
+        main = torch.cuda.current_stream(dev)
+        aux = self._aux_stream(dev) if self.use_aux_stream else main
+        # Branch 1 (aux stream): anchor targets + RPN losses (:81-85) - independent of the proposal path
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            gt_rpn_loc, gt_rpn_label = self.anchor_target_creator(bboxes, r['anchors'], img_size, n_gt=n_gt, keys=ak)
+            _, g_locs = ops.smooth_l1(r['locs'].view(n * A, 4), 4, gt_rpn_loc.view(n * A, 4), gt_rpn_label.view(-1),
+                                      n * A, self.rpn_sigma, out=losses[0])
+            _, g_scores = ops.softmax_ce(r['scores'].view(n * A, 2), gt_rpn_label.view(-1), n * A, 2, (1, 2, 0, 1),
+                                         out=losses[1])
+        # Branch 2 (main stream): proposals -> sampled RoIs and targets
         t = self.proposal_target_creator.sample_batch(
             r['rois'], r['levels'], r['n_rois'], bboxes, labels, n_gt,
             masks=masks.contiguous() if self.binary_mask else None,
             keypoints=None if self.binary_mask else masks.contiguous(),
             loc_normalize_mean=self.loc_normalize_mean, loc_normalize_std=self.loc_normalize_std,
             mask_size=m.head.mask_size, keys=pk, mask_rows=self.mask_rows)
-        gt_rpn_loc, gt_rpn_label = self.anchor_target_creator(bboxes, r['anchors'], img_size, n_gt=n_gt, keys=ak)
 
-        losses = torch.empty((5, 2), dtype=torch.float32, device=dev)
-        A = r['anchors'].shape[0]
-        # RPN losses (:81-85)
-        _, g_locs = ops.smooth_l1(r['locs'].view(n * A, 4), 4, gt_rpn_loc.view(n * A, 4), gt_rpn_label.view(-1), n * A,
-                                  self.rpn_sigma, out=losses[0])
-        _, g_scores = ops.softmax_ce(r['scores'].view(n * A, 2), gt_rpn_label.view(-1), n * A, 2, (1, 2, 0, 1), out=losses[1])
-
-        # head (:88-89) on the n*n_sample sampled rows (padding rows have label -1 and get zero gradient)
+        # head (:88-89) on the n*n_sample sampled rows (padding rows have label -1 and get zero gradient): the box branch
+        # runs on the aux stream concurrently with the (much larger) mask branch on the main stream
         head = m.head
         S = self.proposal_target_creator.n_sample
         R = n * S
         scales = m.extractor.spatial_scales
-        box = head.box_branch(features, t['rois_xy5'], t['sample_levels'], scales)
-        ld = head.out_p
-        g_box = torch.empty_like(box)
-        ops.softmax_ce(box, t['gt_roi_label'], R, head.n_class, (1, ld, 0, 1), Kfill=head.LOC0, gx=g_box, out=losses[3])
-        ops.smooth_l1(box, ld, t['gt_roi_loc'], t['gt_roi_label'], R, self.roi_sigma, gfill=ld - head.LOC0,
-                      col0=head.LOC0, gx=g_box, out=losses[2])
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            box = head.box_branch(features, t['rois_xy5'], t['sample_levels'], scales)
+            ld = head.out_p
+            g_box = torch.empty_like(box)
+            ops.softmax_ce(box, t['gt_roi_label'], R, head.n_class, (1, ld, 0, 1), Kfill=head.LOC0, gx=g_box, out=losses[3])
+            ops.smooth_l1(box, ld, t['gt_roi_loc'], t['gt_roi_label'], R, self.roi_sigma, gfill=ld - head.LOC0,
+                          col0=head.LOC0, gx=g_box, out=losses[2])
 
         rows = t['mask_rows']
         if rows == S:
@@ -170,6 +186,10 @@ class FPNMaskRCNNTrainChain(object):
             ops.softmax_ce(mask_out, t['gt_roi_mask'].view(-1), Rm * K, Hm * Wm, (K, Hm * Wm * Cm, 1, Cm), gx=g_mask,
                            out=losses[4])
 
+        main.wait_stream(aux)
+        if aux is not main:             # allocated on the aux stream, consumed by the RPN backward on the main stream
+            g_locs.record_stream(main)
+            g_scores.record_stream(main)
         total = ops.loss_total(losses)
         self.observation = {'rpn_loc_loss': losses[0, 0], 'rpn_cls_loss': losses[1, 0], 'roi_loc_loss': losses[2, 0],
                             'roi_cls_loss': losses[3, 0], 'mask_loss': losses[4, 0], 'loss': total[0]}
@@ -188,7 +208,15 @@ class FPNMaskRCNNTrainChain(object):
         features, g_locs, g_scores, g_box, g_mask = self._bwd
         hook = self.grad_ready_hook
         g_feats = [torch.empty_like(f) for f in features]
-        m.head.backward(g_box, g_mask, g_feats)
+        dev = features[0].device
+        main = torch.cuda.current_stream(dev)
+        aux = self._aux_stream(dev) if self.use_aux_stream else main
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            m.head.backward_box(g_box, g_feats)            # overwrites g_feats (first pooled size)
+        g_pool = m.head.backward_mask_convs(g_mask)       # main stream: the mask branch down to its pooled input
+        main.wait_stream(aux)
+        m.head.backward_mask_pool(g_pool, g_feats)        # accumulates into g_feats (second pooled size)
         if hook:
             hook(self._offset_of('head/'))
         m.rpn.backward(g_locs, g_scores, g_feats)

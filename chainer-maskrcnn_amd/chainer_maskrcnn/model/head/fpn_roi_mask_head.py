@@ -128,6 +128,11 @@ class FPNRoIMaskHead(object):
     def backward(self, g_box_out, g_mask, g_feats):
         """g_box_out (R, out_p), g_mask (Rm,28,28,Cm) or None; g_feats: per-level gradient buffers, fully
         overwritten by the first ROIAlign backward and accumulated into by the second."""
+        self.backward_box(g_box_out, g_feats)
+        if g_mask is not None:
+            self.backward_mask_pool(self.backward_mask_convs(g_mask), g_feats)
+
+    def backward_box(self, g_box_out, g_feats):
         t1, t2, t3, t4, pool_shape, rois, levels, scales = self.box_tape
         R = g_box_out.shape[0]
         g = self.box_out.bwd(t4, g_box_out.view(R, 1, 1, -1))
@@ -135,26 +140,33 @@ class FPNRoIMaskHead(object):
         g = self.fc1.bwd(t2, g)
         g = self.conv1.bwd(t1, g.view(pool_shape))
         roi_align_fpn_bwd(g, g_feats, rois, levels, self.roi_size_box, scales, accumulate=False)
-        if g_mask is not None:
-            tapes, td, tc2, rois, levels, scales = self.mask_tape
-            if self.upsample2x:
-                g_mask = ops.bilinear2x_bwd(g_mask)
-            g = self.conv2.bwd(tc2, g_mask)
-            # deconv bias gradient = column sums of g (over all output pixels): take it from a filter-gradient
-            # call of the shuffled tensor below (gb4 of length 4*C, summed over the 4 sub-pixel copies)
-            g4 = ops.pixel_shuffle2x(g, inverse=True)
-            C = self.channels
-            gb4 = torch.empty((4 * C,), dtype=torch.float32, device=g.device)
-            gw = self.ps.g(self.deconv1.name + '/W')
-            x_in = td[0]
-            from chainer_maskrcnn._hip import nn as hnn
-            hnn.conv2d_bwd_filter_raw(x_in, g4, tuple(gw.shape), 1, 0, True, gw=gw, gb=gb4, accumulate=False)
-            gb = self.ps.g(self.deconv_b)
-            ops.add(gb4[0:C], gb4[C:2 * C], out=gb)
-            ops.add(gb, gb4[2 * C:3 * C], out=gb)
-            ops.add(gb, gb4[3 * C:4 * C], out=gb)
-            g = hnn.conv2d_bwd_data_raw(g4, self.deconv1.W, tuple(x_in.shape), 1, 0)
-            for cv, t in zip(reversed(self.mask_convs), reversed(tapes)):
-                g = cv.bwd(t, g)
-            roi_align_fpn_bwd(g, g_feats, rois, levels, self.roi_size_mask, scales, accumulate=True)
-        self.box_tape = self.mask_tape = None
+        self.box_tape = None
+
+    def backward_mask_convs(self, g_mask):
+        """Mask / keypoint branch backward down to the gradient of its pooled input."""
+        from chainer_maskrcnn._hip import nn as hnn
+        tapes, td, tc2, rois, levels, scales = self.mask_tape
+        if self.upsample2x:
+            g_mask = ops.bilinear2x_bwd(g_mask)
+        g = self.conv2.bwd(tc2, g_mask)
+        # deconv bias gradient = column sums of g over all output pixels: the filter-gradient call on the shuffled
+        # tensor yields gb4 of length 4*C, summed over the 4 sub-pixel copies
+        g4 = ops.pixel_shuffle2x(g, inverse=True)
+        C = self.channels
+        gb4 = torch.empty((4 * C,), dtype=torch.float32, device=g.device)
+        gw = self.ps.g(self.deconv1.name + '/W')
+        x_in = td[0]
+        hnn.conv2d_bwd_filter_raw(x_in, g4, tuple(gw.shape), 1, 0, True, gw=gw, gb=gb4, accumulate=False)
+        gb = self.ps.g(self.deconv_b)
+        ops.add(gb4[0:C], gb4[C:2 * C], out=gb)
+        ops.add(gb, gb4[2 * C:3 * C], out=gb)
+        ops.add(gb, gb4[3 * C:4 * C], out=gb)
+        g = hnn.conv2d_bwd_data_raw(g4, self.deconv1.W, tuple(x_in.shape), 1, 0)
+        for cv, t in zip(reversed(self.mask_convs), reversed(tapes)):
+            g = cv.bwd(t, g)
+        return g
+
+    def backward_mask_pool(self, g_pool, g_feats):
+        tapes, td, tc2, rois, levels, scales = self.mask_tape
+        roi_align_fpn_bwd(g_pool, g_feats, rois, levels, self.roi_size_mask, scales, accumulate=True)
+        self.mask_tape = None

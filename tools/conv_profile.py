@@ -17,6 +17,7 @@ args = [torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'ma
 for _ in range(3):
     opt.update(chain, *args, 1.0)
 hnn.PROFILE = []
+chain.use_aux_stream = False
 opt.update(chain, *args, 1.0)
 torch.cuda.synchronize()
 agg = {}
