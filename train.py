@@ -110,22 +110,15 @@ def run(args, keypoints=False):
 
 
 def save_npz(path, faster_rcnn):
-    ps = faster_rcnn.ps
-    d = {n: ps.p(n).detach().cpu().numpy() for n in ps.names()}
-    d.update({n: v.cpu().numpy() for n, v in ps.buffers.items()})
-    np.savez(path, **d)
+    """Chainer-NPZ key names and array layouts (chainer_maskrcnn/utils/chainer_npz.py), like snapshot_object."""
+    from chainer_maskrcnn.utils import chainer_npz
+    chainer_npz.save_npz(path, faster_rcnn)
 
 
 def load_npz(path, faster_rcnn):
-    """strict=False like train.py:99-101: parameters present in the file with the right shape are loaded."""
-    z = np.load(path)
-    ps = faster_rcnn.ps
-    for n in ps.names():
-        if n in z.files and tuple(z[n].shape) == tuple(ps.p(n).shape):
-            ps.p(n).copy_(torch.from_numpy(z[n]))
-    for n, v in ps.buffers.items():
-        if n in z.files and tuple(z[n].shape) == tuple(v.shape):
-            v.copy_(torch.from_numpy(z[n]))
+    """strict=False like train.py:99-101: keys present in the file are loaded, the rest keep their initial values."""
+    from chainer_maskrcnn.utils import chainer_npz
+    return chainer_npz.load_npz(path, faster_rcnn, strict=False)
 
 
 def main():
