@@ -58,6 +58,15 @@ def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu=False, want_gres=False):
     return gx, gres, gg, gb
 
 
+def bn_infer_fwd(x, gamma, beta, mean, var, residual=None, relu=False, eps=2e-5):
+    _ck(x, gamma, beta, mean, var, residual)
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().mrcnn_bn_infer_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(var), ptr(residual), ptr(y),
+                                       x.numel() // C, C, eps, int(relu), stream_ptr()))
+    return y
+
+
 def relu_bwd(gy, y, out=None):
     _ck(gy, y)
     out = torch.empty_like(gy) if out is None else out
@@ -358,3 +367,40 @@ def anchor_target(anchors, gt_boxes, n_gt, img_size, keys=None, n_sample=256, po
                                         float(img_size[1]), ptr(keys), n_sample, pos_iou_thresh, neg_iou_thresh, pos_ratio,
                                         int(keys is not None), ptr(loc), ptr(label), ptr(ws), ws.numel(), stream_ptr()))
     return loc, label
+
+
+# ---- inference post-processing --------------------------------------------------------------------
+def detect_decode(rois, box_out, n_class, loc0, scale, mean, std, size):
+    """rois (R,4), box_out (R,ld) -> cls_bbox (R,4) in original-image pixels, prob (R,n_class)."""
+    _ck(rois, box_out)
+    R, ld = box_out.shape
+    cls_bbox = _empty((R, 4), rois.device)
+    prob = _empty((R, n_class), rois.device)
+    m4 = (ctypes.c_float * 4)(*mean)
+    s4 = (ctypes.c_float * 4)(*std)
+    check(lib().mrcnn_detect_decode_f32(ptr(rois), R, ptr(box_out), ld, n_class, loc0, float(scale),
+                                        ctypes.cast(m4, ctypes.c_void_p), ctypes.cast(s4, ctypes.c_void_p), float(size[0]),
+                                        float(size[1]), ptr(cls_bbox), ptr(prob), stream_ptr()))
+    return cls_bbox, prob
+
+
+def class_nms(cls_bbox, prob, l_begin, l_end, score_thresh, nms_thresh):
+    """-> keep_idx (n_class,R) int32, keep_cnt (n_class,) int32."""
+    _ck(cls_bbox, prob)
+    R, n_class = prob.shape
+    keep_idx = torch.full((n_class, max(R, 1)), -1, dtype=i32, device=prob.device)
+    keep_cnt = torch.zeros((n_class,), dtype=i32, device=prob.device)
+    if R > 0:
+        check(lib().mrcnn_class_nms_f32(ptr(cls_bbox), ptr(prob), R, n_class, l_begin, l_end, float(score_thresh),
+                                        float(nms_thresh), ptr(keep_idx), ptr(keep_cnt), stream_ptr()))
+    return keep_idx, keep_cnt
+
+
+def mask_paste(mask_logits, label, bbox, size):
+    """mask_logits (D,S,S,Cm) NHWC, label (D,) int32, bbox (D,4) -> (D,H,W) uint8."""
+    _ck(mask_logits, label, bbox)
+    D, S, _, Cm = mask_logits.shape
+    out = torch.empty((D, size[0], size[1]), dtype=torch.uint8, device=mask_logits.device)
+    check(lib().mrcnn_mask_paste_f32(ptr(mask_logits), D, S, Cm, ptr(label), ptr(bbox), size[0], size[1], ptr(out),
+                                     stream_ptr()))
+    return out

@@ -90,6 +90,7 @@ class FPNRoIMaskHead(object):
         h, t3 = self.fc2.fwd(h)
         o, t4 = self.box_out.fwd(h)
         self.box_tape = (t1, t2, t3, t4, tuple(pool.shape), rois_xy5, levels, spatial_scales)
+        self.last_box_out = o.view(R, self.out_p)
         return o.view(R, self.out_p)          # [:, :n_class] scores, [:, LOC0:LOC0+4] loc
 
     def mask_branch(self, xs, rois_xy5, levels, spatial_scales):

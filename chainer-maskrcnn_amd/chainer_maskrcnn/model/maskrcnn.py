@@ -98,6 +98,70 @@ class MaskRCNN(object):
         roi_cls_locs, roi_scores = self.head(h, indices_and_rois, levels, self.extractor.spatial_scales, train=False)
         return roi_cls_locs, roi_scores, rois, roi_indices, levels
 
+    def prepare(self, img):
+        """maskrcnn.py:261-276: resize so that the short side is min_size unless the long side would exceed max_size,
+        then scale to [0,1] (no mean subtraction - SURVEY.md App. B-3).  img (3,H,W) float32 tensor with values 0..255
+        on the device.  The bilinear resize itself is host-pipeline work (chainercv.transforms.resize) done
+        here with torch's half-pixel bilinear interpolation."""
+        _, H, W = img.shape
+        oh, ow = self.prepare_size(H, W)
+        img = torch.nn.functional.interpolate(img[None].float(), size=(oh, ow), mode='bilinear', align_corners=False)[0]
+        return img / 255
+
+    def predict(self, imgs):
+        """maskrcnn.py:157-259: imgs = list of (3,H,W) float32 tensors (0..255).  Returns (masks, labels, scores) -
+        lists with one entry per image: masks (D,H,W) bool, labels (D,) int32 in [0, n_fg_class-1], scores (D,) float32 -
+        and keeps the boxes in ``self.last_bboxes``.  One device->host copy per image (the per-class keep counts)."""
+        from chainer_maskrcnn.nn import core
+        masks, labels, scores, bboxes = [], [], [], []
+        keep_train, keep_core = self.train, core.TRAIN
+        self.train, core.TRAIN = False, False
+        try:
+            for img in imgs:
+                size = tuple(img.shape[1:])
+                x = self.prepare(img.to(self.device))
+                scale = x.shape[2] / size[1]
+                roi_cls_locs, roi_scores, rois, roi_indices, levels = self.__call__(x[None].contiguous(), scale=scale)
+                box_out = self.head.last_box_out
+                cls_bbox, prob = ops.detect_decode(rois.contiguous(), box_out, self.n_class, self.head.LOC0, scale,
+                                                   self.loc_normalize_mean, self.loc_normalize_std, size)
+                bbox, label, score, level = self._suppress(cls_bbox, prob, levels)
+                D = bbox.shape[0]
+                if D > 0 and self.predict_mask:
+                    xy5 = torch.cat((torch.zeros((D, 1), device=self.device), bbox[:, [1, 0, 3, 2]] * scale), dim=1).contiguous()
+                    m = self.head.mask_branch(self.head.x, xy5, level.to(torch.int32).contiguous(),
+                                              self.extractor.spatial_scales)
+                    mask = ops.mask_paste(m, label.contiguous(), bbox.contiguous(), size).bool()
+                else:
+                    mask = torch.zeros((D,) + size, dtype=torch.bool, device=self.device)
+                masks.append(mask)
+                labels.append(label)
+                scores.append(score)
+                bboxes.append(bbox)
+        finally:
+            self.train, core.TRAIN = keep_train, keep_core
+        self.last_bboxes = bboxes
+        return masks, labels, scores
+
+    def _suppress(self, cls_bbox, prob, levels):
+        """maskrcnn.py:278-312 on the device: for every foreground class l (skipping the LAST class when masks are
+        predicted - the reference's off-by-one guard, :288-291): prob[:, l] > score_thresh, NMS(nms_thresh) in
+        descending score order; results concatenated over classes, labels l-1."""
+        l_end = self.n_class - 1 if self.predict_mask else self.n_class
+        keep_idx, keep_cnt = ops.class_nms(cls_bbox, prob, 1, l_end, self.score_thresh, self.nms_thresh)
+        cnt = keep_cnt.cpu().tolist()                   # the one host sync of predict()
+        sel, lab = [], []
+        for l in range(1, l_end):
+            if cnt[l]:
+                sel.append(keep_idx[l, :cnt[l]])
+                lab.append(torch.full((cnt[l],), l - 1, dtype=torch.int32, device=prob.device))
+        if not sel:
+            z = torch.zeros((0,), dtype=torch.long, device=prob.device)
+            return cls_bbox[z], z.to(torch.int32), prob[z, 0], levels[z]
+        sel = torch.cat(sel).long()
+        lab = torch.cat(lab)
+        return cls_bbox[sel], lab, prob[sel, (lab + 1).long()], levels[sel]
+
     def prepare_size(self, H, W):
         """Scaled size of maskrcnn.py:261-271 (min side -> min_size unless the max side would exceed max_size)."""
         scale = self.min_size / min(H, W)

@@ -22,6 +22,9 @@ from chainer_maskrcnn._hip import nn as hnn
 from chainer_maskrcnn._hip import ops
 
 
+# chainer.config.train: BatchNorm uses batch statistics (True) or the running averages (False, MaskRCNN.predict).
+TRAIN = True
+
 # Weight-gradient GEMMs on a second stream (joined by join_side_stream() at the end of backward).
 FILTER_GRAD_ON_SIDE_STREAM = True
 
@@ -191,6 +194,10 @@ class BatchNorm(object):
 
     def fwd(self, x, relu=False, residual=None):
         gamma, beta = self.ps.p(self.name + '/gamma'), self.ps.p(self.name + '/beta')
+        if not TRAIN:
+            y = ops.bn_infer_fwd(x, gamma, beta, self.ps.buffers[self.name + '/avg_mean'],
+                                 self.ps.buffers[self.name + '/avg_var'], residual, relu)
+            return y, None
         y, mean, invstd = ops.bn_train_fwd(x, gamma, beta, residual, relu, self.ps.buffers[self.name + '/avg_mean'],
                                            self.ps.buffers[self.name + '/avg_var'])
         return y, (x, y, mean, invstd, relu)

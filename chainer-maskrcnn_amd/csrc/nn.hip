@@ -152,6 +152,28 @@ __global__ __launch_bounds__(NT) void k_bn_apply(const float *__restrict__ x, co
     }
 }
 
+// Inference-mode BN (running statistics): y = gamma*(x-avg_mean)/sqrt(avg_var+eps) + beta (+ residual) (ReLU).
+__global__ __launch_bounds__(NT) void k_bn_infer(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                 const float *__restrict__ beta, const float *__restrict__ mean,
+                                                 const float *__restrict__ var, const float *__restrict__ res,
+                                                 float *__restrict__ y, size_t n4, int C4, float eps, int relu) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4) * 4;
+        const float4 v = ld4(x + i * 4), g = ld4(gamma + c), b = ld4(beta + c), m = ld4(mean + c), va = ld4(var + c);
+        float4 o;
+        o.x = g.x * ((v.x - m.x) * (1.0f / sqrtf(va.x + eps))) + b.x;
+        o.y = g.y * ((v.y - m.y) * (1.0f / sqrtf(va.y + eps))) + b.y;
+        o.z = g.z * ((v.z - m.z) * (1.0f / sqrtf(va.z + eps))) + b.z;
+        o.w = g.w * ((v.w - m.w) * (1.0f / sqrtf(va.w + eps))) + b.w;
+        if (res) {
+            const float4 r = ld4(res + i * 4);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        st4(y + i * 4, o);
+    }
+}
+
 // BN backward reductions: per channel sum(dz), sum(dz*xhat) with dz = relu ? gy*(y>0) : gy.
 __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__ gy, const float *__restrict__ x,
                                                        const float *__restrict__ y, const float *__restrict__ mean,
@@ -704,6 +726,17 @@ extern "C" int mrcnn_random_keys_dev_u32(uint32_t *out, size_t n, unsigned long 
         MRCNN_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_advance_seed, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_bn_infer_fwd_f32(const float *x, const float *gamma, const float *beta, const float *mean,
+                                      const float *var, const float *residual, float *y, int P, int C, float eps,
+                                      int relu, void *stream) {
+    if (int e = chk(x && gamma && beta && mean && var && y && P > 0 && C > 0 && (C % 4) == 0, "bn_infer_fwd: bad args")) return e;
+    const size_t n4 = (size_t)P * C / 4;
+    hipLaunchKernelGGL(k_bn_infer, dim3(ew_grid(n4)), dim3(NT), 0, (hipStream_t)stream, x, gamma, beta, mean, var, residual, y,
+                       n4, C / 4, eps, relu);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

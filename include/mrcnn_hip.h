@@ -154,6 +154,10 @@ int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const float *y, cons
                            const float *save_mean, const float *save_invstd, float *gx, float *gres,
                            float *ggamma, float *gbeta, int P, int C, int relu, void *ws, size_t ws_bytes,
                            void *stream);
+/* Inference-mode BN with the running statistics (chainer.config.train == False, maskrcnn.py:171-172). */
+int mrcnn_bn_infer_fwd_f32(const float *x, const float *gamma, const float *beta, const float *mean,
+                           const float *var, const float *residual, float *y, int P, int C, float eps, int relu,
+                           void *stream);
 int mrcnn_relu_bwd_f32(const float *gy, const float *y, float *gx, size_t n, void *stream);
 int mrcnn_add_f32(const float *a, const float *b, float *out, size_t n, void *stream);
 int mrcnn_maxpool2x2_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
@@ -249,6 +253,23 @@ int mrcnn_anchor_target_f32(const float *anchors, int A, const float *gt_boxes, 
                             int N, float img_h, float img_w, const uint32_t *keys, int n_sample,
                             float pos_iou_thresh, float neg_iou_thresh, float pos_ratio, int do_sample,
                             float *gt_rpn_loc, int32_t *gt_rpn_label, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Inference post-processing (predict.hip).  Replace the host code of
+ * chainer_maskrcnn/model/maskrcnn.py:178-210 (decode + softmax), :278-312 (_suppress: per-class score filter +
+ * ChainerCV NMS) and :231-246 (sigmoid, channel pick, cv2.resize to the box, threshold, paste).
+ *   rois (R,4) yx in network-input pixels; box_out (R,ld): columns [0,n_class) scores, [loc0,loc0+4) class-agnostic loc
+ *   cls_bbox (R,4) yx in original-image pixels; prob (R,n_class)
+ *   keep_idx (n_class,R) int32: RoI indices kept for class l in selection (descending score) order; keep_cnt (n_class)
+ *   mask_logits (D,S,S,Cm) NHWC; label (D) 0-based class = mask channel; bbox (D,4); out (D,H,W) uint8 {0,1}
+ * ---------------------------------------------------------------------------------------- */
+int mrcnn_detect_decode_f32(const float *rois, int R, const float *box_out, int ld, int n_class, int loc0,
+                            float scale, const float *loc_mean4, const float *loc_std4, float size_h, float size_w,
+                            float *cls_bbox, float *prob, void *stream);
+int mrcnn_class_nms_f32(const float *cls_bbox, const float *prob, int R, int n_class, int l_begin, int l_end,
+                        float score_thresh, float nms_thresh, int32_t *keep_idx, int32_t *keep_cnt, void *stream);
+int mrcnn_mask_paste_f32(const float *mask_logits, int D, int S, int Cm, const int32_t *label, const float *bbox,
+                         int H, int W, unsigned char *out, void *stream);
 
 #ifdef __cplusplus
 }
