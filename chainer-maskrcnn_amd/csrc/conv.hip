@@ -48,6 +48,7 @@ struct ConvP {
     int M, Ng;            // GEMM M and N extents
     int ksplit, kchunk;   // BWD_FILTER: number of K splits, pixels per split;  FWD / BWD_DATA: splits, K steps per split
     float *slab;          // FWD / BWD_DATA split-K: (ksplit, M, ldc) partial sums
+    unsigned bytes_a, bytes_b;   // sizes of the a / b tensors (buffer descriptors of the bounds-checked gather loads)
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -223,14 +224,25 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         f_invW = 1.0f / (float)p.Wo; f_invH = 1.0f / (float)p.Ho;
     }
 
+    // Gather loads are hardware bounds-checked buffer loads (T8): a predicate that is false turns the byte offset into
+    // 0xFFFFFFFF, which is outside the descriptor's range, so the load returns 0 - no branch, no select, and the zero
+    // padding of the convolution costs one v_cndmask per load instead of four per stored value.
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.a, 0, p.bytes_a, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void *)p.b, 0, p.bytes_b, 0x00020000);
     float4 ra[NA], rb[NB];
-    unsigned okmask = 0;      // bit i: ra[i] is real data, bit 8+i: rb[i]; applied when the values go to LDS
-    auto ld = [&](bool ok, const float *base, int off, int bit) -> float4 {
-        okmask |= ok ? (1u << bit) : 0u;
-        return ldg4(base + (ok ? off : 0));
+    auto ldA = [&](bool ok, int off) -> float4 {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (unsigned)off * 4u : 0xFFFFFFFFu, 0, 0);
+        float4 f;
+        __builtin_memcpy(&f, &v, 16);
+        return f;
+    };
+    auto ldB = [&](bool ok, int off) -> float4 {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? (unsigned)off * 4u : 0xFFFFFFFFu, 0, 0);
+        float4 f;
+        __builtin_memcpy(&f, &v, 16);
+        return f;
     };
     auto load_step = [&](int s) {
-        okmask = 0;
         if (MODE == MODE_FWD && SMALLC) {
             const int chunk = s * 8 + kc;                 // tap index of this thread's 16-B chunk
             const bool tv = chunk < taps;
@@ -240,10 +252,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             for (int i = 0; i < NA; ++i) {
                 const int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
                 const bool ok = tv & (bool)((rowmask >> i) & 1u) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-                ra[i] = ld(ok, p.a, a_off[i] + toff, i);
+                ra[i] = ldA(ok, a_off[i] + toff);
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = ld(tv && ((colmask >> i) & 1u), p.b, b_off[i] + chunk * 4, 8 + i);
+            for (int i = 0; i < NB; ++i) rb[i] = ldB(tv && ((colmask >> i) & 1u), b_off[i] + chunk * 4);
         } else if (MODE == MODE_FWD) {
             const int cs = s % cin_steps, t = s / cin_steps;     // wave-uniform
             const int kw = t % p.KW, kh = t / p.KW;
@@ -253,10 +265,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             for (int i = 0; i < NA; ++i) {
                 const int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
                 const bool ok = (bool)((rowmask >> i) & 1u) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-                ra[i] = ld(ok, p.a, a_off[i] + toff, i);
+                ra[i] = ldA(ok, a_off[i] + toff);
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = ld((colmask >> i) & 1u, p.b, b_off[i] + woff, 8 + i);
+            for (int i = 0; i < NB; ++i) rb[i] = ldB((colmask >> i) & 1u, b_off[i] + woff);
         } else if (MODE == MODE_BWD_DATA) {
             // gx[n,hi,wi,ci] = sum_{kh,kw,co} gy[n, hi+pad-kh, wi+pad-kw, co] * w[co][kh][kw][ci]   (stride 1)
             const int cs = s % cout_steps, t = s / cout_steps;
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             for (int i = 0; i < NA; ++i) {
                 const int ho = a_h0[i] - kh, wo = a_w0[i] - kw;
                 const bool ok = (bool)((rowmask >> i) & 1u) & ((unsigned)ho < (unsigned)p.Ho) & ((unsigned)wo < (unsigned)p.Wo);
-                ra[i] = ld(ok, p.a, a_off[i] + toff, i);
+                ra[i] = ldA(ok, a_off[i] + toff);
             }
             const int ci = n0 + rcB * 4;
             const int wbase = t * p.Cin + ci;
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int co = cs * BK + k0B + B_KPP * i;
-                rb[i] = ld(ci < p.Ng, p.b, co * krow + wbase, 8 + i);
+                rb[i] = ldB(ci < p.Ng, co * krow + wbase);
             }
         } else {
             // gw[co][kh][kw][ci] = sum_pix gy[pix][co] * x[pix shifted by (kh,kw)][ci]
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int pix = kbeg + s * BK + k0A + A_KPP * i;
-                ra[i] = ld(pix < kend && co < p.M, p.a, pix * p.Cout + co, i);
+                ra[i] = ldA(pix < kend && co < p.M, pix * p.Cout + co);
             }
             const int xc = SMALLC ? 4 : p.Cin;
 #pragma unroll
@@ -294,20 +306,20 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
                 divmod_small(q, p.Ho, f_invH, n, ho);
                 const int hi = ho * p.stride - p.pad + f_kh, wi = wo * p.stride - p.pad + f_kw;
                 const bool ok = pv & f_cv & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-                rb[i] = ld(ok, p.b, ((n * p.H + hi) * p.W + wi) * xc + f_ci, 8 + i);
+                rb[i] = ldB(ok, ((n * p.H + hi) * p.W + wi) * xc + f_ci);
             }
         }
     };
     auto store_step = [&]() {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const float4 v = zero_unless(okmask, i, ra[i]);
+            const float4 v = ra[i];
             if (A_KC) *reinterpret_cast<float4 *>(&sA[(r0 + 32 * i) * LDK + kc * 4]) = v;
             else *reinterpret_cast<float4 *>(&sA[(k0A + A_KPP * i) * LDA + rcA * 4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const float4 v = zero_unless(okmask, 8 + i, rb[i]);
+            const float4 v = rb[i];
             if (B_KC) *reinterpret_cast<float4 *>(&sB[(r0 + 32 * i) * LDK + kc * 4]) = v;
             else *reinterpret_cast<float4 *>(&sB[(k0B + B_KPP * i) * LDB + rcB * 4]) = v;
         }
@@ -318,13 +330,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         store_step();
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
-            if (s + 1 < nsteps) load_step(sbeg + s + 1);   // global -> registers: in flight during the MFMAs below
+            // Always load (the last iteration re-reads its own step: harmless) so that the gather address arithmetic and
+            // the global loads share ONE basic block with the MFMAs and the scheduler can interleave them.
+            load_step(sbeg + min(s + 1, nsteps - 1));
             mma_step<A_KC, B_KC, BM_, BN_>(sA, sB, acc, wm, wn, lane);
             __syncthreads();
-            if (s + 1 < nsteps) {
-                store_step();
-                __syncthreads();
-            }
+            store_step();
+            __syncthreads();
         }
     }
 
@@ -544,7 +556,7 @@ int check_conv(const void *a, const void *b, const void *c, int N, int H, int W,
                                "conv2d: Cin (%d) must be 4 or a multiple of %d... Cout (%d) a multiple of %d (the host layer pads)", Cin, BK, Cout, BK);
     if (conv_out(H, KH, stride, pad) <= 0 || conv_out(W, KW, stride, pad) <= 0)
         return mrcnn::fail_arg(MRCNN_E_INVALID, "conv2d: empty output");
-    const long long lim = (1ll << 31) - 1;
+    const long long lim = (1ll << 30) - 1;      // element offsets are 32-bit and byte sizes fit a buffer descriptor
     const long long Ho_ = conv_out(H, KH, stride, pad), Wo_ = conv_out(W, KW, stride, pad);
     if ((long long)N * H * W * Cin > lim || (long long)N * Ho_ * Wo_ * Cout > lim || (long long)Cout * KH * KW * Cin > lim ||
         (long long)N * std::max<long long>(H * W, Ho_ * Wo_) >= (1ll << 24))
@@ -646,6 +658,7 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
     if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     p.a = x; p.b = w; p.c = y; p.bias = bias; p.relu = relu;
+    p.bytes_a = (unsigned)((size_t)N * H * W * Cin * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
     p.M = N * p.Ho * p.Wo; p.Ng = Cout;
     const int nsteps = p.smallc ? (KH * KW + 7) / 8 : KH * KW * (Cin / BK);
     return run_data_conv<MODE_FWD>(p, nsteps, Cout, ws, ws_bytes, (hipStream_t)stream);
@@ -661,6 +674,7 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
     p.a = gy; p.b = w; p.c = gx; p.accumulate = accumulate;
+    p.bytes_a = (unsigned)((size_t)N * p.Ho * p.Wo * Cout * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
     p.M = N * H * W; p.Ng = Cin;
     return run_data_conv<MODE_BWD_DATA>(p, KH * KW * (Cout / BK), Cin, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -692,6 +706,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     float *bias_part = (float *)ws + wcount * p.ksplit;
     const bool use_slabs = p.ksplit > 1 || accumulate;
     p.a = gy; p.b = x; p.c = use_slabs ? slabs : gw;
+    p.bytes_a = (unsigned)((size_t)N * p.Ho * p.Wo * Cout * 4); p.bytes_b = (unsigned)((size_t)N * H * W * Cin * 4);
     p.M = Cout; p.Ng = p.smallc ? KH * KW * 4 : Cin;
     launch_conv<MODE_BWD_FILTER>(p, dim3(1, 1, (p.smallc ? 1 : KH * KW) * p.ksplit), filter_tile(p), st);
     MRCNN_LAUNCH_CHECK();
