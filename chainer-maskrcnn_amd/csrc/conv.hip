@@ -334,6 +334,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             // the global loads share ONE basic block with the MFMAs and the scheduler can interleave them.
             load_step(sbeg + min(s + 1, nsteps - 1));
             mma_step<A_KC, B_KC, BM_, BN_>(sA, sB, acc, wm, wn, lane);
+            // schedule: the gather loads go out after the first quarter of the step's MFMAs (their address arithmetic is
+            // hidden under those), so the data is back long before the LDS stores at the end of the step
+            __builtin_amdgcn_sched_group_barrier(0x8, (TM * TN * 16) / 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x20, NA + NB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, (TM * TN * 16) * 3 / 4, 0);
             __syncthreads();
             store_step();
             __syncthreads();
