@@ -49,18 +49,17 @@ struct ConvP {
     int ksplit, kchunk;   // BWD_FILTER: number of K splits, pixels per split;  FWD / BWD_DATA: splits, K steps per split
     float *slab;          // FWD / BWD_DATA split-K: (ksplit, M, ldc) partial sums
     unsigned bytes_a, bytes_b;   // sizes of the a / b tensors (buffer descriptors of the bounds-checked gather loads)
+    // The grid is 1-D.  Workgroup ids are first remapped so that every XCD (ids equal mod 8 share one, and its L2)
+    // works on a contiguous range of virtual ids; a virtual id decodes to
+    //   FWD / BWD_DATA: ((M tile * tiles_n + N tile) * ksplit + split)   - the N tiles of an M tile share its A rows
+    //   BWD_FILTER:     (((split * taps + tap) * tiles_m + M tile) * tiles_n + N tile) - one split = one pixel range
+    int tiles_m, tiles_n, remap_n;
+    // FWD / BWD_DATA tail split: tiles [0, tail_full) are whole, each later tile is computed by tail_ks workgroups
+    // (tail_kchunk K steps each, ids >= remap_n = tail_full) that write partial tiles to `slab`.
+    int tail_ks, tail_full, tail_kchunk;
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-// Predicated 16-B loads WITHOUT a branch: the load is always issued (from the tensor base when the predicate is
-// false) and the zero-select is applied when the value is written to LDS (store_step), AFTER the MFMAs of the current
-// step, so the load stays in flight across them.  A conditional load makes hipcc branch around it and wait vmcnt(0)
-// at the join, which serialises the staging pipeline (cdna_hip_programming.md section 5, "Three .s-level traps" (c)).
-__device__ __forceinline__ float4 zero_unless(unsigned mask, int bit, float4 v) {
-    const bool ok = (mask >> bit) & 1u;
-    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-}
-
 // ---- MFMA over one staged K step -----------------------------------------------------------
 // The workgroup tile is BM_ x BN_ (128 or 64 each), 2x2 waves, a wave owns (BM_/2) x (BN_/2) = TM x TN MFMA tiles.
 template <bool A_KC, bool B_KC, int BM_, int BN_>
@@ -130,21 +129,45 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     constexpr int B_ELEMS = B_KC ? BN_ * LDK : BK * LDB;
     constexpr int NA = BM_ / 32, NB = BN_ / 32;          // float4 loads per thread per K step
     // RC loader geometry: a k-row of width Wd floats is covered by Wd/4 threads; 256/(Wd/4) k-rows per pass
-    constexpr int A_TPR = BM_ / 4, A_KPP = CONV_THREADS / A_TPR;
     constexpr int B_TPR = BN_ / 4, B_KPP = CONV_THREADS / B_TPR;
     __shared__ __attribute__((aligned(16))) float sA[A_ELEMS];
     __shared__ __attribute__((aligned(16))) float sB[B_ELEMS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // blockIdx.x walks M tiles fastest so that neighbouring workgroups share the B (weight) panel.
-    const int m0 = blockIdx.x * BM_, n0 = blockIdx.y * BN_;
-    const int split = (MODE == MODE_BWD_FILTER) ? (int)(blockIdx.z % p.ksplit) : (int)blockIdx.z;
-    const int tap = (MODE == MODE_BWD_FILTER) ? (int)(blockIdx.z / p.ksplit) : 0;   // kh*KW+kw
+    int vid = blockIdx.x;
+    if (vid < p.remap_n) {        // bijective XCD remap (cdna_hip_programming.md T1)
+        const int q = p.remap_n >> 3, r = p.remap_n & 7, xcd = vid & 7;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vid >> 3);
+    }
+    int bx, by, split, tap = 0;
+    bool tailchunk = false;       // this workgroup computes a K chunk of one of the last (tail) tiles
+    int tail_idx = 0;
+    if (MODE == MODE_BWD_FILTER) {
+        by = vid % p.tiles_n; vid /= p.tiles_n;
+        bx = vid % p.tiles_m; vid /= p.tiles_m;
+        const int ntap = SMALLC ? 1 : p.KH * p.KW;
+        tap = vid % ntap;                       // kh*KW+kw
+        split = vid / ntap;
+    } else {
+        int tile;
+        if (p.tail_ks && vid >= p.tail_full) {
+            const int q = vid - p.tail_full;
+            tail_idx = q / p.tail_ks;
+            split = q - tail_idx * p.tail_ks;
+            tile = p.tail_full + tail_idx;
+            tailchunk = true;
+        } else {
+            tile = vid / p.ksplit;
+            split = vid - tile * p.ksplit;
+        }
+        bx = tile / p.tiles_n;
+        by = tile - bx * p.tiles_n;
+    }
+    const int m0 = bx * BM_, n0 = by * BN_;
 
     // KC loader role: 16-B chunk kc of rows r0+32i.   RC loader role: columns 4*rc.. of k index k0 + KPP*i.
     const int kc = tid & 7, r0 = tid >> 3;
-    const int rcA = tid % A_TPR, k0A = tid / A_TPR;
     const int rcB = tid % B_TPR, k0B = tid / B_TPR;
     const int taps = p.KH * p.KW;
 
@@ -204,24 +227,58 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         kend = min(P, kbeg + p.kchunk);
         nsteps = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
     }
-    if (MODE != MODE_BWD_FILTER && p.ksplit > 1) {
-        sbeg = split * p.kchunk;
-        nsteps = max(0, min(nsteps, sbeg + p.kchunk) - sbeg);
+    if (MODE != MODE_BWD_FILTER && (p.ksplit > 1 || tailchunk)) {
+        const int kch = tailchunk ? p.tail_kchunk : p.kchunk;
+        sbeg = split * kch;
+        nsteps = max(0, min(nsteps, sbeg + kch) - sbeg);
     }
-    // BWD_FILTER constants
-    int f_kh = 0, f_kw = 0, f_ci = 0;
-    bool f_cv = false;
-    float f_invW = 0.f, f_invH = 0.f;
+    // BWD_FILTER loader: thread (fp = tid/8, fc = tid%8) stages pixel kbeg + 32*step + fp of both operands, 16-B
+    // channel chunks fc, fc+8, ... (128-B runs per pixel and load instruction).  One pixel per thread means ONE
+    // coordinate walk per step: (h0, w0) = top-left input coordinate of the pixel's window and off0 = its element offset
+    // are advanced by BK pixels = dN images + dH rows + dW columns with at most one carry each.  (A divmod per load,
+    // the obvious form, is ~170 VALU instructions per step and costs 8 % on the 3x3 256->256 layers.)
+    const int fp = tid >> 3, fc = tid & 7;
+    int f_kh = 0, f_kw = 0;
+    int f_khv[NB], f_kwv[NB], f_toff[NB];      // SMALLC: a column chunk is a tap, so the tap differs per load
+    unsigned f_amask = 0, f_bmask = 0;          // bit i: channel chunk fc + 8i exists
+    int f_h0 = 0, f_w0 = 0, f_off0 = 0, f_aoff = 0, f_pix = 0;
+    int f_sw = 0, f_sh = 0, f_doff = 0, f_wlim = 0, f_hlim = 0, f_wback = 0, f_hback = 0, f_c1off = 0, f_c2off = 0;
     if (MODE == MODE_BWD_FILTER) {
         f_kw = tap % p.KW; f_kh = tap / p.KW;
-        f_ci = n0 + rcB * 4;
-        f_cv = f_ci < p.Ng;
-        if (SMALLC) {                               // column = (tap, 4 channels)
-            const int tp = f_ci >> 2;
-            f_cv = tp < taps;
-            f_kw = tp % p.KW; f_kh = tp / p.KW; f_ci = 0;
+        const int xc = SMALLC ? 4 : p.Cin;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) f_amask |= (m0 + (fc + 8 * i) * 4 < p.M) ? (1u << i) : 0u;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int col = n0 + (fc + 8 * i) * 4;
+            if (SMALLC) {                               // column = (tap, 4 channels)
+                const int tp = col >> 2;
+                f_bmask |= (tp < taps) ? (1u << i) : 0u;
+                f_kwv[i] = tp % p.KW; f_khv[i] = tp / p.KW;
+                f_toff[i] = (f_khv[i] * p.W + f_kwv[i]) * 4;
+            } else {
+                f_bmask |= (col < p.Ng) ? (1u << i) : 0u;
+                f_khv[i] = f_kh; f_kwv[i] = f_kw;
+                f_toff[i] = (f_kh * p.W + f_kw) * xc + col;
+            }
         }
-        f_invW = 1.0f / (float)p.Wo; f_invH = 1.0f / (float)p.Ho;
+        const float invW = 1.0f / (float)p.Wo, invH = 1.0f / (float)p.Ho;
+        const int P = p.N * p.Ho * p.Wo;
+        f_pix = kbeg + fp;
+        int q, wo, n, ho;
+        divmod_small(min(f_pix, P - 1), p.Wo, invW, q, wo);
+        divmod_small(q, p.Ho, invH, n, ho);
+        f_h0 = ho * p.stride - p.pad;
+        f_w0 = wo * p.stride - p.pad;
+        f_off0 = ((n * p.H + f_h0) * p.W + f_w0) * xc;
+        f_aoff = f_pix * p.Cout + m0 + fc * 4;
+        const int dq = BK / p.Wo, dW = BK - dq * p.Wo, dN = dq / p.Ho, dH = dq - dN * p.Ho;
+        f_sw = dW * p.stride; f_sh = dH * p.stride;
+        f_doff = ((dN * p.H + f_sh) * p.W + f_sw) * xc;
+        f_wback = p.Wo * p.stride; f_hback = p.Ho * p.stride;
+        f_wlim = f_wback - p.pad; f_hlim = f_hback - p.pad;
+        f_c1off = (p.stride * p.W - f_wback) * xc;
+        f_c2off = (p.H - f_hback) * p.W * xc;
     }
 
     // Gather loads are hardware bounds-checked buffer loads (T8): a predicate that is false turns the byte offset into
@@ -290,24 +347,23 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             }
         } else {
             // gw[co][kh][kw][ci] = sum_pix gy[pix][co] * x[pix shifted by (kh,kw)][ci]
-            const int co = m0 + rcA * 4;
+            const bool pv = f_pix < kend;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int pix = kbeg + s * BK + k0A + A_KPP * i;
-                ra[i] = ldA(pix < kend && co < p.M, pix * p.Cout + co);
-            }
-            const int xc = SMALLC ? 4 : p.Cin;
+            for (int i = 0; i < NA; ++i) ra[i] = ldA(pv & (bool)((f_amask >> i) & 1u), f_aoff + 32 * i);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int pix = kbeg + s * BK + k0B + B_KPP * i;
-                const bool pv = pix < kend;
-                int q, wo, n, ho;
-                divmod_small(pv ? pix : 0, p.Wo, f_invW, q, wo);
-                divmod_small(q, p.Ho, f_invH, n, ho);
-                const int hi = ho * p.stride - p.pad + f_kh, wi = wo * p.stride - p.pad + f_kw;
-                const bool ok = pv & f_cv & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-                rb[i] = ldB(ok, ((n * p.H + hi) * p.W + wi) * xc + f_ci);
+                const int hi = f_h0 + f_khv[i], wi = f_w0 + f_kwv[i];
+                const bool ok = pv & (bool)((f_bmask >> i) & 1u) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+                rb[i] = ldB(ok, f_off0 + f_toff[i]);
             }
+            // advance the pixel by BK
+            f_pix += BK;
+            f_aoff += BK * p.Cout;
+            f_w0 += f_sw; f_h0 += f_sh; f_off0 += f_doff;
+            const bool c1 = f_w0 >= f_wlim;
+            f_w0 -= c1 ? f_wback : 0; f_h0 += c1 ? p.stride : 0; f_off0 += c1 ? f_c1off : 0;
+            const bool c2 = f_h0 >= f_hlim;
+            f_h0 -= c2 ? f_hback : 0; f_off0 += c2 ? f_c2off : 0;
         }
     };
     auto store_step = [&]() {
@@ -315,12 +371,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         for (int i = 0; i < NA; ++i) {
             const float4 v = ra[i];
             if (A_KC) *reinterpret_cast<float4 *>(&sA[(r0 + 32 * i) * LDK + kc * 4]) = v;
-            else *reinterpret_cast<float4 *>(&sA[(k0A + A_KPP * i) * LDA + rcA * 4]) = v;
+            else *reinterpret_cast<float4 *>(&sA[fp * LDA + (fc + 8 * i) * 4]) = v;                // BWD_FILTER
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const float4 v = rb[i];
             if (B_KC) *reinterpret_cast<float4 *>(&sB[(r0 + 32 * i) * LDK + kc * 4]) = v;
+            else if (MODE == MODE_BWD_FILTER) *reinterpret_cast<float4 *>(&sB[fp * LDB + (fc + 8 * i) * 4]) = v;
             else *reinterpret_cast<float4 *>(&sB[(k0B + B_KPP * i) * LDB + rcB * 4]) = v;
         }
     };
@@ -349,12 +406,16 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     const int r = lane & 31, h = lane >> 5;
     size_t ldc;
     float *cbase;
-    const bool partial = (MODE != MODE_BWD_FILTER) && p.ksplit > 1;     // raw partial sums go to slab `split`
+    const bool partial = (MODE != MODE_BWD_FILTER) && (p.ksplit > 1 || tailchunk);     // raw partial sums go to a slab
     if (MODE == MODE_FWD) { ldc = p.Cout; cbase = partial ? p.slab + (size_t)split * p.M * ldc : p.c; }
     else if (MODE == MODE_BWD_DATA) { ldc = p.Cin; cbase = partial ? p.slab + (size_t)split * p.M * ldc : p.c; }
     else {
         ldc = (size_t)taps * (SMALLC ? 4 : p.Cin);
         cbase = p.c + (size_t)split * p.Cout * ldc + (SMALLC ? 0 : (size_t)tap * p.Cin);
+    }
+    if (MODE != MODE_BWD_FILTER && tailchunk) {      // tile-local (BM_ x BN_) slab of chunk `split` of tail tile `tail_idx`
+        ldc = BN_;
+        cbase = p.slab + ((size_t)tail_idx * p.tail_ks + split) * (BM_ * BN_) - ((size_t)m0 * BN_ + n0);
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -429,22 +490,28 @@ TileChoice choose_tile(long long M, long long Ng, long long z) {
 }
 
 template <int MODE>
-void launch_conv(const ConvP &p, dim3 grid_z1, TileChoice t, hipStream_t st) {
-    if (p.smallc) {      // image layer: fixed tiles (fwd: Cout = 64 wide; filter gradient: Cout = 64 x 196 columns)
-        if (MODE == MODE_FWD) {
-            const dim3 grid(mrcnn::cdiv(p.M, 128), mrcnn::cdiv(p.Ng, 64), grid_z1.z);
-            hipLaunchKernelGGL((k_conv_igemm<MODE_FWD, 128, 64, true>), grid, dim3(CONV_THREADS), 0, st, p);
-        } else {
-            const dim3 grid(mrcnn::cdiv(p.M, 64), mrcnn::cdiv(p.Ng, 128), grid_z1.z);
-            hipLaunchKernelGGL((k_conv_igemm<MODE_BWD_FILTER, 64, 128, true>), grid, dim3(CONV_THREADS), 0, st, p);
-        }
+void launch_conv(ConvP &p, int zdim, TileChoice t, hipStream_t st) {
+    // zdim: BWD_FILTER taps * ksplit; FWD / BWD_DATA ksplit
+    if (p.smallc) t = (MODE == MODE_FWD) ? TileChoice{128, 64} : TileChoice{64, 128};   // image layer: fixed tiles
+    p.tiles_m = mrcnn::cdiv(p.M, t.bm);
+    p.tiles_n = mrcnn::cdiv(p.Ng, t.bn);
+    const int tiles = p.tiles_m * p.tiles_n;
+    int total = tiles * zdim;
+    p.remap_n = total;
+    if (MODE != MODE_BWD_FILTER && p.tail_ks) {
+        p.remap_n = p.tail_full;
+        total = p.tail_full + (tiles - p.tail_full) * p.tail_ks;
+    }
+    const dim3 grid(total), blk(CONV_THREADS);
+    if (p.smallc) {
+        if (MODE == MODE_FWD) hipLaunchKernelGGL((k_conv_igemm<MODE_FWD, 128, 64, true>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((k_conv_igemm<MODE_BWD_FILTER, 64, 128, true>), grid, blk, 0, st, p);
         return;
     }
-    const dim3 grid(mrcnn::cdiv(p.M, t.bm), mrcnn::cdiv(p.Ng, t.bn), grid_z1.z);
-    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 128, false>), grid, dim3(CONV_THREADS), 0, st, p);
-    else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64, false>), grid, dim3(CONV_THREADS), 0, st, p);
-    else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 128, false>), grid, dim3(CONV_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 64, false>), grid, dim3(CONV_THREADS), 0, st, p);
+    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 128, false>), grid, blk, 0, st, p);
+    else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64, false>), grid, blk, 0, st, p);
+    else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 128, false>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 64, false>), grid, blk, 0, st, p);
 }
 
 // Sum split-K slabs: out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]  (deterministic order).
@@ -487,6 +554,33 @@ __global__ __launch_bounds__(256) void k_sum_slabs_ep(const float *__restrict__ 
     *reinterpret_cast<float4 *>(out + i * 4) = s;
 }
 
+// Tail-split epilogue: tile `tail_full + blockIdx.y` = sum of its tail_ks tile-local slabs (fixed order) + bias, ReLU,
+// accumulate; one thread per float4 of the bm x bn tile.
+__global__ __launch_bounds__(256) void k_tail_sum(const float *__restrict__ slab, float *__restrict__ c,
+                                                  const float *__restrict__ bias, int relu, int accumulate, int M, int Ng,
+                                                  int ldc, int tiles_n, int tail_full, int ks, int bm, int bn) {
+    const int e4 = blockIdx.x * 256 + threadIdx.x;
+    if (e4 * 4 >= bm * bn) return;
+    const int tile = tail_full + blockIdx.y;
+    const int bx = tile / tiles_n, by = tile - bx * tiles_n;
+    const int ml = (e4 * 4) / bn, nl = (e4 * 4) - ml * bn;
+    const int m = bx * bm + ml, n = by * bn + nl;
+    if (m >= M || n >= Ng) return;
+    float *dst = c + (size_t)m * ldc + n;
+    float4 s = accumulate ? ldg4(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *src = slab + (size_t)blockIdx.y * ks * (bm * bn) + (size_t)e4 * 4;
+    for (int k = 0; k < ks; ++k) {
+        const float4 v = ldg4(src + (size_t)k * (bm * bn));
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+        const float4 b = ldg4(bias + n);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    *reinterpret_cast<float4 *>(dst) = s;
+}
+
 // Column sums of a (P, C) matrix (bias gradient): out[c] = sum_p g[p][c]; two-stage, deterministic.
 // Stage 1: thread = (channel group of 4, row lane), float4 streaming loads, a block owns a contiguous chunk of rows.
 // Stage 2: 64 channels x 16 slices per 1024-thread block, slices added in order.
@@ -511,7 +605,15 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(P, r0 + rows_per_blk);
     for (int cg = cg0; cg < C4; cg += G) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = r0 + rr; r < r1; r += RPI) {
+        int r = r0 + rr;
+        for (; r + 3 * RPI < r1; r += 4 * RPI) {         // four rows in flight, added in row order
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ldg4(g + (size_t)(r + j * RPI) * C + cg * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+        }
+        for (; r < r1; r += RPI) {
             const float4 v = ldg4(g + (size_t)r * C + cg * 4);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
@@ -612,6 +714,21 @@ void data_plan(ConvP &p, TileChoice &t, int nsteps) {
     const long long fill = 2ll * g_cus();
     p.ksplit = 1;
     p.kchunk = nsteps;
+    p.tail_ks = 0;
+    if (!p.smallc && tiles >= fill) {
+        // Tail split: a grid of r.x rounds of workgroup slots (x small) pays a whole extra round for its last few tiles,
+        // which run on a nearly empty chip.  Those tiles are split along K into ~one round of short workgroups instead.
+        const long long S = slots_for<MODE>(t.bm, t.bn), rem = tiles % S;
+        if (tiles > S && rem > 0 && rem * 2 <= S && nsteps >= 8 && tiles * 16 < (1ll << 31)) {
+            long long ks = std::min<long long>(std::min<long long>(S / rem, nsteps / 4), 16);
+            if (ks >= 2) {
+                p.tail_kchunk = (int)((nsteps + ks - 1) / ks);
+                p.tail_ks = (nsteps + p.tail_kchunk - 1) / p.tail_kchunk;
+                p.tail_full = (int)(tiles - rem);
+            }
+        }
+        return;
+    }
     if (p.smallc || tiles >= fill || nsteps < 16) return;
     long long ks = std::min<long long>(std::min<long long>(fill / tiles, nsteps / 8), 16);
     if (ks < 2) return;
@@ -619,6 +736,10 @@ void data_plan(ConvP &p, TileChoice &t, int nsteps) {
     p.ksplit = (nsteps + p.kchunk - 1) / p.kchunk;
 }
 size_t data_ws_bytes(const ConvP &p, long long ldc) { return p.ksplit > 1 ? (size_t)p.ksplit * p.M * ldc * sizeof(float) : 0; }
+size_t tail_ws_bytes(const ConvP &p, const TileChoice &t) {
+    const long long tiles = (long long)mrcnn::cdiv(p.M, t.bm) * mrcnn::cdiv(p.Ng, t.bn);
+    return p.tail_ks ? (size_t)(tiles - p.tail_full) * p.tail_ks * t.bm * t.bn * sizeof(float) : 0;
+}
 
 template <int MODE>
 int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes, hipStream_t st) {
@@ -628,8 +749,20 @@ int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes
         if (!ws || ws_bytes < data_ws_bytes(p, ldc)) { p.ksplit = 1; p.kchunk = nsteps; }      // no workspace: unsplit
         else p.slab = (float *)ws;
     }
-    launch_conv<MODE>(p, dim3(1, 1, p.ksplit), t, st);
+    if (p.tail_ks) {
+        if (!ws || ws_bytes < tail_ws_bytes(p, t)) p.tail_ks = 0;                              // no workspace: no tail split
+        else p.slab = (float *)ws;
+    }
+    launch_conv<MODE>(p, p.ksplit, t, st);
     MRCNN_LAUNCH_CHECK();
+    if (p.tail_ks) {
+        const int tiles = mrcnn::cdiv(p.M, t.bm) * mrcnn::cdiv(p.Ng, t.bn);
+        hipLaunchKernelGGL(k_tail_sum, dim3(mrcnn::cdiv(t.bm * t.bn / 4, 256), tiles - p.tail_full), dim3(256), 0, st, p.slab, p.c,
+                           MODE == MODE_FWD ? p.bias : nullptr, MODE == MODE_FWD ? p.relu : 0,
+                           MODE == MODE_BWD_DATA ? p.accumulate : 0, p.M, p.Ng, (int)ldc, p.tiles_n, p.tail_full, p.tail_ks,
+                           t.bm, t.bn);
+        MRCNN_LAUNCH_CHECK();
+    }
     if (p.ksplit > 1) {
         const size_t n4 = (size_t)p.M * ldc / 4;
         hipLaunchKernelGGL(k_sum_slabs_ep, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, p.slab, p.c, n4, p.ksplit, (int)(ldc / 4),
@@ -654,7 +787,9 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
     long long need = 0;
     if (a < cap) need = std::max(need, a);
     if (b < cap) need = std::max(need, b);
-    return (size_t)need * 16 * sizeof(float);
+    // tail split: at most one round of workgroup slots of partial 128x128 tiles (<= 4 workgroups per CU)
+    const size_t tail = (size_t)4 * g_cus() * 128 * 128 * sizeof(float);
+    return std::max((size_t)need * 16 * sizeof(float), tail);
 }
 
 extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
@@ -713,7 +848,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     p.a = gy; p.b = x; p.c = use_slabs ? slabs : gw;
     p.bytes_a = (unsigned)((size_t)N * p.Ho * p.Wo * Cout * 4); p.bytes_b = (unsigned)((size_t)N * H * W * Cin * 4);
     p.M = Cout; p.Ng = p.smallc ? KH * KW * 4 : Cin;
-    launch_conv<MODE_BWD_FILTER>(p, dim3(1, 1, (p.smallc ? 1 : KH * KW) * p.ksplit), filter_tile(p), st);
+    launch_conv<MODE_BWD_FILTER>(p, (p.smallc ? 1 : KH * KW) * p.ksplit, filter_tile(p), st);
     MRCNN_LAUNCH_CHECK();
     if (use_slabs) {
         const size_t n4 = wcount / 4;

@@ -56,12 +56,20 @@ __global__ __launch_bounds__(NT) void k_bn_stats_partial(const float *__restrict
     for (int cg = cg0; cg < C4; cg += G) {
         const float4 K = ld4(x + cg * 4);
         float4 a = f4(0.f), b = f4(0.f);
-        for (int r = r0 + rr; r < r1; r += RPI) {
-            const float4 v = ld4(x + (size_t)r * C + cg * 4);
+        auto acc = [&](const float4 v) {
             const float dx = v.x - K.x, dy = v.y - K.y, dz = v.z - K.z, dw = v.w - K.w;
             a.x += dx; a.y += dy; a.z += dz; a.w += dw;
             b.x = fmaf(dx, dx, b.x); b.y = fmaf(dy, dy, b.y); b.z = fmaf(dz, dz, b.z); b.w = fmaf(dw, dw, b.w);
+        };
+        int r = r0 + rr;
+        for (; r + 3 * RPI < r1; r += 4 * RPI) {         // four rows in flight, accumulated in row order
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ld4(x + (size_t)(r + j * RPI) * C + cg * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc(v[j]);
         }
+        for (; r < r1; r += RPI) acc(ld4(x + (size_t)r * C + cg * 4));
         s1[t] = a; s2[t] = b;
         __syncthreads();
         if (rr == 0) {
@@ -186,18 +194,29 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__
     for (int cg = cg0; cg < C4; cg += G) {
         const float4 m = ld4(mean + cg * 4), s = ld4(invstd + cg * 4);
         float4 a = f4(0.f), b = f4(0.f);
-        for (int r = r0 + rr; r < r1; r += RPI) {
-            const size_t o = (size_t)r * C + cg * 4;
-            float4 g = ld4(gy + o);
-            const float4 v = ld4(x + o);
+        auto acc = [&](float4 g, const float4 v, const float4 yy) {
             if (relu) {
-                const float4 yy = ld4(y + o);
                 g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
                 g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
             }
             a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
             b.x = fmaf(g.x, (v.x - m.x) * s.x, b.x); b.y = fmaf(g.y, (v.y - m.y) * s.y, b.y);
             b.z = fmaf(g.z, (v.z - m.z) * s.z, b.z); b.w = fmaf(g.w, (v.w - m.w) * s.w, b.w);
+        };
+        const float *yr = relu ? y : gy;                  // without ReLU the third stream is not read at all
+        int r = r0 + rr;
+        for (; r + RPI < r1; r += 2 * RPI) {              // two rows (six loads) in flight, accumulated in row order
+            const size_t o0 = (size_t)r * C + cg * 4, o1 = (size_t)(r + RPI) * C + cg * 4;
+            const float4 g0 = ld4(gy + o0), v0 = ld4(x + o0), g1 = ld4(gy + o1), v1 = ld4(x + o1);
+            float4 y0 = g0, y1 = g1;
+            if (relu) { y0 = ld4(yr + o0); y1 = ld4(yr + o1); }
+            acc(g0, v0, y0);
+            acc(g1, v1, y1);
+        }
+        for (; r < r1; r += RPI) {
+            const size_t o = (size_t)r * C + cg * 4;
+            const float4 g = ld4(gy + o), v = ld4(x + o);
+            acc(g, v, relu ? ld4(yr + o) : g);
         }
         s1[t] = a; s2[t] = b;
         __syncthreads();

@@ -85,3 +85,32 @@ def test_conv_rejects_unpadded_channels():
     from chainer_maskrcnn._hip import MrcnnHipError
     with pytest.raises(MrcnnHipError):
         hnn.conv2d_fwd_raw(torch.zeros((1, 4, 4, 3), device=DEV), torch.zeros((32, 3, 3, 3), device=DEV), None, 1, 1, False)
+
+
+# Grids a little larger than a whole number of rounds of workgroup slots take the tail-split path (the last tiles are
+# computed by several workgroups along K and summed from slabs).  The slot count is 512 or 768 depending on the
+# kernel's occupancy, so two pixel counts are used: 800 and 1050 M tiles of 128 rows.
+@pytest.mark.parametrize('hw', [(320, 320), (420, 320)])
+@pytest.mark.parametrize('k,cin,cout', [(1, 256, 128), (3, 32, 160)])
+def test_conv_tail_split_forward_and_backward_data(hw, k, cin, cout):
+    H, W = hw
+    pad = k // 2
+    g = torch.Generator().manual_seed(H + k)
+    x = torch.randn((1, H, W, cin), generator=g)
+    w = torch.randn((cout, k, k, cin), generator=g) / (k * k * cin) ** 0.5
+    b = torch.randn((cout,), generator=g)
+    ref = _ref_conv(x, w, b, 1, pad).clamp_min(0)
+    got = hnn.conv2d_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), 1, pad, True)
+    got2 = hnn.conv2d_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), 1, pad, True)
+    assert torch.equal(got, got2)
+    err = (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-5, err
+    # backward-data with accumulation into an existing gradient
+    gy = torch.randn((1, H, W, cout), generator=g)
+    base = torch.randn((1, H, W, cin), generator=g)
+    refx = F.conv_transpose2d(gy.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), None, stride=1,
+                              padding=pad).permute(0, 2, 3, 1) + base.double()
+    out = base.to(DEV).clone()
+    hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (1, H, W, cin), 1, pad, out=out)
+    err = (out.cpu().double() - refx).abs().max().item() / refx.abs().max().item()
+    assert err < 1e-5, err

@@ -30,8 +30,8 @@ print('%-10s %9s %2s %5s %5s %4s %8s %7s %6s' % ('kind', 'pixels', 'k', 'cin', '
 for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2]):
     print('%-10s %9d %2d %5d %5d %4d %8.3f %7.1f %6.2f' % (key + (a[0], a[2], a[1] / a[2] / 1e9, 100 * a[2] / tot)))
 
-print('--- by time lost vs 115 TF/s')
-lost = sorted(((a[2] - a[1] / 115e9, key, a) for key, a in agg.items()), reverse=True)
+print('--- by time lost vs 135 TF/s')
+lost = sorted(((a[2] - a[1] / 135e9, key, a) for key, a in agg.items()), reverse=True)
 for l_, key, a in lost[:28]:
     print('%-10s %9d %2d %5d %5d %4d %8.3f %7.1f  lost %.3f ms' % (key + (a[0], a[2], a[1] / a[2] / 1e9, l_)))
 print('total lost', sum(l_ for l_, _, _ in lost if l_ > 0))
