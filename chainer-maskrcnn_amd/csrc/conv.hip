@@ -130,8 +130,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     constexpr int NA = BM_ / 32, NB = BN_ / 32;          // float4 loads per thread per K step
     // RC loader geometry: a k-row of width Wd floats is covered by Wd/4 threads; 256/(Wd/4) k-rows per pass
     constexpr int B_TPR = BN_ / 4, B_KPP = CONV_THREADS / B_TPR;
-    __shared__ __attribute__((aligned(16))) float sA[A_ELEMS];
-    __shared__ __attribute__((aligned(16))) float sB[B_ELEMS];
+    // one LDS array: the A and B stages of the K loop, reused by the epilogue as four per-wave 32 x 36 transpose tiles
+    constexpr int EPI_LD = 36, EPI_ELEMS = 4 * 32 * EPI_LD;
+    constexpr int SMEM_ELEMS = (A_ELEMS + B_ELEMS) > EPI_ELEMS ? (A_ELEMS + B_ELEMS) : EPI_ELEMS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_ELEMS];
+    float *const sA = smem, *const sB = smem + A_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -281,6 +284,21 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         f_c2off = (p.H - f_hback) * p.W * xc;
     }
 
+    // FWD / BWD_DATA: K step s = (tap t = kh*KW + kw, channel step cs) is walked incrementally in scalar registers (a
+    // div/mod of s per step is ~45 SALU instructions in front of the step's loads).
+    int w_cs = 0, w_kh = 0, w_kw = 0, w_toff = 0, w_boff = 0;
+    if (MODE == MODE_FWD && !SMALLC) {
+        const int t = sbeg / cin_steps;
+        w_cs = sbeg - t * cin_steps; w_kh = t / p.KW; w_kw = t - w_kh * p.KW;
+        w_toff = (w_kh * p.W + w_kw) * p.Cin + w_cs * BK;
+    }
+    if (MODE == MODE_BWD_DATA) {
+        const int t = sbeg / cout_steps;
+        w_cs = sbeg - t * cout_steps; w_kh = t / p.KW; w_kw = t - w_kh * p.KW;
+        w_toff = -(w_kh * p.Wo + w_kw) * p.Cout + w_cs * BK;
+        w_boff = w_cs * BK * (taps * p.Cin) + t * p.Cin;
+    }
+
     // Gather loads are hardware bounds-checked buffer loads (T8): a predicate that is false turns the byte offset into
     // 0xFFFFFFFF, which is outside the descriptor's range, so the load returns 0 - no branch, no select, and the zero
     // padding of the convolution costs one v_cndmask per load instead of four per stored value.
@@ -314,37 +332,49 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) rb[i] = ldB(tv && ((colmask >> i) & 1u), b_off[i] + chunk * 4);
         } else if (MODE == MODE_FWD) {
-            const int cs = s % cin_steps, t = s / cin_steps;     // wave-uniform
-            const int kw = t % p.KW, kh = t / p.KW;
-            const int toff = (kh * p.W + kw) * p.Cin + cs * BK + kc * 4;
-            const int woff = t * p.Cin + cs * BK + kc * 4;
+            const int toff = w_toff + kc * 4;
+            const int woff = s * BK + kc * 4;            // the weight K axis (tap, channel) is contiguous
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
+                const int hi = a_h0[i] + w_kh, wi = a_w0[i] + w_kw;
                 const bool ok = (bool)((rowmask >> i) & 1u) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
                 ra[i] = ldA(ok, a_off[i] + toff);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) rb[i] = ldB((colmask >> i) & 1u, b_off[i] + woff);
+            // next step: channel block, then kw, then kh
+            const bool tapdone = ++w_cs == cin_steps;
+            w_toff += BK;
+            w_cs = tapdone ? 0 : w_cs;
+            w_kw += tapdone ? 1 : 0;
+            const bool rowdone = w_kw == p.KW;
+            w_kw = rowdone ? 0 : w_kw;
+            w_kh += rowdone ? 1 : 0;
+            w_toff += rowdone ? (p.W - p.KW) * p.Cin : 0;
         } else if (MODE == MODE_BWD_DATA) {
             // gx[n,hi,wi,ci] = sum_{kh,kw,co} gy[n, hi+pad-kh, wi+pad-kw, co] * w[co][kh][kw][ci]   (stride 1)
-            const int cs = s % cout_steps, t = s / cout_steps;
-            const int kw = t % p.KW, kh = t / p.KW;
-            const int toff = -(kh * p.Wo + kw) * p.Cout + cs * BK + kc * 4;
+            const int toff = w_toff + kc * 4;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int ho = a_h0[i] - kh, wo = a_w0[i] - kw;
+                const int ho = a_h0[i] - w_kh, wo = a_w0[i] - w_kw;
                 const bool ok = (bool)((rowmask >> i) & 1u) & ((unsigned)ho < (unsigned)p.Ho) & ((unsigned)wo < (unsigned)p.Wo);
                 ra[i] = ldA(ok, a_off[i] + toff);
             }
             const int ci = n0 + rcB * 4;
-            const int wbase = t * p.Cin + ci;
             const int krow = taps * p.Cin;
+            const int wbase = w_boff + ci + k0B * krow;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int co = cs * BK + k0B + B_KPP * i;
-                rb[i] = ldB(ci < p.Ng, co * krow + wbase);
-            }
+            for (int i = 0; i < NB; ++i) rb[i] = ldB(ci < p.Ng, wbase + B_KPP * i * krow);
+            const bool tapdone = ++w_cs == cout_steps;
+            w_toff += BK; w_boff += BK * krow;
+            w_cs = tapdone ? 0 : w_cs;
+            w_kw += tapdone ? 1 : 0;
+            w_toff -= tapdone ? 2 * p.Cout : 0;
+            w_boff += tapdone ? p.Cin - p.Cout * krow : 0;
+            const bool rowdone = w_kw == p.KW;
+            w_kw = rowdone ? 0 : w_kw;
+            w_kh += rowdone ? 1 : 0;
+            w_toff -= rowdone ? (p.Wo - p.KW) * p.Cout : 0;
         } else {
             // gw[co][kh][kw][ci] = sum_pix gy[pix][co] * x[pix shifted by (kh,kw)][ci]
             const bool pv = f_pix < kend;
@@ -417,22 +447,36 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         ldc = BN_;
         cbase = p.slab + ((size_t)tail_idx * p.tail_ks + split) * (BM_ * BN_) - ((size_t)m0 * BN_ + n0);
     }
+    // Each 32 x 32 MFMA tile is transposed through the wave's private LDS tile (the K loop's last barrier has passed,
+    // so the staging buffers are free) and leaves as float4 stores, 8 rows x 128 B per instruction; the accumulator
+    // layout itself would give 4-B stores, 16 instructions per tile, which bounds the low-K (1x1, 64..256 channel) layers.
+    float *const et = smem + wave * (32 * EPI_LD);
+    const int er = lane >> 3, ec = (lane & 7) * 4;         // read side: rows er + 8j, columns ec..ec+3
+    const bool plain = !partial;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn * (BN_ / 2) + tn * 32 + r;
-            const bool nv = n < p.Ng;
-            float bv = 0.0f;
-            if (MODE == MODE_FWD && !partial) bv = p.bias ? p.bias[nv ? n : 0] : 0.0f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * (BM_ / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            for (int e = 0; e < 16; ++e) et[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_LD + r] = acc[tm][tn][e];
+            const int n = n0 + wn * (BN_ / 2) + tn * 32 + ec;
+            const bool nv = n < p.Ng;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == MODE_FWD && plain && p.bias) bv = ldg4(p.bias + (nv ? n : 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = er + 8 * j;
+                const int m = m0 + wm * (BM_ / 2) + tm * 32 + row;
+                float4 v = *reinterpret_cast<const float4 *>(&et[row * EPI_LD + ec]);
                 if (!nv || m >= p.M) continue;
-                float v = acc[tm][tn][e] + bv;
-                if (MODE == MODE_FWD && p.relu && !partial) v = fmaxf(v, 0.0f);
-                if (MODE == MODE_BWD_DATA && p.accumulate && !partial) v += cbase[(size_t)m * ldc + n];
-                cbase[(size_t)m * ldc + n] = v;
+                float *dst = cbase + (size_t)m * ldc + n;
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (MODE == MODE_FWD && p.relu && plain) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (MODE == MODE_BWD_DATA && p.accumulate && plain) {
+                    const float4 o = ldg4(dst);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *reinterpret_cast<float4 *>(dst) = v;
             }
         }
 }
