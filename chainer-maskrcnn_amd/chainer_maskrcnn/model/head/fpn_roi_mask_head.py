@@ -16,6 +16,7 @@ import torch
 
 from chainer_maskrcnn import _hip
 from chainer_maskrcnn._hip import lib, check, ptr, stream_ptr, ops
+from chainer_maskrcnn._hip.nn import workspace
 from chainer_maskrcnn.nn.core import Conv, ParamStore, normal, pad_to
 
 
@@ -43,9 +44,11 @@ def roi_align_fpn_fwd(xs, rois_xy5, levels, out_size, scales, sampling_ratio=2):
 def roi_align_fpn_bwd(gy, gxs, rois_xy5, levels, out_size, scales, accumulate, sampling_ratio=2):
     L, arr_p, Hs, Ws, sc = _level_args(gxs, scales)
     N, C = gxs[0].shape[0], gxs[0].shape[3]
+    nb = lib().mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, N, C)
+    ws = workspace(nb, gy.device) if nb else None
     check(lib().mrcnn_roi_align_fpn_bwd_f32(ptr(gy), arr_p, Hs, Ws, sc, L, N, C, ptr(rois_xy5), ptr(levels),
                                             rois_xy5.shape[0], out_size, out_size, sampling_ratio, int(accumulate),
-                                            stream_ptr()))
+                                            ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()))
 
 
 class FPNRoIMaskHead(object):

@@ -19,6 +19,7 @@
 // each wave walks the non-zero (ph,pw) pairs of its cell with wave-uniform control flow
 // (ballot + readlane), streaming gy rows through L1/L2.
 #include "common.h"
+#include <algorithm>
 
 #pragma clang fp contract(off)
 
@@ -85,6 +86,11 @@ struct Levels {
     float scale[MRCNN_MAX_LEVELS];
     int tile_begin[MRCNN_MAX_LEVELS + 1];
     int tiles_x[MRCNN_MAX_LEVELS], tiles_y[MRCNN_MAX_LEVELS];
+    // backward RoI split: on a coarse level (few tiles, many RoIs - the reference maps most RoIs to the coarsest levels)
+    // each tile is computed by split[l] workgroups, workgroup z taking the RoIs with index % split == z and writing a
+    // partial map to slab[l] + z * (N*H*W*C); k_sum_level_slabs adds the partial maps in z order (deterministic).
+    int split[MRCNN_MAX_LEVELS];
+    float *slab[MRCNN_MAX_LEVELS];
     int L;
 };
 
@@ -237,13 +243,17 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
     int l = 0;
     while (l + 1 < lv.L && tile_id >= lv.tile_begin[l + 1]) ++l;
     int t = tile_id - lv.tile_begin[l];
+    const int nsplit = lv.split[l];
+    const int zsplit = t % nsplit;               // adjacent workgroups = the splits of one tile (same gy rows, same L2)
+    t /= nsplit;
     const int per_img = lv.tiles_x[l] * lv.tiles_y[l];
     const int n = t / per_img;
     t -= n * per_img;
     const int ty0 = (t / lv.tiles_x[l]) * TH, tx0 = (t % lv.tiles_x[l]) * TW;
     const int H = lv.H[l], W = lv.W[l];
     const float scale = lv.scale[l];
-    float *gxb = lv.gx[l] + (size_t)n * H * W * C;
+    float *gxb = (nsplit > 1 ? lv.slab[l] + (size_t)zsplit * N * H * W * C : lv.gx[l]) + (size_t)n * H * W * C;
+    if (nsplit > 1) accumulate = 0;              // partial maps are always written whole
     const float inv_cnt = 1.0f / (float)(sr * sr);
     PatchQueue<QCAP> &q = sQ[wave];
     const int cy0 = (wave >> 1) * PT, cx0 = (wave & 1) * PT;      // this wave's patch inside the tile
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
                 int li = levels ? levels[i] : 0;
                 li = min(max(li, 0), lv.L - 1);
                 const float *roi = rois + (size_t)i * 5;
-                if (li == l && (int)roi[0] == n) {
+                if (li == l && (int)roi[0] == n && (nsplit == 1 || i % nsplit == zsplit)) {
                     const RoiGeom g = roi_geom(roi, scale, PH, PW, sr);
                     f = (g.y1f - 2.0f < (float)(ty0 + TH)) && (g.y1f + g.rh + 2.0f > (float)ty0) &&
                         (g.x1f - 2.0f < (float)(tx0 + TW)) && (g.x1f + g.rw + 2.0f > (float)tx0);
@@ -513,14 +523,61 @@ bool fast_bwd_ok(int C, int PH, int PW, int sr, int R) {
     return (C % 4) == 0 && PH <= PB && PW <= PB && sr > 0 && (long long)R * PH * PW < (1ll << 31);
 }
 
+// out = (accumulate ? out : 0) + sum_z slab[z]   (n4 float4 per map, z order)
+__global__ __launch_bounds__(256) void k_sum_level_slabs(const float *__restrict__ slab, float *__restrict__ out, size_t n4,
+                                                         int nsplit, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = accumulate ? ld4(out + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 0;
+    for (; z + 4 <= nsplit; z += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ld4(slab + ((size_t)(z + j) * n4 + i) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+    }
+    for (; z < nsplit; ++z) {
+        const float4 v = ld4(slab + ((size_t)z * n4 + i) * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(out + i * 4) = a;
+}
+
+// RoI split of a level: enough workgroups to occupy the chip when the level has few tiles.
+int level_split(int H, int W, int N) {
+    const int tiles = mrcnn::cdiv(W, TW) * mrcnn::cdiv(H, TH) * N;
+    if (tiles >= 256) return 1;
+    return std::min(32, mrcnn::cdiv(512, tiles));
+}
+size_t bwd_ws_bytes(const int *Hs, const int *Ws, int L, int N, int C) {
+    size_t b = 0;
+    for (int l = 0; l < L; ++l) {
+        const int sp = level_split(Hs[l], Ws[l], N);
+        if (sp > 1) b += (size_t)sp * N * Hs[l] * Ws[l] * C * sizeof(float);
+    }
+    return b;
+}
+
 int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, const int32_t *levels, int R,
-                     int C, int PH, int PW, int sr, int accumulate, hipStream_t st) {
+                     int C, int PH, int PW, int sr, int accumulate, void *ws, size_t ws_bytes, hipStream_t st) {
     int total = 0;
+    size_t need = 0;
+    for (int l = 0; l < lv.L; ++l) need += level_split(lv.H[l], lv.W[l], N) > 1
+        ? (size_t)level_split(lv.H[l], lv.W[l], N) * N * lv.H[l] * lv.W[l] * C * sizeof(float) : 0;
+    const bool can_split = ws && ws_bytes >= need && R > 0;
+    float *wp = (float *)ws;
     for (int l = 0; l < lv.L; ++l) {
         lv.tiles_x[l] = mrcnn::cdiv(lv.W[l], TW);
         lv.tiles_y[l] = mrcnn::cdiv(lv.H[l], TH);
+        lv.split[l] = can_split ? level_split(lv.H[l], lv.W[l], N) : 1;
+        lv.slab[l] = nullptr;
+        if (lv.split[l] > 1) {
+            lv.slab[l] = wp;
+            wp += (size_t)lv.split[l] * N * lv.H[l] * lv.W[l] * C;
+        }
         lv.tile_begin[l] = total;
-        total += lv.tiles_x[l] * lv.tiles_y[l] * N;
+        total += lv.tiles_x[l] * lv.tiles_y[l] * N * lv.split[l];
     }
     lv.tile_begin[lv.L] = total;
     const int chunk = mrcnn::cdiv(total, 8);
@@ -531,6 +588,13 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
         hipLaunchKernelGGL(k_roi_align_bwd_nhwc<16>, dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois,
                            levels, R, N, C, PH, PW, sr, chunk, accumulate);
     MRCNN_LAUNCH_CHECK();
+    for (int l = 0; l < lv.L; ++l)
+        if (lv.split[l] > 1) {
+            const size_t n4 = (size_t)N * lv.H[l] * lv.W[l] * C / 4;
+            hipLaunchKernelGGL(k_sum_level_slabs, dim3((unsigned)mrcnn::cdiv(n4, 256)), dim3(256), 0, st, lv.slab[l], lv.gx[l], n4,
+                               lv.split[l], accumulate);
+            MRCNN_LAUNCH_CHECK();
+        }
     return 0;
 }
 
@@ -566,7 +630,7 @@ extern "C" int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C
     if (layout == MRCNN_LAYOUT_NHWC && fast_bwd_ok(C, PH, PW, sampling_ratio, R)) {
         Levels lv{};
         lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
-        return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, st);
+        return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, nullptr, 0, st);
     }
     MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * C * H * W, st));
     if (R == 0) return 0;
@@ -612,14 +676,19 @@ extern "C" int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs
 extern "C" int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws,
                                            const float *scales, int L, int N, int C, const float *rois,
                                            const int32_t *levels, int R, int PH, int PW,
-                                           int sampling_ratio, int accumulate, void *stream) {
+                                           int sampling_ratio, int accumulate, void *ws, size_t ws_bytes, void *stream) {
     if (!gxs || (R > 0 && (!rois || !levels || !gy))) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd: null pointer");
     if (N <= 0 || C <= 0 || PH <= 0 || PW <= 0 || R < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd: bad sizes");
     if (!fast_bwd_ok(C, PH, PW, sampling_ratio, R))
         return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd: needs C%%4==0, PH,PW<=%d, sampling_ratio>0", PB);
     Levels lv{};
     if (int e = fill_levels(lv, nullptr, gxs, Hs, Ws, scales, L)) return e;
-    return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, accumulate, (hipStream_t)stream);
+    return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int L, int N, int C) {
+    if (!Hs || !Ws || L <= 0 || L > MRCNN_MAX_LEVELS || N <= 0 || C <= 0) return 0;
+    return bwd_ws_bytes(Hs, Ws, L, N, C);
 }
 
 extern "C" int mrcnn_roi_align_sample_tables(const float *rois, int R, int H, int W, int PH, int PW,

@@ -81,6 +81,11 @@ int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C, int H, in
  *   y / gy          (R,PH,PW,C) f32
  *   accumulate      backward: 0 = every gxs[l] is overwritten (zero where no RoI lands),
  *                   1 = gradients are added to gxs[l] (second pooled size over the same pyramid)
+ *   ws, ws_bytes    backward: optional device scratch of mrcnn_roi_align_fpn_bwd_workspace_bytes() bytes.  With it,
+ *                   levels with few 8x8 tiles (the coarse ones, where map_rois_to_fpn_levels puts most RoIs) are
+ *                   computed by several workgroups per tile over disjoint RoI subsets and summed in fixed order;
+ *                   without it (NULL) one workgroup per tile does all the RoIs.  Results are bit-reproducible
+ *                   either way (the two modes differ from each other by summation order only).
  * Only MRCNN_LAYOUT_NHWC with C%4==0 is supported. */
 int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs, const int *Ws,
                                 const float *scales, int L, int N, int C, const float *rois,
@@ -89,7 +94,8 @@ int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs, const int
 int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws,
                                 const float *scales, int L, int N, int C, const float *rois,
                                 const int32_t *levels, int R, int PH, int PW,
-                                int sampling_ratio, int accumulate, void *stream);
+                                int sampling_ratio, int accumulate, void *ws, size_t ws_bytes, void *stream);
+size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int L, int N, int C);
 
 /* Verification hook for the "ROIAlign indices bit-exact" contract: dumps, for every RoI and
  * both axes, the integer corner cells and float weights of every sample exactly as the

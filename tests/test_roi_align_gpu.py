@@ -153,3 +153,48 @@ def test_config2_full_size_properties_and_sampled_parity():
     roi_align_2d(xt, rt, 7, 7, 0.25).backward(gsub)
     want_gx = ora.roi_align_bwd(gy[sub], xy[sub], x.shape, 0.25, 2)
     np.testing.assert_allclose(xt.grad.cpu().numpy(), want_gx, rtol=1e-5, atol=2e-5 * np.abs(gy).max())
+
+
+@pytest.mark.parametrize('P', [7, 14])
+def test_fpn_backward_coarse_levels_split_matches_oracle(P):
+    """Multi-level backward with most RoIs on the coarse levels (what map_rois_to_fpn_levels produces): the
+    RoI-split path (several workgroups per tile + ordered slab sum) against the per-level oracle, with and
+    without accumulation, bit-reproducible run to run, and equal (to rounding) to the unsplit path."""
+    from chainer_maskrcnn.model.head import fpn_roi_mask_head as hd
+    rs = np.random.RandomState(40 + P)
+    N, C = 2, 8
+    shapes = [(40, 48), (20, 24), (10, 12), (5, 6)]
+    scales = [1 / 4., 1 / 8., 1 / 16., 1 / 32.]
+    R = 150
+    xy = rand_rois_xy(rs, R, N, 40, 48, 0.25)
+    lev = rs.choice(4, size=R, p=[0.05, 0.1, 0.35, 0.5]).astype(np.int32)
+    gy = rs.standard_normal((R, P, P, C)).astype(np.float32)
+    base = [rs.standard_normal((N, h, w, C)).astype(np.float32) for h, w in shapes]
+    want = []
+    for l, (h, w) in enumerate(shapes):
+        sel = np.nonzero(lev == l)[0]
+        g = ora.roi_align_bwd(np.ascontiguousarray(gy[sel].transpose(0, 3, 1, 2)), xy[sel], (N, C, h, w), scales[l], 2)
+        want.append(g.transpose(0, 2, 3, 1))
+    rt, lt, gyt = torch.from_numpy(xy).to(DEV), torch.from_numpy(lev).to(DEV), torch.from_numpy(gy).to(DEV)
+
+    def run(accumulate, use_ws):
+        gxs = [torch.from_numpy(b).to(DEV).clone() for b in base]
+        if use_ws:
+            hd.roi_align_fpn_bwd(gyt, gxs, rt, lt, P, scales, accumulate=accumulate)
+        else:
+            L, arr_p, Hs, Ws, sc = hd._level_args(gxs, scales)
+            _hip.check(_hip.lib().mrcnn_roi_align_fpn_bwd_f32(_hip.ptr(gyt), arr_p, Hs, Ws, sc, L, N, C, _hip.ptr(rt),
+                                                               _hip.ptr(lt), R, P, P, 2, int(accumulate), None, 0,
+                                                               _hip.stream_ptr()))
+        return [g.cpu().numpy() for g in gxs]
+
+    L, arr_p, Hs, Ws, sc = hd._level_args([torch.from_numpy(b) for b in base], scales)
+    assert _hip.lib().mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, N, C) > 0     # these levels do split
+    tol = dict(rtol=1e-5, atol=2e-5 * np.abs(gy).max())
+    for acc in (False, True):
+        a, a2, b = run(acc, True), run(acc, True), run(acc, False)
+        for l in range(4):
+            ref = want[l] + (base[l] if acc else 0)
+            np.testing.assert_allclose(a[l], ref, **tol)
+            np.testing.assert_allclose(b[l], ref, **tol)
+            np.testing.assert_array_equal(a[l], a2[l])

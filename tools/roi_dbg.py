@@ -14,7 +14,7 @@ lev = torch.zeros((R_,), dtype=torch.int32, device=dev)
 lib = _hip.lib()
 arr = (ctypes.c_void_p * 1)(gx.data_ptr()); Hs = (ctypes.c_int * 1)(H); Ws = (ctypes.c_int * 1)(W); sc = (ctypes.c_float * 1)(0.25)
 def run(flag):
-    _hip.check(lib.mrcnn_roi_align_fpn_bwd_f32(_hip.ptr(gyt), arr, Hs, Ws, sc, 1, N, C, _hip.ptr(rois), _hip.ptr(lev), R_, PH, PW, 2, flag, _hip.stream_ptr()))
+    _hip.check(lib.mrcnn_roi_align_fpn_bwd_f32(_hip.ptr(gyt), arr, Hs, Ws, sc, 1, N, C, _hip.ptr(rois), _hip.ptr(lev), R_, PH, PW, 2, flag, None, 0, _hip.stream_ptr()))
 for flag, name in ((0, 'full'), (2, 'no phase B'), (6, 'no list, no phase B'), (14, 'no tables, no list, no phase B')):
     for _ in range(10): run(flag)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
