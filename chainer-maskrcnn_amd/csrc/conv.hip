@@ -11,16 +11,19 @@
 // Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate, bit-wise an fmaf chain) - gfx950
 // has no TF32/xf32, and the parity bar is 1e-3 relative fp32.
 //
-// One workgroup (256 threads = 2x2 waves) computes a 128 x 128 tile of C = A * B with a 32-deep
-// K step staged through LDS (single buffer, next step's global loads in flight during the
-// MFMAs).  Each wave owns 64 x 64 = 2x2 MFMA tiles (64 accumulator VGPRs).  Operand tiles live in
-// LDS either "k-contiguous" (KC: [row][k], read with ds_read_b128) or "row-contiguous" (RC:
-// [k][row], read with ds_read_b32), whichever matches how the operand sits in HBM:
+// One workgroup (256 threads = 2x2 waves) computes a BM x BN tile (128x128, 128x64, 64x128, 64x64) of C = A * B with
+// a 32-deep K step staged through LDS (single buffer, next step's global loads in flight during the MFMAs).  Each
+// wave owns (BM/2) x (BN/2) = TM x TN MFMA tiles of 32x32.  Operand tiles live in LDS either "k-contiguous" (KC:
+// [row][k], read with ds_read_b128) or "row-contiguous" (RC: [k][row], read with ds_read_b32), whichever matches how
+// the operand sits in HBM:
 //   forward          A = im2col(x)  KC (gathered rows)   B = w            KC
 //   backward-data    A = im2col(gy) KC (gathered rows)   B = w[co][..ci]  RC   (k = cout)
 //   backward-filter  A = gy         RC (k = pixel)       B = x gathered   RC   (k = pixel), split-K
 // Within each 8-wide k group lane half h uses k = 4h..4h+3 (for both operands), which is a
 // permutation of the K sum and lets one ds_read_b128 feed four MFMAs.
+// Grid: 1-D with an XCD remap; tiles just past a whole number of rounds of resident workgroups are split along K
+// ("tail split"); all partial sums go to slabs that are added in fixed order (bit-reproducible results).
+// Epilogue: 32x32 accumulator tiles are transposed through per-wave LDS tiles and stored as float4.
 #include "common.h"
 #include <algorithm>
 
