@@ -44,8 +44,9 @@ def bn_train_fwd(x, gamma, beta, residual=None, relu=False, running_mean=None, r
     return y, mean, invstd
 
 
-def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu=False, want_gres=False):
-    _ck(gy, x, y, gamma, mean, invstd)
+def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu=False, want_gres=False, beta=None):
+    """y None + beta given (BN + ReLU without residual): the ReLU mask is recomputed from x."""
+    _ck(gy, x, y, gamma, mean, invstd, beta)
     C = x.shape[-1]
     P = x.numel() // C
     gx = torch.empty_like(x)
@@ -53,7 +54,7 @@ def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu=False, want_gres=False):
     gg = _empty((C,), x.device)
     gb = _empty((C,), x.device)
     ws = workspace(lib().mrcnn_bn_workspace_bytes(P, C), x.device)
-    check(lib().mrcnn_bn_train_bwd_f32(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(gx), ptr(gres),
+    check(lib().mrcnn_bn_train_bwd_f32(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(gx), ptr(gres),
                                        ptr(gg), ptr(gb), P, C, int(relu), ptr(ws), ws.numel(), stream_ptr()))
     return gx, gres, gg, gb
 

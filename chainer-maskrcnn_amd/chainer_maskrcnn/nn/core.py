@@ -200,7 +200,9 @@ class BatchNorm(object):
             return y, None
         y, mean, invstd = ops.bn_train_fwd(x, gamma, beta, residual, relu, self.ps.buffers[self.name + '/avg_mean'],
                                            self.ps.buffers[self.name + '/avg_var'])
-        return y, (x, y, mean, invstd, relu)
+        # BN + ReLU without a residual: backward recomputes the ReLU mask from x (bitwise the forward's y), so y is not
+        # kept for (or read by) the backward pass
+        return y, (x, y if (residual is not None or not relu) else None, mean, invstd, relu)
 
     def bwd(self, ctx, gy, want_gres=False):
         x, y, mean, invstd, relu = ctx
@@ -210,7 +212,8 @@ class BatchNorm(object):
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if want_gres else None
         ws = hnn.workspace(lib().mrcnn_bn_workspace_bytes(P, C), x.device)
-        check(lib().mrcnn_bn_train_bwd_f32(ptr(gy), ptr(x), ptr(y), ptr(self.ps.p(self.name + '/gamma')), ptr(mean),
+        check(lib().mrcnn_bn_train_bwd_f32(ptr(gy), ptr(x), ptr(y), ptr(self.ps.p(self.name + '/gamma')),
+                                           ptr(self.ps.p(self.name + '/beta')), ptr(mean),
                                            ptr(invstd), ptr(gx), ptr(gres), ptr(self.ps.g(self.name + '/gamma')),
                                            ptr(self.ps.g(self.name + '/beta')), P, C, int(relu), ptr(ws), ws.numel(),
                                            stream_ptr()))

@@ -183,8 +183,11 @@ __global__ __launch_bounds__(NT) void k_bn_infer(const float *__restrict__ x, co
 }
 
 // BN backward reductions: per channel sum(dz), sum(dz*xhat) with dz = relu ? gy*(y>0) : gy.
+// relu: 0 none, 1 mask = (y > 0) read from memory, 2 mask = (gamma*xhat + beta > 0) recomputed from x with the forward's
+// exact expression (bitwise the same y; only for BN + ReLU without a residual) - one HBM stream less.
 __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__ gy, const float *__restrict__ x,
-                                                       const float *__restrict__ y, const float *__restrict__ mean,
+                                                       const float *__restrict__ y, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, const float *__restrict__ mean,
                                                        const float *__restrict__ invstd, int P, int C, int G, int RPI,
                                                        int rows_per_blk, int relu, float *__restrict__ part) {
     __shared__ float4 s1[NT], s2[NT];
@@ -193,8 +196,13 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(P, r0 + rows_per_blk);
     for (int cg = cg0; cg < C4; cg += G) {
         const float4 m = ld4(mean + cg * 4), s = ld4(invstd + cg * 4);
+        const float4 ga = relu == 2 ? ld4(gamma + cg * 4) : f4(0.f), be = relu == 2 ? ld4(beta + cg * 4) : f4(0.f);
         float4 a = f4(0.f), b = f4(0.f);
-        auto acc = [&](float4 g, const float4 v, const float4 yy) {
+        auto acc = [&](float4 g, const float4 v, float4 yy) {
+            if (relu == 2) {
+                yy.x = ga.x * ((v.x - m.x) * s.x) + be.x; yy.y = ga.y * ((v.y - m.y) * s.y) + be.y;
+                yy.z = ga.z * ((v.z - m.z) * s.z) + be.z; yy.w = ga.w * ((v.w - m.w) * s.w) + be.w;
+            }
             if (relu) {
                 g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
                 g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
@@ -203,20 +211,20 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__
             b.x = fmaf(g.x, (v.x - m.x) * s.x, b.x); b.y = fmaf(g.y, (v.y - m.y) * s.y, b.y);
             b.z = fmaf(g.z, (v.z - m.z) * s.z, b.z); b.w = fmaf(g.w, (v.w - m.w) * s.w, b.w);
         };
-        const float *yr = relu ? y : gy;                  // without ReLU the third stream is not read at all
+        const float *yr = relu == 1 ? y : gy;             // only mode 1 reads the third stream
         int r = r0 + rr;
         for (; r + RPI < r1; r += 2 * RPI) {              // two rows (six loads) in flight, accumulated in row order
             const size_t o0 = (size_t)r * C + cg * 4, o1 = (size_t)(r + RPI) * C + cg * 4;
             const float4 g0 = ld4(gy + o0), v0 = ld4(x + o0), g1 = ld4(gy + o1), v1 = ld4(x + o1);
             float4 y0 = g0, y1 = g1;
-            if (relu) { y0 = ld4(yr + o0); y1 = ld4(yr + o1); }
+            if (relu == 1) { y0 = ld4(yr + o0); y1 = ld4(yr + o1); }
             acc(g0, v0, y0);
             acc(g1, v1, y1);
         }
         for (; r < r1; r += RPI) {
             const size_t o = (size_t)r * C + cg * 4;
             const float4 g = ld4(gy + o), v = ld4(x + o);
-            acc(g, v, relu ? ld4(yr + o) : g);
+            acc(g, v, relu == 1 ? ld4(yr + o) : g);
         }
         s1[t] = a; s2[t] = b;
         __syncthreads();
@@ -250,17 +258,24 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float *__restrict__ g
                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
                                                      const float *__restrict__ gbeta, const float *__restrict__ ggamma,
                                                      float *__restrict__ gx, float *__restrict__ gres, size_t n4, int C4,
-                                                     float invP, int relu) {
+                                                     float invP, int relu, const float *__restrict__ beta) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
         const int c = (int)(i % C4) * 4;
         float4 g = ld4(gy + i * 4);
         const float4 v = ld4(x + i * 4);
+        const float4 ga = ld4(gamma + c), m = ld4(mean + c), s = ld4(invstd + c), gb = ld4(gbeta + c), gg = ld4(ggamma + c);
         if (relu) {
-            const float4 yy = ld4(y + i * 4);
+            float4 yy;
+            if (relu == 2) {
+                const float4 be = ld4(beta + c);
+                yy.x = ga.x * ((v.x - m.x) * s.x) + be.x; yy.y = ga.y * ((v.y - m.y) * s.y) + be.y;
+                yy.z = ga.z * ((v.z - m.z) * s.z) + be.z; yy.w = ga.w * ((v.w - m.w) * s.w) + be.w;
+            } else {
+                yy = ld4(y + i * 4);
+            }
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
-        const float4 ga = ld4(gamma + c), m = ld4(mean + c), s = ld4(invstd + c), gb = ld4(gbeta + c), gg = ld4(ggamma + c);
         float4 o;
         o.x = ga.x * s.x * (g.x - gb.x * invP - ((v.x - m.x) * s.x) * (gg.x * invP));
         o.y = ga.y * s.y * (g.y - gb.y * invP - ((v.y - m.y) * s.y) * (gg.y * invP));
@@ -603,24 +618,25 @@ extern "C" int mrcnn_bn_train_fwd_f32(const float *x, const float *gamma, const 
     return 0;
 }
 
-extern "C" int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const float *y, const float *gamma,
+extern "C" int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const float *y, const float *gamma, const float *beta,
                                       const float *save_mean, const float *save_invstd, float *gx, float *gres,
                                       float *ggamma, float *gbeta, int P, int C, int relu, void *ws, size_t ws_bytes,
                                       void *stream) {
     if (int e = chk(gy && x && gamma && save_mean && save_invstd && gx && ggamma && gbeta && ws, "bn_train_bwd: null pointer")) return e;
-    if (int e = chk(!relu || y, "bn_train_bwd: relu needs y")) return e;
+    if (int e = chk(!relu || y || beta, "bn_train_bwd: relu needs y, or beta to recompute the mask")) return e;
+    const int rmode = !relu ? 0 : (y ? 1 : 2);
     if (int e = chk(P > 0 && C > 0 && (C % 4) == 0, "bn_train_bwd: need P>0, C%4==0")) return e;
     if (ws_bytes < mrcnn_bn_workspace_bytes(P, C)) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "bn_train_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const RedPlan r = red_plan(P, C);
-    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(r.nblk), dim3(NT), 0, st, gy, x, y, save_mean, save_invstd, P, C, r.G, r.RPI,
-                       r.rows_per_blk, relu, (float *)ws);
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(r.nblk), dim3(NT), 0, st, gy, x, y, gamma, beta, save_mean, save_invstd, P, C, r.G,
+                       r.RPI, r.rows_per_blk, rmode, (float *)ws);
     MRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_bwd_final, dim3(mrcnn::cdiv(C, 64)), dim3(1024), 0, st, (const float *)ws, r.nblk, C, gbeta, ggamma);
     MRCNN_LAUNCH_CHECK();
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, gy, x, y, gamma, save_mean, save_invstd, gbeta,
-                       ggamma, gx, gres, n4, C / 4, 1.0f / (float)P, relu);
+                       ggamma, gx, gres, n4, C / 4, 1.0f / (float)P, rmode, beta);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -155,8 +155,10 @@ int mrcnn_bn_train_fwd_f32(const float *x, const float *gamma, const float *beta
                            float *running_var, int P, int C, float eps, float decay, int relu, void *ws,
                            size_t ws_bytes, void *stream);
 /* dz = relu ? gy*(y>0) : gy;  gx = BN backward of dz;  gres (nullable) = dz (gradient of the residual
- * input);  ggamma, gbeta (C) overwritten. */
-int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const float *y, const float *gamma,
+ * input);  ggamma, gbeta (C) overwritten.  y may be NULL when relu != 0, the forward had no residual and beta is
+ * given: the mask is then recomputed from x as gamma*(x-mean)*invstd + beta > 0 with the forward's exact expression
+ * (bitwise the same mask, one HBM stream less).  beta is otherwise unused (nullable). */
+int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const float *y, const float *gamma, const float *beta,
                            const float *save_mean, const float *save_invstd, float *gx, float *gres,
                            float *ggamma, float *gbeta, int P, int C, int relu, void *ws, size_t ws_bytes,
                            void *stream);

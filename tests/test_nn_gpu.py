@@ -55,6 +55,11 @@ def test_bn_train_fwd_bwd(shape, relu, res):
     # bit-reproducible reductions
     gx2, _, gg2, _ = ops.bn_train_bwd(gy.float().to(DEV), xd, yd, gamma.detach().float().to(DEV), m, s, relu, res)
     assert torch.equal(gx, gx2) and torch.equal(gg, gg2)
+    if relu and not res:
+        # ReLU mask recomputed from x instead of read from y: bitwise the same gradients
+        gx3, _, gg3, gb3 = ops.bn_train_bwd(gy.float().to(DEV), xd, None, gamma.detach().float().to(DEV), m, s, relu, False,
+                                            beta=beta.detach().float().to(DEV))
+        assert torch.equal(gx, gx3) and torch.equal(gg, gg3) and torch.equal(gb, gb3)
 
 
 @pytest.mark.parametrize('shape', [(2, 8, 8, 16), (1, 9, 7, 64), (2, 5, 5, 8), (1, 1, 1, 4)])

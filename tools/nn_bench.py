@@ -28,8 +28,8 @@ for P, C, cnt in SHAPES:
     g = torch.ones((C,), device=dev); b = torch.zeros((C,), device=dev)
     y, m, s = ops.bn_train_fwd(x, g, b, relu=True)
     f = timed(lambda: ops.bn_train_fwd(x, g, b, relu=True))
-    bw = timed(lambda: ops.bn_train_bwd(gy, x, y, g, m, s, relu=True))
+    bw = timed(lambda: ops.bn_train_bwd(gy, x, None, g, m, s, relu=True, beta=b))
     nb = P * C * 4
-    print('%8d %5d %3d %9.1f %8.0f %9.1f %8.0f' % (P, C, cnt, f, 3 * nb / f / 1e3, bw, 7 * nb / bw / 1e3))
+    print('%8d %5d %3d %9.1f %8.0f %9.1f %8.0f' % (P, C, cnt, f, 3 * nb / f / 1e3, bw, 5 * nb / bw / 1e3))
     tf += f * cnt; tb += bw * cnt
 print('per step: fwd %.2f ms  bwd %.2f ms' % (tf / 1e3, tb / 1e3))
