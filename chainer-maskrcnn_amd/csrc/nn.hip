@@ -458,6 +458,84 @@ __global__ __launch_bounds__(NT) void k_pixel_shuffle(const float *__restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Algebraic merge of the mask branch's last two layers.  The reference applies NO non-linearity between the 2x2/2
+// deconvolution and the final 1x1 convolution (head/fpn_roi_mask_head.py:83, fpn_roi_keypoint_head.py:93:
+// `mask = self.conv2(self.deconv1(mask))`), so their composition is ONE 2x2/2 deconvolution to K2 channels:
+//   Wm[ab][k][ci] = sum_o W2[k][o] * Wd[ab][o][ci],   bm[k] = b2[k] + sum_o W2[k][o] * bd[o]
+// (4x fewer MACs on the 28x28 maps and no (R,28,28,C) intermediate).  The parameters stay Wd, bd, W2, b2; their
+// gradients follow from the merged layer's filter gradient G[ab][k][ci] and bias gradient gb4[ab][k]:
+//   gWd[ab][o][ci] = sum_k W2[k][o] * G[ab][k][ci]           gbd[o] = sum_k W2[k][o] * gsum[k]
+//   gW2[k][o] = sum_ab sum_ci G[ab][k][ci] * Wd[ab][o][ci] + gsum[k] * bd[o]     gb2[k] = gsum[k] = sum_ab gb4[ab][k]
+// Exact in real arithmetic; fixed summation order (bit-reproducible).  All matrices are tiny (<= 1 MB).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_deconv_merge_fwd(const float *__restrict__ wd, const float *__restrict__ bd,
+                                                         const float *__restrict__ w2, const float *__restrict__ b2,
+                                                         float *__restrict__ wm, float *__restrict__ bm, int C, int Cin,
+                                                         int K2, int ld2) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    const int total = 4 * K2 * Cin;
+    if (i < total) {
+        const int ci = i % Cin, k = (i / Cin) % K2, ab = i / (Cin * K2);
+        const float *w2r = w2 + (size_t)k * ld2, *wdc = wd + (size_t)ab * C * Cin + ci;
+        float a = 0.0f;
+        for (int o = 0; o < C; ++o) a = fmaf(w2r[o], wdc[(size_t)o * Cin], a);
+        wm[i] = a;
+    } else if (i < total + K2) {
+        const int k = i - total;
+        float a = b2 ? b2[k] : 0.0f;
+        for (int o = 0; o < C; ++o) a = fmaf(w2[(size_t)k * ld2 + o], bd[o], a);
+        bm[k] = a;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_deconv_merge_bwd_wd(const float *__restrict__ G, const float *__restrict__ gb4,
+                                                            const float *__restrict__ w2, float *__restrict__ gwd,
+                                                            float *__restrict__ gbd, float *__restrict__ gb2, int C,
+                                                            int Cin, int K2, int ld2) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    const int total = 4 * C * Cin;
+    if (i < total) {
+        const int ci = i % Cin, o = (i / Cin) % C, ab = i / (Cin * C);
+        const float *g = G + (size_t)ab * K2 * Cin + ci;
+        float a = 0.0f;
+        for (int k = 0; k < K2; ++k) a = fmaf(w2[(size_t)k * ld2 + o], g[(size_t)k * Cin], a);
+        gwd[i] = a;
+    } else if (i < total + C) {
+        const int o = i - total;
+        float a = 0.0f;
+        for (int k = 0; k < K2; ++k) {
+            const float gs = ((gb4[k] + gb4[K2 + k]) + gb4[2 * K2 + k]) + gb4[3 * K2 + k];
+            a = fmaf(w2[(size_t)k * ld2 + o], gs, a);
+        }
+        gbd[o] = a;
+    } else if (i < total + C + K2) {
+        const int k = i - total - C;
+        if (gb2) gb2[k] = ((gb4[k] + gb4[K2 + k]) + gb4[2 * K2 + k]) + gb4[3 * K2 + k];
+    }
+}
+
+// one wave per (k, o): lanes stride over ci, fixed-order butterfly reduction
+__global__ __launch_bounds__(NT) void k_deconv_merge_bwd_w2(const float *__restrict__ G, const float *__restrict__ gb4,
+                                                            const float *__restrict__ wd, const float *__restrict__ bd,
+                                                            float *__restrict__ gw2, int C, int Cin, int K2, int ld2) {
+    const int wv = (blockIdx.x * NT + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wv >= K2 * C) return;
+    const int o = wv % C, k = wv / C;
+    float a = 0.0f;
+    for (int ab = 0; ab < 4; ++ab) {
+        const float *g = G + ((size_t)ab * K2 + k) * Cin, *w = wd + ((size_t)ab * C + o) * Cin;
+        for (int ci = lane; ci < Cin; ci += 64) a = fmaf(g[ci], w[ci], a);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+    if (lane == 0) {
+        const float gs = ((gb4[k] + gb4[K2 + k]) + gb4[2 * K2 + k]) + gb4[3 * K2 + k];
+        gw2[(size_t)k * ld2 + o] = fmaf(gs, bd[o], a);
+    }
+}
+
 // v = momentum*v - lr*(g + wd*p); p += v   (Chainer WeightDecay hook then MomentumSGD).  20 B/param.
 __global__ __launch_bounds__(NT) void k_sgd(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ v,
                                             size_t n, float lr, float momentum, float wd) {
@@ -711,6 +789,31 @@ extern "C" int mrcnn_pixel_shuffle2x_f32(const float *src, const float *bias, fl
     if (int e = chk(src && dst && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "pixel_shuffle2x: bad args")) return e;
     hipLaunchKernelGGL(k_pixel_shuffle, dim3(ew_grid((size_t)N * H * W * C)), dim3(NT), 0, (hipStream_t)stream, src, inverse ? nullptr : bias, dst, N,
                        H, W, C / 4, inverse);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_deconv_merge_fwd_f32(const float *wd, const float *bd, const float *w2, const float *b2, float *wm,
+                                          float *bm, int C, int Cin, int K2, int ld2, void *stream) {
+    if (int e = chk(wd && bd && w2 && wm && bm, "deconv_merge_fwd: null pointer")) return e;
+    if (int e = chk(C > 0 && Cin > 0 && K2 > 0 && ld2 >= C, "deconv_merge_fwd: bad sizes")) return e;
+    const int total = 4 * K2 * Cin + K2;
+    hipLaunchKernelGGL(k_deconv_merge_fwd, dim3(mrcnn::cdiv(total, NT)), dim3(NT), 0, (hipStream_t)stream, wd, bd, w2, b2, wm, bm, C,
+                       Cin, K2, ld2);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_deconv_merge_bwd_f32(const float *G, const float *gb4, const float *wd, const float *bd,
+                                          const float *w2, float *gwd, float *gbd, float *gw2, float *gb2, int C,
+                                          int Cin, int K2, int ld2, void *stream) {
+    if (int e = chk(G && gb4 && wd && bd && w2 && gwd && gbd && gw2, "deconv_merge_bwd: null pointer")) return e;
+    if (int e = chk(C > 0 && Cin > 0 && K2 > 0 && ld2 >= C, "deconv_merge_bwd: bad sizes")) return e;
+    hipStream_t st = (hipStream_t)stream;
+    const int t1 = 4 * C * Cin + C + K2;
+    hipLaunchKernelGGL(k_deconv_merge_bwd_wd, dim3(mrcnn::cdiv(t1, NT)), dim3(NT), 0, st, G, gb4, w2, gwd, gbd, gb2, C, Cin, K2, ld2);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_deconv_merge_bwd_w2, dim3(mrcnn::cdiv(K2 * C * 64, NT)), dim3(NT), 0, st, G, gb4, wd, bd, gw2, C, Cin, K2, ld2);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

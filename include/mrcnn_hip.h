@@ -181,6 +181,19 @@ int mrcnn_subsample_bwd_f32(const float *gsub, float *gx, int N, int H, int W, i
 /* 2x2/2 deconvolution data movement: (N,H,W,[2][2][C]) <-> (N,2H,2W,C); inverse != 0 is the backward. */
 int mrcnn_pixel_shuffle2x_f32(const float *src, const float *bias, float *dst, int N, int H, int W, int C, int inverse,
                               void *stream);      /* bias (C, nullable) is added in the forward direction */
+/* Algebraic merge of the mask / keypoint branch's last two layers: the reference has no non-linearity between the
+ * 2x2/2 deconvolution and the final 1x1 convolution (head/fpn_roi_mask_head.py:83, fpn_roi_keypoint_head.py:93), so
+ * conv2(deconv1(x)) is one 2x2/2 deconvolution to K2 channels (4x fewer MACs at 28x28, no (R,28,28,C) intermediate).
+ *   wd (4*C, Cin) rows (a*2+b)*C + o;  bd (C);  w2 (K2, ld2 >= C) (columns >= C are channel padding and are left
+ *   untouched in gw2);  b2 (K2, nullable)
+ *   fwd: wm (4*K2, Cin) rows (a*2+b)*K2 + k = W2 * Wd[ab];  bm (K2) = b2 + W2 * bd
+ *   bwd: G (4*K2, Cin), gb4 (4*K2) = filter / bias gradient of the merged layer  ->  gwd, gbd, gw2, gb2 (nullable),
+ *        all overwritten; exact gradients of the un-merged parameters, fixed summation order. */
+int mrcnn_deconv_merge_fwd_f32(const float *wd, const float *bd, const float *w2, const float *b2, float *wm,
+                               float *bm, int C, int Cin, int K2, int ld2, void *stream);
+int mrcnn_deconv_merge_bwd_f32(const float *G, const float *gb4, const float *wd, const float *bd,
+                               const float *w2, float *gwd, float *gbd, float *gw2, float *gb2, int C,
+                               int Cin, int K2, int ld2, void *stream);
 /* Bilinear x2 with corner alignment (Chainer F.resize_images, chainer_maskrcnn/model/head/fpn_roi_keypoint_head.py:
  * 80-81,109): x (N,H,W,C) -> y (N,2H,2W,C); bwd is the exact adjoint (owner-computes, no atomics). */
 int mrcnn_bilinear2x_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
