@@ -80,8 +80,9 @@ def conv2d_fwd_raw(x, w, b, stride, pad, relu):
     return y
 
 
-def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None):
-    """out given => gx is accumulated into it (fan-out points of the graph), else allocated."""
+def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None, relu_x=None):
+    """out given => gx is accumulated into it (fan-out points of the graph), else allocated.
+    relu_x = the layer's input when it came out of a ReLU: gx is masked with (relu_x > 0) in the epilogue."""
     N, H, W, Cin = x_shape
     Cout, KH, KW, _ = w.shape
     assert gy.is_contiguous()
@@ -90,7 +91,7 @@ def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None):
     nb = lib().mrcnn_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     ws = workspace(nb, gy.device) if nb else None
     with _prof('bwd_data', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout):
-        check(lib().mrcnn_conv2d_bwd_data_f32(ptr(gy), ptr(w), ptr(gx), N, H, W, Cin, Cout, KH, KW,
+        check(lib().mrcnn_conv2d_bwd_data_f32(ptr(gy), ptr(w), ptr(gx), ptr(relu_x), N, H, W, Cin, Cout, KH, KW,
                                               stride, pad, int(acc), ptr(ws), ws.numel() if ws is not None else 0,
                                               stream_ptr()))
     return gx

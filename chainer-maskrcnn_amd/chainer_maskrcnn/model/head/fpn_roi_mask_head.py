@@ -143,7 +143,8 @@ class FPNRoIMaskHead(object):
         hnn.LOGICAL = (dc.cin, 4 * c2.cout)
         try:
             G, gb4 = hnn.conv2d_bwd_filter_raw(x_in, g4, tuple(wm.shape), 1, 0, True)
-            g = hnn.conv2d_bwd_data_raw(g4, wm, tuple(x_in.shape), 1, 0)
+            # x_in is the ReLU output of the last mask conv: its ReLU backward is fused here
+            g = hnn.conv2d_bwd_data_raw(g4, wm, tuple(x_in.shape), 1, 0, relu_x=x_in if self.mask_convs else None)
         finally:
             hnn.LOGICAL = None
         ps = self.ps
@@ -182,10 +183,11 @@ class FPNRoIMaskHead(object):
     def backward_box(self, g_box_out, g_feats):
         t1, t2, t3, t4, pool_shape, rois, levels, scales = self.box_tape
         R = g_box_out.shape[0]
-        g = self.box_out.bwd(t4, g_box_out.view(R, 1, 1, -1))
-        g = self.fc2.bwd(t3, g)
-        g = self.fc1.bwd(t2, g)
-        g = self.conv1.bwd(t1, g.view(pool_shape))
+        # every layer's input is the ReLU output of the layer below: the ReLU backward rides in the data-gradient epilogue
+        g = self.box_out.bwd(t4, g_box_out.view(R, 1, 1, -1), mask_gx=True)
+        g = self.fc2.bwd(t3, g, gy_masked=True, mask_gx=True)
+        g = self.fc1.bwd(t2, g, gy_masked=True, mask_gx=True)
+        g = self.conv1.bwd(t1, g.view(pool_shape), gy_masked=True)
         roi_align_fpn_bwd(g, g_feats, rois, levels, self.roi_size_box, scales, accumulate=False)
         self.box_tape = None
 
@@ -197,8 +199,9 @@ class FPNRoIMaskHead(object):
             g_mask = ops.bilinear2x_bwd(g_mask)
         if self.merge_deconv:
             g = self._merged_deconv_bwd(td, g_mask)
-            for cv, t in zip(reversed(self.mask_convs), reversed(tapes)):
-                g = cv.bwd(t, g)
+            n = len(self.mask_convs)
+            for i in range(n - 1, -1, -1):          # inputs of convs 1.. are ReLU outputs; conv 0 reads the pooled features
+                g = self.mask_convs[i].bwd(tapes[i], g, gy_masked=True, mask_gx=(i > 0))
             return g
         g = self.conv2.bwd(tc2, g_mask)
         # deconv bias gradient = column sums of g over all output pixels: the filter-gradient call on the shuffled

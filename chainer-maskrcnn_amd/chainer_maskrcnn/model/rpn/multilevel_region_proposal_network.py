@@ -97,7 +97,7 @@ class MultilevelRegionProposalNetwork(object):
         first = True
         for (c1, c2, oshape, a_off), gf in zip(self.tape, g_feats):
             g_o = ops.rpn_unpack_grad(g_locs, g_scores, oshape, self.n_anchor, a_off)
-            g_h = self.head.bwd(c2, g_o, accumulate_params=not first)
-            self.conv.bwd(c1, g_h, gx_acc=gf, accumulate_params=not first)
+            g_h = self.head.bwd(c2, g_o, accumulate_params=not first, mask_gx=True)     # + ReLU backward of self.conv
+            self.conv.bwd(c1, g_h, gx_acc=gf, accumulate_params=not first, gy_masked=True)
             first = False
         self.tape = None

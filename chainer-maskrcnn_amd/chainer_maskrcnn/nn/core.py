@@ -140,11 +140,14 @@ class Conv(object):
         hnn.LOGICAL = None
         return y, (x, y if relu else None)
 
-    def bwd(self, ctx, gy, need_gx=True, gx_acc=None, accumulate_params=False):
+    def bwd(self, ctx, gy, need_gx=True, gx_acc=None, accumulate_params=False, gy_masked=False, mask_gx=False):
         """gy: gradient w.r.t. the (post-ReLU) output.  gx_acc: tensor to accumulate gx into.
-        accumulate_params: add into the parameter gradients (layer applied several times)."""
+        accumulate_params: add into the parameter gradients (layer applied several times).
+        gy_masked: the producer of gy already applied this layer's ReLU mask (the layer above ran with mask_gx).
+        mask_gx: this layer's input is itself a ReLU output - zero gx where x <= 0 in the data-gradient epilogue,
+        which is the ReLU backward of the layer below (call that layer with gy_masked=True)."""
         x, y = ctx
-        if y is not None:
+        if y is not None and not gy_masked:
             gy = ops.relu_bwd(gy, y)
         gw = self.ps.g(self.name + '/W')
         gb = self.ps.g(self.name + '/b') if self.has_bias else None
@@ -165,7 +168,10 @@ class Conv(object):
             if not need_gx:
                 return None
             if self.stride == 1:
-                return hnn.conv2d_bwd_data_raw(gy, self.W, tuple(x.shape), 1, self.pad, out=gx_acc)
+                assert not (mask_gx and gx_acc is not None)
+                return hnn.conv2d_bwd_data_raw(gy, self.W, tuple(x.shape), 1, self.pad, out=gx_acc,
+                                               relu_x=x if mask_gx else None)
+            assert not mask_gx
             assert self.k == 1 and self.pad == 0, 'strided backward-data only for 1x1 convolutions'
             g_sub = self.bwd_data_sub(gy)
         finally:

@@ -42,6 +42,7 @@ struct ConvP {
     const float *b;       // FWD: w      BWD_DATA: w      BWD_FILTER: x
     float *c;             // FWD: y      BWD_DATA: gx     BWD_FILTER: gw or split-K slab
     const float *bias;    // FWD only (nullable)
+    const float *relu_x;  // BWD_DATA only (nullable): the layer's input; gx is zeroed where relu_x <= 0 (fused ReLU backward)
     int N, H, W, Cin;     // input tensor (x / gx)
     int Ho, Wo, Cout;     // output tensor (y / gy)
     int KH, KW, stride, pad;
@@ -479,6 +480,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
                     const float4 o = ldg4(dst);
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
+                if (MODE == MODE_BWD_DATA && p.relu_x && plain) {
+                    const float4 xm = ldg4(p.relu_x + (size_t)m * ldc + n);
+                    v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f;
+                    v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
+                }
                 *reinterpret_cast<float4 *>(dst) = v;
             }
         }
@@ -585,7 +591,7 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ sla
 // FWD / BWD_DATA split-K epilogue: out[m][n] = (accumulate ? out : 0) + sum_s slab[s][m][n] + bias[n], optional ReLU.
 __global__ __launch_bounds__(256) void k_sum_slabs_ep(const float *__restrict__ slabs, float *__restrict__ out, size_t n4,
                                                       int ksplit, int ldc4, const float *__restrict__ bias, int relu,
-                                                      int accumulate) {
+                                                      int accumulate, const float *__restrict__ relu_x) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     float4 s = accumulate ? ldg4(out + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -598,6 +604,10 @@ __global__ __launch_bounds__(256) void k_sum_slabs_ep(const float *__restrict__ 
         s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
     }
     if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    if (relu_x) {
+        const float4 xm = ldg4(relu_x + i * 4);
+        s.x = xm.x > 0.f ? s.x : 0.f; s.y = xm.y > 0.f ? s.y : 0.f; s.z = xm.z > 0.f ? s.z : 0.f; s.w = xm.w > 0.f ? s.w : 0.f;
+    }
     *reinterpret_cast<float4 *>(out + i * 4) = s;
 }
 
@@ -605,7 +615,8 @@ __global__ __launch_bounds__(256) void k_sum_slabs_ep(const float *__restrict__ 
 // accumulate; one thread per float4 of the bm x bn tile.
 __global__ __launch_bounds__(256) void k_tail_sum(const float *__restrict__ slab, float *__restrict__ c,
                                                   const float *__restrict__ bias, int relu, int accumulate, int M, int Ng,
-                                                  int ldc, int tiles_n, int tail_full, int ks, int bm, int bn) {
+                                                  int ldc, int tiles_n, int tail_full, int ks, int bm, int bn,
+                                                  const float *__restrict__ relu_x) {
     const int e4 = blockIdx.x * 256 + threadIdx.x;
     if (e4 * 4 >= bm * bn) return;
     const int tile = tail_full + blockIdx.y;
@@ -625,6 +636,10 @@ __global__ __launch_bounds__(256) void k_tail_sum(const float *__restrict__ slab
         s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
     }
     if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    if (relu_x) {
+        const float4 xm = ldg4(relu_x + (size_t)m * ldc + n);
+        s.x = xm.x > 0.f ? s.x : 0.f; s.y = xm.y > 0.f ? s.y : 0.f; s.z = xm.z > 0.f ? s.z : 0.f; s.w = xm.w > 0.f ? s.w : 0.f;
+    }
     *reinterpret_cast<float4 *>(dst) = s;
 }
 
@@ -807,14 +822,14 @@ int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes
         hipLaunchKernelGGL(k_tail_sum, dim3(mrcnn::cdiv(t.bm * t.bn / 4, 256), tiles - p.tail_full), dim3(256), 0, st, p.slab, p.c,
                            MODE == MODE_FWD ? p.bias : nullptr, MODE == MODE_FWD ? p.relu : 0,
                            MODE == MODE_BWD_DATA ? p.accumulate : 0, p.M, p.Ng, (int)ldc, p.tiles_n, p.tail_full, p.tail_ks,
-                           t.bm, t.bn);
+                           t.bm, t.bn, MODE == MODE_BWD_DATA ? p.relu_x : nullptr);
         MRCNN_LAUNCH_CHECK();
     }
     if (p.ksplit > 1) {
         const size_t n4 = (size_t)p.M * ldc / 4;
         hipLaunchKernelGGL(k_sum_slabs_ep, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, p.slab, p.c, n4, p.ksplit, (int)(ldc / 4),
                            MODE == MODE_FWD ? p.bias : nullptr, MODE == MODE_FWD ? p.relu : 0,
-                           MODE == MODE_BWD_DATA ? p.accumulate : 0);
+                           MODE == MODE_BWD_DATA ? p.accumulate : 0, MODE == MODE_BWD_DATA ? p.relu_x : nullptr);
         MRCNN_LAUNCH_CHECK();
     }
     return 0;
@@ -851,7 +866,7 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
     return run_data_conv<MODE_FWD>(p, nsteps, Cout, ws, ws_bytes, (hipStream_t)stream);
 }
 
-extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, int N, int H, int W,
+extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, const float *relu_x, int N, int H, int W,
                                          int Cin, int Cout, int KH, int KW, int stride, int pad,
                                          int accumulate, void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_conv(gy, w, gx, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
@@ -860,7 +875,8 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
                                                     "handled by the host as a subsample + stride-1 conv)", stride);
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
-    p.a = gy; p.b = w; p.c = gx; p.accumulate = accumulate;
+    if (relu_x && accumulate) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: relu_x with accumulate");
+    p.a = gy; p.b = w; p.c = gx; p.accumulate = accumulate; p.relu_x = relu_x;
     p.bytes_a = (unsigned)((size_t)N * p.Ho * p.Wo * Cout * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
     p.M = N * H * W; p.Ng = Cin;
     return run_data_conv<MODE_BWD_DATA>(p, KH * KW * (Cout / BK), Cin, ws, ws_bytes, (hipStream_t)stream);

@@ -129,7 +129,9 @@ size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int 
 int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                          void *ws, size_t ws_bytes, void *stream);
-int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, int N, int H, int W, int Cin,
+/* relu_x (nullable, same shape as gx): the layer's input when it is the output of a ReLU; gx is then zeroed where
+ * relu_x <= 0, i.e. the ReLU backward of the layer below is fused into this epilogue (not with accumulate). */
+int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, const float *relu_x, int N, int H, int W, int Cin,
                               int Cout, int KH, int KW, int stride, int pad, int accumulate, void *ws,
                               size_t ws_bytes, void *stream);
 size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW,

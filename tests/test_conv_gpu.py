@@ -114,3 +114,16 @@ def test_conv_tail_split_forward_and_backward_data(hw, k, cin, cout):
     hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (1, H, W, cin), 1, pad, out=out)
     err = (out.cpu().double() - refx).abs().max().item() / refx.abs().max().item()
     assert err < 1e-5, err
+
+
+@pytest.mark.parametrize('case', [(1, 16, 20, 64, 160, 3, 1, 1), (2, 64, 64, 256, 64, 1, 1, 0), (1, 320, 320, 32, 160, 3, 1, 1)])
+def test_conv_backward_data_fused_relu_mask(case):
+    """relu_x: gx is zeroed where the layer's input (a ReLU output) is <= 0 - on the plain, split-K and tail-split paths."""
+    N, H, W, Cin, Cout, K, s, p = case
+    g = torch.Generator().manual_seed(7 + sum(case))
+    x = torch.randn((N, H, W, Cin), generator=g).clamp_min(0).to(DEV)
+    w = (torch.randn((Cout, K, K, Cin), generator=g) / (K * K * Cin) ** 0.5).to(DEV)
+    gy = torch.randn((N, H, W, Cout), generator=g).to(DEV)
+    plain = hnn.conv2d_bwd_data_raw(gy, w, tuple(x.shape), s, p)
+    fused = hnn.conv2d_bwd_data_raw(gy, w, tuple(x.shape), s, p, relu_x=x)
+    assert torch.equal(fused, torch.where(x > 0, plain, torch.zeros_like(plain)))
