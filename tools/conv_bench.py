@@ -10,6 +10,11 @@ SHAPES = [  # N, H, W, Cin, Cout, k, pad
     (2, 64, 64, 1024, 256, 1, 0), (2, 64, 64, 256, 1024, 1, 0), (2, 128, 128, 128, 128, 3, 1),
     (2, 256, 256, 64, 256, 1, 0), (2, 256, 256, 64, 64, 3, 1), (2, 32, 32, 512, 512, 3, 1), (512, 1, 1, 12544, 1024, 1, 0),
 ]
+if os.environ.get('CONV_BENCH_SET') == 'medium':
+    SHAPES = [(2, 128, 128, 128, 128, 3, 1), (2, 64, 64, 256, 256, 3, 1), (2, 64, 64, 1024, 256, 1, 0), (2, 64, 64, 256, 1024, 1, 0),
+              (2, 128, 128, 128, 512, 1, 0), (2, 128, 128, 512, 128, 1, 0), (2, 32, 32, 512, 512, 3, 1), (2, 32, 32, 512, 2048, 1, 0),
+              (2, 32, 32, 2048, 512, 1, 0), (2, 256, 256, 64, 64, 3, 1), (2, 256, 256, 64, 256, 1, 0), (2, 256, 256, 256, 64, 1, 0),
+              (2, 16, 16, 256, 256, 3, 1), (2, 128, 128, 256, 256, 3, 1)]
 def timeit(f, n=20):
     for _ in range(3): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
