@@ -1,0 +1,234 @@
+"""CPU tests of the host data pipeline: COCO index + mask decoding without pycocotools, the
+reference's loaders and transforms, the prefetching batch loader.  A tiny COCO-format dataset is written to a
+temporary directory (lossless PNG files, so pixel values can be checked)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'chainer-maskrcnn_amd'))
+
+from chainer_maskrcnn.dataset import coco_api, transforms  # noqa: E402
+from chainer_maskrcnn.dataset.coco_dataset import COCOMaskLoader, COCOKeypointsLoader  # noqa: E402
+from chainer_maskrcnn.dataset.loader import BatchLoader, collate  # noqa: E402
+
+
+def _rle_to_string(cnts):
+    """maskApi.c rleToString (test-side inverse of rle_from_string)."""
+    s = bytearray()
+    for i, c in enumerate(cnts):
+        x = int(c)
+        if i > 2:
+            x -= int(cnts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1f
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            s.append(ch + 48)
+    return bytes(s).decode('ascii')
+
+
+def test_rle_string_roundtrip_and_decode():
+    rs = np.random.RandomState(0)
+    for _ in range(20):
+        h, w = rs.randint(3, 40, 2)
+        m = (rs.rand(h, w) < 0.4).astype(np.uint8)
+        flat = m.T.reshape(-1)                       # column-major
+        change = np.flatnonzero(np.diff(flat)) + 1
+        runs = np.diff(np.concatenate([[0], change, [flat.size]]))
+        if flat[0] == 1:
+            runs = np.concatenate([[0], runs])
+        s = _rle_to_string(runs)
+        np.testing.assert_array_equal(coco_api.rle_from_string(s), runs)
+        np.testing.assert_array_equal(coco_api.rle_decode(runs, h, w), m)
+    with pytest.raises(ValueError):
+        coco_api.rle_decode([3, 2], 2, 2)
+
+
+def test_polygon_box_covers_exactly_its_pixels():
+    # pycocotools: an axis-aligned integer box polygon has area w*h and covers rows y..y+h-1, columns x..x+w-1
+    for (x, y, w, h) in [(2, 3, 5, 6), (0, 0, 4, 4), (7, 1, 1, 9)]:
+        poly = np.array([x, y, x + w, y, x + w, y + h, x, y + h], np.float64)
+        m = coco_api.rle_decode(coco_api.rle_from_polygon(poly, 12, 14), 12, 14)
+        want = np.zeros((12, 14), np.uint8)
+        want[y:y + h, x:x + w] = 1
+        np.testing.assert_array_equal(m, want)
+
+
+def test_polygon_interior_and_exterior_pixels():
+    rs = np.random.RandomState(3)
+    H, W = 60, 70
+    yy, xx = np.mgrid[0:H, 0:W]
+    for _ in range(10):
+        c = rs.uniform(20, 40, 2)
+        ang = np.sort(rs.uniform(0, 2 * np.pi, 7))
+        rad = rs.uniform(8, 18, 7)
+        px, py = c[0] + rad * np.cos(ang), c[1] + rad * np.sin(ang)        # star-shaped => simple polygon
+        m = coco_api.rle_decode(coco_api.rle_from_polygon(np.stack([px, py], 1).reshape(-1), H, W), H, W)
+
+        def signed_margin(qx, qy):      # > 0 inside; distance to the boundary
+            inside = np.zeros(qx.shape, bool)
+            dist = np.full(qx.shape, np.inf)
+            n = len(px)
+            for i in range(n):
+                x0, y0, x1, y1 = px[i], py[i], px[(i + 1) % n], py[(i + 1) % n]
+                cond = ((y0 > qy) != (y1 > qy)) & (qx < (x1 - x0) * (qy - y0) / (y1 - y0 + 1e-30) + x0)
+                inside ^= cond
+                t = np.clip(((qx - x0) * (x1 - x0) + (qy - y0) * (y1 - y0)) / ((x1 - x0) ** 2 + (y1 - y0) ** 2), 0, 1)
+                dist = np.minimum(dist, np.hypot(qx - (x0 + t * (x1 - x0)), qy - (y0 + t * (y1 - y0))))
+            return np.where(inside, dist, -dist)
+        # maskApi samples on pixel corners of a x5 grid: pixels well inside are set, pixels well outside are clear
+        mar = signed_margin(xx + 0.5, yy + 0.5)
+        assert m[mar > 1.0].all()
+        assert not m[mar < -1.0].any()
+        assert abs(int(m.sum()) - int((mar > 0).sum())) <= 0.12 * (mar > 0).sum()
+
+
+def test_resize_linear_matches_oracle_restatement_and_nearest_rule():
+    from oracle.predict import cv2_resize_linear_f32
+    rs = np.random.RandomState(1)
+    for (h, w, oh, ow) in [(7, 9, 20, 13), (30, 40, 12, 57), (5, 5, 5, 5), (16, 16, 32, 32), (33, 21, 11, 7)]:
+        img = rs.rand(3, h, w).astype(np.float32) * 255
+        got = transforms.resize_linear(img, (oh, ow))
+        for c in range(3):
+            np.testing.assert_array_equal(got[c], cv2_resize_linear_f32(img[c], (ow, oh)))
+        m = rs.randint(0, 2, (h, w)).astype(np.uint8)
+        n = transforms.resize_nearest(m, (oh, ow))
+        for y in range(oh):
+            for x in range(ow):
+                assert n[y, x] == m[min(int(np.floor(y * (h / oh))), h - 1), min(int(np.floor(x * (w / ow))), w - 1)]
+
+
+@pytest.fixture(scope='module')
+def tiny_coco(tmp_path_factory):
+    from PIL import Image
+    root = tmp_path_factory.mktemp('coco')
+    os.makedirs(root / 'annotations')
+    os.makedirs(root / 'train2017')
+    rs = np.random.RandomState(5)
+    images, anns = [], []
+    cats = [{'id': 1, 'name': 'person'}, {'id': 7, 'name': 'train'}, {'id': 90, 'name': 'toothbrush'}]
+    sizes = [(48, 64), (80, 60), (50, 50), (64, 96)]
+    aid = 1
+    for i, (h, w) in enumerate(sizes):
+        arr = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        Image.fromarray(arr).save(root / 'train2017' / ('img%d.png' % i))
+        images.append({'id': 100 + i, 'file_name': 'img%d.png' % i, 'height': h, 'width': w})
+        np.save(root / ('img%d.npy' % i), arr)
+    # image 0: a polygon person + an RLE train; image 1: toothbrush box polygon + tiny person; image 2: only a train; image 3: none
+    anns.append({'id': aid, 'image_id': 100, 'category_id': 1, 'bbox': [10.6, 5.2, 20.9, 30.7], 'iscrowd': 0,
+                 'segmentation': [[10, 5, 31, 5, 31, 36, 10, 36]], 'keypoints': [12, 8, 2] * 17, 'num_keypoints': 17}); aid += 1
+    m = np.zeros((48, 64), np.uint8); m[20:30, 40:60] = 1
+    flat = m.T.reshape(-1); change = np.flatnonzero(np.diff(flat)) + 1
+    runs = np.diff(np.concatenate([[0], change, [flat.size]])).tolist()
+    anns.append({'id': aid, 'image_id': 100, 'category_id': 7, 'bbox': [40, 20, 20, 10], 'iscrowd': 1,
+                 'segmentation': {'size': [48, 64], 'counts': runs}}); aid += 1
+    anns.append({'id': aid, 'image_id': 101, 'category_id': 90, 'bbox': [5, 6, 30, 40], 'iscrowd': 0,
+                 'segmentation': [[5, 6, 35, 6, 35, 46, 5, 46]]}); aid += 1
+    anns.append({'id': aid, 'image_id': 101, 'category_id': 1, 'bbox': [1, 1, 0.4, 0.2], 'iscrowd': 0,
+                 'segmentation': [[1, 1, 2, 1, 2, 2]], 'keypoints': [0, 0, 0] * 17, 'num_keypoints': 0}); aid += 1
+    anns.append({'id': aid, 'image_id': 102, 'category_id': 7, 'bbox': [0, 0, 50, 50], 'iscrowd': 0,
+                 'segmentation': {'size': [50, 50], 'counts': _rle_to_string([0, 2500])}}); aid += 1
+    ds = {'images': images, 'annotations': anns, 'categories': cats}
+    json.dump(ds, open(root / 'annotations' / 'instances_train2017.json', 'w'))
+    kp = {'images': images, 'categories': cats[:1], 'annotations': [a for a in anns if a['category_id'] == 1]}
+    json.dump(kp, open(root / 'annotations' / 'person_keypoints_train2017.json', 'w'))
+    return root
+
+
+def test_mask_loader_mirrors_reference_semantics(tiny_coco):
+    root = str(tiny_coco)
+    ds = COCOMaskLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017',
+                        category_filter=['person', 'toothbrush'])
+    assert ds.cat_ids == [1, 90]
+    assert [n for n, _ in ds.img_infos] == ['img0.png', 'img1.png']              # OR over the categories; img2 has only a train
+    img, bbox, label, masks = ds.get_example(0)
+    np.testing.assert_array_equal(img, np.load(root + '/img0.npy').transpose(2, 0, 1).astype(np.float32))
+    np.testing.assert_array_equal(bbox, [[5, 10, 35, 30]])                        # int-truncated x,y,w,h -> y1,x1,y2,x2
+    np.testing.assert_array_equal(label, [0])
+    assert masks[0].shape == (48, 64) and masks[0][5:36, 10:31].all() and masks[0].sum() == 31 * 21
+    img, bbox, label, masks = ds.get_example(1)
+    np.testing.assert_array_equal(label, [1, 0])                                  # index in the filtered category list
+    np.testing.assert_array_equal(bbox[1], [1, 1, 1, 1])                          # w = h = 0 after truncation
+    assert ds._contain_large_enough_annotation(101) and not ds._contain_large_annotation_only(101)
+    with pytest.raises(IndexError):
+        ds.get_example(2)
+    allc = COCOMaskLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017')
+    assert len(allc) == 3
+    i = [n for n, _ in allc.img_infos].index('img0.png')
+    _, _, label, masks = allc.get_example(i)
+    np.testing.assert_array_equal(label, [0, 1])
+    assert masks[1][20:30, 40:60].all() and masks[1].sum() == 200                 # uncompressed RLE
+    i = [n for n, _ in allc.img_infos].index('img2.png')
+    assert allc.get_example(i)[3][0].all()                                        # compressed RLE string
+    with pytest.raises(ValueError):
+        COCOMaskLoader(split='test')
+
+
+def test_keypoint_loader(tiny_coco):
+    root = str(tiny_coco)
+    ds = COCOKeypointsLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017')
+    assert len(ds) == 2
+    img, bbox, kps = ds.get_example(1)
+    assert kps.shape == (1, 17, 3)
+    np.testing.assert_array_equal(bbox, [[1, 1, 2, 2]])                           # w, h clamped to >= 1
+
+
+class _Sizes(object):
+    min_size, max_size = 96, 128
+
+
+def test_transform_and_collate(tiny_coco):
+    root = str(tiny_coco)
+    ds = COCOMaskLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017')
+    tf = transforms.Transform(_Sizes())
+    i0 = [n for n, _ in ds.img_infos].index('img0.png')
+    raw = ds.get_example(i0)
+    img, bbox, label, masks, scale = tf(raw)
+    assert img.shape == (3, 96, 128) and masks.shape == (2, 96, 128) and masks.dtype == np.uint8      # 48x64 * 2
+    assert scale == 2.0 and img.max() <= 1.0
+    np.testing.assert_allclose(bbox[0], [10, 20, 71, 61])                        # (5,10,35,30)*2, then y2,x2 += 1
+    i1 = [n for n, _ in ds.img_infos].index('img1.png')
+    ex1 = tf(ds.get_example(i1))
+    assert ex1[0].shape == (3, 128, 96)                                           # 80x60: long side capped at 128
+    b = collate([tf(raw), ex1])
+    assert b['imgs'].shape == (2, 3, 128, 128) and b['masks'].shape == (2, 2, 128, 128)
+    assert (b['imgs'][0, :, 96:] == 0).all() and (b['masks'][1, :, :, 96:] == 0).all()
+    np.testing.assert_array_equal(b['labels'], [[0, 1], [2, 0]])
+    b1 = collate([tf(raw)], max_gt=4)
+    np.testing.assert_array_equal(b1['labels'], [[0, 1, -1, -1]])
+    kt = transforms.KeypointTransform(_Sizes())
+    kd = COCOKeypointsLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017')
+    img, bbox, label, kp, scale = kt(kd.get_example(0))
+    np.testing.assert_allclose(kp[0, 0], [8 * scale, 12 * scale, 2])              # (x,y,v) -> (y,x,v) scaled
+    assert label.tolist() == [0]
+
+
+def test_batch_loader_order_sharding_and_padding(tiny_coco):
+    root = str(tiny_coco)
+    ds = COCOMaskLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017')
+    tf = transforms.Transform(_Sizes())
+
+    def take(rank, world, n, workers):
+        ld = BatchLoader(ds, tf, batch_size=1, shuffle=True, seed=3, rank=rank, world=world, num_workers=workers, max_gt=3)
+        out = [next(ld) for _ in range(n)]
+        ld.close()
+        return out
+    a, b = take(0, 1, 7, 1), take(0, 1, 7, 3)
+    for x, y in zip(a, b):                                # deterministic order whatever the worker count
+        np.testing.assert_array_equal(x['imgs'], y['imgs'])
+        np.testing.assert_array_equal(x['labels'], y['labels'])
+    assert a[0]['labels'].shape == (1, 3) and a[0]['imgs'].shape[2] % 64 == 0
+    r0, r1 = take(0, 2, 3, 2), take(1, 2, 3, 2)
+    perm = np.random.RandomState(3).permutation(3)
+    shapes = {i: tf(ds[i])[0].shape for i in range(3)}
+    for k, batch in enumerate(r0[:2]):
+        idx = perm[0::2][k % 2] if k < 2 else None
+        assert batch['imgs'][0, :, :shapes[idx][1], :shapes[idx][2]].shape == shapes[idx]
+    assert not np.array_equal(r0[0]['imgs'].shape, ()) and r1[0]['imgs'].shape[0] == 1

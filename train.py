@@ -3,8 +3,10 @@
 model, :107-109 optimizer, :117-132 updater wiring, :134-161 snapshot / LR shift / log), on the MI355X-native path.
 
 The reference's train.py imports chainer / chainercv / chainerui / cv2 / pycocotools (train.py:1-8), none of which
-exist on the target machine, so this is the repo's own counterpart: same CLI, synthetic COCO-shaped data
-(--synthetic, the default; the COCO loader is a SURVEY.md section 8f "next" row), JSON-lines log in --out.
+exist on the target machine, so this is the repo's own counterpart: same CLI, JSON-lines log in --out.  Data:
+synthetic COCO-shaped batches (--synthetic 1, the default - the box has no dataset), or real COCO through
+chainer_maskrcnn/dataset (--synthetic 0 --anno-dir data/annotations --img-dir data --data-type 2017: the
+reference's COCOMaskLoader / COCOKeypointsLoader + Transform, a prefetching loader, no pycocotools / cv2).
 Multi GPU: launch with `python -m torch.distributed.run --nproc-per-node N train.py --multi-gpu 1 ...`
 (one process per GPU, RCCL all-reduce of the flat gradient buffer; the reference forks 8 workers itself).
 """
@@ -39,7 +41,12 @@ def build_parser(keypoints=False):
         parser.add_argument('--head-arch', '-a', type=str, default='fpn')
         parser.add_argument('--multi-gpu', '-m', type=int, default=0)
         parser.add_argument('--batch-size', '-b', type=int, default=1)
-    parser.add_argument('--synthetic', type=int, default=1, help='synthetic COCO-shaped batches (only data source on this path)')
+    parser.add_argument('--synthetic', type=int, default=1, help='1: synthetic COCO-shaped batches; 0: COCO from --anno-dir / --img-dir')
+    parser.add_argument('--anno-dir', default='data/annotations')
+    parser.add_argument('--img-dir', default='data')
+    parser.add_argument('--data-type', default='2017')
+    parser.add_argument('--num-workers', type=int, default=8, help='decode / transform threads of the COCO loader')
+    parser.add_argument('--max-gt', type=int, default=0, help='instances kept per image (0: all; static shapes when > 0)')
     parser.add_argument('--image-size', type=int, nargs=2, default=[800, 800])
     parser.add_argument('--log-interval', type=int, default=100)
     parser.add_argument('--snapshot-interval', type=int, default=5000)
@@ -71,6 +78,10 @@ def run(args, keypoints=False):
                 n_fg = len(f.read().strip().split('\n'))
         faster_rcnn = MaskRCNN(n_fg_class=n_fg, backbone=args.backbone, head_arch=args.head_arch, device=dev)
         model = FPNMaskRCNNTrainChain(faster_rcnn, mask_loss_fun=calc_mask_loss)
+    labels = None
+    if not keypoints and os.path.exists(args.label_file):
+        with open(args.label_file) as f:
+            labels = f.read().strip().split('\n')
     faster_rcnn.use_preset('evaluate')
     if args.weight and os.path.exists(args.weight):
         load_npz(args.weight, faster_rcnn)
@@ -85,11 +96,30 @@ def run(args, keypoints=False):
     log = open(os.path.join(args.out, 'log'), 'a') if rank == 0 else None
     keys = ('loss', 'rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
     acc = {k: 0.0 for k in keys}
+    loader = None
+    if not args.synthetic:          # train.py:111-126: COCOMaskLoader(category_filter=labels, data_type='2017') + Transform
+        from chainer_maskrcnn.dataset.coco_dataset import COCOMaskLoader, COCOKeypointsLoader
+        from chainer_maskrcnn.dataset.transforms import Transform, KeypointTransform
+        from chainer_maskrcnn.dataset.loader import BatchLoader
+        if keypoints:
+            data = COCOKeypointsLoader(anno_dir=args.anno_dir, img_dir=args.img_dir, data_type=args.data_type)
+            tf = KeypointTransform(faster_rcnn)
+        else:
+            data = COCOMaskLoader(anno_dir=args.anno_dir, img_dir=args.img_dir, data_type=args.data_type, category_filter=labels)
+            tf = Transform(faster_rcnn)
+        loader = BatchLoader(data, tf, batch_size=bs, shuffle=True, seed=1234, rank=rank, world=world,
+                             num_workers=args.num_workers, max_gt=args.max_gt or None, keypoints=keypoints, device=dev)
     t0 = time.time()
     for it in range(1, args.iteration + 1):
-        b = make_batch(it * world + rank, bs, H, W, G=8, n_fg_class=n_fg, n_keypoints=K)
-        batch = [torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')]
-        optimizer.update(model, *batch, 1.0)
+        if loader is not None:
+            b = next(loader)
+            batch = [b[k] for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')]
+            scale = float(b['scales'][0])
+        else:
+            b = make_batch(it * world + rank, bs, H, W, G=8, n_fg_class=n_fg, n_keypoints=K)
+            batch = [torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')]
+            scale = 1.0
+        optimizer.update(model, *batch, scale)
         if it % args.log_interval == 0 or it == args.iteration:       # one device->host sync per log interval
             obs = {k: float(v) for k, v in model.observation.items()}
             if any(not np.isfinite(v) for v in obs.values()):
