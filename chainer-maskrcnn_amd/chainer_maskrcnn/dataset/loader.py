@@ -44,6 +44,38 @@ def collate(examples, max_gt=None, keypoints=False, size_multiple=64):
     return out
 
 
+class _PinnedRing(object):
+    """Persistent pinned staging buffers (pinning memory per batch costs milliseconds): K slots, each a grow-only byte
+    buffer per tensor name; a slot is reused only after the copies issued from it have completed (event)."""
+
+    def __init__(self, slots=3):
+        self.slots = [dict(bufs={}, event=None) for _ in range(slots)]
+        self.i = 0
+
+    def next_slot(self):
+        slot = self.slots[self.i % len(self.slots)]
+        self.i += 1
+        if slot['event'] is not None:
+            slot['event'].synchronize()
+        return slot
+
+    @staticmethod
+    def upload(slot, name, arr, dev):
+        import torch
+        arr = np.ascontiguousarray(arr)
+        n = arr.nbytes
+        buf = slot['bufs'].get(name)
+        if buf is None or buf.numel() < n:
+            buf = torch.empty((max(n, 1) * 5 // 4,), dtype=torch.uint8).pin_memory()
+            slot['bufs'][name] = buf
+        if n:       # NumPy copy: a torch CPU copy_ fans out over every core of the box (OpenMP) and starves the workers
+            np.copyto(buf.numpy()[:n], arr.reshape(-1).view(np.uint8))
+        out = torch.empty(arr.shape, dtype=torch.from_numpy(arr[:0].reshape(-1)).dtype, device=dev)
+        if n:
+            out.view(-1).view(torch.uint8).copy_(buf[:n], non_blocking=True)
+        return out
+
+
 class BatchLoader(object):
     """Endless iterator of device batches.  ``rank``/``world`` shard the (seeded, per-epoch) permutation."""
 
@@ -61,6 +93,7 @@ class BatchLoader(object):
         self._threads += [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, num_workers))]
         self._window = prefetch * batch_size
         self._stream = None
+        self._ring = _PinnedRing()
         for t in self._threads:
             t.start()
 
@@ -114,7 +147,56 @@ class BatchLoader(object):
     def __iter__(self):
         return self
 
+    def _next_device_batch(self):
+        """transform = RawTransform: raw uint8 images / masks are uploaded at their original size and resized on the GPU
+        into the padded batch tensors (10x fewer PCIe bytes, no host resize)."""
+        import torch
+        from chainer_maskrcnn._hip import lib, check, ptr
+        dev = torch.device(self.device)
+        exs = [self._next_example() for _ in range(self.bs)]
+        N = len(exs)
+        G = self.max_gt or max(1, max(e[1].shape[0] for e in exs))
+        H = -(-max(e[5][0] for e in exs) // 64) * 64
+        W = -(-max(e[5][1] for e in exs) // 64) * 64
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        bboxes = np.zeros((N, G, 4), np.float32)
+        labels = np.full((N, G), -1, np.int32)
+        scales = np.zeros((N,), np.float32)
+        slot = self._ring.next_slot()
+        with torch.cuda.stream(self._stream):
+            st = self._stream.cuda_stream
+            imgs = torch.zeros((N, 3, H, W), dtype=torch.float32, device=dev)
+            extra = (torch.zeros((N, G, exs[0][3].shape[1], 3), dtype=torch.float32, device=dev) if self.keypoints
+                     else torch.zeros((N, G, H, W), dtype=torch.uint8, device=dev))
+            keep = []
+            for i, (img, bbox, label, ext, scale, (oh, ow)) in enumerate(exs):
+                g = min(G, bbox.shape[0])
+                bboxes[i, :g], labels[i, :g], scales[i] = bbox[:g], label[:g], scale
+                raw = self._ring.upload(slot, 'img%d' % i, img, dev)
+                check(lib().mrcnn_image_resize_u8_f32(ptr(raw), img.shape[0], img.shape[1], ptr(imgs[i]), oh, ow, H, W, 255.0, st))
+                keep.append(raw)
+                if self.keypoints:
+                    extra[i, :g] = self._ring.upload(slot, 'kp%d' % i, ext[:g], dev)
+                elif g > 0:
+                    m = self._ring.upload(slot, 'mask%d' % i, ext[:g], dev)
+                    check(lib().mrcnn_mask_resize_nearest_u8(ptr(m), g, ext.shape[1], ext.shape[2], ptr(extra[i]), oh, ow, H, W, st))
+                    keep.append(m)
+            out = {'imgs': imgs, 'bboxes': self._ring.upload(slot, 'bboxes', bboxes, dev),
+                   'labels': self._ring.upload(slot, 'labels', labels, dev),
+                   'keypoints' if self.keypoints else 'masks': extra, 'scales': scales}
+            slot['event'] = torch.cuda.Event()
+            slot['event'].record(self._stream)
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_stream(self._stream)
+        for v in list(out.values()) + keep:
+            if torch.is_tensor(v):
+                v.record_stream(cur)
+        return out
+
     def __next__(self):
+        if getattr(self.transform, 'out_size', None) is not None and self.device is not None and str(self.device).startswith('cuda'):
+            return self._next_device_batch()
         batch = collate([self._next_example() for _ in range(self.bs)], self.max_gt, self.keypoints)
         if self.device is None:
             return batch
@@ -125,12 +207,15 @@ class BatchLoader(object):
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=dev)
         out = {}
+        slot = self._ring.next_slot()
         with torch.cuda.stream(self._stream):
             for k, v in batch.items():
                 if k == 'scales':                      # consumed by the host (a float per step): stays a NumPy array
                     out[k] = v
                     continue
-                out[k] = torch.from_numpy(v).pin_memory().to(dev, non_blocking=True)
+                out[k] = self._ring.upload(slot, k, v, dev)
+            slot['event'] = torch.cuda.Event()
+            slot['event'].record(self._stream)
         torch.cuda.current_stream(dev).wait_stream(self._stream)
         for v in out.values():
             if torch.is_tensor(v):

@@ -107,3 +107,33 @@ class KeypointTransform(object):
         kp = keypoints[:, :, [1, 0]]
         kp = np.concatenate([kp * scale, keypoints[:, :, 2, None]], axis=2)
         return img, bbox, label, kp, scale
+
+
+class RawTransform(object):
+    """Host half of the device-side Transform: everything except the two resizes, which run on the GPU
+    (mrcnn_image_resize_u8_f32 / mrcnn_mask_resize_nearest_u8) on the raw uint8 data.  Returns
+    (img_u8 (H,W,3), bbox, label, masks_u8 (G,H,W) | keypoints, scale, (oH,oW))."""
+
+    def __init__(self, faster_rcnn, keypoints=False):
+        self.min_size, self.max_size, self.keypoints = faster_rcnn.min_size, faster_rcnn.max_size, keypoints
+
+    def out_size(self, H, W):
+        scale = self.min_size / min(H, W)
+        if scale * max(H, W) > self.max_size:
+            scale = self.max_size / max(H, W)
+        return int(H * scale), int(W * scale)
+
+    def __call__(self, in_data):
+        img = in_data[0]
+        _, H, W = img.shape
+        o_H, o_W = self.out_size(H, W)
+        scale = o_H / H
+        img_u8 = np.ascontiguousarray(img.transpose(1, 2, 0)).astype(np.uint8)      # decoded JPEGs are integer-valued
+        bbox = resize_bbox(in_data[1], (H, W), (o_H, o_W))
+        if self.keypoints:
+            keypoints = in_data[2].astype(np.float32)
+            kp = np.concatenate([keypoints[:, :, [1, 0]] * scale, keypoints[:, :, 2, None]], axis=2)
+            return img_u8, bbox, np.zeros(bbox.shape[0], dtype=np.int32), kp, scale, (o_H, o_W)
+        bbox[:, 2:] = np.maximum(bbox[:, 2:], bbox[:, 2:] + 1)
+        masks = np.stack([np.asarray(m, np.uint8) for m in in_data[3]]) if len(in_data[3]) else np.zeros((0, H, W), np.uint8)
+        return img_u8, bbox, np.asarray(in_data[2], np.int32), masks, scale, (o_H, o_W)

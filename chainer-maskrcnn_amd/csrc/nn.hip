@@ -536,6 +536,58 @@ __global__ __launch_bounds__(NT) void k_deconv_merge_bwd_w2(const float *__restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Device side of the training Transform (train.py:21-37): the host decodes the JPEG and rasterises the polygons, the
+// raw uint8 image and masks cross PCIe at their ORIGINAL size (10x fewer bytes than the prepared float32 tensors) and
+// are resized here, straight into the (zero-padded) batch tensors.  Interpolation rules = OpenCV's, restated exactly as
+// in chainer_maskrcnn/dataset/transforms.py (bit-identical results: same float operations, no contraction):
+//   INTER_LINEAR  fx = (float)((dx + 0.5) * (src/dst) - 0.5), sx = floor(fx), clamped taps; horizontal then vertical
+//   INTER_NEAREST sx = min(floor(dx * (src/dst)), src - 1)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void linear_tap(int d, int dst, int src, int &s0, int &s1, float &a0, float &a1) {
+    const double scale = 1.0 / ((double)dst / (double)src);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= src - 1) { f = 0.f; s = src - 1; }
+    s0 = s; s1 = min(s + 1, src - 1);
+    a0 = 1.0f - f; a1 = f;
+}
+
+// src (H,W,3) uint8 -> dst[c][y][x] (planes of dst_h x dst_w, written for y < oh, x < ow), values / div
+__global__ __launch_bounds__(NT) void k_image_resize_u8(const uint8_t *__restrict__ src, int H, int W, float *__restrict__ dst,
+                                                        int oh, int ow, int dst_h, int dst_w, float div) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= oh * ow) return;
+    const int y = i / ow, x = i - y * ow;
+    int x0, x1, y0, y1;
+    float a0, a1, b0, b1;
+    linear_tap(x, ow, W, x0, x1, a0, a1);
+    linear_tap(y, oh, H, y0, y1, b0, b1);
+    const uint8_t *r0 = src + (size_t)y0 * W * 3, *r1 = src + (size_t)y1 * W * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float top = (float)r0[x0 * 3 + c] * a0 + (float)r0[x1 * 3 + c] * a1;
+        const float bot = (float)r1[x0 * 3 + c] * a0 + (float)r1[x1 * 3 + c] * a1;
+        dst[((size_t)c * dst_h + y) * dst_w + x] = (top * b0 + bot * b1) / div;
+    }
+}
+
+// src (G,H,W) uint8 -> dst (G, dst_h, dst_w), written for y < oh, x < ow
+__global__ __launch_bounds__(NT) void k_mask_resize_nearest_u8(const uint8_t *__restrict__ src, int G, int H, int W,
+                                                               uint8_t *__restrict__ dst, int oh, int ow, int dst_h, int dst_w) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= (size_t)G * oh * ow) return;
+    const int x = (int)(i % ow);
+    const int y = (int)((i / ow) % oh);
+    const int g = (int)(i / ((size_t)ow * oh));
+    const int sx = min((int)floor((double)x * (1.0 / ((double)ow / (double)W))), W - 1);
+    const int sy = min((int)floor((double)y * (1.0 / ((double)oh / (double)H))), H - 1);
+    dst[((size_t)g * dst_h + y) * dst_w + x] = src[((size_t)g * H + sy) * W + sx];
+}
+
 // v = momentum*v - lr*(g + wd*p); p += v   (Chainer WeightDecay hook then MomentumSGD).  20 B/param.
 __global__ __launch_bounds__(NT) void k_sgd(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ v,
                                             size_t n, float lr, float momentum, float wd) {
@@ -814,6 +866,28 @@ extern "C" int mrcnn_deconv_merge_bwd_f32(const float *G, const float *gb4, cons
     hipLaunchKernelGGL(k_deconv_merge_bwd_wd, dim3(mrcnn::cdiv(t1, NT)), dim3(NT), 0, st, G, gb4, w2, gwd, gbd, gb2, C, Cin, K2, ld2);
     MRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_deconv_merge_bwd_w2, dim3(mrcnn::cdiv(K2 * C * 64, NT)), dim3(NT), 0, st, G, gb4, wd, bd, gw2, C, Cin, K2, ld2);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_image_resize_u8_f32(const uint8_t *src, int H, int W, float *dst, int oh, int ow, int dst_h, int dst_w,
+                                         float div, void *stream) {
+    if (int e = chk(src && dst, "image_resize: null pointer")) return e;
+    if (int e = chk(H > 0 && W > 0 && oh > 0 && ow > 0 && dst_h >= oh && dst_w >= ow, "image_resize: bad sizes")) return e;
+    hipLaunchKernelGGL(k_image_resize_u8, dim3(mrcnn::cdiv(oh * ow, NT)), dim3(NT), 0, (hipStream_t)stream, src, H, W, dst, oh, ow,
+                       dst_h, dst_w, div);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_mask_resize_nearest_u8(const uint8_t *src, int G, int H, int W, uint8_t *dst, int oh, int ow, int dst_h,
+                                            int dst_w, void *stream) {
+    if (G == 0) return 0;
+    if (int e = chk(src && dst, "mask_resize_nearest: null pointer")) return e;
+    if (int e = chk(G > 0 && H > 0 && W > 0 && oh > 0 && ow > 0 && dst_h >= oh && dst_w >= ow, "mask_resize_nearest: bad sizes")) return e;
+    const size_t n = (size_t)G * oh * ow;
+    hipLaunchKernelGGL(k_mask_resize_nearest_u8, dim3((unsigned)mrcnn::cdiv(n, (size_t)NT)), dim3(NT), 0, (hipStream_t)stream, src, G,
+                       H, W, dst, oh, ow, dst_h, dst_w);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

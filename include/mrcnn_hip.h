@@ -202,6 +202,14 @@ int mrcnn_bilinear2x_fwd_f32(const float *x, float *y, int N, int H, int W, int 
 int mrcnn_bilinear2x_bwd_f32(const float *gy, float *gx, int N, int H, int W, int C, void *stream);
 /* x (N,3,H,W) NCHW -> y (N,H,W,4) NHWC with a zero 4th channel (the image layer's operand layout). */
 int mrcnn_image_nchw3_to_nhwc4_f32(const float *x, float *y, int N, int H, int W, void *stream);
+/* Device side of the training Transform (train.py:21-37; chainer_maskrcnn/dataset/transforms.py is the host form):
+ * the raw uint8 image (H,W,3) / instance masks (G,H,W) are resized into planes of a zero-initialised padded batch tensor
+ * (dst_h x dst_w per plane; rows < oh and columns < ow are written).  cv2.resize INTER_LINEAR / INTER_NEAREST
+ * coordinate rules; the image is divided by `div` (255 = MaskRCNN.prepare, maskrcnn.py:274). */
+int mrcnn_image_resize_u8_f32(const uint8_t *src, int H, int W, float *dst, int oh, int ow, int dst_h, int dst_w,
+                              float div, void *stream);
+int mrcnn_mask_resize_nearest_u8(const uint8_t *src, int G, int H, int W, uint8_t *dst, int oh, int ow, int dst_h,
+                                 int dst_w, void *stream);
 /* n uint32 sampler keys from a counter-based hash of (seed, index). */
 int mrcnn_random_keys_u32(uint32_t *out, size_t n, unsigned long long seed, void *stream);
 /* Same with the seed in device memory (state[0]); the call also advances the state, so a replayed HIP graph draws

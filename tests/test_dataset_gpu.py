@@ -62,3 +62,26 @@ def test_coco_files_to_training_step(tmp_path):
             assert obs['mask_loss'] > 0 and obs['rpn_cls_loss'] > 0
     finally:
         ld.close()
+
+
+def test_device_transform_equals_host_transform(tmp_path):
+    """RawTransform + the two resize kernels produce bit-identical batches to the host Transform + collate."""
+    from chainer_maskrcnn.dataset.transforms import RawTransform
+
+    class Sizes(object):
+        min_size, max_size = 200, 256
+    root = str(tmp_path)
+    _write_dataset(root, n_img=5)
+    ds = COCOMaskLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017')
+    host = BatchLoader(ds, Transform(Sizes()), batch_size=2, shuffle=True, seed=2, num_workers=2, max_gt=4, device=DEV)
+    devl = BatchLoader(ds, RawTransform(Sizes()), batch_size=2, shuffle=True, seed=2, num_workers=2, max_gt=4, device=DEV)
+    try:
+        for _ in range(4):
+            a, b = next(host), next(devl)
+            assert torch.equal(a['imgs'], b['imgs'])
+            assert torch.equal(a['masks'], b['masks'])
+            assert torch.equal(a['bboxes'], b['bboxes']) and torch.equal(a['labels'], b['labels'])
+            np.testing.assert_array_equal(a['scales'], b['scales'])
+    finally:
+        host.close()
+        devl.close()

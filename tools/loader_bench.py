@@ -7,7 +7,7 @@ import numpy as np
 from PIL import Image
 from chainer_maskrcnn.dataset.coco_dataset import COCOMaskLoader
 from chainer_maskrcnn.dataset.loader import BatchLoader
-from chainer_maskrcnn.dataset.transforms import Transform
+from chainer_maskrcnn.dataset.transforms import Transform, RawTransform
 
 
 class Sizes(object):
@@ -46,3 +46,18 @@ for workers in (1, 2, 4, 8, 16):
     dt = time.perf_counter() - t0
     ld.close()
     print('workers %2d: %.1f images/s (%d CPUs visible)' % (workers, n / dt, os.cpu_count()))
+
+import torch
+if torch.cuda.is_available():
+    dev = torch.device('cuda:0')
+    for name, t in (('host Transform + H2D of the prepared batch', tf), ('RawTransform + device resize', RawTransform(Sizes()))):
+        for workers in (4, 8, 16):
+            ld = BatchLoader(ds, t, batch_size=2, num_workers=workers, max_gt=8, device=dev)
+            next(ld); torch.cuda.synchronize()
+            t0 = time.perf_counter(); n = 0
+            while time.perf_counter() - t0 < 4.0:
+                b = next(ld); n += 2
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ld.close()
+            print('%-46s workers %2d: %.1f images/s' % (name, workers, n / dt))

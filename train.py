@@ -99,14 +99,14 @@ def run(args, keypoints=False):
     loader = None
     if not args.synthetic:          # train.py:111-126: COCOMaskLoader(category_filter=labels, data_type='2017') + Transform
         from chainer_maskrcnn.dataset.coco_dataset import COCOMaskLoader, COCOKeypointsLoader
-        from chainer_maskrcnn.dataset.transforms import Transform, KeypointTransform
+        from chainer_maskrcnn.dataset.transforms import RawTransform
         from chainer_maskrcnn.dataset.loader import BatchLoader
         if keypoints:
             data = COCOKeypointsLoader(anno_dir=args.anno_dir, img_dir=args.img_dir, data_type=args.data_type)
-            tf = KeypointTransform(faster_rcnn)
+            tf = RawTransform(faster_rcnn, keypoints=True)      # host decodes, the GPU resizes (dataset/loader.py)
         else:
             data = COCOMaskLoader(anno_dir=args.anno_dir, img_dir=args.img_dir, data_type=args.data_type, category_filter=labels)
-            tf = Transform(faster_rcnn)
+            tf = RawTransform(faster_rcnn)
         loader = BatchLoader(data, tf, batch_size=bs, shuffle=True, seed=1234, rank=rank, world=world,
                              num_workers=args.num_workers, max_gt=args.max_gt or None, keypoints=keypoints, device=dev)
     t0 = time.time()
