@@ -131,21 +131,27 @@ class FPNMaskRCNNTrainChain(object):
 
         features = m.extractor(m.to_nhwc4(imgs))
         m.rpn.train = True
-        r = m.rpn.forward_padded(features, img_size, scale)
-
         pk, ak = self.sampler_keys if self.sampler_keys is not None else (None, None)
         losses = torch.empty((5, 2), dtype=torch.float32, device=dev)
-        A = r['anchors'].shape[0]
         main = torch.cuda.current_stream(dev)
         aux = self._aux_stream(dev) if self.use_aux_stream else main
-        # Branch 1 (aux stream): anchor targets + RPN losses (:81-85) - independent of the proposal path
-        aux.wait_stream(main)
-        with torch.cuda.stream(aux):
-            gt_rpn_loc, gt_rpn_label = self.anchor_target_creator(bboxes, r['anchors'], img_size, n_gt=n_gt, keys=ak)
-            _, g_locs = ops.smooth_l1(r['locs'].view(n * A, 4), 4, gt_rpn_loc.view(n * A, 4), gt_rpn_label.view(-1),
-                                      n * A, self.rpn_sigma, out=losses[0])
-            _, g_scores = ops.softmax_ce(r['scores'].view(n * A, 2), gt_rpn_label.view(-1), n * A, 2, (1, 2, 0, 1),
-                                         out=losses[1])
+        br1 = {}
+
+        def rpn_loss_branch(locs, scores, anchors):
+            # Branch 1 (aux stream): anchor targets + RPN losses (:81-85).  It needs the RPN head outputs only, so it is
+            # enqueued before the proposal kernels and runs beside them.
+            A_ = anchors.shape[0]
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                br1['loc'], br1['label'] = self.anchor_target_creator(bboxes, anchors, img_size, n_gt=n_gt, keys=ak)
+                _, br1['g_locs'] = ops.smooth_l1(locs.view(n * A_, 4), 4, br1['loc'].view(n * A_, 4), br1['label'].view(-1),
+                                                 n * A_, self.rpn_sigma, out=losses[0])
+                _, br1['g_scores'] = ops.softmax_ce(scores.view(n * A_, 2), br1['label'].view(-1), n * A_, 2, (1, 2, 0, 1),
+                                                    out=losses[1])
+
+        r = m.rpn.forward_padded(features, img_size, scale, after_heads=rpn_loss_branch)
+        A = r['anchors'].shape[0]
+        gt_rpn_loc, gt_rpn_label, g_locs, g_scores = br1['loc'], br1['label'], br1['g_locs'], br1['g_scores']
         # Branch 2 (main stream): proposals -> sampled RoIs and targets
         t = self.proposal_target_creator.sample_batch(
             r['rois'], r['levels'], r['n_rois'], bboxes, labels, n_gt,

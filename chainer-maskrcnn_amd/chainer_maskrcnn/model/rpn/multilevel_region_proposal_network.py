@@ -59,9 +59,12 @@ class MultilevelRegionProposalNetwork(object):
             self._anchor_cache[key] = torch.from_numpy(np.concatenate(a, axis=0)).to(device)
         return self._anchor_cache[key]
 
-    def forward_padded(self, xs, img_size, scale=1., debug=False):
+    def forward_padded(self, xs, img_size, scale=1., debug=False, after_heads=None):
         """xs: NHWC pyramid levels.  Returns a dict: locs (N,A,4), scores (N,A,2), anchors (A,4) and the
-        padded proposal outputs of ops.rpn_proposals (rois, roi_indices, levels, n_rois)."""
+        padded proposal outputs of ops.rpn_proposals (rois, roi_indices, levels, n_rois).
+        ``after_heads(locs, scores, anchors)`` is called once the head outputs are enqueued and BEFORE the proposal
+        kernels are: work that only needs the head outputs (anchor targets, RPN losses) can be put on another stream
+        there and overlaps the latency-bound proposal chain (decode, radix sort, NMS: ~0.8 ms of tiny kernels)."""
         N = xs[0].shape[0]
         dev = xs[0].device
         shapes = [(x.shape[1], x.shape[2]) for x in xs]
@@ -77,6 +80,8 @@ class MultilevelRegionProposalNetwork(object):
             tape.append((c1, c2, tuple(o.shape), a_off))
             a_off += x.shape[1] * x.shape[2] * self.n_anchor
         self.tape = tape
+        if after_heads is not None:
+            after_heads(locs, scores, anchors)
         pl = self.proposal_layer
         n_pre = pl.n_train_pre_nms if self.train else pl.n_test_pre_nms
         n_post = pl.n_train_post_nms if self.train else pl.n_test_post_nms

@@ -43,5 +43,5 @@ namespace mrcnn {
 // Device radix sort of 64-bit keys (sort.hip; rocPRIM device primitive, the only library call in
 // the library).  tmp == nullptr: returns the temporary-storage size in *tmp_bytes.
 int sort_u64(const unsigned long long *in, unsigned long long *out, size_t n, bool descending, void *tmp,
-             size_t *tmp_bytes, hipStream_t st);
+             size_t *tmp_bytes, hipStream_t st, unsigned end_bit = 64);
 }  // namespace mrcnn

@@ -67,7 +67,8 @@ __device__ __forceinline__ unsigned orderable(float f) {     // monotone float -
 
 __global__ __launch_bounds__(256) void k_decode(const float *__restrict__ locs, const float *__restrict__ scores,
                                                 const float *__restrict__ anchors, int N, int A, float img_h, float img_w,
-                                                float min_size, float *__restrict__ boxes, u64 *__restrict__ keys) {
+                                                float min_size, float *__restrict__ boxes, u64 *__restrict__ keys, int ib,
+                                                int batched) {
     const long long total = (long long)N * A;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int a = (int)(i % A);
@@ -83,26 +84,29 @@ __global__ __launch_bounds__(256) void k_decode(const float *__restrict__ locs, 
         *reinterpret_cast<float4 *>(boxes + (size_t)i * 4) = make_float4(y1, x1, y2, x2);
         const bool ok = (y2 - y1 >= min_size) && (x2 - x1 >= min_size);
         const float sc = scores[(size_t)i * 2 + 1];
-        // [63] valid | [62:31] orderable score | [30:0] anchor index: descending sort => (score desc, index desc)
-        keys[i] = ok ? ((1ull << 63) | ((u64)orderable(sc) << 31) | (u64)a) : 0ull;
+        // [image N-1-n] | valid | orderable score (32) | anchor index (ib bits): ONE descending sort of all images =>
+        // image n's keys land in segment n, ordered (score desc, index desc); invalid keys close their segment
+        const u64 img = batched ? (u64)(N - 1 - (int)(i / A)) << (ib + 33) : 0ull;
+        keys[i] = img | (ok ? ((1ull << (ib + 32)) | ((u64)orderable(sc) << ib) | (u64)a) : 0ull);
     }
 }
 
 // Gather the first n_pre sorted boxes; n_valid[n] = min(n_pre, #valid).
 __global__ __launch_bounds__(256) void k_gather_sorted(const u64 *__restrict__ keys_sorted, const float *__restrict__ boxes,
                                                        int A, int n_pre, float *__restrict__ sboxes,
-                                                       int32_t *__restrict__ sidx, int32_t *__restrict__ n_valid) {
+                                                       int32_t *__restrict__ sidx, int32_t *__restrict__ n_valid, int ib) {
     const int n = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pre || i >= A) return;
     const u64 *ks = keys_sorted + (size_t)n * A;
+    const u64 vbit = 1ull << (ib + 32);
     const u64 k = ks[i];
-    if (k == 0ull) return;
-    const int a = (int)(k & 0x7FFFFFFFull);
+    if (!(k & vbit)) return;
+    const int a = (int)(k & ((1ull << ib) - 1ull));
     *reinterpret_cast<float4 *>(sboxes + ((size_t)n * n_pre + i) * 4) =
         *reinterpret_cast<const float4 *>(boxes + ((size_t)n * A + a) * 4);
     sidx[(size_t)n * n_pre + i] = a;
-    if (i + 1 == n_pre || i + 1 == A || ks[i + 1] == 0ull) n_valid[n] = i + 1;
+    if (i + 1 == n_pre || i + 1 == A || !(ks[i + 1] & vbit)) n_valid[n] = i + 1;
 }
 
 // ---- NMS ---------------------------------------------------------------------------------------
@@ -188,10 +192,22 @@ __global__ __launch_bounds__(NMS_RED_THREADS) void k_nms_reduce(const u64 *__res
         __syncthreads();
         const int K = s_cnt, Wd = nb - c - 1;
         if (K > 0 && Wd > 0 && s_kept < n_post) {
-            for (int idx = tid; idx < K * Wd; idx += NMS_RED_THREADS) {
-                const int b = s_list[idx / Wd], w = c + 1 + idx % Wd;
-                const u64 v = mk[(size_t)(c * 64 + b) * nblk + w];
-                if (v) atomicOr(&rem[w], v);
+            // four independent loads in flight per thread (the loop is latency-bound: ~12 rounds per chunk otherwise)
+            const int total = K * Wd;
+            for (int idx = tid; idx < total; idx += 4 * NMS_RED_THREADS) {
+                u64 v[4];
+                int w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int id = idx + j * NMS_RED_THREADS;
+                    const bool ok = id < total;
+                    const int q = ok ? id / Wd : 0;
+                    w[j] = c + 1 + (ok ? id - q * Wd : 0);
+                    v[j] = ok ? mk[(size_t)(c * 64 + s_list[q]) * nblk + w[j]] : 0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (v[j]) atomicOr(&rem[w[j]], v[j]);
             }
         }
         __syncthreads();
@@ -259,7 +275,7 @@ PropLayout prop_layout(int N, int A, int n_pre, int n_post) {
     L.mask = o; o += al((size_t)N * n_pre * L.nblk * 8);
     L.keep = o; o += al((size_t)N * n_post * 4);
     size_t tb = 0;
-    mrcnn::sort_u64(nullptr, nullptr, (size_t)A, true, nullptr, &tb, nullptr);
+    mrcnn::sort_u64(nullptr, nullptr, (size_t)A * N, true, nullptr, &tb, nullptr);        // one sort over all images
     L.sort_tmp_bytes = tb;
     L.sort_tmp = o; o += al(tb);
     L.total = o;
@@ -316,16 +332,26 @@ extern "C" int mrcnn_rpn_proposals_f32(const float *locs, const float *scores, c
     int32_t *sidx = (int32_t *)(w + L.sidx), *n_valid = (int32_t *)(w + L.n_valid), *keep = (int32_t *)(w + L.keep);
     u64 *mask = (u64 *)(w + L.mask);
     const long long total = (long long)N * A;
+    int ib = 1, nbits = 0;
+    while ((1ll << ib) < A) ++ib;
+    while ((1ll << nbits) < N) ++nbits;
+    const int batched = (33 + ib + nbits <= 64);       // all images in ONE radix sort (a sort is ~16 tiny launches)
     hipLaunchKernelGGL(k_decode, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, locs, scores,
-                       anchors, N, A, img_h, img_w, min_size, boxes, keys);
+                       anchors, N, A, img_h, img_w, min_size, boxes, keys, ib, batched);
     MRCNN_LAUNCH_CHECK();
-    for (int n = 0; n < N; ++n) {
+    if (batched) {
         size_t tb = L.sort_tmp_bytes;
-        if (int e = mrcnn::sort_u64(keys + (size_t)n * A, keys_sorted + (size_t)n * A, (size_t)A, true, w + L.sort_tmp, &tb, st)) return e;
+        if (int e = mrcnn::sort_u64(keys, keys_sorted, (size_t)total, true, w + L.sort_tmp, &tb, st, 33 + ib + nbits)) return e;
+    } else {
+        for (int n = 0; n < N; ++n) {
+            size_t tb = L.sort_tmp_bytes;
+            if (int e = mrcnn::sort_u64(keys + (size_t)n * A, keys_sorted + (size_t)n * A, (size_t)A, true, w + L.sort_tmp, &tb, st,
+                                        33 + ib)) return e;
+        }
     }
     MRCNN_HIP_TRY(hipMemsetAsync(n_valid, 0, sizeof(int32_t) * N, st));
     hipLaunchKernelGGL(k_gather_sorted, dim3(mrcnn::cdiv(n_pre, 256), N), dim3(256), 0, st, keys_sorted, boxes, A, n_pre,
-                       sboxes, sidx, n_valid);
+                       sboxes, sidx, n_valid, ib);
     MRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_nms_mask, dim3(L.nblk, L.nblk, N), dim3(64), 0, st, sboxes, n_valid, n_pre, L.nblk, nms_thresh, mask);
     MRCNN_LAUNCH_CHECK();
