@@ -129,12 +129,16 @@ class FPNMaskRCNNTrainChain(object):
         bboxes = bboxes.contiguous()
         labels = labels.to(i32).contiguous()
 
+        main = torch.cuda.current_stream(dev)
+        aux = self._aux_stream(dev) if self.use_aux_stream else main
+        if getattr(m.head, 'merge_deconv', False):      # composed deconv1*conv2 weights: ready long before the mask branch
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                m.head.compose_deconv(dev)
         features = m.extractor(m.to_nhwc4(imgs))
         m.rpn.train = True
         pk, ak = self.sampler_keys if self.sampler_keys is not None else (None, None)
         losses = torch.empty((5, 2), dtype=torch.float32, device=dev)
-        main = torch.cuda.current_stream(dev)
-        aux = self._aux_stream(dev) if self.use_aux_stream else main
         br1 = {}
 
         def rpn_loss_branch(locs, scores, anchors):

@@ -117,14 +117,31 @@ class FPNRoIMaskHead(object):
         self.mask_tape = (tapes, td, t2, rois_xy5, levels, spatial_scales)
         return m                               # (Rm, mask_size, mask_size, pad32(mask_out_channels)) NHWC
 
-    def _merged_deconv_fwd(self, h):
-        from chainer_maskrcnn._hip import nn as hnn
+    def compose_deconv(self, device):
+        """Composed weights of deconv1 and conv2 for the current parameters.  The train chain calls this at the start of
+        the step on its second stream (the parameters are final then), so the small composition kernel is off the
+        critical path; ``mask_branch`` composes on demand otherwise."""
         dc, c2, C = self.deconv1, self.conv2, self.channels
         K2 = c2.cout_p
-        wm = torch.empty((4 * K2, 1, 1, dc.cin_p), dtype=torch.float32, device=h.device)
-        bm = torch.empty((K2,), dtype=torch.float32, device=h.device)
+        wm = torch.empty((4 * K2, 1, 1, dc.cin_p), dtype=torch.float32, device=device)
+        bm = torch.empty((K2,), dtype=torch.float32, device=device)
         check(lib().mrcnn_deconv_merge_fwd_f32(ptr(dc.W), ptr(self.ps.p(self.deconv_b)), ptr(c2.W), ptr(c2.b), ptr(wm), ptr(bm),
                                                C, dc.cin_p, K2, c2.cin_p, stream_ptr()))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._composed = (wm, bm, ev)
+        return wm, bm, ev
+
+    def _merged_deconv_fwd(self, h):
+        from chainer_maskrcnn._hip import nn as hnn
+        dc, c2 = self.deconv1, self.conv2
+        composed = getattr(self, '_composed', None)
+        self._composed = None                      # valid for one forward pass: the parameters change every step
+        wm, bm, ev = composed if composed is not None else self.compose_deconv(h.device)
+        cur = torch.cuda.current_stream(h.device)
+        cur.wait_event(ev)                         # composed on another stream at the start of the step
+        wm.record_stream(cur)
+        bm.record_stream(cur)
         hnn.LOGICAL = (dc.cin, 4 * c2.cout)
         try:
             d = hnn.conv2d_fwd_raw(h, wm, None, 1, 0, False)
