@@ -61,6 +61,9 @@ struct ConvP {
     // FWD / BWD_DATA tail split: tiles [0, tail_full) are whole, each later tile is computed by tail_ks workgroups
     // (tail_kchunk K steps each, ids >= remap_n = tail_full) that write partial tiles to `slab`.
     int tail_ks, tail_full, tail_kchunk;
+    // FWD as the batched GEMM of the Winograd path: GEMM rows [k*wbatch_rows, (k+1)*wbatch_rows) use weight matrix k
+    // (b + k*Ng*Cin); wbatch_rows is a multiple of every tile height.  0 = ordinary convolution.
+    int wbatch_rows;
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         for (int i = 0; i < NB; ++i) {
             const int n = n0 + r0 + 32 * i;
             colmask |= (n < p.Ng) ? (1u << i) : 0u;
-            b_off[i] = (n < p.Ng ? n : 0) * krow;
+            b_off[i] = ((p.wbatch_rows ? (m0 / p.wbatch_rows) * p.Ng : 0) + (n < p.Ng ? n : 0)) * krow;
         }
     }
 
@@ -835,6 +838,199 @@ int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions with many pixels (mask head, FPN and RPN 3x3 on the
+// fine levels): 2.25x fewer multiplications than the direct form, 77 % of the step's MACs are such layers.
+//   U[k] = G g G^T  (k = 4i+j, one Cout x Cin matrix per k)        filter transform (4 MB, every call: weights change)
+//   V[k] = B^T d B  (one T x Cin matrix per k; T = N * ceil(H/2) * ceil(W/2) tiles)   k_wino_input
+//   M[k] = V[k] U[k]^T                                             ONE launch of the 1x1 forward kernel over 16*Tp rows
+//   Y    = A^T M A + bias, ReLU / accumulate / ReLU mask           k_wino_output
+// Non-fused: V and M cross HBM once each (they are 4x the activation size); measured against the direct kernel below.
+// Backward-data is the same pipeline on gy with the 180-degree-rotated, channel-transposed filter.
+// Sums are in fixed order (bit-reproducible); rounding differs from the direct kernel by a few ulp.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WINO_ROWS = 128;          // Tp = T rounded up to this: a GEMM tile never straddles two k
+
+bool wino_ok(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (KH != 3 || KW != 3 || stride != 1 || pad != 1) return false;
+    // measured on gfx950 (tools/conv_bench.py): with >= 256 channels the GEMMs are deep enough (K >= 256) to win from
+    // 2048 pixels up (+25..45 %); at 128 channels Winograd ties the direct kernel, at 64 it loses; below 2048 pixels the
+    // four launches are latency-bound
+    if (Cin % BK || Cout % BK || Cin < 256 || Cout < 256) return false;
+    const long long T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    if ((long long)N * H * W < 2048) return false;
+    const long long Tp = (T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS;
+    return 16 * Tp < (1ll << 24) && 16 * Tp * std::max(Cin, Cout) < (1ll << 30);    // limits of the GEMM kernel's offsets
+}
+struct WinoLayout { size_t u, v, m, inner, total; long long T, Tp; };
+WinoLayout wino_layout(int N, int H, int W, int Cin, int Cout) {
+    WinoLayout L;
+    L.T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    L.Tp = (L.T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    size_t o = 0;
+    L.u = o; o += al((size_t)16 * Cout * Cin * 4);
+    L.v = o; o += al((size_t)16 * L.Tp * Cin * 4);
+    L.m = o; o += al((size_t)16 * L.Tp * Cout * 4);
+    L.inner = o; o += (size_t)4 * g_cus() * 128 * 128 * sizeof(float);              // tail-split slabs of the GEMM launch
+    L.total = o;
+    return L;
+}
+size_t wino_ws_bytes(int N, int H, int W, int Cin, int Cout) { return wino_layout(N, H, W, Cin, Cout).total; }
+
+// U[k][co][ci] from w (Cout,3,3,Cin).  transposed: the backward-data filter w'[ci][u][v][co] = w[co][2-u][2-v][ci],
+// written as U[k][ci][co] (the GEMM's "Cout" axis is then Cin).
+__global__ __launch_bounds__(256) void k_wino_filter(const float *__restrict__ w, float *__restrict__ U, int Cout, int Cin,
+                                                     int transposed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * Cin) return;
+    const int ci = i % Cin, co = i / Cin;
+    float g[3][3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int uu = transposed ? 2 - u : u, vv = transposed ? 2 - v : v;
+            g[u][v] = w[(((size_t)co * 3 + uu) * 3 + vv) * Cin + ci];
+        }
+    float t[4][3];          // G g
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        t[0][v] = g[0][v];
+        t[1][v] = 0.5f * ((g[0][v] + g[1][v]) + g[2][v]);
+        t[2][v] = 0.5f * ((g[0][v] - g[1][v]) + g[2][v]);
+        t[3][v] = g[2][v];
+    }
+    const size_t stride = (size_t)Cout * Cin;
+    const size_t o = transposed ? (size_t)ci * Cout + co : (size_t)co * Cin + ci;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        U[(size_t)(r * 4 + 0) * stride + o] = t[r][0];
+        U[(size_t)(r * 4 + 1) * stride + o] = 0.5f * ((t[r][0] + t[r][1]) + t[r][2]);
+        U[(size_t)(r * 4 + 2) * stride + o] = 0.5f * ((t[r][0] - t[r][1]) + t[r][2]);
+        U[(size_t)(r * 4 + 3) * stride + o] = t[r][2];
+    }
+}
+
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// V[k][t][c] = (B^T d B)[k], d = the 4x4 input patch of tile t (rows 2ty-1 .. 2ty+2, zero outside).  Thread = (t, 4 channels).
+__global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
+                                                    int th, int tw, long long T, long long Tp) {
+    const int C4 = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * C4) return;
+    const int c = (int)(i % C4) * 4;
+    long long t = i / C4;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int n = (int)(t / ((long long)tw * th));
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = 2 * ty - 1 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ww = 2 * tx - 1 + q;
+            const bool ok = (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W;
+            d[r][q] = ok ? ldg4(x + (((size_t)n * H + h) * W + ww) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float4 b[4][4];         // B^T d
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        b[0][q] = f4sub(d[0][q], d[2][q]);
+        b[1][q] = f4add(d[1][q], d[2][q]);
+        b[2][q] = f4sub(d[2][q], d[1][q]);
+        b[3][q] = f4sub(d[1][q], d[3][q]);
+    }
+    const size_t ks = (size_t)Tp * C;
+    float *o = V + (size_t)t * C + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        *reinterpret_cast<float4 *>(o + (size_t)(r * 4 + 0) * ks) = f4sub(b[r][0], b[r][2]);
+        *reinterpret_cast<float4 *>(o + (size_t)(r * 4 + 1) * ks) = f4add(b[r][1], b[r][2]);
+        *reinterpret_cast<float4 *>(o + (size_t)(r * 4 + 2) * ks) = f4sub(b[r][2], b[r][1]);
+        *reinterpret_cast<float4 *>(o + (size_t)(r * 4 + 3) * ks) = f4sub(b[r][1], b[r][3]);
+    }
+}
+
+// y (2x2 pixels of tile t) = A^T M A + bias, then ReLU | + old y (accumulate) | zeroed where relu_x <= 0.
+__global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ Mb, float *__restrict__ y, int N, int H, int W, int C,
+                                                     int th, int tw, long long T, long long Tp, const float *__restrict__ bias,
+                                                     int relu, int accumulate, const float *__restrict__ relu_x) {
+    const int C4 = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * C4) return;
+    const int c = (int)(i % C4) * 4;
+    long long t = i / C4;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int n = (int)(t / ((long long)tw * th));
+    const size_t ks = (size_t)Tp * C;
+    const float *src = Mb + (size_t)t * C + c;
+    float4 m[4][4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m[k >> 2][k & 3] = ldg4(src + (size_t)k * ks);
+    float4 s[2][4];         // A^T m
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        s[0][q] = f4add(f4add(m[0][q], m[1][q]), m[2][q]);
+        s[1][q] = f4sub(f4sub(m[1][q], m[2][q]), m[3][q]);
+    }
+    const float4 bv = bias ? ldg4(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int h = 2 * ty + a, ww = 2 * tx + b;
+            if (h >= H || ww >= W) continue;
+            float4 v = b == 0 ? f4add(f4add(s[a][0], s[a][1]), s[a][2]) : f4sub(f4sub(s[a][1], s[a][2]), s[a][3]);
+            v = f4add(v, bv);
+            const size_t off = (((size_t)n * H + h) * W + ww) * C + c;
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (accumulate) v = f4add(v, ldg4(y + off));
+            if (relu_x) {
+                const float4 xm = ldg4(relu_x + off);
+                v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f; v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4 *>(y + off) = v;
+        }
+}
+
+// in (N,H,W,Cin) -> out (N,H,W,Cout); w is always the layer's (Cout_layer,3,3,Cin_layer) weight tensor: transposed selects
+// the backward-data filter (then Cin here = the layer's Cout and Cout here = the layer's Cin).
+int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, int Cin, int Cout, bool transposed,
+              const float *bias, int relu, int accumulate, const float *relu_x, void *ws, size_t ws_bytes, hipStream_t st) {
+    const WinoLayout L = wino_layout(N, H, W, Cin, Cout);
+    char *base = (char *)ws;
+    float *U = (float *)(base + L.u), *V = (float *)(base + L.v), *Mb = (float *)(base + L.m);
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    // the layer's weight tensor is (Cout_layer, 3, 3, Cin_layer): forward Cout_layer = Cout; transposed Cout_layer = Cin
+    hipLaunchKernelGGL(k_wino_filter, dim3(mrcnn::cdiv(Cout * Cin, 256)), dim3(256), 0, st, w, U, transposed ? Cin : Cout,
+                       transposed ? Cout : Cin, transposed ? 1 : 0);
+    MRCNN_LAUNCH_CHECK();
+    if (L.Tp > L.T)         // padded rows of V feed the GEMM: keep them finite (their products are never read)
+        for (int k = 0; k < 16; ++k)
+            MRCNN_HIP_TRY(hipMemsetAsync(V + ((size_t)k * L.Tp + L.T) * Cin, 0, (size_t)(L.Tp - L.T) * Cin * 4, st));
+    const long long nin = L.T * (Cin / 4), nout = L.T * (Cout / 4);
+    hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, in, V, N, H, W, Cin, th, tw, L.T, L.Tp);
+    MRCNN_LAUNCH_CHECK();
+    // batched GEMM: 1x1 "convolution" over 16*Tp pixels, weight matrix selected by the row block
+    ConvP p = make_p(1, 1, (int)(16 * L.Tp), Cin, Cout, 1, 1, 1, 0);
+    p.a = V; p.b = U; p.c = Mb;
+    p.bytes_a = (unsigned)((size_t)16 * L.Tp * Cin * 4); p.bytes_b = (unsigned)((size_t)16 * Cout * Cin * 4);
+    p.M = (int)(16 * L.Tp); p.Ng = Cout;
+    p.wbatch_rows = (int)L.Tp;
+    if (int e = run_data_conv<MODE_FWD>(p, Cin / BK, Cout, base + L.inner, ws_bytes - L.inner, st)) return e;
+    hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, Mb, out, N, H, W, Cout, th, tw, L.T,
+                       L.Tp, bias, relu, accumulate, relu_x);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
@@ -851,13 +1047,18 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
     if (b < cap) need = std::max(need, b);
     // tail split: at most one round of workgroup slots of partial 128x128 tiles (<= 4 workgroups per CU)
     const size_t tail = (size_t)4 * g_cus() * 128 * 128 * sizeof(float);
-    return std::max((size_t)need * 16 * sizeof(float), tail);
+    size_t bytes = std::max((size_t)need * 16 * sizeof(float), tail);
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad))           // same call serves forward (Cin->Cout) and backward-data (Cout->Cin)
+        bytes = std::max(bytes, std::max(wino_ws_bytes(N, H, W, Cin, Cout), wino_ws_bytes(N, H, W, Cout, Cin)));
+    return bytes;
 }
 
 extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                                     int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                                     void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cin, Cout))
+        return wino_conv(x, w, y, N, H, W, Cin, Cout, false, bias, relu, 0, nullptr, ws, ws_bytes, (hipStream_t)stream);
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     p.a = x; p.b = w; p.c = y; p.bias = bias; p.relu = relu;
     p.bytes_a = (unsigned)((size_t)N * H * W * Cin * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
@@ -876,6 +1077,8 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
     if (relu_x && accumulate) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: relu_x with accumulate");
+    if (wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cout, Cin))
+        return wino_conv(gy, w, gx, N, H, W, Cout, Cin, true, nullptr, 0, accumulate, relu_x, ws, ws_bytes, (hipStream_t)stream);
     p.a = gy; p.b = w; p.c = gx; p.accumulate = accumulate; p.relu_x = relu_x;
     p.bytes_a = (unsigned)((size_t)N * p.Ho * p.Wo * Cout * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
     p.M = N * H * W; p.Ng = Cin;

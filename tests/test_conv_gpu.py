@@ -127,3 +127,37 @@ def test_conv_backward_data_fused_relu_mask(case):
     plain = hnn.conv2d_bwd_data_raw(gy, w, tuple(x.shape), s, p)
     fused = hnn.conv2d_bwd_data_raw(gy, w, tuple(x.shape), s, p, relu_x=x)
     assert torch.equal(fused, torch.where(x > 0, plain, torch.zeros_like(plain)))
+
+
+# 3x3 / stride 1 / pad 1 layers with >= 2048 pixels and >= 256 channels take the Winograd F(2x2,3x3) path (filter,
+# input and output transforms + one batched 1x1 GEMM launch).  Tolerance 3e-5 of the tensor scale: the transforms add a
+# few ulp to the direct kernel's error; odd sizes exercise the clipped edge tiles and the padded GEMM rows.
+@pytest.mark.parametrize('case', [(2, 48, 48, 256, 256), (1, 67, 63, 256, 288), (3, 40, 36, 320, 256)])
+def test_conv_winograd_forward_and_backward_data(case):
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(31 + sum(case))
+    x = torch.randn((N, H, W, Cin), generator=g)
+    w = torch.randn((Cout, 3, 3, Cin), generator=g) / (9 * Cin) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    ref = _ref_conv(x, w, b, 1, 1)
+    got = hnn.conv2d_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), 1, 1, False)
+    assert torch.equal(got, hnn.conv2d_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), 1, 1, False))       # reproducible
+    err = (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-5, err
+    got = hnn.conv2d_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), 1, 1, True)
+    err = (got.cpu().double() - ref.clamp_min(0)).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-5, err
+    # backward-data: plain, accumulating, and with the fused ReLU mask
+    gy = torch.randn((N, H, W, Cout), generator=g)
+    refx = F.conv_transpose2d(gy.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), None, stride=1,
+                              padding=1).permute(0, 2, 3, 1)
+    gx = hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (N, H, W, Cin), 1, 1)
+    sc = refx.abs().max().item()
+    assert (gx.cpu().double() - refx).abs().max().item() / sc < 3e-5
+    base = torch.randn((N, H, W, Cin), generator=g)
+    out = base.to(DEV).clone()
+    hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (N, H, W, Cin), 1, 1, out=out)
+    assert (out.cpu().double() - (refx + base.double())).abs().max().item() / sc < 3e-5
+    xr = torch.randn((N, H, W, Cin), generator=g).clamp_min(0).to(DEV)
+    fused = hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (N, H, W, Cin), 1, 1, relu_x=xr)
+    assert torch.equal(fused, torch.where(xr > 0, gx, torch.zeros_like(gx)))
