@@ -156,8 +156,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     if (MODE == MODE_BWD_FILTER) {
         by = vid % p.tiles_n; vid /= p.tiles_n;
         bx = vid % p.tiles_m; vid /= p.tiles_m;
-        const int ntap = SMALLC ? 1 : p.KH * p.KW;
-        tap = vid % ntap;                       // kh*KW+kw
+        const int ntap = SMALLC ? 1 : (p.wbatch_rows ? 16 : p.KH * p.KW);
+        tap = vid % ntap;                       // kh*KW+kw (Winograd batch mode: the GEMM index k)
         split = vid / ntap;
     } else {
         int tile;
@@ -255,6 +255,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     int f_sw = 0, f_sh = 0, f_doff = 0, f_wlim = 0, f_hlim = 0, f_wback = 0, f_hback = 0, f_c1off = 0, f_c2off = 0;
     if (MODE == MODE_BWD_FILTER) {
         f_kw = tap % p.KW; f_kh = tap / p.KW;
+        if (p.wbatch_rows) f_kw = f_kh = 0;        // batched 1x1 GEMMs: `tap` selects the operand block, not a shift
         const int xc = SMALLC ? 4 : p.Cin;
 #pragma unroll
         for (int i = 0; i < NA; ++i) f_amask |= (m0 + (fc + 8 * i) * 4 < p.M) ? (1u << i) : 0u;
@@ -280,8 +281,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         divmod_small(q, p.Ho, invH, n, ho);
         f_h0 = ho * p.stride - p.pad;
         f_w0 = wo * p.stride - p.pad;
-        f_off0 = ((n * p.H + f_h0) * p.W + f_w0) * xc;
-        f_aoff = f_pix * p.Cout + m0 + fc * 4;
+        f_off0 = ((n * p.H + f_h0) * p.W + f_w0) * xc + (p.wbatch_rows ? tap * p.wbatch_rows * xc : 0);
+        f_aoff = f_pix * p.Cout + m0 + fc * 4 + (p.wbatch_rows ? tap * p.wbatch_rows * p.Cout : 0);
         const int dq = BK / p.Wo, dW = BK - dq * p.Wo, dN = dq / p.Ho, dH = dq - dN * p.Ho;
         f_sw = dW * p.stride; f_sh = dH * p.stride;
         f_doff = ((dN * p.H + f_sh) * p.W + f_sw) * xc;
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     if (MODE == MODE_FWD) { ldc = p.Cout; cbase = partial ? p.slab + (size_t)split * p.M * ldc : p.c; }
     else if (MODE == MODE_BWD_DATA) { ldc = p.Cin; cbase = partial ? p.slab + (size_t)split * p.M * ldc : p.c; }
     else {
-        ldc = (size_t)taps * (SMALLC ? 4 : p.Cin);
+        ldc = (size_t)(p.wbatch_rows ? 16 : taps) * (SMALLC ? 4 : p.Cin);
         cbase = p.c + (size_t)split * p.Cout * ldc + (SMALLC ? 0 : (size_t)tap * p.Cin);
     }
     if (MODE != MODE_BWD_FILTER && tailchunk) {      // tile-local (BM_ x BN_) slab of chunk `split` of tail tile `tail_idx`
@@ -760,7 +761,7 @@ void filter_plan(const ConvP &p, int &ksplit, int &kchunk) {
     const long long P = (long long)p.N * p.Ho * p.Wo;
     const TileChoice t = filter_tile(p);
     const long long tiles = p.smallc ? (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.KH * p.KW * 4, t.bn)
-                                     : (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.Cin, t.bn) * p.KH * p.KW;
+                                     : (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.Cin, t.bn) * (p.wbatch_rows ? 16 : p.KH * p.KW);
     const long long slots = p.smallc ? slots_of<MODE_BWD_FILTER, 64, 128, true>() : slots_for<MODE_BWD_FILTER>(t.bm, t.bn);
     const long long maxsplit = std::max(1ll, P / (8 * BK));
     long long want = slots / tiles;                               // one full round
@@ -1000,6 +1001,127 @@ __global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ M
         }
 }
 
+// W[k][t][c] = (A dy A^T)[k]: the 2x2 output-gradient tile t, zero outside the image.  Thread = (t, 4 channels).
+__global__ __launch_bounds__(256) void k_wino_gy(const float *__restrict__ gy, float *__restrict__ Wt, int N, int H, int W, int C,
+                                                 int th, int tw, long long T, long long Tp) {
+    const int C4 = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * C4) return;
+    const int c = (int)(i % C4) * 4;
+    long long t = i / C4;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int n = (int)(t / ((long long)tw * th));
+    float4 y[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int h = 2 * ty + a, ww = 2 * tx + b;
+            y[a][b] = (h < H && ww < W) ? ldg4(gy + (((size_t)n * H + h) * W + ww) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 r[4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        r[0][b] = y[0][b];
+        r[1][b] = f4add(y[0][b], y[1][b]);
+        r[2][b] = f4sub(y[0][b], y[1][b]);
+        r[3][b] = f4sub(z, y[1][b]);
+    }
+    const size_t ks = (size_t)Tp * C;
+    float *o = Wt + (size_t)t * C + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<float4 *>(o + (size_t)(q * 4 + 0) * ks) = r[q][0];
+        *reinterpret_cast<float4 *>(o + (size_t)(q * 4 + 1) * ks) = f4add(r[q][0], r[q][1]);
+        *reinterpret_cast<float4 *>(o + (size_t)(q * 4 + 2) * ks) = f4sub(r[q][0], r[q][1]);
+        *reinterpret_cast<float4 *>(o + (size_t)(q * 4 + 3) * ks) = f4sub(z, r[q][1]);
+    }
+}
+
+// gw[co][u][v][ci] (+)= (G^T dU G)[u][v], dU[co][k][ci] = sum over tiles of W[k][t][co] * V[k][t][ci].
+__global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restrict__ dU, float *__restrict__ gw, int Cout, int Cin,
+                                                          int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * Cin) return;
+    const int ci = i % Cin, co = i / Cin;
+    float D[4][4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) D[k >> 2][k & 3] = dU[((size_t)co * 16 + k) * Cin + ci];
+    float r[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[0][j] = D[0][j] + 0.5f * (D[1][j] + D[2][j]);
+        r[1][j] = 0.5f * (D[1][j] - D[2][j]);
+        r[2][j] = 0.5f * (D[1][j] + D[2][j]) + D[3][j];
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        float o[3];
+        o[0] = r[u][0] + 0.5f * (r[u][1] + r[u][2]);
+        o[1] = 0.5f * (r[u][1] - r[u][2]);
+        o[2] = 0.5f * (r[u][1] + r[u][2]) + r[u][3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            float *dst = gw + (((size_t)co * 3 + u) * 3 + v) * Cin + ci;
+            *dst = accumulate ? *dst + o[v] : o[v];
+        }
+    }
+}
+
+struct WinoFLayout { size_t v, w, slabs, du, total; long long T, Tp; int ksplit, kchunk; };
+WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
+    WinoFLayout L;
+    L.T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    L.Tp = (L.T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS;
+    ConvP p = make_p(1, 1, (int)L.Tp, Cin, Cout, 1, 1, 1, 0);
+    p.wbatch_rows = (int)L.Tp;
+    filter_plan(p, L.ksplit, L.kchunk);
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    size_t o = 0;
+    L.v = o; o += al((size_t)16 * L.Tp * Cin * 4);
+    L.w = o; o += al((size_t)16 * L.Tp * Cout * 4);
+    L.slabs = o; o += al((size_t)L.ksplit * Cout * 16 * Cin * 4);
+    L.du = o; o += al((size_t)Cout * 16 * Cin * 4);
+    L.total = o;
+    return L;
+}
+
+int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, int W, int Cin, int Cout, int accumulate, void *ws,
+                    hipStream_t st) {
+    const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
+    char *base = (char *)ws;
+    float *V = (float *)(base + L.v), *Wt = (float *)(base + L.w), *slabs = (float *)(base + L.slabs), *dU = (float *)(base + L.du);
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    if (L.Tp > L.T)         // padded rows are summed by the GEMM: they must be zero
+        for (int k = 0; k < 16; ++k) {
+            MRCNN_HIP_TRY(hipMemsetAsync(V + ((size_t)k * L.Tp + L.T) * Cin, 0, (size_t)(L.Tp - L.T) * Cin * 4, st));
+            MRCNN_HIP_TRY(hipMemsetAsync(Wt + ((size_t)k * L.Tp + L.T) * Cout, 0, (size_t)(L.Tp - L.T) * Cout * 4, st));
+        }
+    const long long nin = L.T * (Cin / 4), nout = L.T * (Cout / 4);
+    hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, x, V, N, H, W, Cin, th, tw, L.T, L.Tp);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_wino_gy, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, gy, Wt, N, H, W, Cout, th, tw, L.T, L.Tp);
+    MRCNN_LAUNCH_CHECK();
+    ConvP p = make_p(1, 1, (int)L.Tp, Cin, Cout, 1, 1, 1, 0);
+    p.wbatch_rows = (int)L.Tp;
+    p.ksplit = L.ksplit; p.kchunk = L.kchunk;
+    p.a = Wt; p.b = V; p.c = L.ksplit > 1 ? slabs : dU;
+    p.bytes_a = (unsigned)((size_t)16 * L.Tp * Cout * 4); p.bytes_b = (unsigned)((size_t)16 * L.Tp * Cin * 4);
+    p.M = Cout; p.Ng = Cin;
+    launch_conv<MODE_BWD_FILTER>(p, 16 * p.ksplit, filter_tile(p), st);
+    MRCNN_LAUNCH_CHECK();
+    if (L.ksplit > 1) {
+        const size_t n4 = (size_t)Cout * 16 * Cin / 4;
+        hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, L.ksplit, 0);
+        MRCNN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_wino_filter_grad, dim3(mrcnn::cdiv(Cout * Cin, 256)), dim3(256), 0, st, dU, gw, Cout, Cin, accumulate);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
 // in (N,H,W,Cin) -> out (N,H,W,Cout); w is always the layer's (Cout_layer,3,3,Cin_layer) weight tensor: transposed selects
 // the backward-data filter (then Cin here = the layer's Cout and Cout here = the layer's Cin).
 int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, int Cin, int Cout, bool transposed,
@@ -1095,6 +1217,7 @@ extern "C" size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, i
     const size_t wsz = (size_t)Cout * KH * KW * Cin * sizeof(float);
     const size_t P = (size_t)N * p.Ho * p.Wo;
     const size_t bias_part = (size_t)col_plan((int)P, Cout).nblk * Cout * sizeof(float);
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) return wino_filter_layout(N, H, W, Cin, Cout).total + bias_part + 256;
     return wsz * ksplit + bias_part + 256;     // slabs are also used for ksplit == 1 when accumulating
 }
 
@@ -1106,6 +1229,20 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     if (!ws || ws_bytes < need) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "conv2d_bwd_filter: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) {
+        const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
+        if (int e = wino_bwd_filter(x, gy, gw, N, H, W, Cin, Cout, accumulate, ws, st)) return e;
+        if (gbias) {
+            float *bias_part = (float *)((char *)ws + L.total);
+            const int P = N * p.Ho * p.Wo;
+            const ColPlan cp = col_plan(P, Cout);
+            hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, gy, bias_part, P, Cout, cp.G, cp.RPI, cp.rows_per_blk);
+            MRCNN_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, 64)), dim3(1024), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
+            MRCNN_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     filter_plan(p, p.ksplit, p.kchunk);
     const size_t wcount = (size_t)Cout * KH * KW * Cin;
     float *slabs = (float *)ws;

@@ -161,3 +161,17 @@ def test_conv_winograd_forward_and_backward_data(case):
     xr = torch.randn((N, H, W, Cin), generator=g).clamp_min(0).to(DEV)
     fused = hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (N, H, W, Cin), 1, 1, relu_x=xr)
     assert torch.equal(fused, torch.where(xr > 0, gx, torch.zeros_like(gx)))
+    # filter gradient (Winograd F(3x3, 2x2)): overwrite, accumulate, bias gradient, reproducibility
+    xd = x.double().requires_grad_(False)
+    wref = torch.autograd.functional.vjp(
+        lambda ww: F.conv2d(xd.permute(0, 3, 1, 2), ww.permute(0, 3, 1, 2), None, stride=1, padding=1).permute(0, 2, 3, 1),
+        w.double(), gy.double())[1]
+    gw, gb = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True)
+    gw2, _ = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True)
+    assert torch.equal(gw, gw2)
+    assert (gw.cpu().double() - wref).abs().max().item() / wref.abs().max().item() < 3e-5
+    gbref = gy.double().sum((0, 1, 2))
+    assert (gb.cpu().double() - gbref).abs().max().item() / gbref.abs().max().item() < 2e-5
+    acc_w, acc_b = (torch.ones_like(gw), torch.ones_like(gb))
+    hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True, gw=acc_w, gb=acc_b, accumulate=True)
+    assert (acc_w.cpu().double() - (wref + 1)).abs().max().item() / wref.abs().max().item() < 3e-5
