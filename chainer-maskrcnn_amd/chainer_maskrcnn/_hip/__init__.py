@@ -40,7 +40,7 @@ def _parse_header(path):
     src = open(path).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     sigs = {}
-    for m in re.finditer(r'\b(int|size_t|const char \*)\s*(mrcnn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', src):
+    for m in re.finditer(r'\b(long long|int|size_t|const char \*)\s*(mrcnn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', src):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         if name in _MANUAL:
             sigs[name] = _MANUAL[name]
@@ -54,7 +54,7 @@ def _parse_header(path):
             else:
                 ty = ' '.join(a.replace('const ', '').split()[:-1])
                 argtypes.append(_CTYPE[ty])
-        sigs[name] = ({'int': c_int, 'size_t': c_size_t}[ret], argtypes)
+        sigs[name] = ({'int': c_int, 'size_t': c_size_t, 'long long': ctypes.c_longlong}[ret], argtypes)
     return sigs
 
 

@@ -20,13 +20,14 @@ LOGICAL = None
 
 
 class _prof(object):
-    def __init__(self, kind, n_out_pix, KH, KW, cin, cout):
+    def __init__(self, kind, n_out_pix, KH, KW, cin, cout, geom=None):
         self.on = PROFILE is not None
         if self.on:
+            executed = lib().mrcnn_conv2d_executed_macs(*geom) if geom is not None else n_out_pix * KH * KW * cin * cout
             if LOGICAL is not None:
                 cin, cout = LOGICAL
             self.rec = [kind, n_out_pix * KH * KW * cin * cout, torch.cuda.Event(enable_timing=True),
-                        torch.cuda.Event(enable_timing=True), (n_out_pix, KH, cin, cout)]
+                        torch.cuda.Event(enable_timing=True), (n_out_pix, KH, cin, cout), executed]
 
     def __enter__(self):
         if self.on:
@@ -74,7 +75,7 @@ def conv2d_fwd_raw(x, w, b, stride, pad, relu):
                     dtype=torch.float32, device=x.device)
     nb = lib().mrcnn_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     ws = workspace(nb, x.device) if nb else None
-    with _prof('fwd', N * y.shape[1] * y.shape[2], KH, KW, Cin, Cout):
+    with _prof('fwd', N * y.shape[1] * y.shape[2], KH, KW, Cin, Cout, (N, H, W, Cin, Cout, KH, KW, stride, pad)):
         check(lib().mrcnn_conv2d_fwd_f32(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cout, KH, KW,
                                          stride, pad, int(relu), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()))
     return y
@@ -90,7 +91,7 @@ def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None, relu_x=None):
     gx = out if acc else torch.empty(x_shape, dtype=torch.float32, device=gy.device)
     nb = lib().mrcnn_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     ws = workspace(nb, gy.device) if nb else None
-    with _prof('bwd_data', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout):
+    with _prof('bwd_data', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout, (N, H, W, Cin, Cout, KH, KW, stride, pad)):
         check(lib().mrcnn_conv2d_bwd_data_f32(ptr(gy), ptr(w), ptr(gx), ptr(relu_x), N, H, W, Cin, Cout, KH, KW,
                                               stride, pad, int(acc), ptr(ws), ws.numel() if ws is not None else 0,
                                               stream_ptr()))
@@ -108,7 +109,7 @@ def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias, gw=None, gb=No
         gb = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     nbytes = lib().mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     ws = workspace(nbytes, x.device)
-    with _prof('bwd_filter', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout):
+    with _prof('bwd_filter', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout, (N, H, W, Cin, Cout, KH, KW, stride, pad)):
         check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x), ptr(gy), ptr(gw), ptr(gb) if want_bias else None, N, H, W, Cin,
                                                 Cout, KH, KW, stride, pad, int(acc), ptr(ws), ws.numel(), stream_ptr()))
     return gw, gb

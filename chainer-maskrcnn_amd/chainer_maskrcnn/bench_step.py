@@ -82,12 +82,14 @@ def bench_step(args, rank, world):
     recs, hnn.PROFILE = hnn.PROFILE, None
     chain.use_aux_stream = True
     agg = {}
-    for kind, macs, e0, e1, _shape in recs:
-        a = agg.setdefault(kind, [0, 0.0, 0.0])
+    for kind, macs, e0, e1, _shape, executed in recs:
+        a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += 2.0 * macs
         a[2] += e0.elapsed_time(e1) * 1e-3
+        a[3] += 2.0 * executed
     flops = sum(a[1] for a in agg.values()) / n_prof
+    exe_flops = sum(a[3] for a in agg.values()) / n_prof
     secs = sum(a[2] for a in agg.values()) / n_prof
     launches = sum(a[0] for a in agg.values()) // n_prof
     ach = flops / secs / 1e12
@@ -105,9 +107,16 @@ def bench_step(args, rank, world):
                      'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
                      'algorithmic_flops_per_step': flops, 'conv_ms_per_step': round(secs * 1e3, 3),
+                     'mfma_executed': {'flops_per_step': exe_flops, 'TFLOPs': round(exe_flops / secs / 1e12, 3),
+                                       'frac_of_peak': round(exe_flops / secs / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
                      'by_kind': {k: {'launches': a[0] // n_prof, 'TFLOPs': round(a[1] / a[2] / 1e12, 3),
+                                     'executed_TFLOPs': round(a[3] / a[2] / 1e12, 3),
                                      'ms': round(a[2] / n_prof * 1e3, 3)} for k, a in agg.items()},
-                     'note': 'HIP events around every conv launch on %d instrumented steps right after the timed region' % n_prof},
+                     'note': 'HIP events around every conv call on %d instrumented steps right after the timed region. '
+                             'achieved = ALGORITHMIC flops (2 x the direct convolution\'s MACs on un-padded channels) / time; the '
+                             '3x3 layers with >= 256 channels run as Winograd F(2x2,3x3) (transforms + batched GEMM inside the '
+                             'bracket), which executes 2.25x fewer MFMA flops than it is credited with: mfma_executed is what the '
+                             'pipes really do (padded channels included)' % n_prof},
     }
     if alt is not None:
         out['config']['images_per_sec_mask_branch_on_positive_rows_only'] = round(alt, 3)

@@ -853,14 +853,16 @@ int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int WINO_ROWS = 128;          // Tp = T rounded up to this: a GEMM tile never straddles two k
 
+int g_wino_min_channels = 256, g_wino_min_pixels = 2048;
+
 bool wino_ok(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     if (KH != 3 || KW != 3 || stride != 1 || pad != 1) return false;
     // measured on gfx950 (tools/conv_bench.py): with >= 256 channels the GEMMs are deep enough (K >= 256) to win from
     // 2048 pixels up (+25..45 %); at 128 channels Winograd ties the direct kernel, at 64 it loses; below 2048 pixels the
     // four launches are latency-bound
-    if (Cin % BK || Cout % BK || Cin < 256 || Cout < 256) return false;
+    if (Cin % BK || Cout % BK || Cin < g_wino_min_channels || Cout < g_wino_min_channels) return false;
     const long long T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
-    if ((long long)N * H * W < 2048) return false;
+    if ((long long)N * H * W < g_wino_min_pixels) return false;
     const long long Tp = (T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS;
     return 16 * Tp < (1ll << 24) && 16 * Tp * std::max(Cin, Cout) < (1ll << 30);    // limits of the GEMM kernel's offsets
 }
@@ -1173,6 +1175,24 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
     if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad))           // same call serves forward (Cin->Cout) and backward-data (Cout->Cin)
         bytes = std::max(bytes, std::max(wino_ws_bytes(N, H, W, Cin, Cout), wino_ws_bytes(N, H, W, Cout, Cin)));
     return bytes;
+}
+
+extern "C" int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels) {
+    if (min_channels < BK || min_pixels < 1) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_winograd_thresholds: min_channels >= %d, min_pixels >= 1", BK);
+    g_wino_min_channels = min_channels;
+    g_wino_min_pixels = min_pixels;
+    return 0;
+}
+
+extern "C" long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    // multiply-accumulates the MFMA pipes actually execute for one pass (forward, backward-data or backward-filter)
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) {
+        const long long T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
+        return 16ll * ((T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS) * Cin * Cout;
+    }
+    const long long Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
+    return (long long)N * Ho * Wo * KH * KW * (Cin == 4 ? 4 : Cin) * Cout;
 }
 
 extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,

@@ -164,3 +164,14 @@ def test_reference_api_surface():
     R = rois.shape[0]
     assert roi_cls_locs.shape == (R, 4) and roi_scores.shape == (R, 81) and mask.shape == (R, 80, 28, 28)
     assert roi_indices.shape == (R,) and R <= 2000
+
+
+def test_step_matches_oracle_with_winograd_everywhere():
+    """The same whole-step parity check with the Winograd thresholds lowered so that every 3x3 / stride-1 layer of the
+    small test network (ResNet conv2's, FPN, RPN, box and mask heads) takes the F(2x2,3x3) kernels in all three passes."""
+    from chainer_maskrcnn import _hip
+    _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(32, 64))
+    try:
+        test_step_losses_and_gradients_match_oracle('all')
+    finally:
+        _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048))

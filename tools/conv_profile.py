@@ -21,7 +21,7 @@ chain.use_aux_stream = False
 opt.update(chain, *args, 1.0)
 torch.cuda.synchronize()
 agg = {}
-for kind, macs, e0, e1, shape in hnn.PROFILE:
+for kind, macs, e0, e1, shape, _ex in hnn.PROFILE:
     a = agg.setdefault((kind,) + shape, [0, 0.0, 0.0])
     a[0] += 1; a[1] += 2.0 * macs; a[2] += e0.elapsed_time(e1)
 tot = sum(a[2] for a in agg.values())
