@@ -63,7 +63,7 @@ struct ConvP {
     int tail_ks, tail_full, tail_kchunk;
     // FWD as the batched GEMM of the Winograd path: GEMM rows [k*wbatch_rows, (k+1)*wbatch_rows) use weight matrix k
     // (b + k*Ng*Cin); wbatch_rows is a multiple of every tile height.  0 = ordinary convolution.
-    int wbatch_rows;
+    int wbatch_rows, wbatch_n;   // wbatch_n = number of GEMMs (16 or 36)
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     if (MODE == MODE_BWD_FILTER) {
         by = vid % p.tiles_n; vid /= p.tiles_n;
         bx = vid % p.tiles_m; vid /= p.tiles_m;
-        const int ntap = SMALLC ? 1 : (p.wbatch_rows ? 16 : p.KH * p.KW);
+        const int ntap = SMALLC ? 1 : (p.wbatch_rows ? p.wbatch_n : p.KH * p.KW);
         tap = vid % ntap;                       // kh*KW+kw (Winograd batch mode: the GEMM index k)
         split = vid / ntap;
     } else {
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     if (MODE == MODE_FWD) { ldc = p.Cout; cbase = partial ? p.slab + (size_t)split * p.M * ldc : p.c; }
     else if (MODE == MODE_BWD_DATA) { ldc = p.Cin; cbase = partial ? p.slab + (size_t)split * p.M * ldc : p.c; }
     else {
-        ldc = (size_t)(p.wbatch_rows ? 16 : taps) * (SMALLC ? 4 : p.Cin);
+        ldc = (size_t)(p.wbatch_rows ? p.wbatch_n : taps) * (SMALLC ? 4 : p.Cin);
         cbase = p.c + (size_t)split * p.Cout * ldc + (SMALLC ? 0 : (size_t)tap * p.Cin);
     }
     if (MODE != MODE_BWD_FILTER && tailchunk) {      // tile-local (BM_ x BN_) slab of chunk `split` of tail tile `tail_idx`
@@ -761,7 +761,7 @@ void filter_plan(const ConvP &p, int &ksplit, int &kchunk) {
     const long long P = (long long)p.N * p.Ho * p.Wo;
     const TileChoice t = filter_tile(p);
     const long long tiles = p.smallc ? (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.KH * p.KW * 4, t.bn)
-                                     : (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.Cin, t.bn) * (p.wbatch_rows ? 16 : p.KH * p.KW);
+                                     : (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.Cin, t.bn) * (p.wbatch_rows ? p.wbatch_n : p.KH * p.KW);
     const long long slots = p.smallc ? slots_of<MODE_BWD_FILTER, 64, 128, true>() : slots_for<MODE_BWD_FILTER>(t.bm, t.bn);
     const long long maxsplit = std::max(1ll, P / (8 * BK));
     long long want = slots / tiles;                               // one full round
@@ -841,229 +841,309 @@ int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions with many pixels (mask head, FPN and RPN 3x3 on the
-// fine levels): 2.25x fewer multiplications than the direct form, 77 % of the step's MACs are such layers.
-//   U[k] = G g G^T  (k = 4i+j, one Cout x Cin matrix per k)        filter transform (4 MB, every call: weights change)
-//   V[k] = B^T d B  (one T x Cin matrix per k; T = N * ceil(H/2) * ceil(W/2) tiles)   k_wino_input
-//   M[k] = V[k] U[k]^T                                             ONE launch of the 1x1 forward kernel over 16*Tp rows
+// Winograd F(m x m, 3x3), m = 2 or 4, for the 3x3 / stride 1 / pad 1 convolutions with >= 256 channels (mask head, FPN
+// and RPN 3x3, res4 / res5 conv2): 2.25x (m = 2) or 4x (m = 4) fewer multiplications than the direct form; 77 % of the
+// step's MACs are such layers.  a = m + 2, nk = a*a (16 or 36), T = N * ceil(H/m) * ceil(W/m) tiles.
+//   U[k] = G g G^T   (one Cout x Cin matrix per k)                 k_wino_filter (every call: the weights change)
+//   V[k] = B^T d B   (one T x Cin matrix per k)                    k_wino_input
+//   M[k] = V[k] U[k]^T                                             ONE launch of the 1x1 forward kernel over nk*Tp rows
 //   Y    = A^T M A + bias, ReLU / accumulate / ReLU mask           k_wino_output
-// Non-fused: V and M cross HBM once each (they are 4x the activation size); measured against the direct kernel below.
-// Backward-data is the same pipeline on gy with the 180-degree-rotated, channel-transposed filter.
-// Sums are in fixed order (bit-reproducible); rounding differs from the direct kernel by a few ulp.
+// Backward-data = the same pipeline on gy with the rotated, channel-transposed filter.  Backward-filter:
+//   dU[k] = sum_t (A dY A^T)[k][t]^T (B^T d B)[k][t]               k_wino_gy, k_wino_input, ONE batched filter-gradient launch
+//   dg    = G^T dU G                                               k_wino_filter_grad
+// Non-fused: V, M cross HBM once each (4x / 2.25x the activation size).  m is chosen per layer to minimise nk * T (m = 4
+// unless the map is tiny or padding waste dominates).  Matrices: Lavin & Gray, points (0, +-1, +-2, inf) for m = 4.
+// Sums are in fixed order (bit-reproducible); rounding differs from the direct kernel (m = 2: a few ulp, m = 4: ~1e-5).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int WINO_ROWS = 128;          // Tp = T rounded up to this: a GEMM tile never straddles two k
 
-int g_wino_min_channels = 256, g_wino_min_pixels = 2048;
+int g_wino_min_channels = 256, g_wino_min_pixels = 2048, g_wino_tile = 0;      // tile 0 = automatic, 2 or 4 = forced
 
 bool wino_ok(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     if (KH != 3 || KW != 3 || stride != 1 || pad != 1) return false;
     // measured on gfx950 (tools/conv_bench.py): with >= 256 channels the GEMMs are deep enough (K >= 256) to win from
-    // 2048 pixels up (+25..45 %); at 128 channels Winograd ties the direct kernel, at 64 it loses; below 2048 pixels the
-    // four launches are latency-bound
+    // 2048 pixels up; at 128 channels Winograd ties the direct kernel, at 64 it loses; below 2048 pixels the four launches
+    // are latency-bound
     if (Cin % BK || Cout % BK || Cin < g_wino_min_channels || Cout < g_wino_min_channels) return false;
-    const long long T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
     if ((long long)N * H * W < g_wino_min_pixels) return false;
+    const long long T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
     const long long Tp = (T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS;
     return 16 * Tp < (1ll << 24) && 16 * Tp * std::max(Cin, Cout) < (1ll << 30);    // limits of the GEMM kernel's offsets
 }
-struct WinoLayout { size_t u, v, m, inner, total; long long T, Tp; };
+int wino_m(int H, int W) {
+    if (g_wino_tile == 2 || g_wino_tile == 4) return g_wino_tile;
+    const long long c2 = 16ll * ((H + 1) / 2) * ((W + 1) / 2), c4 = 36ll * ((H + 3) / 4) * ((W + 3) / 4);
+    return c4 < c2 ? 4 : 2;
+}
+struct WinoGeom { int m, a, nk, th, tw; long long T, Tp; };
+WinoGeom wino_geom(int N, int H, int W) {
+    WinoGeom g;
+    g.m = wino_m(H, W); g.a = g.m + 2; g.nk = g.a * g.a;
+    g.th = (H + g.m - 1) / g.m; g.tw = (W + g.m - 1) / g.m;
+    g.T = (long long)N * g.th * g.tw;
+    g.Tp = (g.T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS;
+    return g;
+}
+struct WinoLayout { size_t u, v, m, inner, total; WinoGeom g; };
 WinoLayout wino_layout(int N, int H, int W, int Cin, int Cout) {
     WinoLayout L;
-    L.T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
-    L.Tp = (L.T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS;
+    L.g = wino_geom(N, H, W);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t o = 0;
-    L.u = o; o += al((size_t)16 * Cout * Cin * 4);
-    L.v = o; o += al((size_t)16 * L.Tp * Cin * 4);
-    L.m = o; o += al((size_t)16 * L.Tp * Cout * 4);
+    L.u = o; o += al((size_t)L.g.nk * Cout * Cin * 4);
+    L.v = o; o += al((size_t)L.g.nk * L.g.Tp * Cin * 4);
+    L.m = o; o += al((size_t)L.g.nk * L.g.Tp * Cout * 4);
     L.inner = o; o += (size_t)4 * g_cus() * 128 * 128 * sizeof(float);              // tail-split slabs of the GEMM launch
     L.total = o;
     return L;
 }
 size_t wino_ws_bytes(int N, int H, int W, int Cin, int Cout) { return wino_layout(N, H, W, Cin, Cout).total; }
 
+// ---- the 1-D transforms (T = float or V4) --------------------------------------------------------------------------
+struct V4 { float x, y, z, w; };
+__device__ __forceinline__ V4 operator+(V4 a, V4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ V4 operator-(V4 a, V4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+__device__ __forceinline__ V4 operator*(float s, V4 a) { return {s * a.x, s * a.y, s * a.z, s * a.w}; }
+__device__ __forceinline__ V4 v4ld(const float *p) { const float4 f = ldg4(p); return {f.x, f.y, f.z, f.w}; }
+__device__ __forceinline__ void v4st(float *p, V4 v) { *reinterpret_cast<float4 *>(p) = make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ V4 v4zero() { return {0.f, 0.f, 0.f, 0.f}; }
+
+template <int M_, typename T> __device__ __forceinline__ void wino_bt(const T (&d)[M_ + 2], T (&r)[M_ + 2]) {      // B^T d
+    if (M_ == 2) {
+        r[0] = d[0] - d[2]; r[1] = d[1] + d[2]; r[2] = d[2] - d[1]; r[3] = d[1] - d[3];
+    } else {
+        r[0] = (4.0f * d[0] - 5.0f * d[2]) + d[4];
+        r[1] = (d[4] + d[3]) - 4.0f * (d[1] + d[2]);
+        r[2] = (d[4] - d[3]) + 4.0f * (d[1] - d[2]);
+        r[3] = (d[4] - d[2]) + 2.0f * (d[3] - d[1]);
+        r[4] = (d[4] - d[2]) - 2.0f * (d[3] - d[1]);
+        r[5] = (4.0f * d[1] - 5.0f * d[3]) + d[5];
+    }
+}
+template <int M_, typename T> __device__ __forceinline__ void wino_at(const T (&m)[M_ + 2], T (&s)[M_]) {           // A^T m
+    if (M_ == 2) {
+        s[0] = (m[0] + m[1]) + m[2]; s[1] = (m[1] - m[2]) - m[3];
+    } else {
+        const T p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4];
+        s[0] = (m[0] + p12) + p34;
+        s[1] = m12 + 2.0f * m34;
+        s[2] = p12 + 4.0f * p34;
+        s[3] = (m12 + 8.0f * m34) + m[5];
+    }
+}
+template <int M_, typename T> __device__ __forceinline__ void wino_a(const T (&y)[M_], T (&t)[M_ + 2], T zero) {    // A y
+    if (M_ == 2) {
+        t[0] = y[0]; t[1] = y[0] + y[1]; t[2] = y[0] - y[1]; t[3] = zero - y[1];
+    } else {
+        const T e = y[0] + y[2], o = y[1] + y[3], e4 = y[0] + 4.0f * y[2], o8 = 2.0f * y[1] + 8.0f * y[3];
+        t[0] = y[0]; t[1] = e + o; t[2] = e - o; t[3] = e4 + o8; t[4] = e4 - o8; t[5] = y[3];
+    }
+}
+template <int M_> __device__ __forceinline__ void wino_g(const float (&g)[3], float (&t)[M_ + 2]) {                   // G g
+    if (M_ == 2) {
+        t[0] = g[0]; t[1] = 0.5f * ((g[0] + g[1]) + g[2]); t[2] = 0.5f * ((g[0] - g[1]) + g[2]); t[3] = g[2];
+    } else {
+        const float e = g[0] + g[2];
+        t[0] = 0.25f * g[0];
+        t[1] = (-1.0f / 6.0f) * (e + g[1]);
+        t[2] = (-1.0f / 6.0f) * (e - g[1]);
+        t[3] = (g[0] * (1.0f / 24.0f) + g[2] * (1.0f / 6.0f)) + g[1] * (1.0f / 12.0f);
+        t[4] = (g[0] * (1.0f / 24.0f) + g[2] * (1.0f / 6.0f)) - g[1] * (1.0f / 12.0f);
+        t[5] = g[2];
+    }
+}
+template <int M_> __device__ __forceinline__ void wino_gt(const float (&D)[M_ + 2], float (&r)[3]) {                  // G^T D
+    if (M_ == 2) {
+        r[0] = D[0] + 0.5f * (D[1] + D[2]); r[1] = 0.5f * (D[1] - D[2]); r[2] = 0.5f * (D[1] + D[2]) + D[3];
+    } else {
+        const float p12 = D[1] + D[2], m12 = D[1] - D[2], p34 = D[3] + D[4], m34 = D[3] - D[4];
+        r[0] = (0.25f * D[0] - p12 * (1.0f / 6.0f)) + p34 * (1.0f / 24.0f);
+        r[1] = m34 * (1.0f / 12.0f) - m12 * (1.0f / 6.0f);
+        r[2] = (p34 * (1.0f / 6.0f) - p12 * (1.0f / 6.0f)) + D[5];
+    }
+}
+
 // U[k][co][ci] from w (Cout,3,3,Cin).  transposed: the backward-data filter w'[ci][u][v][co] = w[co][2-u][2-v][ci],
 // written as U[k][ci][co] (the GEMM's "Cout" axis is then Cin).
+template <int M_>
 __global__ __launch_bounds__(256) void k_wino_filter(const float *__restrict__ w, float *__restrict__ U, int Cout, int Cin,
                                                      int transposed) {
+    constexpr int A_ = M_ + 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Cout * Cin) return;
     const int ci = i % Cin, co = i / Cin;
-    float g[3][3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const int uu = transposed ? 2 - u : u, vv = transposed ? 2 - v : v;
-            g[u][v] = w[(((size_t)co * 3 + uu) * 3 + vv) * Cin + ci];
-        }
-    float t[4][3];          // G g
+    float t[A_][3];          // G g, column by column
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
-        t[0][v] = g[0][v];
-        t[1][v] = 0.5f * ((g[0][v] + g[1][v]) + g[2][v]);
-        t[2][v] = 0.5f * ((g[0][v] - g[1][v]) + g[2][v]);
-        t[3][v] = g[2][v];
+        float g[3], c[A_];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int uu = transposed ? 2 - u : u, vv = transposed ? 2 - v : v;
+            g[u] = w[(((size_t)co * 3 + uu) * 3 + vv) * Cin + ci];
+        }
+        wino_g<M_>(g, c);
+#pragma unroll
+        for (int r = 0; r < A_; ++r) t[r][v] = c[r];
     }
     const size_t stride = (size_t)Cout * Cin;
     const size_t o = transposed ? (size_t)ci * Cout + co : (size_t)co * Cin + ci;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        U[(size_t)(r * 4 + 0) * stride + o] = t[r][0];
-        U[(size_t)(r * 4 + 1) * stride + o] = 0.5f * ((t[r][0] + t[r][1]) + t[r][2]);
-        U[(size_t)(r * 4 + 2) * stride + o] = 0.5f * ((t[r][0] - t[r][1]) + t[r][2]);
-        U[(size_t)(r * 4 + 3) * stride + o] = t[r][2];
+    for (int r = 0; r < A_; ++r) {
+        float row[A_];
+        wino_g<M_>(t[r], row);
+#pragma unroll
+        for (int q = 0; q < A_; ++q) U[(size_t)(r * A_ + q) * stride + o] = row[q];
     }
 }
 
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-
-// V[k][t][c] = (B^T d B)[k], d = the 4x4 input patch of tile t (rows 2ty-1 .. 2ty+2, zero outside).  Thread = (t, 4 channels).
+// V[k][t][c] = (B^T d B)[k], d = the a x a input patch of tile t (rows m*ty-1 .., zero outside).  Thread = (t, 4 channels).
+template <int M_>
 __global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
                                                     int th, int tw, long long T, long long Tp) {
+    constexpr int A_ = M_ + 2;
     const int C4 = C / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= T * C4) return;
     const int c = (int)(i % C4) * 4;
-    long long t = i / C4;
+    const long long t = i / C4;
     const int tx = (int)(t % tw);
     const int ty = (int)((t / tw) % th);
     const int n = (int)(t / ((long long)tw * th));
-    float4 d[4][4];
+    V4 b[A_][A_];           // B^T d, built column by column
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int h = 2 * ty - 1 + r;
+    for (int q = 0; q < A_; ++q) {
+        const int ww = M_ * tx - 1 + q;
+        V4 d[A_], r[A_];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ww = 2 * tx - 1 + q;
+        for (int rr = 0; rr < A_; ++rr) {
+            const int h = M_ * ty - 1 + rr;
             const bool ok = (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W;
-            d[r][q] = ok ? ldg4(x + (((size_t)n * H + h) * W + ww) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d[rr] = ok ? v4ld(x + (((size_t)n * H + h) * W + ww) * C + c) : v4zero();
         }
-    }
-    float4 b[4][4];         // B^T d
+        wino_bt<M_, V4>(d, r);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        b[0][q] = f4sub(d[0][q], d[2][q]);
-        b[1][q] = f4add(d[1][q], d[2][q]);
-        b[2][q] = f4sub(d[2][q], d[1][q]);
-        b[3][q] = f4sub(d[1][q], d[3][q]);
+        for (int rr = 0; rr < A_; ++rr) b[rr][q] = r[rr];
     }
     const size_t ks = (size_t)Tp * C;
     float *o = V + (size_t)t * C + c;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        *reinterpret_cast<float4 *>(o + (size_t)(r * 4 + 0) * ks) = f4sub(b[r][0], b[r][2]);
-        *reinterpret_cast<float4 *>(o + (size_t)(r * 4 + 1) * ks) = f4add(b[r][1], b[r][2]);
-        *reinterpret_cast<float4 *>(o + (size_t)(r * 4 + 2) * ks) = f4sub(b[r][2], b[r][1]);
-        *reinterpret_cast<float4 *>(o + (size_t)(r * 4 + 3) * ks) = f4sub(b[r][1], b[r][3]);
+    for (int rr = 0; rr < A_; ++rr) {
+        V4 row[A_];
+        wino_bt<M_, V4>(b[rr], row);
+#pragma unroll
+        for (int q = 0; q < A_; ++q) v4st(o + (size_t)(rr * A_ + q) * ks, row[q]);
     }
 }
 
-// y (2x2 pixels of tile t) = A^T M A + bias, then ReLU | + old y (accumulate) | zeroed where relu_x <= 0.
+// y (m x m pixels of tile t) = A^T M A + bias, then ReLU | + old y (accumulate) | zeroed where relu_x <= 0.
+template <int M_>
 __global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ Mb, float *__restrict__ y, int N, int H, int W, int C,
                                                      int th, int tw, long long T, long long Tp, const float *__restrict__ bias,
                                                      int relu, int accumulate, const float *__restrict__ relu_x) {
+    constexpr int A_ = M_ + 2;
     const int C4 = C / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= T * C4) return;
     const int c = (int)(i % C4) * 4;
-    long long t = i / C4;
+    const long long t = i / C4;
     const int tx = (int)(t % tw);
     const int ty = (int)((t / tw) % th);
     const int n = (int)(t / ((long long)tw * th));
     const size_t ks = (size_t)Tp * C;
     const float *src = Mb + (size_t)t * C + c;
-    float4 m[4][4];
+    V4 s[M_][A_];           // A^T m, column by column
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m[k >> 2][k & 3] = ldg4(src + (size_t)k * ks);
-    float4 s[2][4];         // A^T m
+    for (int q = 0; q < A_; ++q) {
+        V4 m[A_], r[M_];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        s[0][q] = f4add(f4add(m[0][q], m[1][q]), m[2][q]);
-        s[1][q] = f4sub(f4sub(m[1][q], m[2][q]), m[3][q]);
+        for (int rr = 0; rr < A_; ++rr) m[rr] = v4ld(src + (size_t)(rr * A_ + q) * ks);
+        wino_at<M_, V4>(m, r);
+#pragma unroll
+        for (int a = 0; a < M_; ++a) s[a][q] = r[a];
     }
-    const float4 bv = bias ? ldg4(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const V4 bv = bias ? v4ld(bias + c) : v4zero();
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < M_; ++a) {
+        V4 row[M_];
+        wino_at<M_, V4>(s[a], row);
+        const int h = M_ * ty + a;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int h = 2 * ty + a, ww = 2 * tx + b;
+        for (int b = 0; b < M_; ++b) {
+            const int ww = M_ * tx + b;
             if (h >= H || ww >= W) continue;
-            float4 v = b == 0 ? f4add(f4add(s[a][0], s[a][1]), s[a][2]) : f4sub(f4sub(s[a][1], s[a][2]), s[a][3]);
-            v = f4add(v, bv);
+            V4 v = row[b] + bv;
             const size_t off = (((size_t)n * H + h) * W + ww) * C + c;
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (accumulate) v = f4add(v, ldg4(y + off));
+            if (accumulate) v = v + v4ld(y + off);
             if (relu_x) {
-                const float4 xm = ldg4(relu_x + off);
+                const V4 xm = v4ld(relu_x + off);
                 v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f; v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
             }
-            *reinterpret_cast<float4 *>(y + off) = v;
+            v4st(y + off, v);
         }
+    }
 }
 
-// W[k][t][c] = (A dy A^T)[k]: the 2x2 output-gradient tile t, zero outside the image.  Thread = (t, 4 channels).
+// W[k][t][c] = (A dy A^T)[k]: the m x m output-gradient tile t, zero outside the image.  Thread = (t, 4 channels).
+template <int M_>
 __global__ __launch_bounds__(256) void k_wino_gy(const float *__restrict__ gy, float *__restrict__ Wt, int N, int H, int W, int C,
                                                  int th, int tw, long long T, long long Tp) {
+    constexpr int A_ = M_ + 2;
     const int C4 = C / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= T * C4) return;
     const int c = (int)(i % C4) * 4;
-    long long t = i / C4;
+    const long long t = i / C4;
     const int tx = (int)(t % tw);
     const int ty = (int)((t / tw) % th);
     const int n = (int)(t / ((long long)tw * th));
-    float4 y[2][2];
+    V4 r[A_][M_];           // A y, column by column
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < M_; ++b) {
+        const int ww = M_ * tx + b;
+        V4 y[M_], col[A_];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int h = 2 * ty + a, ww = 2 * tx + b;
-            y[a][b] = (h < H && ww < W) ? ldg4(gy + (((size_t)n * H + h) * W + ww) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < M_; ++a) {
+            const int h = M_ * ty + a;
+            y[a] = (h < H && ww < W) ? v4ld(gy + (((size_t)n * H + h) * W + ww) * C + c) : v4zero();
         }
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 r[4][2];
+        wino_a<M_, V4>(y, col, v4zero());
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        r[0][b] = y[0][b];
-        r[1][b] = f4add(y[0][b], y[1][b]);
-        r[2][b] = f4sub(y[0][b], y[1][b]);
-        r[3][b] = f4sub(z, y[1][b]);
+        for (int q = 0; q < A_; ++q) r[q][b] = col[q];
     }
     const size_t ks = (size_t)Tp * C;
     float *o = Wt + (size_t)t * C + c;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<float4 *>(o + (size_t)(q * 4 + 0) * ks) = r[q][0];
-        *reinterpret_cast<float4 *>(o + (size_t)(q * 4 + 1) * ks) = f4add(r[q][0], r[q][1]);
-        *reinterpret_cast<float4 *>(o + (size_t)(q * 4 + 2) * ks) = f4sub(r[q][0], r[q][1]);
-        *reinterpret_cast<float4 *>(o + (size_t)(q * 4 + 3) * ks) = f4sub(z, r[q][1]);
+    for (int q = 0; q < A_; ++q) {
+        V4 row[A_];
+        wino_a<M_, V4>(r[q], row, v4zero());
+#pragma unroll
+        for (int j = 0; j < A_; ++j) v4st(o + (size_t)(q * A_ + j) * ks, row[j]);
     }
 }
 
 // gw[co][u][v][ci] (+)= (G^T dU G)[u][v], dU[co][k][ci] = sum over tiles of W[k][t][co] * V[k][t][ci].
+template <int M_>
 __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restrict__ dU, float *__restrict__ gw, int Cout, int Cin,
                                                           int accumulate) {
+    constexpr int A_ = M_ + 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Cout * Cin) return;
     const int ci = i % Cin, co = i / Cin;
-    float D[4][4];
+    float r[3][A_];         // G^T D, column by column
 #pragma unroll
-    for (int k = 0; k < 16; ++k) D[k >> 2][k & 3] = dU[((size_t)co * 16 + k) * Cin + ci];
-    float r[3][4];
+    for (int j = 0; j < A_; ++j) {
+        float D[A_], c3[3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r[0][j] = D[0][j] + 0.5f * (D[1][j] + D[2][j]);
-        r[1][j] = 0.5f * (D[1][j] - D[2][j]);
-        r[2][j] = 0.5f * (D[1][j] + D[2][j]) + D[3][j];
+        for (int q = 0; q < A_; ++q) D[q] = dU[((size_t)co * (A_ * A_) + q * A_ + j) * Cin + ci];
+        wino_gt<M_>(D, c3);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) r[u][j] = c3[u];
     }
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         float o[3];
-        o[0] = r[u][0] + 0.5f * (r[u][1] + r[u][2]);
-        o[1] = 0.5f * (r[u][1] - r[u][2]);
-        o[2] = 0.5f * (r[u][1] + r[u][2]) + r[u][3];
+        wino_gt<M_>(r[u], o);
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
             float *dst = gw + (((size_t)co * 3 + u) * 3 + v) * Cin + ci;
@@ -1072,20 +1152,26 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restric
     }
 }
 
-struct WinoFLayout { size_t v, w, slabs, du, total; long long T, Tp; int ksplit, kchunk; };
+#define WINO_LAUNCH(KERN, G, GRID, ...)                                                              \
+    do {                                                                                             \
+        if ((G).m == 2) hipLaunchKernelGGL((KERN<2>), GRID, dim3(256), 0, st, __VA_ARGS__);          \
+        else hipLaunchKernelGGL((KERN<4>), GRID, dim3(256), 0, st, __VA_ARGS__);                     \
+        MRCNN_LAUNCH_CHECK();                                                                        \
+    } while (0)
+
+struct WinoFLayout { size_t v, w, slabs, du, total; WinoGeom g; int ksplit, kchunk; };
 WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
     WinoFLayout L;
-    L.T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
-    L.Tp = (L.T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS;
-    ConvP p = make_p(1, 1, (int)L.Tp, Cin, Cout, 1, 1, 1, 0);
-    p.wbatch_rows = (int)L.Tp;
+    L.g = wino_geom(N, H, W);
+    ConvP p = make_p(1, 1, (int)L.g.Tp, Cin, Cout, 1, 1, 1, 0);
+    p.wbatch_rows = (int)L.g.Tp; p.wbatch_n = L.g.nk;
     filter_plan(p, L.ksplit, L.kchunk);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t o = 0;
-    L.v = o; o += al((size_t)16 * L.Tp * Cin * 4);
-    L.w = o; o += al((size_t)16 * L.Tp * Cout * 4);
-    L.slabs = o; o += al((size_t)L.ksplit * Cout * 16 * Cin * 4);
-    L.du = o; o += al((size_t)Cout * 16 * Cin * 4);
+    L.v = o; o += al((size_t)L.g.nk * L.g.Tp * Cin * 4);
+    L.w = o; o += al((size_t)L.g.nk * L.g.Tp * Cout * 4);
+    L.slabs = o; o += al((size_t)L.ksplit * Cout * L.g.nk * Cin * 4);
+    L.du = o; o += al((size_t)Cout * L.g.nk * Cin * 4);
     L.total = o;
     return L;
 }
@@ -1093,34 +1179,31 @@ WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
 int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, int W, int Cin, int Cout, int accumulate, void *ws,
                     hipStream_t st) {
     const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
+    const WinoGeom &g = L.g;
     char *base = (char *)ws;
     float *V = (float *)(base + L.v), *Wt = (float *)(base + L.w), *slabs = (float *)(base + L.slabs), *dU = (float *)(base + L.du);
-    const int th = (H + 1) / 2, tw = (W + 1) / 2;
-    if (L.Tp > L.T)         // padded rows are summed by the GEMM: they must be zero
-        for (int k = 0; k < 16; ++k) {
-            MRCNN_HIP_TRY(hipMemsetAsync(V + ((size_t)k * L.Tp + L.T) * Cin, 0, (size_t)(L.Tp - L.T) * Cin * 4, st));
-            MRCNN_HIP_TRY(hipMemsetAsync(Wt + ((size_t)k * L.Tp + L.T) * Cout, 0, (size_t)(L.Tp - L.T) * Cout * 4, st));
+    if (g.Tp > g.T)         // padded rows are summed by the GEMM: they must be zero
+        for (int k = 0; k < g.nk; ++k) {
+            MRCNN_HIP_TRY(hipMemsetAsync(V + ((size_t)k * g.Tp + g.T) * Cin, 0, (size_t)(g.Tp - g.T) * Cin * 4, st));
+            MRCNN_HIP_TRY(hipMemsetAsync(Wt + ((size_t)k * g.Tp + g.T) * Cout, 0, (size_t)(g.Tp - g.T) * Cout * 4, st));
         }
-    const long long nin = L.T * (Cin / 4), nout = L.T * (Cout / 4);
-    hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, x, V, N, H, W, Cin, th, tw, L.T, L.Tp);
-    MRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_wino_gy, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, gy, Wt, N, H, W, Cout, th, tw, L.T, L.Tp);
-    MRCNN_LAUNCH_CHECK();
-    ConvP p = make_p(1, 1, (int)L.Tp, Cin, Cout, 1, 1, 1, 0);
-    p.wbatch_rows = (int)L.Tp;
+    const long long nin = g.T * (Cin / 4), nout = g.T * (Cout / 4);
+    WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), x, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
+    WINO_LAUNCH(k_wino_gy, g, dim3((unsigned)((nout + 255) / 256)), gy, Wt, N, H, W, Cout, g.th, g.tw, g.T, g.Tp);
+    ConvP p = make_p(1, 1, (int)g.Tp, Cin, Cout, 1, 1, 1, 0);
+    p.wbatch_rows = (int)g.Tp; p.wbatch_n = g.nk;
     p.ksplit = L.ksplit; p.kchunk = L.kchunk;
     p.a = Wt; p.b = V; p.c = L.ksplit > 1 ? slabs : dU;
-    p.bytes_a = (unsigned)((size_t)16 * L.Tp * Cout * 4); p.bytes_b = (unsigned)((size_t)16 * L.Tp * Cin * 4);
+    p.bytes_a = (unsigned)((size_t)g.nk * g.Tp * Cout * 4); p.bytes_b = (unsigned)((size_t)g.nk * g.Tp * Cin * 4);
     p.M = Cout; p.Ng = Cin;
-    launch_conv<MODE_BWD_FILTER>(p, 16 * p.ksplit, filter_tile(p), st);
+    launch_conv<MODE_BWD_FILTER>(p, g.nk * p.ksplit, filter_tile(p), st);
     MRCNN_LAUNCH_CHECK();
     if (L.ksplit > 1) {
-        const size_t n4 = (size_t)Cout * 16 * Cin / 4;
+        const size_t n4 = (size_t)Cout * g.nk * Cin / 4;
         hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, L.ksplit, 0);
         MRCNN_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_wino_filter_grad, dim3(mrcnn::cdiv(Cout * Cin, 256)), dim3(256), 0, st, dU, gw, Cout, Cin, accumulate);
-    MRCNN_LAUNCH_CHECK();
+    WINO_LAUNCH(k_wino_filter_grad, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), dU, gw, Cout, Cin, accumulate);
     return 0;
 }
 
@@ -1129,29 +1212,26 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
 int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, int Cin, int Cout, bool transposed,
               const float *bias, int relu, int accumulate, const float *relu_x, void *ws, size_t ws_bytes, hipStream_t st) {
     const WinoLayout L = wino_layout(N, H, W, Cin, Cout);
+    const WinoGeom &g = L.g;
     char *base = (char *)ws;
     float *U = (float *)(base + L.u), *V = (float *)(base + L.v), *Mb = (float *)(base + L.m);
-    const int th = (H + 1) / 2, tw = (W + 1) / 2;
     // the layer's weight tensor is (Cout_layer, 3, 3, Cin_layer): forward Cout_layer = Cout; transposed Cout_layer = Cin
-    hipLaunchKernelGGL(k_wino_filter, dim3(mrcnn::cdiv(Cout * Cin, 256)), dim3(256), 0, st, w, U, transposed ? Cin : Cout,
-                       transposed ? Cout : Cin, transposed ? 1 : 0);
-    MRCNN_LAUNCH_CHECK();
-    if (L.Tp > L.T)         // padded rows of V feed the GEMM: keep them finite (their products are never read)
-        for (int k = 0; k < 16; ++k)
-            MRCNN_HIP_TRY(hipMemsetAsync(V + ((size_t)k * L.Tp + L.T) * Cin, 0, (size_t)(L.Tp - L.T) * Cin * 4, st));
-    const long long nin = L.T * (Cin / 4), nout = L.T * (Cout / 4);
-    hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, in, V, N, H, W, Cin, th, tw, L.T, L.Tp);
-    MRCNN_LAUNCH_CHECK();
-    // batched GEMM: 1x1 "convolution" over 16*Tp pixels, weight matrix selected by the row block
-    ConvP p = make_p(1, 1, (int)(16 * L.Tp), Cin, Cout, 1, 1, 1, 0);
+    WINO_LAUNCH(k_wino_filter, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), w, U, transposed ? Cin : Cout, transposed ? Cout : Cin,
+                transposed ? 1 : 0);
+    if (g.Tp > g.T)         // padded rows of V feed the GEMM: keep them finite (their products are never read)
+        for (int k = 0; k < g.nk; ++k)
+            MRCNN_HIP_TRY(hipMemsetAsync(V + ((size_t)k * g.Tp + g.T) * Cin, 0, (size_t)(g.Tp - g.T) * Cin * 4, st));
+    const long long nin = g.T * (Cin / 4), nout = g.T * (Cout / 4);
+    WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), in, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
+    // batched GEMM: 1x1 "convolution" over nk*Tp pixels, weight matrix selected by the row block
+    ConvP p = make_p(1, 1, (int)(g.nk * g.Tp), Cin, Cout, 1, 1, 1, 0);
     p.a = V; p.b = U; p.c = Mb;
-    p.bytes_a = (unsigned)((size_t)16 * L.Tp * Cin * 4); p.bytes_b = (unsigned)((size_t)16 * Cout * Cin * 4);
-    p.M = (int)(16 * L.Tp); p.Ng = Cout;
-    p.wbatch_rows = (int)L.Tp;
+    p.bytes_a = (unsigned)((size_t)g.nk * g.Tp * Cin * 4); p.bytes_b = (unsigned)((size_t)g.nk * Cout * Cin * 4);
+    p.M = (int)(g.nk * g.Tp); p.Ng = Cout;
+    p.wbatch_rows = (int)g.Tp; p.wbatch_n = g.nk;
     if (int e = run_data_conv<MODE_FWD>(p, Cin / BK, Cout, base + L.inner, ws_bytes - L.inner, st)) return e;
-    hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, Mb, out, N, H, W, Cout, th, tw, L.T,
-                       L.Tp, bias, relu, accumulate, relu_x);
-    MRCNN_LAUNCH_CHECK();
+    WINO_LAUNCH(k_wino_output, g, dim3((unsigned)((nout + 255) / 256)), Mb, out, N, H, W, Cout, g.th, g.tw, g.T, g.Tp, bias, relu,
+                accumulate, relu_x);
     return 0;
 }
 
@@ -1177,10 +1257,12 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
     return bytes;
 }
 
-extern "C" int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels) {
-    if (min_channels < BK || min_pixels < 1) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_winograd_thresholds: min_channels >= %d, min_pixels >= 1", BK);
+extern "C" int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels, int tile) {
+    if (min_channels < BK || min_pixels < 1 || (tile != 0 && tile != 2 && tile != 4))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "set_winograd_thresholds: min_channels >= %d, min_pixels >= 1, tile 0/2/4", BK);
     g_wino_min_channels = min_channels;
     g_wino_min_pixels = min_pixels;
+    g_wino_tile = tile;
     return 0;
 }
 
@@ -1188,8 +1270,8 @@ extern "C" long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, in
     // multiply-accumulates the MFMA pipes actually execute for one pass (forward, backward-data or backward-filter)
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
     if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) {
-        const long long T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
-        return 16ll * ((T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS) * Cin * Cout;
+        const WinoGeom g = wino_geom(N, H, W);
+        return (long long)g.nk * g.Tp * Cin * Cout;
     }
     const long long Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
     return (long long)N * Ho * Wo * KH * KW * (Cin == 4 ? 4 : Cin) * Cout;

@@ -127,12 +127,13 @@ int mrcnn_roi_align_sample_tables(const float *rois, int R, int H, int W, int PH
  * ---------------------------------------------------------------------------------------- */
 size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 /* Multiply-accumulates the MFMA pipes execute for ONE pass (forward, backward-data or backward-filter) of this layer:
- * N*Ho*Wo*KH*KW*Cin*Cout for the direct kernels, 16 * tiles * Cin * Cout (2.25x fewer) where the 3x3 / stride 1 /
- * pad 1 layer takes the Winograd F(2x2,3x3) path (>= 256 channels, >= 2048 pixels).  For roofline accounting. */
+ * N*Ho*Wo*KH*KW*Cin*Cout for the direct kernels, (m+2)^2 * tiles * Cin * Cout (2.25x / 4x fewer) where the 3x3 /
+ * stride 1 / pad 1 layer takes the Winograd F(m x m,3x3) path (>= 256 channels, >= 2048 pixels).  For roofline accounting. */
 long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
-/* Process-wide selection thresholds of the Winograd path (defaults 256 channels, 2048 pixels: measured break-even on
- * gfx950).  Lowering them is how the tests run whole small networks through the Winograd kernels. */
-int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels);
+/* Process-wide selection of the Winograd path: thresholds (defaults 256 channels, 2048 pixels: measured break-even on
+ * gfx950) and output tile (0 = per layer, whichever of F(2x2,3x3) / F(4x4,3x3) needs fewer multiplications; 2 or 4 =
+ * forced).  Lowering the thresholds is how the tests run whole small networks through the Winograd kernels. */
+int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels, int tile);
 int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                          void *ws, size_t ws_bytes, void *stream);

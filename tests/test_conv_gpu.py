@@ -132,8 +132,18 @@ def test_conv_backward_data_fused_relu_mask(case):
 # 3x3 / stride 1 / pad 1 layers with >= 2048 pixels and >= 256 channels take the Winograd F(2x2,3x3) path (filter,
 # input and output transforms + one batched 1x1 GEMM launch).  Tolerance 3e-5 of the tensor scale: the transforms add a
 # few ulp to the direct kernel's error; odd sizes exercise the clipped edge tiles and the padded GEMM rows.
-@pytest.mark.parametrize('case', [(2, 48, 48, 256, 256), (1, 67, 63, 256, 288), (3, 40, 36, 320, 256)])
-def test_conv_winograd_forward_and_backward_data(case):
+@pytest.mark.parametrize('tile,tol', [(2, 3e-5), (4, 3e-4)])
+@pytest.mark.parametrize('case', [(2, 48, 48, 256, 256), (1, 67, 63, 256, 288), (3, 40, 36, 320, 256), (16, 14, 14, 256, 256)])
+def test_conv_winograd_forward_and_backward_data(case, tile, tol):
+    from chainer_maskrcnn import _hip
+    _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048, tile))
+    try:
+        _winograd_case(case, tol)
+    finally:
+        _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048, 0))
+
+
+def _winograd_case(case, tol):
     N, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(31 + sum(case))
     x = torch.randn((N, H, W, Cin), generator=g)
@@ -143,21 +153,21 @@ def test_conv_winograd_forward_and_backward_data(case):
     got = hnn.conv2d_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), 1, 1, False)
     assert torch.equal(got, hnn.conv2d_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), 1, 1, False))       # reproducible
     err = (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-    assert err < 3e-5, err
+    assert err < tol, err
     got = hnn.conv2d_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), 1, 1, True)
     err = (got.cpu().double() - ref.clamp_min(0)).abs().max().item() / ref.abs().max().item()
-    assert err < 3e-5, err
+    assert err < tol, err
     # backward-data: plain, accumulating, and with the fused ReLU mask
     gy = torch.randn((N, H, W, Cout), generator=g)
     refx = F.conv_transpose2d(gy.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), None, stride=1,
                               padding=1).permute(0, 2, 3, 1)
     gx = hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (N, H, W, Cin), 1, 1)
     sc = refx.abs().max().item()
-    assert (gx.cpu().double() - refx).abs().max().item() / sc < 3e-5
+    assert (gx.cpu().double() - refx).abs().max().item() / sc < tol
     base = torch.randn((N, H, W, Cin), generator=g)
     out = base.to(DEV).clone()
     hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (N, H, W, Cin), 1, 1, out=out)
-    assert (out.cpu().double() - (refx + base.double())).abs().max().item() / sc < 3e-5
+    assert (out.cpu().double() - (refx + base.double())).abs().max().item() / sc < tol
     xr = torch.randn((N, H, W, Cin), generator=g).clamp_min(0).to(DEV)
     fused = hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (N, H, W, Cin), 1, 1, relu_x=xr)
     assert torch.equal(fused, torch.where(xr > 0, gx, torch.zeros_like(gx)))
@@ -169,9 +179,11 @@ def test_conv_winograd_forward_and_backward_data(case):
     gw, gb = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True)
     gw2, _ = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True)
     assert torch.equal(gw, gw2)
-    assert (gw.cpu().double() - wref).abs().max().item() / wref.abs().max().item() < 3e-5
+    errw = (gw.cpu().double() - wref).abs().max().item() / wref.abs().max().item()
+    print('winograd errors: fwd %.2e filter-grad %.2e' % (err, errw))
+    assert errw < tol, errw
     gbref = gy.double().sum((0, 1, 2))
     assert (gb.cpu().double() - gbref).abs().max().item() / gbref.abs().max().item() < 2e-5
     acc_w, acc_b = (torch.ones_like(gw), torch.ones_like(gb))
     hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True, gw=acc_w, gb=acc_b, accumulate=True)
-    assert (acc_w.cpu().double() - (wref + 1)).abs().max().item() / wref.abs().max().item() < 3e-5
+    assert (acc_w.cpu().double() - (wref + 1)).abs().max().item() / wref.abs().max().item() < tol

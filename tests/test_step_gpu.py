@@ -166,12 +166,14 @@ def test_reference_api_surface():
     assert roi_indices.shape == (R,) and R <= 2000
 
 
-def test_step_matches_oracle_with_winograd_everywhere():
+@pytest.mark.parametrize('tile', [2])
+def test_step_matches_oracle_with_winograd_everywhere(tile):
     """The same whole-step parity check with the Winograd thresholds lowered so that every 3x3 / stride-1 layer of the
-    small test network (ResNet conv2's, FPN, RPN, box and mask heads) takes the F(2x2,3x3) kernels in all three passes."""
+    small test network (ResNet conv2's, FPN, RPN, box and mask heads) takes the F(2x2,3x3) / F(4x4,3x3) kernels in all
+    three passes."""
     from chainer_maskrcnn import _hip
-    _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(32, 64))
+    _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(32, 64, tile))
     try:
         test_step_losses_and_gradients_match_oracle('all')
     finally:
-        _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048))
+        _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048, 0))
