@@ -65,7 +65,9 @@ def conv_out(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
-def conv2d_fwd_raw(x, w, b, stride, pad, relu):
+def conv2d_fwd_raw(x, w, b, stride, pad, relu, keep_v=False):
+    """keep_v: returns (y, v) - v = the Winograd-transformed input of layers that take that path (else None), for the
+    filter-gradient call of the same layer (conv2d_bwd_filter_raw(..., wino_v=v))."""
     _hip.require_cuda(x, w)
     N, H, W, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
@@ -75,10 +77,15 @@ def conv2d_fwd_raw(x, w, b, stride, pad, relu):
                     dtype=torch.float32, device=x.device)
     nb = lib().mrcnn_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     ws = workspace(nb, x.device) if nb else None
+    v = None
+    if keep_v:
+        vb = lib().mrcnn_conv2d_winograd_v_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+        if vb:
+            v = torch.empty((vb // 4,), dtype=torch.float32, device=x.device)
     with _prof('fwd', N * y.shape[1] * y.shape[2], KH, KW, Cin, Cout, (N, H, W, Cin, Cout, KH, KW, stride, pad)):
         check(lib().mrcnn_conv2d_fwd_f32(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cout, KH, KW,
-                                         stride, pad, int(relu), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()))
-    return y
+                                         stride, pad, int(relu), ptr(v), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()))
+    return (y, v) if keep_v else y
 
 
 def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None, relu_x=None):
@@ -98,8 +105,9 @@ def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None, relu_x=None):
     return gx
 
 
-def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias, gw=None, gb=None, accumulate=None):
-    """gw / gb given: written in place (accumulate=True adds - layers applied several times); else allocated."""
+def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias, gw=None, gb=None, accumulate=None, wino_v=None):
+    """gw / gb given: written in place (accumulate=True adds - layers applied several times); else allocated.
+    wino_v: the transformed input kept by conv2d_fwd_raw(..., keep_v=True) of the same layer."""
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w_shape
     assert gy.is_contiguous() and x.is_contiguous()
@@ -111,5 +119,5 @@ def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias, gw=None, gb=No
     ws = workspace(nbytes, x.device)
     with _prof('bwd_filter', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout, (N, H, W, Cin, Cout, KH, KW, stride, pad)):
         check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x), ptr(gy), ptr(gw), ptr(gb) if want_bias else None, N, H, W, Cin,
-                                                Cout, KH, KW, stride, pad, int(acc), ptr(ws), ws.numel(), stream_ptr()))
+                                                Cout, KH, KW, stride, pad, int(acc), ptr(wino_v), ptr(ws), ws.numel(), stream_ptr()))
     return gw, gb

@@ -136,9 +136,11 @@ class Conv(object):
     def fwd(self, x, relu=None):
         relu = self.relu if relu is None else relu
         hnn.LOGICAL = (self.cin, self.cout)
-        y = hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu)
+        # training: layers on the Winograd path keep their transformed input for the filter-gradient pass
+        y, v = hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu, keep_v=True) if TRAIN else \
+            (hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu), None)
         hnn.LOGICAL = None
-        return y, (x, y if relu else None)
+        return y, (x, y if relu else None, v)
 
     def bwd(self, ctx, gy, need_gx=True, gx_acc=None, accumulate_params=False, gy_masked=False, mask_gx=False):
         """gy: gradient w.r.t. the (post-ReLU) output.  gx_acc: tensor to accumulate gx into.
@@ -146,7 +148,7 @@ class Conv(object):
         gy_masked: the producer of gy already applied this layer's ReLU mask (the layer above ran with mask_gx).
         mask_gx: this layer's input is itself a ReLU output - zero gx where x <= 0 in the data-gradient epilogue,
         which is the ReLU backward of the layer below (call that layer with gy_masked=True)."""
-        x, y = ctx
+        x, y, v = ctx
         if y is not None and not gy_masked:
             gy = ops.relu_bwd(gy, y)
         gw = self.ps.g(self.name + '/W')
@@ -159,12 +161,14 @@ class Conv(object):
                 side.wait_stream(main)                      # gy (and x) are complete on the main stream
                 with torch.cuda.stream(side):
                     hnn.conv2d_bwd_filter_raw(x, gy, tuple(gw.shape), self.stride, self.pad, self.has_bias, gw=gw, gb=gb,
-                                              accumulate=accumulate_params)
+                                              accumulate=accumulate_params, wino_v=v)
                 gy.record_stream(side)                      # allocator: do not recycle gy before the side kernel is done
                 x.record_stream(side)
+                if v is not None:
+                    v.record_stream(side)
             else:
                 hnn.conv2d_bwd_filter_raw(x, gy, tuple(gw.shape), self.stride, self.pad, self.has_bias, gw=gw, gb=gb,
-                                          accumulate=accumulate_params)
+                                          accumulate=accumulate_params, wino_v=v)
             if not need_gx:
                 return None
             if self.stride == 1:

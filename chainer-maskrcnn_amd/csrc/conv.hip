@@ -971,7 +971,8 @@ __global__ __launch_bounds__(256) void k_wino_filter(const float *__restrict__ w
     constexpr int A_ = M_ + 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Cout * Cin) return;
-    const int ci = i % Cin, co = i / Cin;
+    // the 36 (16) writes per thread dominate: threads run along the output's contiguous axis (ci, or co when transposed)
+    const int ci = transposed ? i / Cout : i % Cin, co = transposed ? i % Cout : i / Cin;
     float t[A_][3];          // G g, column by column
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
@@ -1177,18 +1178,19 @@ WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
 }
 
 int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, int W, int Cin, int Cout, int accumulate, void *ws,
-                    hipStream_t st) {
+                    hipStream_t st, const float *v_cached) {
     const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
     const WinoGeom &g = L.g;
     char *base = (char *)ws;
-    float *V = (float *)(base + L.v), *Wt = (float *)(base + L.w), *slabs = (float *)(base + L.slabs), *dU = (float *)(base + L.du);
+    float *Vw = (float *)(base + L.v), *Wt = (float *)(base + L.w), *slabs = (float *)(base + L.slabs), *dU = (float *)(base + L.du);
+    const float *V = v_cached ? v_cached : Vw;       // the forward pass's transformed input, kept by the caller
     if (g.Tp > g.T)         // padded rows are summed by the GEMM: they must be zero
         for (int k = 0; k < g.nk; ++k) {
-            MRCNN_HIP_TRY(hipMemsetAsync(V + ((size_t)k * g.Tp + g.T) * Cin, 0, (size_t)(g.Tp - g.T) * Cin * 4, st));
+            if (!v_cached) MRCNN_HIP_TRY(hipMemsetAsync(Vw + ((size_t)k * g.Tp + g.T) * Cin, 0, (size_t)(g.Tp - g.T) * Cin * 4, st));
             MRCNN_HIP_TRY(hipMemsetAsync(Wt + ((size_t)k * g.Tp + g.T) * Cout, 0, (size_t)(g.Tp - g.T) * Cout * 4, st));
         }
     const long long nin = g.T * (Cin / 4), nout = g.T * (Cout / 4);
-    WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), x, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
+    if (!v_cached) WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), x, Vw, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
     WINO_LAUNCH(k_wino_gy, g, dim3((unsigned)((nout + 255) / 256)), gy, Wt, N, H, W, Cout, g.th, g.tw, g.T, g.Tp);
     ConvP p = make_p(1, 1, (int)g.Tp, Cin, Cout, 1, 1, 1, 0);
     p.wbatch_rows = (int)g.Tp; p.wbatch_n = g.nk;
@@ -1210,11 +1212,12 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
 // in (N,H,W,Cin) -> out (N,H,W,Cout); w is always the layer's (Cout_layer,3,3,Cin_layer) weight tensor: transposed selects
 // the backward-data filter (then Cin here = the layer's Cout and Cout here = the layer's Cin).
 int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, int Cin, int Cout, bool transposed,
-              const float *bias, int relu, int accumulate, const float *relu_x, void *ws, size_t ws_bytes, hipStream_t st) {
+              const float *bias, int relu, int accumulate, const float *relu_x, void *ws, size_t ws_bytes, hipStream_t st,
+              float *v_keep) {
     const WinoLayout L = wino_layout(N, H, W, Cin, Cout);
     const WinoGeom &g = L.g;
     char *base = (char *)ws;
-    float *U = (float *)(base + L.u), *V = (float *)(base + L.v), *Mb = (float *)(base + L.m);
+    float *U = (float *)(base + L.u), *V = v_keep ? v_keep : (float *)(base + L.v), *Mb = (float *)(base + L.m);
     // the layer's weight tensor is (Cout_layer, 3, 3, Cin_layer): forward Cout_layer = Cout; transposed Cout_layer = Cin
     WINO_LAUNCH(k_wino_filter, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), w, U, transposed ? Cin : Cout, transposed ? Cout : Cin,
                 transposed ? 1 : 0);
@@ -1277,12 +1280,19 @@ extern "C" long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, in
     return (long long)N * Ho * Wo * KH * KW * (Cin == 4 ? 4 : Cin) * Cout;
 }
 
+extern "C" size_t mrcnn_conv2d_winograd_v_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
+    if (!wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) return 0;
+    const WinoGeom g = wino_geom(N, H, W);
+    return (size_t)g.nk * g.Tp * Cin * sizeof(float);
+}
+
 extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                                     int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
-                                    void *ws, size_t ws_bytes, void *stream) {
+                                    float *wino_v, void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cin, Cout))
-        return wino_conv(x, w, y, N, H, W, Cin, Cout, false, bias, relu, 0, nullptr, ws, ws_bytes, (hipStream_t)stream);
+        return wino_conv(x, w, y, N, H, W, Cin, Cout, false, bias, relu, 0, nullptr, ws, ws_bytes, (hipStream_t)stream, wino_v);
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     p.a = x; p.b = w; p.c = y; p.bias = bias; p.relu = relu;
     p.bytes_a = (unsigned)((size_t)N * H * W * Cin * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
@@ -1302,7 +1312,7 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
     if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
     if (relu_x && accumulate) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: relu_x with accumulate");
     if (wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cout, Cin))
-        return wino_conv(gy, w, gx, N, H, W, Cout, Cin, true, nullptr, 0, accumulate, relu_x, ws, ws_bytes, (hipStream_t)stream);
+        return wino_conv(gy, w, gx, N, H, W, Cout, Cin, true, nullptr, 0, accumulate, relu_x, ws, ws_bytes, (hipStream_t)stream, nullptr);
     p.a = gy; p.b = w; p.c = gx; p.accumulate = accumulate; p.relu_x = relu_x;
     p.bytes_a = (unsigned)((size_t)N * p.Ho * p.Wo * Cout * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
     p.M = N * H * W; p.Ng = Cin;
@@ -1325,7 +1335,7 @@ extern "C" size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, i
 
 extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, float *gw, float *gbias, int N,
                                            int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                           int accumulate, void *ws, size_t ws_bytes, void *stream) {
+                                           int accumulate, const float *wino_v, void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_conv(x, gy, gw, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     const size_t need = mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (!ws || ws_bytes < need) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "conv2d_bwd_filter: workspace %zu < %zu", ws_bytes, need);
@@ -1333,7 +1343,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) {
         const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
-        if (int e = wino_bwd_filter(x, gy, gw, N, H, W, Cin, Cout, accumulate, ws, st)) return e;
+        if (int e = wino_bwd_filter(x, gy, gw, N, H, W, Cin, Cout, accumulate, ws, st, wino_v)) return e;
         if (gbias) {
             float *bias_part = (float *)((char *)ws + L.total);
             const int P = N * p.Ho * p.Wo;

@@ -134,9 +134,13 @@ long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, int Cout, int
  * gfx950) and output tile (0 = per layer, whichever of F(2x2,3x3) / F(4x4,3x3) needs fewer multiplications; 2 or 4 =
  * forced).  Lowering the thresholds is how the tests run whole small networks through the Winograd kernels. */
 int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels, int tile);
+/* wino_v (nullable): caller-owned buffer of mrcnn_conv2d_winograd_v_bytes() bytes (0 = the layer does not take the
+ * Winograd path).  The forward pass leaves its transformed input there and the filter-gradient pass of the same layer
+ * reads it instead of transforming x again (same call geometry, same Winograd settings). */
+size_t mrcnn_conv2d_winograd_v_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
-                         void *ws, size_t ws_bytes, void *stream);
+                         float *wino_v, void *ws, size_t ws_bytes, void *stream);
 /* relu_x (nullable, same shape as gx): the layer's input when it is the output of a ReLU; gx is then zeroed where
  * relu_x <= 0, i.e. the ReLU backward of the layer below is fused into this epilogue (not with accumulate). */
 int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, const float *relu_x, int N, int H, int W, int Cin,
@@ -146,6 +150,7 @@ size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int
                                                int stride, int pad);
 int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, float *gw, float *gbias, int N, int H,
                                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,
+                                const float *wino_v,
                                 void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -179,6 +179,10 @@ def _winograd_case(case, tol):
     gw, gb = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True)
     gw2, _ = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True)
     assert torch.equal(gw, gw2)
+    _, v = hnn.conv2d_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), 1, 1, False, keep_v=True)      # transformed input kept by forward
+    assert v is not None
+    gw3, _ = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True, wino_v=v)
+    assert torch.equal(gw, gw3)
     errw = (gw.cpu().double() - wref).abs().max().item() / wref.abs().max().item()
     print('winograd errors: fwd %.2e filter-grad %.2e' % (err, errw))
     assert errw < tol, errw
