@@ -859,21 +859,24 @@ constexpr int WINO_ROWS = 128;          // Tp = T rounded up to this: a GEMM til
 
 int g_wino_min_channels = 256, g_wino_min_pixels = 2048, g_wino_tile = 0;      // tile 0 = automatic, 2 or 4 = forced
 
+int wino_m(int H, int W) {
+    if (g_wino_tile == 2 || g_wino_tile == 4) return g_wino_tile;
+    const long long c2 = 16ll * ((H + 1) / 2) * ((W + 1) / 2), c4 = 36ll * ((H + 3) / 4) * ((W + 3) / 4);
+    return c4 < c2 ? 4 : 2;
+}
 bool wino_ok(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     if (KH != 3 || KW != 3 || stride != 1 || pad != 1) return false;
     // measured on gfx950 (tools/conv_bench.py): with >= 256 channels the GEMMs are deep enough (K >= 256) to win from
     // 2048 pixels up; at 128 channels Winograd ties the direct kernel, at 64 it loses; below 2048 pixels the four launches
     // are latency-bound
-    if (Cin % BK || Cout % BK || Cin < g_wino_min_channels || Cout < g_wino_min_channels) return false;
+    // F(4x4) does 4x fewer multiplications, so it pays from a quarter of the channels F(2x2) needs (measured: 64 -> 64 on
+    // 256^2 maps 95 -> 78 us, 128 -> 128 on 128^2 83 -> 62 us; with F(2x2) the same layers lose)
+    const int minc = wino_m(H, W) == 4 ? std::max(BK, g_wino_min_channels / 4) : g_wino_min_channels;
+    if (Cin % BK || Cout % BK || Cin < minc || Cout < minc) return false;
     if ((long long)N * H * W < g_wino_min_pixels) return false;
     const long long T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
     const long long Tp = (T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS;
     return 16 * Tp < (1ll << 24) && 16 * Tp * std::max(Cin, Cout) < (1ll << 30);    // limits of the GEMM kernel's offsets
-}
-int wino_m(int H, int W) {
-    if (g_wino_tile == 2 || g_wino_tile == 4) return g_wino_tile;
-    const long long c2 = 16ll * ((H + 1) / 2) * ((W + 1) / 2), c4 = 36ll * ((H + 3) / 4) * ((W + 3) / 4);
-    return c4 < c2 ? 4 : 2;
 }
 struct WinoGeom { int m, a, nk, th, tw; long long T, Tp; };
 WinoGeom wino_geom(int N, int H, int W) {
@@ -1004,9 +1007,14 @@ __global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x,
     constexpr int A_ = M_ + 2;
     const int C4 = C / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * C4) return;
+    if (i >= Tp * C4) return;
     const int c = (int)(i % C4) * 4;
     const long long t = i / C4;
+    if (t >= T) {           // rows that pad T to a multiple of the GEMM tile: zero (the filter-gradient GEMM sums them)
+#pragma unroll
+        for (int k = 0; k < A_ * A_; ++k) v4st(V + ((size_t)k * Tp + t) * C + c, v4zero());
+        return;
+    }
     const int tx = (int)(t % tw);
     const int ty = (int)((t / tw) % th);
     const int n = (int)(t / ((long long)tw * th));
@@ -1092,9 +1100,14 @@ __global__ __launch_bounds__(256) void k_wino_gy(const float *__restrict__ gy, f
     constexpr int A_ = M_ + 2;
     const int C4 = C / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * C4) return;
+    if (i >= Tp * C4) return;
     const int c = (int)(i % C4) * 4;
     const long long t = i / C4;
+    if (t >= T) {           // padded rows: zero
+#pragma unroll
+        for (int k = 0; k < A_ * A_; ++k) v4st(Wt + ((size_t)k * Tp + t) * C + c, v4zero());
+        return;
+    }
     const int tx = (int)(t % tw);
     const int ty = (int)((t / tw) % th);
     const int n = (int)(t / ((long long)tw * th));
@@ -1184,12 +1197,7 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     char *base = (char *)ws;
     float *Vw = (float *)(base + L.v), *Wt = (float *)(base + L.w), *slabs = (float *)(base + L.slabs), *dU = (float *)(base + L.du);
     const float *V = v_cached ? v_cached : Vw;       // the forward pass's transformed input, kept by the caller
-    if (g.Tp > g.T)         // padded rows are summed by the GEMM: they must be zero
-        for (int k = 0; k < g.nk; ++k) {
-            if (!v_cached) MRCNN_HIP_TRY(hipMemsetAsync(Vw + ((size_t)k * g.Tp + g.T) * Cin, 0, (size_t)(g.Tp - g.T) * Cin * 4, st));
-            MRCNN_HIP_TRY(hipMemsetAsync(Wt + ((size_t)k * g.Tp + g.T) * Cout, 0, (size_t)(g.Tp - g.T) * Cout * 4, st));
-        }
-    const long long nin = g.T * (Cin / 4), nout = g.T * (Cout / 4);
+    const long long nin = g.Tp * (Cin / 4), nout = g.Tp * (Cout / 4);      // the transform kernels zero the padded rows
     if (!v_cached) WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), x, Vw, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
     WINO_LAUNCH(k_wino_gy, g, dim3((unsigned)((nout + 255) / 256)), gy, Wt, N, H, W, Cout, g.th, g.tw, g.T, g.Tp);
     ConvP p = make_p(1, 1, (int)g.Tp, Cin, Cout, 1, 1, 1, 0);
@@ -1221,10 +1229,7 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
     // the layer's weight tensor is (Cout_layer, 3, 3, Cin_layer): forward Cout_layer = Cout; transposed Cout_layer = Cin
     WINO_LAUNCH(k_wino_filter, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), w, U, transposed ? Cin : Cout, transposed ? Cout : Cin,
                 transposed ? 1 : 0);
-    if (g.Tp > g.T)         // padded rows of V feed the GEMM: keep them finite (their products are never read)
-        for (int k = 0; k < g.nk; ++k)
-            MRCNN_HIP_TRY(hipMemsetAsync(V + ((size_t)k * g.Tp + g.T) * Cin, 0, (size_t)(g.Tp - g.T) * Cin * 4, st));
-    const long long nin = g.T * (Cin / 4), nout = g.T * (Cout / 4);
+    const long long nin = g.Tp * (Cin / 4), nout = g.T * (Cout / 4);       // k_wino_input zeroes the padded rows of V
     WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), in, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
     // batched GEMM: 1x1 "convolution" over nk*Tp pixels, weight matrix selected by the row block
     ConvP p = make_p(1, 1, (int)(g.nk * g.Tp), Cin, Cout, 1, 1, 1, 0);
