@@ -109,15 +109,18 @@ def run(args, keypoints=False):
             tf = RawTransform(faster_rcnn)
         loader = BatchLoader(data, tf, batch_size=bs, shuffle=True, seed=1234, rank=rank, world=world,
                              num_workers=args.num_workers, max_gt=args.max_gt or None, keypoints=keypoints, device=dev)
+    pool = []
     t0 = time.time()
     for it in range(1, args.iteration + 1):
         if loader is not None:
             b = next(loader)
             batch = [b[k] for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')]
             scale = float(b['scales'][0])
-        else:
-            b = make_batch(it * world + rank, bs, H, W, G=8, n_fg_class=n_fg, n_keypoints=K)
-            batch = [torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')]
+        else:           # a small pool of device-resident synthetic batches, cycled (generating one per step is host-bound)
+            if len(pool) < 8:
+                b = make_batch((len(pool) + 1) * world + rank, bs, H, W, G=8, n_fg_class=n_fg, n_keypoints=K)
+                pool.append([torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')])
+            batch = pool[it % len(pool)]
             scale = 1.0
         optimizer.update(model, *batch, scale)
         if it % args.log_interval == 0 or it == args.iteration:       # one device->host sync per log interval
