@@ -88,9 +88,17 @@ def conv2d_fwd_raw(x, w, b, stride, pad, relu, keep_v=False):
     return (y, v) if keep_v else y
 
 
-def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None, relu_x=None):
+def winograd_w_bytes(x_shape, w_shape, stride, pad):
+    N, H, W, Cin = x_shape
+    Cout, KH, KW, _ = w_shape
+    return lib().mrcnn_conv2d_winograd_w_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+
+
+def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None, relu_x=None, emit_w=False, gb=None, gb_accumulate=False):
     """out given => gx is accumulated into it (fan-out points of the graph), else allocated.
-    relu_x = the layer's input when it came out of a ReLU: gx is masked with (relu_x > 0) in the epilogue."""
+    relu_x = the layer's input when it came out of a ReLU: gx is masked with (relu_x > 0) in the epilogue.
+    emit_w (Winograd layers only): returns (gx, wino_w) - the filter-gradient operand computed from the same read of gy
+    (pass it to conv2d_bwd_filter_raw); gb: the bias gradient is written there from that read too."""
     N, H, W, Cin = x_shape
     Cout, KH, KW, _ = w.shape
     assert gy.is_contiguous()
@@ -98,14 +106,20 @@ def conv2d_bwd_data_raw(gy, w, x_shape, stride, pad, out=None, relu_x=None):
     gx = out if acc else torch.empty(x_shape, dtype=torch.float32, device=gy.device)
     nb = lib().mrcnn_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     ws = workspace(nb, gy.device) if nb else None
+    wt = None
+    if emit_w:
+        wb = lib().mrcnn_conv2d_winograd_w_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+        assert wb > 0, 'emit_w: the layer does not take the Winograd path'
+        wt = torch.empty((wb // 4,), dtype=torch.float32, device=gy.device)
     with _prof('bwd_data', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout, (N, H, W, Cin, Cout, KH, KW, stride, pad)):
         check(lib().mrcnn_conv2d_bwd_data_f32(ptr(gy), ptr(w), ptr(gx), ptr(relu_x), N, H, W, Cin, Cout, KH, KW,
-                                              stride, pad, int(acc), ptr(ws), ws.numel() if ws is not None else 0,
-                                              stream_ptr()))
-    return gx
+                                              stride, pad, int(acc), ptr(wt), ptr(gb) if emit_w else None, int(gb_accumulate),
+                                              ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()))
+    return (gx, wt) if emit_w else gx
 
 
-def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias, gw=None, gb=None, accumulate=None, wino_v=None):
+def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias, gw=None, gb=None, accumulate=None, wino_v=None,
+                          wino_w=None):
     """gw / gb given: written in place (accumulate=True adds - layers applied several times); else allocated.
     wino_v: the transformed input kept by conv2d_fwd_raw(..., keep_v=True) of the same layer."""
     N, H, W, Cin = x.shape
@@ -119,5 +133,6 @@ def conv2d_bwd_filter_raw(x, gy, w_shape, stride, pad, want_bias, gw=None, gb=No
     ws = workspace(nbytes, x.device)
     with _prof('bwd_filter', N * gy.shape[1] * gy.shape[2], KH, KW, Cin, Cout, (N, H, W, Cin, Cout, KH, KW, stride, pad)):
         check(lib().mrcnn_conv2d_bwd_filter_f32(ptr(x), ptr(gy), ptr(gw), ptr(gb) if want_bias else None, N, H, W, Cin,
-                                                Cout, KH, KW, stride, pad, int(acc), ptr(wino_v), ptr(ws), ws.numel(), stream_ptr()))
+                                                Cout, KH, KW, stride, pad, int(acc), ptr(wino_v), ptr(wino_w), ptr(ws), ws.numel(),
+                                                stream_ptr()))
     return gw, gb

@@ -27,6 +27,10 @@ TRAIN = True
 
 # Weight-gradient GEMMs on a second stream (joined by join_side_stream() at the end of backward).
 FILTER_GRAD_ON_SIDE_STREAM = True
+# Winograd layers: one read of gy for the data gradient, the filter-gradient operand and the bias gradient.  Saves ~2 GB of
+# reads per step but the filter gradient then starts after the data gradient (less overlap): same-box A/B 26.80 vs 26.68
+# ms/step (tools/ab_step.py), so it is off.
+WINOGRAD_SHARED_GY_TRANSFORM = False
 
 
 def join_side_stream(device):
@@ -155,6 +159,24 @@ class Conv(object):
         gb = self.ps.g(self.name + '/b') if self.has_bias else None
         hnn.LOGICAL = (self.cin, self.cout)
         try:
+            if WINOGRAD_SHARED_GY_TRANSFORM and need_gx and self.stride == 1 and hnn.winograd_w_bytes(tuple(x.shape), tuple(gw.shape), 1, self.pad) > 0:
+                # Winograd layer: the data-gradient call reads gy once for its own GEMM, the filter-gradient GEMM's
+                # operand and the bias gradient; the filter gradient then runs on the side stream from the two kept
+                # transforms (v from forward, wt from here) beside the next layer's backward
+                assert not (mask_gx and gx_acc is not None)
+                gx, wt = hnn.conv2d_bwd_data_raw(gy, self.W, tuple(x.shape), 1, self.pad, out=gx_acc, relu_x=x if mask_gx else None,
+                                                 emit_w=True, gb=gb, gb_accumulate=accumulate_params)
+                main = torch.cuda.current_stream(gy.device)
+                side = hnn.side_stream(gy.device) if (FILTER_GRAD_ON_SIDE_STREAM and hnn.PROFILE is None) else main
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    hnn.conv2d_bwd_filter_raw(x, gy, tuple(gw.shape), 1, self.pad, False, gw=gw, gb=None,
+                                              accumulate=accumulate_params, wino_v=v, wino_w=wt)
+                if side is not main:
+                    for t_ in (gy, x, v, wt):
+                        if t_ is not None:
+                            t_.record_stream(side)
+                return gx
             if FILTER_GRAD_ON_SIDE_STREAM and hnn.PROFILE is None:
                 main = torch.cuda.current_stream(gy.device)
                 side = hnn.side_stream(gy.device)

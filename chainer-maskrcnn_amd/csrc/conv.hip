@@ -1136,6 +1136,96 @@ __global__ __launch_bounds__(256) void k_wino_gy(const float *__restrict__ gy, f
     }
 }
 
+// Backward pass, one read of gy for three consumers: V = B^T d B (the backward-data GEMM's operand), W = A dy A^T of the
+// inner m x m tile (the filter-gradient GEMM's operand, kept by the caller) and the per-channel sums of gy (bias
+// gradient partials, one row of `bias_part` per block; blocks walk the tiles with a grid stride).  The inner tile is
+// re-read for the second transform: it hits L1 / L2, HBM sees gy once.
+template <int M_>
+__global__ __launch_bounds__(256) void k_wino_gy_dual(const float *__restrict__ gy, float *__restrict__ V, float *__restrict__ Wt,
+                                                      float *__restrict__ bias_part, int N, int H, int W, int C, int th, int tw,
+                                                      long long T, long long Tp) {
+    constexpr int A_ = M_ + 2;
+    __shared__ float4 sred[256];
+    const int C4 = C / 4;
+    const size_t ks = (size_t)Tp * C;
+    V4 bsum = v4zero();
+    const long long total = Tp * C4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const long long t = i / C4;
+        if (t >= T) {
+#pragma unroll
+            for (int k = 0; k < A_ * A_; ++k) {
+                v4st(V + ((size_t)k * Tp + t) * C + c, v4zero());
+                v4st(Wt + ((size_t)k * Tp + t) * C + c, v4zero());
+            }
+            continue;
+        }
+        const int tx = (int)(t % tw);
+        const int ty = (int)((t / tw) % th);
+        const int n = (int)(t / ((long long)tw * th));
+        {
+            V4 b[A_][A_];
+#pragma unroll
+            for (int q = 0; q < A_; ++q) {
+                const int ww = M_ * tx - 1 + q;
+                V4 d[A_], r[A_];
+#pragma unroll
+                for (int rr = 0; rr < A_; ++rr) {
+                    const int h = M_ * ty - 1 + rr;
+                    const bool ok = (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W;
+                    d[rr] = ok ? v4ld(gy + (((size_t)n * H + h) * W + ww) * C + c) : v4zero();
+                }
+                wino_bt<M_, V4>(d, r);
+#pragma unroll
+                for (int rr = 0; rr < A_; ++rr) b[rr][q] = r[rr];
+            }
+            float *o = V + (size_t)t * C + c;
+#pragma unroll
+            for (int rr = 0; rr < A_; ++rr) {
+                V4 row[A_];
+                wino_bt<M_, V4>(b[rr], row);
+#pragma unroll
+                for (int q = 0; q < A_; ++q) v4st(o + (size_t)(rr * A_ + q) * ks, row[q]);
+            }
+        }
+        {
+            V4 r[A_][M_];
+#pragma unroll
+            for (int bq = 0; bq < M_; ++bq) {
+                const int ww = M_ * tx + bq;
+                V4 y[M_], col[A_];
+#pragma unroll
+                for (int a = 0; a < M_; ++a) {
+                    const int h = M_ * ty + a;
+                    y[a] = (h < H && ww < W) ? v4ld(gy + (((size_t)n * H + h) * W + ww) * C + c) : v4zero();
+                    bsum = bsum + y[a];
+                }
+                wino_a<M_, V4>(y, col, v4zero());
+#pragma unroll
+                for (int q = 0; q < A_; ++q) r[q][bq] = col[q];
+            }
+            float *o = Wt + (size_t)t * C + c;
+#pragma unroll
+            for (int q = 0; q < A_; ++q) {
+                V4 row[A_];
+                wino_a<M_, V4>(r[q], row, v4zero());
+#pragma unroll
+                for (int j = 0; j < A_; ++j) v4st(o + (size_t)(q * A_ + j) * ks, row[j]);
+            }
+        }
+    }
+    if (bias_part) {        // threads tid, tid + C4, ... hold the same channel group (256 % C4 == 0 is checked by the host)
+        sred[threadIdx.x] = make_float4(bsum.x, bsum.y, bsum.z, bsum.w);
+        __syncthreads();
+        if ((int)threadIdx.x < C4) {
+            float4 a = sred[threadIdx.x];
+            for (int k = threadIdx.x + C4; k < 256; k += C4) { const float4 q = sred[k]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+            *reinterpret_cast<float4 *>(bias_part + (size_t)blockIdx.x * C + threadIdx.x * 4) = a;
+        }
+    }
+}
+
 // gw[co][u][v][ci] (+)= (G^T dU G)[u][v], dU[co][k][ci] = sum over tiles of W[k][t][co] * V[k][t][ci].
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restrict__ dU, float *__restrict__ gw, int Cout, int Cin,
@@ -1191,7 +1281,7 @@ WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
 }
 
 int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, int W, int Cin, int Cout, int accumulate, void *ws,
-                    hipStream_t st, const float *v_cached) {
+                    hipStream_t st, const float *v_cached, const float *w_cached) {
     const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
     const WinoGeom &g = L.g;
     char *base = (char *)ws;
@@ -1199,11 +1289,11 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     const float *V = v_cached ? v_cached : Vw;       // the forward pass's transformed input, kept by the caller
     const long long nin = g.Tp * (Cin / 4), nout = g.Tp * (Cout / 4);      // the transform kernels zero the padded rows
     if (!v_cached) WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), x, Vw, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
-    WINO_LAUNCH(k_wino_gy, g, dim3((unsigned)((nout + 255) / 256)), gy, Wt, N, H, W, Cout, g.th, g.tw, g.T, g.Tp);
+    if (!w_cached) WINO_LAUNCH(k_wino_gy, g, dim3((unsigned)((nout + 255) / 256)), gy, Wt, N, H, W, Cout, g.th, g.tw, g.T, g.Tp);
     ConvP p = make_p(1, 1, (int)g.Tp, Cin, Cout, 1, 1, 1, 0);
     p.wbatch_rows = (int)g.Tp; p.wbatch_n = g.nk;
     p.ksplit = L.ksplit; p.kchunk = L.kchunk;
-    p.a = Wt; p.b = V; p.c = L.ksplit > 1 ? slabs : dU;
+    p.a = w_cached ? w_cached : Wt; p.b = V; p.c = L.ksplit > 1 ? slabs : dU;
     p.bytes_a = (unsigned)((size_t)g.nk * g.Tp * Cout * 4); p.bytes_b = (unsigned)((size_t)g.nk * g.Tp * Cin * 4);
     p.M = Cout; p.Ng = Cin;
     launch_conv<MODE_BWD_FILTER>(p, g.nk * p.ksplit, filter_tile(p), st);
@@ -1221,7 +1311,7 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
 // the backward-data filter (then Cin here = the layer's Cout and Cout here = the layer's Cin).
 int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, int Cin, int Cout, bool transposed,
               const float *bias, int relu, int accumulate, const float *relu_x, void *ws, size_t ws_bytes, hipStream_t st,
-              float *v_keep) {
+              float *v_keep, float *w_keep = nullptr, float *gbias = nullptr, int gbias_accumulate = 0) {
     const WinoLayout L = wino_layout(N, H, W, Cin, Cout);
     const WinoGeom &g = L.g;
     char *base = (char *)ws;
@@ -1230,7 +1320,25 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
     WINO_LAUNCH(k_wino_filter, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), w, U, transposed ? Cin : Cout, transposed ? Cout : Cin,
                 transposed ? 1 : 0);
     const long long nin = g.Tp * (Cin / 4), nout = g.T * (Cout / 4);       // k_wino_input zeroes the padded rows of V
-    WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), in, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
+    if (w_keep) {           // backward pass: one read of gy feeds this GEMM, the filter-gradient GEMM and the bias gradient
+        const bool wb = gbias && (256 % (Cin / 4)) == 0;
+        const int nblk = (int)std::min<long long>((nin + 255) / 256, 512);
+        float *bias_part = wb ? (float *)(base + L.m) : nullptr;          // M is written only after this kernel has finished
+        WINO_LAUNCH(k_wino_gy_dual, g, dim3(nblk), in, V, w_keep, bias_part, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
+        if (wb) {
+            hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cin, 64)), dim3(1024), 0, st, bias_part, gbias, nblk, Cin, gbias_accumulate);
+            MRCNN_LAUNCH_CHECK();
+        } else if (gbias) {       // channel count that does not tile a 256-thread block: the ordinary two-kernel column sum
+            const int P = N * H * W;
+            const ColPlan cp = col_plan(P, Cin);
+            float *part = (float *)(base + L.m);
+            hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, in, part, P, Cin, cp.G, cp.RPI, cp.rows_per_blk);
+            MRCNN_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cin, 64)), dim3(1024), 0, st, part, gbias, cp.nblk, Cin, gbias_accumulate);
+            MRCNN_LAUNCH_CHECK();
+        }
+    } else
+        WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), in, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
     // batched GEMM: 1x1 "convolution" over nk*Tp pixels, weight matrix selected by the row block
     ConvP p = make_p(1, 1, (int)(g.nk * g.Tp), Cin, Cout, 1, 1, 1, 0);
     p.a = V; p.b = U; p.c = Mb;
@@ -1306,9 +1414,17 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
     return run_data_conv<MODE_FWD>(p, nsteps, Cout, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" size_t mrcnn_conv2d_winograd_w_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
+    if (!wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) return 0;
+    const WinoGeom g = wino_geom(N, H, W);
+    return (size_t)g.nk * g.Tp * Cout * sizeof(float);
+}
+
 extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, const float *relu_x, int N, int H, int W,
                                          int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                         int accumulate, void *ws, size_t ws_bytes, void *stream) {
+                                         int accumulate, float *wino_w, float *gbias, int gbias_accumulate, void *ws,
+                                         size_t ws_bytes, void *stream) {
     if (int e = check_conv(gy, w, gx, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     if (stride != 1)
         return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: stride %d (only 1; strided 1x1 convs are "
@@ -1317,7 +1433,9 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
     if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
     if (relu_x && accumulate) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: relu_x with accumulate");
     if (wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cout, Cin))
-        return wino_conv(gy, w, gx, N, H, W, Cout, Cin, true, nullptr, 0, accumulate, relu_x, ws, ws_bytes, (hipStream_t)stream, nullptr);
+        return wino_conv(gy, w, gx, N, H, W, Cout, Cin, true, nullptr, 0, accumulate, relu_x, ws, ws_bytes, (hipStream_t)stream, nullptr,
+                         wino_w, wino_w ? gbias : nullptr, gbias_accumulate);
+    if (wino_w || gbias) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: wino_w / gbias only on the Winograd path (mrcnn_conv2d_winograd_w_bytes() > 0)");
     p.a = gy; p.b = w; p.c = gx; p.accumulate = accumulate; p.relu_x = relu_x;
     p.bytes_a = (unsigned)((size_t)N * p.Ho * p.Wo * Cout * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
     p.M = N * H * W; p.Ng = Cin;
@@ -1340,7 +1458,8 @@ extern "C" size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, i
 
 extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, float *gw, float *gbias, int N,
                                            int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                           int accumulate, const float *wino_v, void *ws, size_t ws_bytes, void *stream) {
+                                           int accumulate, const float *wino_v, const float *wino_w, void *ws, size_t ws_bytes,
+                                           void *stream) {
     if (int e = check_conv(x, gy, gw, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     const size_t need = mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (!ws || ws_bytes < need) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "conv2d_bwd_filter: workspace %zu < %zu", ws_bytes, need);
@@ -1348,7 +1467,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) {
         const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
-        if (int e = wino_bwd_filter(x, gy, gw, N, H, W, Cin, Cout, accumulate, ws, st, wino_v)) return e;
+        if (int e = wino_bwd_filter(x, gy, gw, N, H, W, Cin, Cout, accumulate, ws, st, wino_v, wino_w)) return e;
         if (gbias) {
             float *bias_part = (float *)((char *)ws + L.total);
             const int P = N * p.Ho * p.Wo;

@@ -143,14 +143,19 @@ int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, floa
                          float *wino_v, void *ws, size_t ws_bytes, void *stream);
 /* relu_x (nullable, same shape as gx): the layer's input when it is the output of a ReLU; gx is then zeroed where
  * relu_x <= 0, i.e. the ReLU backward of the layer below is fused into this epilogue (not with accumulate). */
+/* wino_w (nullable, mrcnn_conv2d_winograd_w_bytes() bytes; only where that is > 0): the Winograd path reads gy ONCE
+ * and leaves the filter-gradient GEMM's operand (A dy A^T) there for the mrcnn_conv2d_bwd_filter_f32 call of the same
+ * layer; with wino_w, gbias (nullable, Cout) receives the bias gradient (column sums of gy; added to when
+ * gbias_accumulate != 0) from the same read. */
+size_t mrcnn_conv2d_winograd_w_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, const float *relu_x, int N, int H, int W, int Cin,
-                              int Cout, int KH, int KW, int stride, int pad, int accumulate, void *ws,
-                              size_t ws_bytes, void *stream);
+                              int Cout, int KH, int KW, int stride, int pad, int accumulate, float *wino_w,
+                              float *gbias, int gbias_accumulate, void *ws, size_t ws_bytes, void *stream);
 size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                                int stride, int pad);
 int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, float *gw, float *gbias, int N, int H,
                                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,
-                                const float *wino_v,
+                                const float *wino_v, const float *wino_w,
                                 void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -176,6 +176,7 @@ def _winograd_case(case, tol):
     wref = torch.autograd.functional.vjp(
         lambda ww: F.conv2d(xd.permute(0, 3, 1, 2), ww.permute(0, 3, 1, 2), None, stride=1, padding=1).permute(0, 2, 3, 1),
         w.double(), gy.double())[1]
+    gbref = gy.double().sum((0, 1, 2))
     gw, gb = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True)
     gw2, _ = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True)
     assert torch.equal(gw, gw2)
@@ -183,10 +184,16 @@ def _winograd_case(case, tol):
     assert v is not None
     gw3, _ = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True, wino_v=v)
     assert torch.equal(gw, gw3)
+    # one read of gy: the data-gradient call also emits the filter-gradient operand and the bias gradient
+    gb4 = torch.zeros((Cout,), device=DEV)
+    gx4, wt = hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (N, H, W, Cin), 1, 1, emit_w=True, gb=gb4)
+    assert torch.equal(gx4, gx)
+    gw4, _ = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, False, wino_v=v, wino_w=wt)
+    assert torch.equal(gw, gw4)
+    assert (gb4.cpu().double() - gbref).abs().max().item() / gbref.abs().max().item() < 2e-5
     errw = (gw.cpu().double() - wref).abs().max().item() / wref.abs().max().item()
     print('winograd errors: fwd %.2e filter-grad %.2e' % (err, errw))
     assert errw < tol, errw
-    gbref = gy.double().sum((0, 1, 2))
     assert (gb.cpu().double() - gbref).abs().max().item() / gbref.abs().max().item() < 2e-5
     acc_w, acc_b = (torch.ones_like(gw), torch.ones_like(gb))
     hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True, gw=acc_w, gb=acc_b, accumulate=True)
