@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(256) void k_wino_gy_dual(const float *__restrict__ 
 // gw[co][u][v][ci] (+)= (G^T dU G)[u][v], dU[co][k][ci] = sum over tiles of W[k][t][co] * V[k][t][ci].
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restrict__ dU, float *__restrict__ gw, int Cout, int Cin,
-                                                          int accumulate) {
+                                                          int accumulate, int nslab) {
     constexpr int A_ = M_ + 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Cout * Cin) return;
@@ -1239,7 +1239,12 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restric
     for (int j = 0; j < A_; ++j) {
         float D[A_], c3[3];
 #pragma unroll
-        for (int q = 0; q < A_; ++q) D[q] = dU[((size_t)co * (A_ * A_) + q * A_ + j) * Cin + ci];
+        for (int q = 0; q < A_; ++q) {          // the split-K slabs of dU are added here, in slab order
+            const size_t o = ((size_t)co * (A_ * A_) + q * A_ + j) * Cin + ci;
+            float a = dU[o];
+            for (int sl = 1; sl < nslab; ++sl) a += dU[(size_t)sl * Cout * (A_ * A_) * Cin + o];
+            D[q] = a;
+        }
         wino_gt<M_>(D, c3);
 #pragma unroll
         for (int u = 0; u < 3; ++u) r[u][j] = c3[u];
@@ -1298,12 +1303,8 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     p.M = Cout; p.Ng = Cin;
     launch_conv<MODE_BWD_FILTER>(p, g.nk * p.ksplit, filter_tile(p), st);
     MRCNN_LAUNCH_CHECK();
-    if (L.ksplit > 1) {
-        const size_t n4 = (size_t)Cout * g.nk * Cin / 4;
-        hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, L.ksplit, 0);
-        MRCNN_LAUNCH_CHECK();
-    }
-    WINO_LAUNCH(k_wino_filter_grad, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), dU, gw, Cout, Cin, accumulate);
+    WINO_LAUNCH(k_wino_filter_grad, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), L.ksplit > 1 ? slabs : dU, gw, Cout, Cin, accumulate,
+                L.ksplit > 1 ? L.ksplit : 1);
     return 0;
 }
 
