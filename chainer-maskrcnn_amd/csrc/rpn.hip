@@ -146,8 +146,12 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ sboxe
 // One 1024-thread workgroup per image walks the boxes in order, 64 at a time.  Wave 0 resolves the intra-chunk
 // dependency on the diagonal 64x64 block with scalar bit operations (the next chunk's diagonal words are already in
 // flight); then ALL threads OR the mask rows of the boxes kept in the chunk into the removed set with independent,
-// coalesced loads (one round of memory latency per chunk instead of one per kept box).
+// coalesced loads (one round of memory latency per chunk instead of one per kept box).  The removed set is maintained
+// for a WINDOW of NMS_WIN chunks ahead only: the walk stops at n_post kept boxes, which with few suppressions is after
+// n_post/64 chunks, so rows are not ORed into words that are never reached; when the walk does cross into the next window
+// every box kept so far is applied to that window's words first.
 constexpr int NMS_RED_THREADS = 1024;
+constexpr int NMS_WIN = 48;
 __global__ __launch_bounds__(NMS_RED_THREADS) void k_nms_reduce(const u64 *__restrict__ mask, const int32_t *__restrict__ n_valid,
                                                                 int n_pre, int nblk, int n_post, int32_t *__restrict__ keep,
                                                                 int32_t *__restrict__ n_keep) {
@@ -164,9 +168,30 @@ __global__ __launch_bounds__(NMS_RED_THREADS) void k_nms_reduce(const u64 *__res
     __syncthreads();
     const int nb = (n + 63) / 64;
     u64 Dn = (wave == 0 && lane < n) ? mk[(size_t)lane * nblk] : 0ull;       // diagonal word of chunk 0
+    int wend = min(nb, NMS_WIN);      // rem[] is complete for words < wend
     for (int c = 0; c < nb; ++c) {
         int kept = s_kept;
         if (kept >= n_post) break;
+        if (c >= wend) {              // open the next window (block-uniform): apply every kept box to its words
+            const int wnew = min(nb, wend + NMS_WIN), Wn = wnew - wend, total = kept * Wn;
+            for (int idx = tid; idx < total; idx += 4 * NMS_RED_THREADS) {
+                u64 v[4];
+                int w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int id = idx + j * NMS_RED_THREADS;
+                    const bool ok = id < total;
+                    const int q = ok ? id / Wn : 0;
+                    w[j] = wend + (ok ? id - q * Wn : 0);
+                    v[j] = ok ? mk[(size_t)kp[q] * nblk + w[j]] : 0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (v[j]) atomicOr(&rem[w[j]], v[j]);
+            }
+            __syncthreads();
+            wend = wnew;
+        }
         if (wave == 0) {
             const u64 D = Dn;
             const int inext = (c + 1) * 64 + lane;
@@ -190,7 +215,7 @@ __global__ __launch_bounds__(NMS_RED_THREADS) void k_nms_reduce(const u64 *__res
             if (lane == 0) { s_cnt = k; s_kept = kept; }
         }
         __syncthreads();
-        const int K = s_cnt, Wd = nb - c - 1;
+        const int K = s_cnt, Wd = wend - c - 1;
         if (K > 0 && Wd > 0 && s_kept < n_post) {
             // four independent loads in flight per thread (the loop is latency-bound: ~12 rounds per chunk otherwise)
             const int total = K * Wd;

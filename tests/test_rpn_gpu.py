@@ -25,7 +25,9 @@ def _rand_boxes(rs, n, size=400.0):
     return np.concatenate([c - hw / 2, c + hw / 2], 1).astype(np.float32)
 
 
-@pytest.mark.parametrize('n,thresh', [(1, 0.7), (63, 0.7), (64, 0.5), (65, 0.3), (1000, 0.7), (5000, 0.7)])
+# 5000 / 12000 boxes = 79 / 188 chunks of 64: the reduction crosses several 48-chunk windows, with light (0.7) and heavy
+# (0.3) suppression
+@pytest.mark.parametrize('n,thresh', [(1, 0.7), (63, 0.7), (64, 0.5), (65, 0.3), (1000, 0.7), (5000, 0.7), (5000, 0.3), (12000, 0.5)])
 def test_nms_keep_list_bit_exact(n, thresh):
     rs = np.random.RandomState(n)
     b = _rand_boxes(rs, n)
