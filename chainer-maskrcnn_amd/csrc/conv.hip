@@ -1303,8 +1303,13 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     p.M = Cout; p.Ng = Cin;
     launch_conv<MODE_BWD_FILTER>(p, g.nk * p.ksplit, filter_tile(p), st);
     MRCNN_LAUNCH_CHECK();
-    WINO_LAUNCH(k_wino_filter_grad, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), L.ksplit > 1 ? slabs : dU, gw, Cout, Cin, accumulate,
-                L.ksplit > 1 ? L.ksplit : 1);
+    if (L.ksplit > 1) {     // a separate, fully parallel slab sum: folding it into k_wino_filter_grad (Cout*Cin threads only) was
+                            // measured 20 % .. 4x slower (tools/wino_sweep.py)
+        const size_t n4 = (size_t)Cout * g.nk * Cin / 4;
+        hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, L.ksplit, 0);
+        MRCNN_LAUNCH_CHECK();
+    }
+    WINO_LAUNCH(k_wino_filter_grad, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), dU, gw, Cout, Cin, accumulate, 1);
     return 0;
 }
 
