@@ -62,6 +62,7 @@ def _parse_header(path):
 SIGNATURES = _parse_header(HEADER_PATH)
 
 _lib = None
+ABI_VERSION = 2          # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
 
 
 class MrcnnHipError(RuntimeError):
@@ -82,8 +83,8 @@ def lib():
             fn = getattr(l, name)      # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if l.mrcnn_abi_version() != 1:
-            raise MrcnnHipError('ABI version mismatch: library %d, binding 1' % l.mrcnn_abi_version())
+        if l.mrcnn_abi_version() != ABI_VERSION:
+            raise MrcnnHipError('ABI version mismatch: library %d, binding %d' % (l.mrcnn_abi_version(), ABI_VERSION))
         _lib = l
     return _lib
 

@@ -27,7 +27,7 @@ class _prof(object):
             if LOGICAL is not None:
                 cin, cout = LOGICAL
             self.rec = [kind, n_out_pix * KH * KW * cin * cout, torch.cuda.Event(enable_timing=True),
-                        torch.cuda.Event(enable_timing=True), (n_out_pix, KH, cin, cout), executed]
+                        torch.cuda.Event(enable_timing=True), (n_out_pix, KH, cin, cout), executed, geom]
 
     def __enter__(self):
         if self.on:

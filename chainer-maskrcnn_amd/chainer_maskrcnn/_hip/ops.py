@@ -170,6 +170,15 @@ def image_nchw3_to_nhwc4(x):
     return y
 
 
+def image_resize_f32(img, oh, ow, div=1.0):
+    """img (C,H,W) float32 -> (C,oh,ow): cv2.resize INTER_LINEAR float rule, then / div (MaskRCNN.prepare)."""
+    _ck(img)
+    C, H, W = img.shape
+    out = _empty((C, oh, ow), img.device)
+    check(lib().mrcnn_image_resize_f32(ptr(img), C, H, W, ptr(out), oh, ow, oh, ow, float(div), stream_ptr()))
+    return out
+
+
 def random_keys(shape, seed, device):
     """uint32 sampler keys stored in an int32 tensor."""
     out = _empty(shape, device, i32)
@@ -310,17 +319,20 @@ def map_rois_to_fpn_levels(rois, k_min=0, k_max=4):
 
 # ---- targets ------------------------------------------------------------------------------------
 def proposal_target(rois, roi_levels, n_rois, gt_boxes, gt_labels, n_gt, keys, n_sample=256, pos_ratio=0.25,
-                    pos_iou_thresh=0.5, neg_hi=0.5, neg_lo=0.0, mean=(0., 0., 0., 0.), std=(0.1, 0.1, 0.2, 0.2)):
+                    pos_iou_thresh=0.5, neg_hi=0.5, neg_lo=0.0, mean=(0., 0., 0., 0.), std=(0.1, 0.1, 0.2, 0.2),
+                    pos_order=None, neg_order=None):
     """rois (N*roi_cap,4) padded, gt_boxes (N,gt_cap,4), gt_labels (N,gt_cap) i32, keys (N,roi_cap+gt_cap) u32 (as int32
-    storage).  Returns dict of per-row outputs (N*n_sample rows)."""
-    _ck(rois, roi_levels, n_rois, gt_boxes, gt_labels, n_gt, keys)
+    storage).  Returns dict of per-row outputs (N*n_sample rows) + 'n_cand' (N,2) candidate-set sizes.
+    pos_order / neg_order (N,n_sample) int32: reference-order mode (see include/mrcnn_hip.h), keys may be None."""
+    _ck(rois, roi_levels, n_rois, gt_boxes, gt_labels, n_gt, keys, pos_order, neg_order)
     N, gt_cap = gt_labels.shape
     roi_cap = rois.shape[0] // N
     dev = rois.device
     R = N * n_sample
     o = dict(sample_roi=_empty((R, 4), dev), rois_xy5=_empty((R, 5), dev), sample_levels=_empty((R,), dev, i32),
              gt_roi_loc=_empty((R, 4), dev), gt_roi_label=_empty((R,), dev, i32), gt_assign=_empty((R,), dev, i32),
-             sample_src=_empty((R,), dev, i32), n_pos=_empty((N,), dev, i32), n_sampled=_empty((N,), dev, i32))
+             sample_src=_empty((R,), dev, i32), n_pos=_empty((N,), dev, i32), n_sampled=_empty((N,), dev, i32),
+             n_cand=_empty((N, 2), dev, i32))
     m4 = (ctypes.c_float * 4)(*mean)
     s4 = (ctypes.c_float * 4)(*std)
     import numpy as np
@@ -330,7 +342,8 @@ def proposal_target(rois, roi_levels, n_rois, gt_boxes, gt_labels, n_gt, keys, n
                                           neg_lo, ctypes.cast(m4, ctypes.c_void_p), ctypes.cast(s4, ctypes.c_void_p),
                                           ptr(o['sample_roi']), ptr(o['rois_xy5']), ptr(o['sample_levels']),
                                           ptr(o['gt_roi_loc']), ptr(o['gt_roi_label']), ptr(o['gt_assign']),
-                                          ptr(o['sample_src']), ptr(o['n_pos']), ptr(o['n_sampled']), stream_ptr()))
+                                          ptr(o['sample_src']), ptr(o['n_pos']), ptr(o['n_sampled']), ptr(pos_order),
+                                          ptr(neg_order), ptr(o['n_cand']), stream_ptr()))
     return o
 
 
@@ -344,13 +357,22 @@ def mask_target(masks, sample_roi, gt_assign, n_pos, n_sample, pos_cap, mask_siz
     return out
 
 
-def keypoint_target(kps, sample_roi, gt_assign, n_pos, n_sample, pos_cap, mask_size):
-    """kps (N,gt_cap,K,3) f32 -> (N*pos_cap, K) int32."""
+def keypoint_target(kps, sample_roi, gt_assign, n_pos, n_sample, pos_cap, mask_size, inplace_quirk=False):
+    """kps (N,gt_cap,K,3) f32 -> (N*pos_cap, K) int32.  inplace_quirk: the reference's in-place gt mutation (App. B-11)."""
     _ck(kps, sample_roi, gt_assign, n_pos)
     N, gt_cap, K, _ = kps.shape
     out = _empty((N * pos_cap, K), kps.device, i32)
     check(lib().mrcnn_keypoint_target_f32(ptr(kps), N, gt_cap, K, ptr(sample_roi), ptr(gt_assign), ptr(n_pos), n_sample,
-                                          pos_cap, mask_size, ptr(out), stream_ptr()))
+                                          pos_cap, mask_size, int(inplace_quirk), ptr(out), stream_ptr()))
+    return out
+
+
+def count_valid_labels(labels):
+    """labels (N,G) int32 (-1 = padding row) -> per-image gt counts (N,) int32, on the device."""
+    _ck(labels)
+    N, G = labels.shape
+    out = _empty((N,), labels.device, i32)
+    check(lib().mrcnn_count_valid_labels_i32(ptr(labels), N, G, ptr(out), stream_ptr()))
     return out
 
 

@@ -58,6 +58,15 @@ def bench_step(args, rank, world):
     loss = float(chain.observation['loss'])
     ips = N * world * args.steps / dt
 
+    dp_report = None
+    if world > 1:       # two more steps with HIP events around every bucket's all-reduce: is the exchange hidden under backward?
+        opt.sync.timing = True
+        for _ in range(2):
+            step()
+        _sync(world)
+        dp_report = opt.sync.timing_report()
+        opt.sync.timing = False
+
     # the same step with the mask branch on the positive rows only (identical loss and gradients)
     alt = None
     if mask_rows == 'all' and world == 1:
@@ -82,7 +91,8 @@ def bench_step(args, rank, world):
     recs, hnn.PROFILE = hnn.PROFILE, None
     chain.use_aux_stream = True
     agg = {}
-    for kind, macs, e0, e1, _shape, executed in recs:
+    for rec in recs:
+        kind, macs, e0, e1, _shape, executed = rec[:6]
         a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += 2.0 * macs
@@ -92,7 +102,8 @@ def bench_step(args, rank, world):
     exe_flops = sum(a[3] for a in agg.values()) / n_prof
     secs = sum(a[2] for a in agg.values()) / n_prof
     launches = sum(a[0] for a in agg.values()) // n_prof
-    ach = flops / secs / 1e12
+    split = _replay_split(recs, n_prof, dev)
+    traffic = _pmc_conv_traffic()
     out = {
         'metric': 'images/sec (1024^2 COCO, bs=2/GPU) at 1/2/4/8 MI355X; ROIAlign bwd HBM GB/s',
         'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -103,23 +114,28 @@ def bench_step(args, rank, world):
                                % ('the <=64 positive' if mask_rows == 'positives' else 'all 256 sampled'),
                    'global_batch': N * world, 'launch_mode': mode, 'parallelism': 'dp%d: RCCL all-reduce of the flat gradient buffer in 25 MB '
                    'buckets on a side stream' % world if world > 1 else 'single GPU', 'final_loss': round(loss, 4)},
-        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm<fwd|bwd_data|bwd_filter> (all %d launches of a step)' % launches,
-                     'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
-                     'algorithmic_flops_per_step': flops, 'conv_ms_per_step': round(secs * 1e3, 3),
-                     'mfma_executed': {'flops_per_step': exe_flops, 'TFLOPs': round(exe_flops / secs / 1e12, 3),
-                                       'frac_of_peak': round(exe_flops / secs / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
-                     'by_kind': {k: {'launches': a[0] // n_prof, 'TFLOPs': round(a[1] / a[2] / 1e12, 3),
+        # frac = MFMA flops the pipes EXECUTE (Winograd layers: (m+2)^2 GEMMs on tiles, padded channels included) over the
+        # whole convolution bracket (GEMM launches + Winograd transforms + slab / column sums) / fp32 MFMA peak: <= 1.
+        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm<fwd|bwd_data|bwd_filter> (all %d convolution calls of a step)' % launches,
+                     'achieved': round(exe_flops / secs / 1e12, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(exe_flops / secs / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+                     'executed_flops_per_step': exe_flops, 'conv_ms_per_step': round(secs * 1e3, 3),
+                     'effective_TFLOPs': round(flops / secs / 1e12, 3), 'algorithmic_flops_per_step': flops,
+                     'gemm_kernels_only': split['gemm'],
+                     'by_kind': {k: {'launches': a[0] // n_prof, 'effective_TFLOPs': round(a[1] / a[2] / 1e12, 3),
                                      'executed_TFLOPs': round(a[3] / a[2] / 1e12, 3),
                                      'ms': round(a[2] / n_prof * 1e3, 3)} for k, a in agg.items()},
-                     'note': 'HIP events around every conv call on %d instrumented steps right after the timed region. '
-                             'achieved = ALGORITHMIC flops (2 x the direct convolution\'s MACs on un-padded channels) / time; the '
-                             '3x3 layers with >= 256 channels run as Winograd F(2x2,3x3) (transforms + batched GEMM inside the '
-                             'bracket), which executes 2.25x fewer MFMA flops than it is credited with: mfma_executed is what the '
-                             'pipes really do (padded channels included)' % n_prof},
+                     'note': 'HIP events around every conv call on %d instrumented single-stream steps right after the timed '
+                             'region.  achieved = executed MFMA flops / bracket time; effective_TFLOPs = 2 x the direct '
+                             'convolution\'s MACs on un-padded channels / the same time (can exceed the peak: Winograd executes '
+                             '2.25x / 4x fewer multiplications).  gemm_kernels_only / roofline_winograd_transforms: the same calls '
+                             'replayed standalone with mrcnn_conv2d_set_debug_skip (GEMMs only / everything but the GEMMs)' % n_prof},
+        'roofline_winograd_transforms': split['aux'],
     }
     if alt is not None:
         out['config']['images_per_sec_mask_branch_on_positive_rows_only'] = round(alt, 3)
+    if dp_report is not None:
+        out['config']['allreduce_rank0'] = dp_report
     return out, model, dev
 
 
@@ -136,3 +152,68 @@ def _max_over_ranks(v, world, dev):
     t = torch.tensor([v], dtype=torch.float64, device=dev)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     return float(t.item())
+
+
+def _pmc_conv_traffic():
+    """HBM bytes per step of the convolution kernels from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        d = json.load(open(os.path.join(root, 'profiles', 'r02_step_pmc_traffic.json')))
+        return d['conv_bracket']['hbm_bytes_per_step']
+    except Exception:
+        return None
+
+
+def _replay_split(recs, n_prof, dev):
+    """Every distinct convolution call of the step replayed standalone (random operands, 3 repetitions, HIP events) with the
+    library's measurement knob: GEMM launches only, and everything but the GEMM launches (Winograd transforms, slab /
+    tail / column sums).  Returns the two roofline objects."""
+    from chainer_maskrcnn._hip import nn as hnn, lib, check
+    HBM_PEAK = 8000.0
+    geoms = {}
+    for rec in recs:
+        geoms[(rec[0], rec[6])] = geoms.get((rec[0], rec[6]), 0) + 1
+    tot = {1: 0.0, 2: 0.0}
+    exe, aux_bytes = 0.0, 0.0
+    keep = hnn.PROFILE
+    hnn.PROFILE = None
+    try:
+        for (kind, g), cnt in geoms.items():
+            cnt = cnt / n_prof
+            N, H, W, Cin, Cout, KH, KW, stride, pad = g
+            Ho, Wo = hnn.conv_out(H, KH, stride, pad), hnn.conv_out(W, KW, stride, pad)
+            x = torch.empty((N, H, W, Cin), device=dev).normal_()
+            w = torch.empty((Cout, KH, KW, Cin), device=dev).normal_()
+            gy = torch.empty((N, Ho, Wo, Cout), device=dev).normal_()
+            v = hnn.conv2d_fwd_raw(x, w, None, stride, pad, False, keep_v=True)[1] if kind == 'bwd_filter' else None
+            fn = {'fwd': lambda: hnn.conv2d_fwd_raw(x, w, None, stride, pad, False, keep_v=True),
+                  'bwd_data': lambda: hnn.conv2d_bwd_data_raw(gy, w, tuple(x.shape), stride, pad),
+                  'bwd_filter': lambda: hnn.conv2d_bwd_filter_raw(x, gy, tuple(w.shape), stride, pad, False, wino_v=v)}[kind]
+            for mask in (2, 1):           # 2: GEMMs only, 1: the rest
+                check(lib().mrcnn_conv2d_set_debug_skip(mask))
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                tot[mask] += e0.elapsed_time(e1) / 3 * 1e-3 * cnt
+            exe += 2.0 * lib().mrcnn_conv2d_executed_macs(*g) * cnt
+            vb = lib().mrcnn_conv2d_winograd_v_bytes(*g)
+            if vb:          # transforms stream: activation in + transformed operand out, GEMM result in + activation out
+                wb = lib().mrcnn_conv2d_winograd_w_bytes(*g)
+                ain, aout = 4.0 * N * H * W * Cin, 4.0 * N * H * W * Cout
+                aux_bytes += cnt * ({'fwd': ain + vb + wb + aout, 'bwd_data': aout + wb + vb + ain, 'bwd_filter': aout + wb}[kind])
+    finally:
+        check(lib().mrcnn_conv2d_set_debug_skip(0))
+        hnn.PROFILE = keep
+    gemm = {'TFLOPs': round(exe / tot[2] / 1e12, 3), 'frac': round(exe / tot[2] / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            'ms_per_step': round(tot[2] * 1e3, 3)}
+    aux = {'bound': 'hbm', 'kernel': 'k_wino_input / k_wino_output / k_wino_gy / k_wino_filter* + slab, tail and column sums',
+           'achieved': round(aux_bytes / tot[1] / 1e9, 1), 'peak': HBM_PEAK, 'unit': 'GB/s',
+           'frac': round(aux_bytes / tot[1] / 1e9 / HBM_PEAK, 4), 'traffic': None, 'ms_per_step': round(tot[1] * 1e3, 3),
+           'algorithmic_bytes_per_step': aux_bytes,
+           'note': 'bytes = activations + transformed operands (V, M / W) of the Winograd calls, each crossing HBM once; the time '
+                   'also contains the split-K slab sums and bias column sums of the direct layers'}
+    return {'gemm': gemm, 'aux': aux}

@@ -60,23 +60,32 @@ class _LossHandle(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        ctx.chain.backward()
+        # g = d(objective)/d(loss): 1 for a plain ``loss.backward()``; ``(loss * k).backward()`` (loss scaling) gives k.
+        # MomentumSGD.update() calls loss.backward() itself and says so (unit_upstream), which skips the scaling pass.
+        ctx.chain.backward(upstream=None if ctx.chain.unit_upstream else g)
         return None, None, None
 
 
 def calc_mask_loss(roi_cls_mask, gt_roi_mask, xp, gt_roi_label):
-    """train.py:50-58 (channel gt_label-1 of the first n_pos rows, sigmoid cross entropy).  On this path the
-    selection, the loss and its gradient are ONE fused kernel (``mrcnn_mask_bce_f32``); the function object is
-    only the tag the train chain dispatches on."""
-    raise RuntimeError('calc_mask_loss is evaluated inside FPNMaskRCNNTrainChain by mrcnn_mask_bce_f32')
+    """train.py:50-58: channel ``gt_label - 1`` of every row, then sigmoid cross entropy of the first n_pos rows against
+    the 28x28 targets.  Passed by name to FPNMaskRCNNTrainChain it is recognised (``fused_kind``) and evaluated as ONE
+    fused kernel (``mrcnn_mask_bce_f32``: selection + loss + gradient); called directly - or copied into user code - the
+    body below runs on the HIP-backed pieces of chainer_maskrcnn/functions/loss.py and gives the same value."""
+    from chainer_maskrcnn import functions as F
+    roi_mask = roi_cls_mask[xp.arange(roi_cls_mask.shape[0]), gt_roi_label - 1]
+    return F.sigmoid_cross_entropy(roi_mask[:gt_roi_mask.shape[0]], gt_roi_mask)
 
 
 calc_mask_loss.fused_kind = 'mask_bce'
 
 
-def calc_keypoint_loss(roi_cls_mask, gt_roi_mask, xp, gt_roi_label):
-    """train_keypoints.py:21-27 (softmax cross entropy over the 56*56 positions of each keypoint)."""
-    raise RuntimeError('calc_keypoint_loss is evaluated inside FPNMaskRCNNTrainChain by mrcnn_softmax_ce_f32')
+def calc_keypoint_loss(roi_cls_mask, gt_roi_mask, xp, gt_roi_label, num_keypoints=17):
+    """train_keypoints.py:21-27: softmax cross entropy over the 56*56 positions of each (positive RoI, keypoint).
+    Fused form: ``mrcnn_softmax_ce_f32`` on the NHWC logits."""
+    from chainer_maskrcnn import functions as F
+    num_positives = gt_roi_mask.shape[0]
+    roi_mask = roi_cls_mask[:num_positives].reshape((num_positives * num_keypoints, -1))
+    return F.softmax_cross_entropy(roi_mask, gt_roi_mask.reshape((-1,)))
 
 
 calc_keypoint_loss.fused_kind = 'keypoint_ce'
@@ -91,11 +100,15 @@ class FPNMaskRCNNTrainChain(object):
         self.rpn_sigma, self.roi_sigma = 3., 1.                  # base-class defaults apply (:25-26)
         self.loc_normalize_mean = faster_rcnn.loc_normalize_mean
         self.loc_normalize_std = faster_rcnn.loc_normalize_std
-        kind = getattr(mask_loss_fun, 'fused_kind', None)
-        if kind not in ('mask_bce', 'keypoint_ce'):
-            raise TypeError('mask_loss_fun must be chainer_maskrcnn...calc_mask_loss / calc_keypoint_loss '
-                            '(the loss runs as a fused HIP kernel)')
-        self.mask_loss_kind = kind
+        if not callable(mask_loss_fun):
+            raise TypeError('mask_loss_fun must be callable: f(roi_cls_mask, gt_roi_mask, xp, gt_roi_label) -> loss')
+        # the two functions of the reference's train scripts are recognised and run as fused kernels; any other callable
+        # is CALLED, like the reference does (:103-104), on device tensors (see _generic_mask_loss)
+        self.mask_loss_fun = mask_loss_fun
+        self.mask_loss_kind = getattr(mask_loss_fun, 'fused_kind', None)
+        if self.mask_loss_kind not in ('mask_bce', 'keypoint_ce'):
+            self.mask_loss_kind = 'generic'
+        self.unit_upstream = False
         self.binary_mask = binary_mask
         self.strict_batch1 = strict_batch1
         self.mask_rows = mask_rows
@@ -103,6 +116,8 @@ class FPNMaskRCNNTrainChain(object):
         self.grad_ready_hook = None         # called with the lowest finished parameter offset during backward (DP overlap)
         self.sampler_keys = None            # (proposal keys, anchor keys) override for parity tests
         self.use_aux_stream = True          # independent branches (RPN losses, box head) on a second compute stream
+        self.keep_outputs = False           # parity tests: keep the head outputs of the last step in self.outputs
+        self.outputs = {}
         self._aux = {}
 
     def _aux_stream(self, dev):
@@ -123,11 +138,12 @@ class FPNMaskRCNNTrainChain(object):
         _, _, H, W = imgs.shape
         img_size = (H, W)
         i32 = torch.int32
-        G = bboxes.shape[1]
-        if n_gt is None:
-            n_gt = torch.full((n,), G, dtype=i32, device=dev)
         bboxes = bboxes.contiguous()
         labels = labels.to(i32).contiguous()
+        if n_gt is None:
+            # padded batches (Chainer's concat_examples / dataset/loader.py pad ragged images with label -1 and zero
+            # boxes): the valid rows are packed first, so the per-image count is #(label >= 0) - counted on the device
+            n_gt = ops.count_valid_labels(labels)
 
         main = torch.cuda.current_stream(dev)
         aux = self._aux_stream(dev) if self.use_aux_stream else main
@@ -180,14 +196,21 @@ class FPNMaskRCNNTrainChain(object):
                           col0=head.LOC0, gx=g_box, out=losses[2])
 
         rows = t['mask_rows']
-        if rows == S:
+        if self.mask_loss_kind == 'generic':
+            g_mask = self._generic_mask_loss(t, features, scales, losses)
+            m_rois, m_levels, m_label = self._generic_inputs
+            mask_out = None
+        elif rows == S:
             m_rois, m_levels, m_label = t['rois_xy5'], t['sample_levels'], t['gt_roi_label']
         else:   # the first `rows` rows of every image block (positives come first)
             m_rois = t['rois_xy5'].view(n, S, 5)[:, :rows].reshape(n * rows, 5)
             m_levels = t['sample_levels'].view(n, S)[:, :rows].reshape(n * rows)
             m_label = t['gt_roi_label'].view(n, S)[:, :rows].reshape(n * rows)
-        mask_out = head.mask_branch(features, m_rois, m_levels, scales)
-        if self.mask_loss_kind == 'mask_bce':
+        if self.mask_loss_kind != 'generic':
+            mask_out = head.mask_branch(features, m_rois, m_levels, scales)
+        if self.mask_loss_kind == 'generic':
+            pass
+        elif self.mask_loss_kind == 'mask_bce':
             _, g_mask = ops.mask_bce(mask_out, t['gt_roi_mask'], m_label, out=losses[4])
         else:
             Rm, Hm, Wm, Cm = mask_out.shape
@@ -205,6 +228,8 @@ class FPNMaskRCNNTrainChain(object):
                             'roi_cls_loss': losses[3, 0], 'mask_loss': losses[4, 0], 'loss': total[0]}
         self._bwd = (features, g_locs.view(n, A, 4), g_scores.view(n, A, 2), g_box, g_mask)
         self.targets = t
+        if self.keep_outputs:
+            self.outputs = dict(features=features, locs=r['locs'], scores=r['scores'], box=box, mask=mask_out)
         self.rpn_targets = (gt_rpn_loc, gt_rpn_label)
         self.mask_inputs = (m_rois, m_levels, m_label)
         self.rpn_out = r
@@ -212,10 +237,48 @@ class FPNMaskRCNNTrainChain(object):
         return _LossHandle.apply(self._anchor, self, total[0])
 
     # ------------------------------------------------------------------------------------------
-    def backward(self):
-        """Explicit backward pass: fills the flat gradient buffer of ``faster_rcnn.ps``."""
+    def _generic_mask_loss(self, t, features, scales, losses):
+        """A user-supplied ``mask_loss_fun`` (not one of the two recognised functions): call it like the reference does
+        (:103-104) - ``roi_cls_mask`` (R, C, S, S) with the positive rows first, ``gt_roi_mask`` with exactly n_pos rows,
+        ``xp``, ``gt_roi_label`` (R,) - under torch autograd on HIP-backed operators (functions/loss.py), and return the
+        gradient w.r.t. the NHWC logits.  Exact row counts need one host sync; this is the compatibility path."""
+        from chainer_maskrcnn.functions import loss as FL
+        m = self.faster_rcnn
+        head = m.head
+        S = self.proposal_target_creator.n_sample
+        n = t['n_pos'].shape[0]
+        n_pos = [int(v) for v in t['n_pos'].cpu().tolist()]
+        n_smp = [int(v) for v in t['n_sampled'].cpu().tolist()]
+        rows_of = lambda x, lo, hi: [x.view(n, S, *x.shape[1:])[i, lo(i):hi(i)] for i in range(n)]
+        order = lambda x: torch.cat(rows_of(x, lambda i: 0, lambda i: n_pos[i]) +
+                                    rows_of(x, lambda i: n_pos[i], lambda i: n_smp[i]), 0).contiguous()
+        m_rois, m_levels, m_label = order(t['rois_xy5']), order(t['sample_levels']), order(t['gt_roi_label'])
+        rows = t['mask_rows']
+        gt = t['gt_roi_mask']
+        gt = torch.cat([gt.view(n, rows, *gt.shape[1:])[i, :n_pos[i]] for i in range(n)], 0).contiguous()
+        self._generic_inputs = (m_rois, m_levels, m_label)
+        mask_out = head.mask_branch(features, m_rois, m_levels, scales)          # (R, S, S, Cp) NHWC
+        leaf = mask_out.detach().requires_grad_(True)
+        C = head.mask_out_channels
+        with torch.enable_grad():
+            x = FL.nhwc_to_nchw(leaf, C).as_subclass(FL.MaskLogits)
+            loss = self.mask_loss_fun(x, gt, FL.XP(leaf.device), m_label)
+            if not torch.is_tensor(loss) or loss.numel() != 1:
+                raise TypeError('mask_loss_fun must return a scalar tensor')
+            (g_mask,) = torch.autograd.grad(loss.reshape(()), leaf)
+        losses[4, 0].copy_(loss.detach().reshape(()))
+        losses[4, 1].fill_(1.0)
+        return g_mask.contiguous()
+
+    def backward(self, upstream=None):
+        """Explicit backward pass: fills the flat gradient buffer of ``faster_rcnn.ps``.  ``upstream`` (device scalar or
+        None = 1): d(objective)/d(loss), multiplied into the four loss-gradient seeds."""
         m = self.faster_rcnn
         features, g_locs, g_scores, g_box, g_mask = self._bwd
+        if upstream is not None:
+            from chainer_maskrcnn.functions.loss import _scale_
+            for g_ in (g_locs, g_scores, g_box, g_mask):
+                _scale_(g_, upstream)
         hook = self.grad_ready_hook
         g_feats = [torch.empty_like(f) for f in features]
         dev = features[0].device

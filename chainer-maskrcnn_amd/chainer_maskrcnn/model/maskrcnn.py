@@ -101,12 +101,11 @@ class MaskRCNN(object):
     def prepare(self, img):
         """maskrcnn.py:261-276: resize so that the short side is min_size unless the long side would exceed max_size,
         then scale to [0,1] (no mean subtraction - SURVEY.md App. B-3).  img (3,H,W) float32 tensor with values 0..255
-        on the device.  The bilinear resize itself is host-pipeline work (chainercv.transforms.resize) done
-        here with torch's half-pixel bilinear interpolation."""
+        on the device.  The resize is chainercv.transforms.resize = cv2.resize INTER_LINEAR on float32, here
+        ``mrcnn_image_resize_f32`` (the same tap rule as the training Transform's device resize)."""
         _, H, W = img.shape
         oh, ow = self.prepare_size(H, W)
-        img = torch.nn.functional.interpolate(img[None].float(), size=(oh, ow), mode='bilinear', align_corners=False)[0]
-        return img / 255
+        return ops.image_resize_f32(img.to(self.device, torch.float32).contiguous(), oh, ow, 255.0)
 
     def predict(self, imgs):
         """maskrcnn.py:157-259: imgs = list of (3,H,W) float32 tensors (0..255).  Returns (masks, labels, scores) -
@@ -125,6 +124,7 @@ class MaskRCNN(object):
                 box_out = self.head.last_box_out
                 cls_bbox, prob = ops.detect_decode(rois.contiguous(), box_out, self.n_class, self.head.LOC0, scale,
                                                    self.loc_normalize_mean, self.loc_normalize_std, size)
+                self.last_rois, self.last_decoded = rois, (cls_bbox, prob)      # parity tests read these
                 bbox, label, score, level = self._suppress(cls_bbox, prob, levels)
                 D = bbox.shape[0]
                 if D > 0 and self.predict_mask:

@@ -41,11 +41,24 @@ class GradientSynchronizer(object):
             self.buckets.append((start, end))
             end = start
         self.next = 0
+        self.timing = False               # bench.py: HIP events around every bucket's all-reduce
+        self._events, self._bwd_end = [], None
         self.stream = torch.cuda.Stream() if grads.is_cuda else None
         self.world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
 
     def begin(self):
         self.next = 0
+        self._events = []
+
+    def _all_reduce(self, sl):
+        if sl.is_cuda and torch.distributed.get_backend(self.group) == 'gloo':
+            # functional check of the multi-process path on ONE GPU (tests; RCCL refuses two ranks on one device): stage
+            # through the host explicitly
+            host = sl.cpu()
+            torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            sl.copy_(host)
+        else:
+            torch.distributed.all_reduce(sl, op=torch.distributed.ReduceOp.SUM, group=self.group)
 
     def _reduce(self, start, end):
         sl = self.grads[start:end]
@@ -54,9 +67,16 @@ class GradientSynchronizer(object):
             from chainer_maskrcnn._hip import nn as hnn
             self.stream.wait_stream(hnn.side_stream(self.grads.device))   # ... on the main and on the weight-gradient stream
             with torch.cuda.stream(self.stream):
-                torch.distributed.all_reduce(sl, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                ev = None
+                if self.timing:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                self._all_reduce(sl)
+                if ev is not None:
+                    ev[1].record()
+                    self._events.append((end - start, ev[0], ev[1]))
         else:
-            torch.distributed.all_reduce(sl, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            self._all_reduce(sl)
 
     def mark_ready(self, offset):
         if self.world == 1:
@@ -71,9 +91,24 @@ class GradientSynchronizer(object):
             return
         self.mark_ready(0)
         if self.stream is not None:
+            if self.timing:
+                self._bwd_end = torch.cuda.Event(enable_timing=True)
+                self._bwd_end.record()               # backward (main stream) is done here; what follows is exposed wait
             torch.cuda.current_stream().wait_stream(self.stream)
         if self.average:
             self.grads.div_(self.world)          # extension (--grad-average); the reference sums
+
+    def timing_report(self):
+        """After a synchronised step with ``timing`` on: per-bucket all-reduce ms (in launch order, last layers first) and
+        the fraction of the communication time that ran under backward (1 - exposed / total)."""
+        if not self._events:
+            return None
+        ms = [e0.elapsed_time(e1) for _, e0, e1 in self._events]
+        total = sum(ms)
+        exposed = max(0.0, self._bwd_end.elapsed_time(self._events[-1][2]))
+        return {'bucket_mb': [round(n * 4 / 2 ** 20, 1) for n, _, _ in self._events], 'bucket_ms': [round(v, 3) for v in ms],
+                'allreduce_ms_total': round(total, 3), 'exposed_ms': round(exposed, 3),
+                'overlap_fraction': round(1.0 - min(exposed, total) / total, 4) if total > 0 else None}
 
 
 class MomentumSGD(object):
@@ -96,9 +131,24 @@ class MomentumSGD(object):
         else:
             raise TypeError('only WeightDecay hooks exist on this path (train.py:109)')
 
-    def enable_data_parallel(self, bucket_bytes=25 << 20, average=False):
+    def enable_data_parallel(self, bucket_bytes=25 << 20, average=False, broadcast=True):
+        """One process per GPU; every rank keeps a replica and applies the same update to the summed gradients.  The
+        replicas must START equal: rank 0's parameters, momentum and BatchNorm running statistics are broadcast once
+        here (the reference's MultiprocessParallelUpdater broadcasts the master's parameters every step,
+        SURVEY.md section 3.5; with identical updates once is enough) - so per-rank ``--weight`` files or seeds cannot
+        silently diverge."""
         self.sync = GradientSynchronizer(self.ps.grads, bucket_bytes, average=average)
         self.target.grad_ready_hook = self.sync.mark_ready
+        if broadcast and self.sync.world > 1:
+            bufs = [self.ps.params, self.ps.momentum] + [self.ps.buffers[k] for k in sorted(self.ps.buffers)]
+            gloo = torch.distributed.get_backend() == 'gloo'
+            for b in bufs:
+                if gloo and b.is_cuda:
+                    h = b.cpu()
+                    torch.distributed.broadcast(h, src=0)
+                    b.copy_(h)
+                else:
+                    torch.distributed.broadcast(b, src=0)
 
     def update(self, lossfun=None, *args, **kwds):
         """Chainer semantics: with ``lossfun`` -> loss = lossfun(*args); backward; update.  Without: update only."""
@@ -107,7 +157,13 @@ class MomentumSGD(object):
             if self.sync is not None:
                 self.sync.begin()
             loss = lossfun(*args, **kwds)
-            loss.backward()
+            if hasattr(lossfun, 'unit_upstream'):       # the train chain: d loss = 1 here, no gradient-scaling pass
+                lossfun.unit_upstream = True
+            try:
+                loss.backward()
+            finally:
+                if hasattr(lossfun, 'unit_upstream'):
+                    lossfun.unit_upstream = False
         if self.sync is not None:
             self.sync.finish()
         ops.sgd_momentum_wd(self.ps.params, self.ps.grads, self.ps.momentum, self.lr, self.momentum, self.weight_decay)
@@ -138,11 +194,20 @@ class GraphedStep(object):
                 optimizer.update(chain, *self.static, scale)
         cur.wait_stream(s)
         torch.cuda.synchronize()
+        self._capture()
+
+    def _capture(self):
+        # the learning rate is a kernel argument baked into the captured launch: re-capture when it changes
+        # (ExponentialShift('lr', 0.1), train.py:139-140)
+        self._lr = self.optimizer.lr
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            optimizer.update(chain, *self.static, scale)
+            self.optimizer.update(self.chain, *self.static, self.scale)
 
     def __call__(self, *batch):
+        if self.optimizer.lr != self._lr:
+            torch.cuda.synchronize()
+            self._capture()
         for dst, src in zip(self.static, batch):
             if src is not dst:
                 dst.copy_(src, non_blocking=True)

@@ -546,6 +546,11 @@ TileChoice choose_tile(long long M, long long Ng, long long z) {
     return {64, 64};
 }
 
+// Measurement knob (mrcnn_conv2d_set_debug_skip; bench.py's roofline split): bit 0 = the MFMA GEMM launches are skipped,
+// bit 1 = every other kernel of the convolution calls (Winograd transforms, slab / tail / column sums) is skipped.
+// Results are garbage while a bit is set; kernel durations do not depend on the data.
+int g_debug_skip = 0;
+
 template <int MODE>
 void launch_conv(ConvP &p, int zdim, TileChoice t, hipStream_t st) {
     // zdim: BWD_FILTER taps * ksplit; FWD / BWD_DATA ksplit
@@ -560,6 +565,7 @@ void launch_conv(ConvP &p, int zdim, TileChoice t, hipStream_t st) {
         total = p.tail_full + (tiles - p.tail_full) * p.tail_ks;
     }
     const dim3 grid(total), blk(CONV_THREADS);
+    if (g_debug_skip & 1) return;
     if (p.smallc) {
         if (MODE == MODE_FWD) hipLaunchKernelGGL((k_conv_igemm<MODE_FWD, 128, 64, true>), grid, blk, 0, st, p);
         else hipLaunchKernelGGL((k_conv_igemm<MODE_BWD_FILTER, 64, 128, true>), grid, blk, 0, st, p);
@@ -823,7 +829,7 @@ int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes
     MRCNN_LAUNCH_CHECK();
     if (p.tail_ks) {
         const int tiles = mrcnn::cdiv(p.M, t.bm) * mrcnn::cdiv(p.Ng, t.bn);
-        hipLaunchKernelGGL(k_tail_sum, dim3(mrcnn::cdiv(t.bm * t.bn / 4, 256), tiles - p.tail_full), dim3(256), 0, st, p.slab, p.c,
+        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_tail_sum, dim3(mrcnn::cdiv(t.bm * t.bn / 4, 256), tiles - p.tail_full), dim3(256), 0, st, p.slab, p.c,
                            MODE == MODE_FWD ? p.bias : nullptr, MODE == MODE_FWD ? p.relu : 0,
                            MODE == MODE_BWD_DATA ? p.accumulate : 0, p.M, p.Ng, (int)ldc, p.tiles_n, p.tail_full, p.tail_ks,
                            t.bm, t.bn, MODE == MODE_BWD_DATA ? p.relu_x : nullptr);
@@ -831,7 +837,7 @@ int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes
     }
     if (p.ksplit > 1) {
         const size_t n4 = (size_t)p.M * ldc / 4;
-        hipLaunchKernelGGL(k_sum_slabs_ep, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, p.slab, p.c, n4, p.ksplit, (int)(ldc / 4),
+        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_sum_slabs_ep, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, p.slab, p.c, n4, p.ksplit, (int)(ldc / 4),
                            MODE == MODE_FWD ? p.bias : nullptr, MODE == MODE_FWD ? p.relu : 0,
                            MODE == MODE_BWD_DATA ? p.accumulate : 0, MODE == MODE_BWD_DATA ? p.relu_x : nullptr);
         MRCNN_LAUNCH_CHECK();
@@ -1263,6 +1269,7 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restric
 
 #define WINO_LAUNCH(KERN, G, GRID, ...)                                                              \
     do {                                                                                             \
+        if (g_debug_skip & 2) break;                                                                 \
         if ((G).m == 2) hipLaunchKernelGGL((KERN<2>), GRID, dim3(256), 0, st, __VA_ARGS__);          \
         else hipLaunchKernelGGL((KERN<4>), GRID, dim3(256), 0, st, __VA_ARGS__);                     \
         MRCNN_LAUNCH_CHECK();                                                                        \
@@ -1306,7 +1313,7 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     if (L.ksplit > 1) {     // a separate, fully parallel slab sum: folding it into k_wino_filter_grad (Cout*Cin threads only) was
                             // measured 20 % .. 4x slower (tools/wino_sweep.py)
         const size_t n4 = (size_t)Cout * g.nk * Cin / 4;
-        hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, L.ksplit, 0);
+        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, L.ksplit, 0);
         MRCNN_LAUNCH_CHECK();
     }
     WINO_LAUNCH(k_wino_filter_grad, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), dU, gw, Cout, Cin, accumulate, 1);
@@ -1332,15 +1339,15 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
         float *bias_part = wb ? (float *)(base + L.m) : nullptr;          // M is written only after this kernel has finished
         WINO_LAUNCH(k_wino_gy_dual, g, dim3(nblk), in, V, w_keep, bias_part, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
         if (wb) {
-            hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cin, 64)), dim3(1024), 0, st, bias_part, gbias, nblk, Cin, gbias_accumulate);
+            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cin, 64)), dim3(1024), 0, st, bias_part, gbias, nblk, Cin, gbias_accumulate);
             MRCNN_LAUNCH_CHECK();
         } else if (gbias) {       // channel count that does not tile a 256-thread block: the ordinary two-kernel column sum
             const int P = N * H * W;
             const ColPlan cp = col_plan(P, Cin);
             float *part = (float *)(base + L.m);
-            hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, in, part, P, Cin, cp.G, cp.RPI, cp.rows_per_blk);
+            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, in, part, P, Cin, cp.G, cp.RPI, cp.rows_per_blk);
             MRCNN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cin, 64)), dim3(1024), 0, st, part, gbias, cp.nblk, Cin, gbias_accumulate);
+            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cin, 64)), dim3(1024), 0, st, part, gbias, cp.nblk, Cin, gbias_accumulate);
             MRCNN_LAUNCH_CHECK();
         }
     } else
@@ -1385,6 +1392,12 @@ extern "C" int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pi
     g_wino_min_channels = min_channels;
     g_wino_min_pixels = min_pixels;
     g_wino_tile = tile;
+    return 0;
+}
+
+extern "C" int mrcnn_conv2d_set_debug_skip(int mask) {
+    if (mask < 0 || mask > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_debug_skip: mask in [0,3]");
+    g_debug_skip = mask;
     return 0;
 }
 
@@ -1478,9 +1491,9 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
             float *bias_part = (float *)((char *)ws + L.total);
             const int P = N * p.Ho * p.Wo;
             const ColPlan cp = col_plan(P, Cout);
-            hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, gy, bias_part, P, Cout, cp.G, cp.RPI, cp.rows_per_blk);
+            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, gy, bias_part, P, Cout, cp.G, cp.RPI, cp.rows_per_blk);
             MRCNN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, 64)), dim3(1024), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
+            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, 64)), dim3(1024), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
             MRCNN_LAUNCH_CHECK();
         }
         return 0;
@@ -1497,15 +1510,15 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     MRCNN_LAUNCH_CHECK();
     if (use_slabs) {
         const size_t n4 = wcount / 4;
-        hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, gw, n4, p.ksplit, accumulate);
+        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, gw, n4, p.ksplit, accumulate);
         MRCNN_LAUNCH_CHECK();
     }
     if (gbias) {
         const int P = N * p.Ho * p.Wo;
         const ColPlan cp = col_plan(P, Cout);
-        hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, gy, bias_part, P, Cout, cp.G, cp.RPI, cp.rows_per_blk);
+        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, gy, bias_part, P, Cout, cp.G, cp.RPI, cp.rows_per_blk);
         MRCNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, 64)), dim3(1024), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
+        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, 64)), dim3(1024), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
         MRCNN_LAUNCH_CHECK();
     }
     return 0;

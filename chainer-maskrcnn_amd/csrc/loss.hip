@@ -9,6 +9,7 @@
 // the loss w.r.t. the logits (d loss = 1), already normalised.  Reductions are two-stage with a
 // fixed order (bit-reproducible).  All are HBM/latency-bound: bytes = 2 x logits (+ targets).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -179,6 +180,90 @@ __global__ __launch_bounds__(NT) void k_mask_bce(const float *__restrict__ x, co
     if (PHASE == 0) block_partial(ls, cnt, part);
 }
 
+// ---- generic (user-supplied mask_loss_fun) building blocks -------------------------------------
+// F.sigmoid_cross_entropy(x, t) with normalize=True, ignore label -1, mean reduction (train.py:57-58).
+template <int PHASE>
+__global__ __launch_bounds__(NT) void k_sigmoid_ce(const float *__restrict__ x, const int32_t *__restrict__ t, long long n,
+                                                   float *__restrict__ part, const float *__restrict__ norm,
+                                                   float *__restrict__ gx) {
+    float ls = 0.f, cnt = 0.f;
+    const float inv = PHASE ? 1.0f / norm[1] : 0.f;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        const int tt = t[i];
+        const float v = x[i], tf = (float)tt;
+        if (PHASE == 0) {
+            if (tt != -1) {
+                ls += -(v * (tf - (v >= 0.f ? 1.f : 0.f)) - log1pf(expf(-fabsf(v))));
+                cnt += 1.f;
+            }
+        } else {
+            gx[i] = tt != -1 ? (1.0f / (1.0f + expf(-v)) - tf) * inv : 0.f;
+        }
+    }
+    if (PHASE == 0) block_partial(ls, cnt, part);
+}
+
+// roi_cls_mask[arange(R), idx] of train.py:55-56 on an NCHW tensor: y[r, p] = x[r, idx[r], p]; negative indices wrap
+// like NumPy's (the background rows carry label 0 - 1 = -1).  BWD: gx zero-filled, gx[r, idx[r], p] = gy[r, p].
+template <int BWD>
+__global__ __launch_bounds__(NT) void k_select_channel(const float *__restrict__ src, const int32_t *__restrict__ idx, int R, int C,
+                                                       int HW, float *__restrict__ dst) {
+    const long long total = BWD ? (long long)R * C * HW : (long long)R * HW;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        if (BWD) {
+            const int p = (int)(i % HW);
+            const long long rc = i / HW;
+            const int c = (int)(rc % C), r = (int)(rc / C);
+            int k = idx[r];
+            k = k < 0 ? k + C : k;
+            dst[i] = c == k ? src[(size_t)r * HW + p] : 0.f;
+        } else {
+            const int p = (int)(i % HW), r = (int)(i / HW);
+            int k = idx[r];
+            k = k < 0 ? k + C : k;
+            dst[i] = src[((size_t)r * C + k) * HW + p];
+        }
+    }
+}
+
+// (R, HW, Cp) NHWC (Cp >= C: padded channels) <-> (R, C, HW) NCHW through a 32x32 LDS tile (both sides coalesced).
+// inverse != 0: NCHW -> NHWC with the padding channels zero-filled.
+__global__ __launch_bounds__(256) void k_nhwc_nchw(const float *__restrict__ src, float *__restrict__ dst, int HW, int Cp, int C,
+                                                   int inverse) {
+    __shared__ float tile[32][33];
+    const int r = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const float *s = src + (size_t)r * (inverse ? (size_t)C * HW : (size_t)HW * Cp);
+    float *d = dst + (size_t)r * (inverse ? (size_t)HW * Cp : (size_t)C * HW);
+    if (!inverse) {
+        for (int j = ty; j < 32; j += 8) {       // read pixel p0+j, channels c0+tx
+            const int p = p0 + j, c = c0 + tx;
+            tile[j][tx] = (p < HW && c < C) ? s[(size_t)p * Cp + c] : 0.f;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {       // write channel c0+j, pixels p0+tx
+            const int c = c0 + j, p = p0 + tx;
+            if (c < C && p < HW) d[(size_t)c * HW + p] = tile[tx][j];
+        }
+    } else {
+        for (int j = ty; j < 32; j += 8) {       // read channel c0+j, pixels p0+tx
+            const int c = c0 + j, p = p0 + tx;
+            tile[j][tx] = (c < C && p < HW) ? s[(size_t)c * HW + p] : 0.f;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {       // write pixel p0+j, channels c0+tx (padding channels = 0)
+            const int p = p0 + j, c = c0 + tx;
+            if (p < HW && c < Cp) d[(size_t)p * Cp + c] = tile[tx][j];
+        }
+    }
+}
+
+// x[i] *= scale[0] (scale in device memory): the upstream gradient of a loss whose gradient was formed for d loss = 1.
+__global__ __launch_bounds__(NT) void k_scale_dev(float *__restrict__ x, size_t n, const float *__restrict__ scale) {
+    const float s = scale[0];
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) x[i] *= s;
+}
+
 // out[0] = sum_i losses[2*i]   (the un-weighted sum of fpn_maskrcnn_train_chain.py:106)
 __global__ void k_loss_total(const float *__restrict__ losses, int n, float *__restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -261,6 +346,54 @@ extern "C" int mrcnn_mask_bce_f32(const float *x, const int32_t *gt, const int32
         hipLaunchKernelGGL(k_mask_bce<1>, dim3(nb), dim3(NT), 0, st, x, gt, label, Rm, HW, Cm, part, loss_out, gx);
         MRCNN_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int mrcnn_sigmoid_ce_f32(const float *x, const int32_t *t, long long n, float *loss_out, float *gx, void *ws,
+                                    size_t ws_bytes, void *stream) {
+    if ((n > 0 && (!x || !t)) || !loss_out || !ws || n < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "sigmoid_ce: bad arguments");
+    if (ws_bytes < mrcnn_loss_workspace_bytes()) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "sigmoid_ce: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)ws;
+    const int nb = grid_for(n);
+    hipLaunchKernelGGL(k_sigmoid_ce<0>, dim3(nb), dim3(NT), 0, st, x, t, n, part, nullptr, nullptr);
+    MRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, part, nb, loss_out);
+    MRCNN_LAUNCH_CHECK();
+    if (gx && n > 0) {
+        hipLaunchKernelGGL(k_sigmoid_ce<1>, dim3(nb), dim3(NT), 0, st, x, t, n, part, loss_out, gx);
+        MRCNN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int mrcnn_select_channel_f32(const float *src, const int32_t *idx, int R, int C, int HW, float *dst, int backward,
+                                        void *stream) {
+    if (R < 0 || C <= 0 || HW <= 0 || (R > 0 && (!src || !idx || !dst)))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "select_channel: bad arguments");
+    if (R == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (backward) hipLaunchKernelGGL(k_select_channel<1>, dim3(grid_for((long long)R * C * HW)), dim3(NT), 0, st, src, idx, R, C, HW, dst);
+    else hipLaunchKernelGGL(k_select_channel<0>, dim3(grid_for((long long)R * HW)), dim3(NT), 0, st, src, idx, R, C, HW, dst);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_nhwc_nchw_f32(const float *src, float *dst, int R, int HW, int Cp, int C, int inverse, void *stream) {
+    if (R < 0 || HW <= 0 || C <= 0 || Cp < C || R > 65535 || (R > 0 && (!src || !dst)))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "nhwc_nchw: bad arguments (R <= 65535)");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(k_nhwc_nchw, dim3(mrcnn::cdiv(HW, 32), mrcnn::cdiv(inverse ? Cp : C, 32), R), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, HW, Cp, C, inverse);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_scale_by_dev_f32(float *x, size_t n, const float *scale, void *stream) {
+    if (!scale || (n > 0 && !x)) return mrcnn::fail_arg(MRCNN_E_INVALID, "scale_by_dev: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_scale_dev, dim3(grid_for((long long)n)), dim3(NT), 0, (hipStream_t)stream, x, n, scale);
+    MRCNN_LAUNCH_CHECK();
     return 0;
 }
 

@@ -575,6 +575,25 @@ __global__ __launch_bounds__(NT) void k_image_resize_u8(const uint8_t *__restric
     }
 }
 
+// float32 planes: src (C,H,W) -> dst (C, dst_h, dst_w) written for y < oh, x < ow, values / div.  MaskRCNN.prepare
+// (maskrcnn.py:261-276) resizes the float32 CHW image with chainercv.transforms.resize = cv2.resize INTER_LINEAR.
+__global__ __launch_bounds__(NT) void k_image_resize_f32(const float *__restrict__ src, int C, int H, int W, float *__restrict__ dst,
+                                                         int oh, int ow, int dst_h, int dst_w, float div) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= oh * ow) return;
+    const int y = i / ow, x = i - y * ow;
+    int x0, x1, y0, y1;
+    float a0, a1, b0, b1;
+    linear_tap(x, ow, W, x0, x1, a0, a1);
+    linear_tap(y, oh, H, y0, y1, b0, b1);
+    for (int c = 0; c < C; ++c) {
+        const float *r0 = src + ((size_t)c * H + y0) * W, *r1 = src + ((size_t)c * H + y1) * W;
+        const float top = r0[x0] * a0 + r0[x1] * a1;
+        const float bot = r1[x0] * a0 + r1[x1] * a1;
+        dst[((size_t)c * dst_h + y) * dst_w + x] = (top * b0 + bot * b1) / div;
+    }
+}
+
 // src (G,H,W) uint8 -> dst (G, dst_h, dst_w), written for y < oh, x < ow
 __global__ __launch_bounds__(NT) void k_mask_resize_nearest_u8(const uint8_t *__restrict__ src, int G, int H, int W,
                                                                uint8_t *__restrict__ dst, int oh, int ow, int dst_h, int dst_w) {
@@ -876,6 +895,16 @@ extern "C" int mrcnn_image_resize_u8_f32(const uint8_t *src, int H, int W, float
     if (int e = chk(H > 0 && W > 0 && oh > 0 && ow > 0 && dst_h >= oh && dst_w >= ow, "image_resize: bad sizes")) return e;
     hipLaunchKernelGGL(k_image_resize_u8, dim3(mrcnn::cdiv(oh * ow, NT)), dim3(NT), 0, (hipStream_t)stream, src, H, W, dst, oh, ow,
                        dst_h, dst_w, div);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_image_resize_f32(const float *src, int C, int H, int W, float *dst, int oh, int ow, int dst_h, int dst_w,
+                                      float div, void *stream) {
+    if (int e = chk(src && dst, "image_resize_f32: null pointer")) return e;
+    if (int e = chk(C > 0 && H > 0 && W > 0 && oh > 0 && ow > 0 && dst_h >= oh && dst_w >= ow, "image_resize_f32: bad sizes")) return e;
+    hipLaunchKernelGGL(k_image_resize_f32, dim3(mrcnn::cdiv(oh * ow, NT)), dim3(NT), 0, (hipStream_t)stream, src, C, H, W, dst,
+                       oh, ow, dst_h, dst_w, div);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

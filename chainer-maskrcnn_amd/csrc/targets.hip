@@ -74,7 +74,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_proposal_target(
     float4 mean, float4 stdv, float *__restrict__ sample_roi, float *__restrict__ rois_xy5,
     int32_t *__restrict__ sample_levels, float *__restrict__ gt_roi_loc, int32_t *__restrict__ gt_roi_label,
     int32_t *__restrict__ gt_assign, int32_t *__restrict__ sample_src, int32_t *__restrict__ n_pos_out,
-    int32_t *__restrict__ n_sample_out) {
+    int32_t *__restrict__ n_sample_out, const int32_t *__restrict__ pos_order, const int32_t *__restrict__ neg_order,
+    int32_t *__restrict__ n_cand) {
     __shared__ u64 skey[PT_CAP];
     __shared__ float smax[PT_CAP];
     __shared__ short sarg[PT_CAP];
@@ -115,7 +116,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_proposal_target(
                 const float m = smax[c];
                 in = phase == 0 ? (m >= pos_thresh) : (m < neg_hi && m >= neg_lo);
             }
-            const uint32_t key = c < nc ? kk[c < nr ? c : roi_cap + (c - nr)] : 0u;
+            // reference-order mode (pos_order / neg_order given): keys are ignored, the sort leaves the candidates in
+            // ascending index order and row j takes the candidate of rank order[j] - np.random.choice's draw order
+            // (proposal_target_creator.py:63-78) supplied by the host
+            const int32_t *order = phase == 0 ? pos_order : neg_order;
+            const uint32_t key = (c < nc && !order) ? kk[c < nr ? c : roi_cap + (c - nr)] : 0u;
             skey[c] = in ? (((u64)key << 32) | (u64)c) : ~0ull;
             local += in ? 1 : 0;
         }
@@ -124,12 +129,21 @@ __global__ __launch_bounds__(PT_THREADS) void k_proposal_target(
         const int avail = scount[phase];
         const int want = phase == 0 ? min(n_pos_max, avail) : min(n_sample - n_pos, avail);
         bitonic_sort(skey, PT_CAP);
-        // the `want` smallest, re-ordered by ascending candidate index (rank sort, want <= 512)
-        for (int j = tid; j < want; j += PT_THREADS) {
-            const int cj = (int)(skey[j] & 0xFFFFFFFFull);
-            int rank = 0;
-            for (int q = 0; q < want; ++q) rank += ((int)(skey[q] & 0xFFFFFFFFull) < cj) ? 1 : 0;
-            ssel[rank] = cj;
+        if (n_cand && tid == 0) n_cand[img * 2 + phase] = avail;
+        const int32_t *order = phase == 0 ? pos_order : neg_order;
+        if (order) {
+            for (int j = tid; j < want; j += PT_THREADS) {
+                const int rk = min(max(order[(size_t)img * n_sample + j], 0), max(avail - 1, 0));
+                ssel[j] = (int)(skey[rk] & 0xFFFFFFFFull);
+            }
+        } else {
+            // the `want` smallest, re-ordered by ascending candidate index (rank sort, want <= 512)
+            for (int j = tid; j < want; j += PT_THREADS) {
+                const int cj = (int)(skey[j] & 0xFFFFFFFFull);
+                int rank = 0;
+                for (int q = 0; q < want; ++q) rank += ((int)(skey[q] & 0xFFFFFFFFull) < cj) ? 1 : 0;
+                ssel[rank] = cj;
+            }
         }
         __syncthreads();
         // emit rows [n_tot, n_tot + want)
@@ -216,13 +230,17 @@ __global__ __launch_bounds__(256) void k_mask_target(const unsigned char *__rest
     }
 }
 
-// Keypoint targets (proposal_target_creator.py:105-127), WITHOUT the reference's in-place mutation of the gt
-// array (a gt assigned to several positives is transformed from its original coordinates each time;
-// deliberate fix recorded in DESIGN.md).  kps (N, gt_cap, K, 3) f32 (y, x, v).
+// Keypoint targets (proposal_target_creator.py:105-127).  kps (N, gt_cap, K, 3) f32 (y, x, v).
+// inplace_quirk == 0: every positive transforms its gt's ORIGINAL coordinates (the sensible reading).
+// inplace_quirk != 0: the reference's behaviour - `kp = mask[idx]` is a view and `kp[:, :2] = ...`
+// writes the transformed coordinates back into the gt array, so a gt assigned to several positives is transformed again
+// from its already-transformed coordinates, in sample order.  Positive j replays the transforms of the earlier positives
+// i < j with the same gt (<= 64 per image) - same float64 arithmetic and float32 stores as NumPy's.
 __global__ __launch_bounds__(64) void k_keypoint_target(const float *__restrict__ kps, int gt_cap, int K,
                                                         const float *__restrict__ sample_roi,
                                                         const int32_t *__restrict__ gt_assign, const int32_t *__restrict__ n_pos,
-                                                        int n_sample, int pos_cap, int msz, int32_t *__restrict__ out) {
+                                                        int n_sample, int pos_cap, int msz, int inplace_quirk,
+                                                        int32_t *__restrict__ out) {
     const int slot = blockIdx.x, img = slot / pos_cap, j = slot % pos_cap;
     int32_t *o = out + (size_t)slot * K;
     const bool live = j < n_pos[img];
@@ -230,17 +248,32 @@ __global__ __launch_bounds__(64) void k_keypoint_target(const float *__restrict_
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         int lab = -1;
         if (live) {
-            const float4 b = *reinterpret_cast<const float4 *>(sample_roi + (size_t)row * 4);
-            const int y0 = (int)b.x, x0 = (int)b.y, y1 = (int)b.z, x1 = (int)b.w;
-            const float *kp = kps + (((size_t)img * gt_cap + gt_assign[row]) * K + k) * 3;
-            // numpy: (kp - [y0,x0]) / [max(y1-y0,1), max(x1-x0,1)] * mask_size in float64, stored to float32
-            const float fy = (float)(((double)kp[0] - (double)y0) / (double)max(y1 - y0, 1) * (double)msz);
-            const float fx = (float)(((double)kp[1] - (double)x0) / (double)max(x1 - x0, 1) * (double)msz);
+            const int g = gt_assign[row];
+            const float *kp = kps + (((size_t)img * gt_cap + g) * K + k) * 3;
+            float fy = kp[0], fx = kp[1];
+            for (int i = inplace_quirk ? 0 : j; i <= j; ++i) {
+                const int ri = img * n_sample + i;
+                if (i != j && gt_assign[ri] != g) continue;
+                const float4 b = *reinterpret_cast<const float4 *>(sample_roi + (size_t)ri * 4);
+                const int y0 = (int)b.x, x0 = (int)b.y, y1 = (int)b.z, x1 = (int)b.w;
+                // numpy: (kp - [y0,x0]) / [max(y1-y0,1), max(x1-x0,1)] * mask_size in float64, stored to float32
+                fy = (float)(((double)fy - (double)y0) / (double)max(y1 - y0, 1) * (double)msz);
+                fx = (float)(((double)fx - (double)x0) / (double)max(x1 - x0, 1) * (double)msz);
+            }
             const int y = (int)fy, x = (int)fx, v = (int)kp[2];
             if (v == 2 && 0 <= y && y < msz && 0 <= x && x < msz) lab = y * msz + x;
         }
         o[k] = lab;
     }
+}
+
+// n_gt[i] = number of rows of image i with label >= 0 (valid rows are packed first; padding rows carry -1).
+__global__ __launch_bounds__(64) void k_count_valid_labels(const int32_t *__restrict__ labels, int G, int32_t *__restrict__ n_gt) {
+    int c = 0;
+    for (int g = threadIdx.x; g < G; g += 64) c += labels[(size_t)blockIdx.x * G + g] >= 0 ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (threadIdx.x == 0) n_gt[blockIdx.x] = c;
 }
 
 // ---- anchor targets ------------------------------------------------------------------------------
@@ -372,8 +405,11 @@ extern "C" int mrcnn_proposal_target_f32(const float *rois, const float *roi_lev
                                          const float *loc_mean4, const float *loc_std4, float *sample_roi,
                                          float *rois_xy5, int32_t *sample_levels, float *gt_roi_loc,
                                          int32_t *gt_roi_label, int32_t *gt_assign, int32_t *sample_src,
-                                         int32_t *n_pos, int32_t *n_sampled, void *stream) {
-    if (!rois || !roi_levels || !n_rois || !gt_boxes || !gt_labels || !n_gt || !keys || !loc_mean4 || !loc_std4 ||
+                                         int32_t *n_pos, int32_t *n_sampled, const int32_t *pos_order,
+                                         const int32_t *neg_order, int32_t *n_cand, void *stream) {
+    if ((pos_order == nullptr) != (neg_order == nullptr))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "proposal_target: pos_order and neg_order go together");
+    if (!rois || !roi_levels || !n_rois || !gt_boxes || !gt_labels || !n_gt || (!keys && !pos_order) || !loc_mean4 || !loc_std4 ||
         !sample_roi || !rois_xy5 || !sample_levels || !gt_roi_loc || !gt_roi_label || !gt_assign || !sample_src ||
         !n_pos || !n_sampled)
         return mrcnn::fail_arg(MRCNN_E_INVALID, "proposal_target: null pointer");
@@ -386,7 +422,7 @@ extern "C" int mrcnn_proposal_target_f32(const float *rois, const float *roi_lev
     hipLaunchKernelGGL(k_proposal_target, dim3(N), dim3(PT_THREADS), 0, (hipStream_t)stream, rois, roi_levels, n_rois,
                        roi_cap, gt_boxes, gt_labels, n_gt, gt_cap, keys, n_sample, n_pos_max, pos_iou_thresh,
                        neg_iou_thresh_hi, neg_iou_thresh_lo, mean, stdv, sample_roi, rois_xy5, sample_levels, gt_roi_loc,
-                       gt_roi_label, gt_assign, sample_src, n_pos, n_sampled);
+                       gt_roi_label, gt_assign, sample_src, n_pos, n_sampled, pos_order, neg_order, n_cand);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -405,12 +441,19 @@ extern "C" int mrcnn_mask_target_u8(const unsigned char *masks, int N, int gt_ca
 
 extern "C" int mrcnn_keypoint_target_f32(const float *keypoints, int N, int gt_cap, int K, const float *sample_roi,
                                          const int32_t *gt_assign, const int32_t *n_pos, int n_sample, int pos_cap,
-                                         int mask_size, int32_t *gt_roi_kp, void *stream) {
+                                         int mask_size, int inplace_quirk, int32_t *gt_roi_kp, void *stream) {
     if (!keypoints || !sample_roi || !gt_assign || !n_pos || !gt_roi_kp || N <= 0 || gt_cap <= 0 || K <= 0 ||
         n_sample <= 0 || pos_cap <= 0 || pos_cap > n_sample || mask_size <= 0)
         return mrcnn::fail_arg(MRCNN_E_INVALID, "keypoint_target: bad arguments");
     hipLaunchKernelGGL(k_keypoint_target, dim3(N * pos_cap), dim3(64), 0, (hipStream_t)stream, keypoints, gt_cap, K,
-                       sample_roi, gt_assign, n_pos, n_sample, pos_cap, mask_size, gt_roi_kp);
+                       sample_roi, gt_assign, n_pos, n_sample, pos_cap, mask_size, inplace_quirk, gt_roi_kp);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_count_valid_labels_i32(const int32_t *labels, int N, int G, int32_t *n_gt, void *stream) {
+    if (!labels || !n_gt || N <= 0 || G <= 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "count_valid_labels: bad arguments");
+    hipLaunchKernelGGL(k_count_valid_labels, dim3(N), dim3(64), 0, (hipStream_t)stream, labels, G, n_gt);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

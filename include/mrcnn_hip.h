@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 1
+#define MRCNN_ABI_VERSION 2
 
 enum {
     MRCNN_OK = 0,
@@ -134,6 +134,10 @@ long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, int Cout, int
  * gfx950) and output tile (0 = per layer, whichever of F(2x2,3x3) / F(4x4,3x3) needs fewer multiplications; 2 or 4 =
  * forced).  Lowering the thresholds is how the tests run whole small networks through the Winograd kernels. */
 int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels, int tile);
+/* Measurement knob for bench.py's roofline split (never set on a product path): bit 0 skips the MFMA GEMM launches of
+ * the convolution calls, bit 1 skips every other kernel they launch (Winograd transforms, slab / tail / column sums).
+ * Outputs are garbage while a bit is set; 0 restores normal operation. */
+int mrcnn_conv2d_set_debug_skip(int mask);
 /* wino_v (nullable): caller-owned buffer of mrcnn_conv2d_winograd_v_bytes() bytes (0 = the layer does not take the
  * Winograd path).  The forward pass leaves its transformed input there and the filter-gradient pass of the same layer
  * reads it instead of transforming x again (same call geometry, same Winograd settings). */
@@ -228,6 +232,10 @@ int mrcnn_image_resize_u8_f32(const uint8_t *src, int H, int W, float *dst, int 
                               float div, void *stream);
 int mrcnn_mask_resize_nearest_u8(const uint8_t *src, int G, int H, int W, uint8_t *dst, int oh, int ow, int dst_h,
                                  int dst_w, void *stream);
+/* MaskRCNN.prepare (chainer_maskrcnn/model/maskrcnn.py:261-276): the float32 CHW image (C,H,W) resized with cv2's
+ * INTER_LINEAR float rule (what chainercv.transforms.resize calls) into planes of dst_h x dst_w, then divided by div. */
+int mrcnn_image_resize_f32(const float *src, int C, int H, int W, float *dst, int oh, int ow, int dst_h, int dst_w,
+                           float div, void *stream);
 /* n uint32 sampler keys from a counter-based hash of (seed, index). */
 int mrcnn_random_keys_u32(uint32_t *out, size_t n, unsigned long long seed, void *stream);
 /* Same with the seed in device memory (state[0]); the call also advances the state, so a replayed HIP graph draws
@@ -251,6 +259,20 @@ int mrcnn_smooth_l1_f32(const float *x, int ldx, const float *t, const int32_t *
                         float *loss_out, float *gx, int ldg, int gfill, void *ws, size_t ws_bytes, void *stream);
 int mrcnn_mask_bce_f32(const float *x, const int32_t *gt, const int32_t *label, int Rm, int HW, int Cm,
                        float *loss_out, float *gx, void *ws, size_t ws_bytes, void *stream);
+/* Building blocks of a USER-SUPPLIED mask_loss_fun (the reference passes a plain Python function: train.py:50-58,98;
+ * train_keypoints.py:21-27): the host layer wraps them as autograd functions (chainer_maskrcnn/functions/loss.py) so
+ * the bodies of those functions run on device tensors.
+ *   sigmoid_ce      chainer.functions.sigmoid_cross_entropy(x, t): normalize=True, ignore label -1, mean; n elements
+ *   select_channel  roi_cls_mask[xp.arange(R), idx] on an NCHW tensor (R,C,HW): y (R,HW); negative idx wraps like NumPy;
+ *                   backward != 0: src = gy (R,HW), dst = gx (R,C,HW) fully written (zeros elsewhere)
+ *   nhwc_nchw       (R,HW,Cp) NHWC with Cp >= C padded channels -> (R,C,HW) NCHW; inverse != 0: back, padding zeroed
+ *   scale_by_dev    x *= scale[0] with the scalar in device memory (upstream gradient of a loss output) */
+int mrcnn_sigmoid_ce_f32(const float *x, const int32_t *t, long long n, float *loss_out, float *gx, void *ws,
+                         size_t ws_bytes, void *stream);
+int mrcnn_select_channel_f32(const float *src, const int32_t *idx, int R, int C, int HW, float *dst, int backward,
+                             void *stream);
+int mrcnn_nhwc_nchw_f32(const float *src, float *dst, int R, int HW, int Cp, int C, int inverse, void *stream);
+int mrcnn_scale_by_dev_f32(float *x, size_t n, const float *scale, void *stream);
 /* out[0] = sum of n (loss, normaliser) pairs' losses: the un-weighted total of fpn_maskrcnn_train_chain.py:106 */
 int mrcnn_loss_total_f32(const float *losses, int n, float *out, void *stream);
 
@@ -283,6 +305,11 @@ int mrcnn_map_rois_to_fpn_levels_f32(const float *rois, int R, int k_min, int k_
  * (host NumPy + cv2) and ChainerCV's AnchorTargetCreator (model/fpn_maskrcnn_train_chain.py:81-82).
  * Per image i the sampler owns rows [i*n_sample, (i+1)*n_sample): positives first, then negatives,
  * then padding (label -1).  keys: uint32 random numbers, (N, roi_cap + gt_cap) / (N, A).
+ * proposal_target, reference-order mode: pos_order / neg_order (both or neither; (N, n_sample) int32) replace the keys -
+ * row j of the positives is the candidate of RANK pos_order[j] among the foreground candidates in ascending index order,
+ * which is np.random.choice(pos_index, size, replace=False) = pos_index[permutation(len)[:size]]
+ * (utils/proposal_target_creator.py:63-78) when the host draws the permutation; n_cand (nullable, (N,2)) returns the
+ * candidate-set sizes the host needs for that draw.
  * ---------------------------------------------------------------------------------------- */
 int mrcnn_proposal_target_f32(const float *rois, const float *roi_levels, const int32_t *n_rois, int roi_cap,
                               const float *gt_boxes, const int32_t *gt_labels, const int32_t *n_gt, int gt_cap,
@@ -290,13 +317,19 @@ int mrcnn_proposal_target_f32(const float *rois, const float *roi_levels, const 
                               float neg_iou_thresh_hi, float neg_iou_thresh_lo, const float *loc_mean4,
                               const float *loc_std4, float *sample_roi, float *rois_xy5, int32_t *sample_levels,
                               float *gt_roi_loc, int32_t *gt_roi_label, int32_t *gt_assign, int32_t *sample_src,
-                              int32_t *n_pos, int32_t *n_sampled, void *stream);
+                              int32_t *n_pos, int32_t *n_sampled, const int32_t *pos_order, const int32_t *neg_order,
+                              int32_t *n_cand, void *stream);
 int mrcnn_mask_target_u8(const unsigned char *masks, int N, int gt_cap, int H, int W, const float *sample_roi,
                          const int32_t *gt_assign, const int32_t *n_pos, int n_sample, int pos_cap, int mask_size,
                          int32_t *gt_roi_mask, void *stream);
+/* inplace_quirk != 0 reproduces the reference's in-place mutation of the gt keypoints (a gt assigned to several
+ * positives is transformed again from its already-transformed coordinates, in sample order). */
 int mrcnn_keypoint_target_f32(const float *keypoints, int N, int gt_cap, int K, const float *sample_roi,
                               const int32_t *gt_assign, const int32_t *n_pos, int n_sample, int pos_cap,
-                              int mask_size, int32_t *gt_roi_kp, void *stream);
+                              int mask_size, int inplace_quirk, int32_t *gt_roi_kp, void *stream);
+/* n_gt[i] = number of labels[i, :] >= 0: the per-image gt counts of a padded batch (Chainer concat_examples pads with
+ * -1; dataset/loader.py does the same), valid rows first.  Used when the caller passes no counts (train.py:117-125). */
+int mrcnn_count_valid_labels_i32(const int32_t *labels, int N, int G, int32_t *n_gt, void *stream);
 size_t mrcnn_anchor_target_workspace_bytes(int N, int A);
 int mrcnn_anchor_target_f32(const float *anchors, int A, const float *gt_boxes, const int32_t *n_gt, int gt_cap,
                             int N, float img_h, float img_w, const uint32_t *keys, int n_sample,

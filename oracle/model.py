@@ -119,20 +119,37 @@ class OracleStep(object):
     """params: dict name -> float64 torch tensor (requires_grad) in the product's storage convention."""
 
     def __init__(self, params, stage_blocks, n_class, loc0, feat_strides=(4, 8, 16, 32, 64), n_anchor=3,
-                 mask_conv_names=('mask1', 'mask2', 'mask3', 'mask4'), n_keypoints=None):
+                 mask_conv_names=('mask1', 'mask2', 'mask3', 'mask4'), n_keypoints=None, bn_buffers=None, tap=None):
+        """bn_buffers: None = training-mode BatchNorm (batch statistics, chainer.config.train True); a dict
+        name -> tensor of the running statistics ('.../avg_mean', '.../avg_var') = inference mode (maskrcnn.py:171-172).
+        tap: name of a bottleneck ('extractor/resnet/res5/b2'): its 3x3 convolution's input and output are kept in
+        ``self.taps`` (the output with retain_grad) so a test can feed them to the device's filter-gradient kernel."""
         self.p = params
+        self.bn_buffers, self.tap, self.taps = bn_buffers, tap, {}
         self.mask_conv_names, self.n_keypoints = mask_conv_names, n_keypoints
         self.stage_blocks = stage_blocks
         self.n_class, self.loc0, self.n_anchor = n_class, loc0, n_anchor
         self.scales = [1.0 / s for s in feat_strides]
 
+    def _bn(self, x, pre, eps=2e-5):
+        p = self.p
+        if self.bn_buffers is None:
+            return bn_train(x, p[pre + '/gamma'], p[pre + '/beta'], eps)
+        mean, var = self.bn_buffers[pre + '/avg_mean'].to(D), self.bn_buffers[pre + '/avg_var'].to(D)
+        return p[pre + '/gamma'] * (x - mean) / torch.sqrt(var + eps) + p[pre + '/beta']
+
     def _bottleneck(self, x, pre, stride, project):
         p = self.p
-        h = F.relu(bn_train(conv(x, p[pre + '/conv1/W'], None, stride), p[pre + '/bn1/gamma'], p[pre + '/bn1/beta']))
-        h = F.relu(bn_train(conv(h, p[pre + '/conv2/W'], None, 1, 1), p[pre + '/bn2/gamma'], p[pre + '/bn2/beta']))
-        h = bn_train(conv(h, p[pre + '/conv3/W']), p[pre + '/bn3/gamma'], p[pre + '/bn3/beta'])
+        h1 = F.relu(self._bn(conv(x, p[pre + '/conv1/W'], None, stride), pre + '/bn1'))
+        y2 = conv(h1, p[pre + '/conv2/W'], None, 1, 1)
+        if self.tap == pre:
+            if y2.requires_grad:
+                y2.retain_grad()
+            self.taps[pre + '/conv2'] = (h1, y2)
+        h = F.relu(self._bn(y2, pre + '/bn2'))
+        h = self._bn(conv(h, p[pre + '/conv3/W']), pre + '/bn3')
         if project:
-            r = bn_train(conv(x, p[pre + '/conv4/W'], None, stride), p[pre + '/bn4/gamma'], p[pre + '/bn4/beta'])
+            r = self._bn(conv(x, p[pre + '/conv4/W'], None, stride), pre + '/bn4')
         else:
             r = x
         return F.relu(h + r)
@@ -140,8 +157,7 @@ class OracleStep(object):
     def extractor(self, img4):
         p = self.p
         e = 'extractor/'
-        h = F.relu(bn_train(conv(img4, p[e + 'resnet/conv1/W'], p[e + 'resnet/conv1/b'], 2, 3),
-                            p[e + 'resnet/bn1/gamma'], p[e + 'resnet/bn1/beta']))
+        h = F.relu(self._bn(conv(img4, p[e + 'resnet/conv1/W'], p[e + 'resnet/conv1/b'], 2, 3), e + 'resnet/bn1'))
         h = maxpool_cover_all(h)
         cs = []
         for name, n, stride in zip(('res2', 'res3', 'res4', 'res5'), self.stage_blocks, (1, 2, 2, 2)):

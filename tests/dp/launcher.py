@@ -1,0 +1,31 @@
+"""Starts the child processes of tests/test_dp_gpu.py and waits for them.  Imports no torch / HIP itself and is started
+by tests/conftest.py BEFORE the pytest process has touched the GPU (children are started from GPU-free processes only)."""
+import os
+import socket
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main(out):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    w = os.path.join(HERE, 'worker.py')
+    log = open(os.path.join(out, 'log.txt'), 'w')
+    rc = subprocess.call([sys.executable, w, 'emu', out], stdout=log, stderr=subprocess.STDOUT)
+    procs = [subprocess.Popen([sys.executable, w, 'dp', str(r), '2', str(port), out], stdout=log, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    for p in procs:
+        try:
+            rc |= p.wait(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc |= 1
+    open(os.path.join(out, 'done'), 'w').write(str(rc))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

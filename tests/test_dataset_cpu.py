@@ -156,7 +156,6 @@ def test_mask_loader_mirrors_reference_semantics(tiny_coco):
     img, bbox, label, masks = ds.get_example(1)
     np.testing.assert_array_equal(label, [1, 0])                                  # index in the filtered category list
     np.testing.assert_array_equal(bbox[1], [1, 1, 1, 1])                          # w = h = 0 after truncation
-    assert ds._contain_large_enough_annotation(101) and not ds._contain_large_annotation_only(101)
     with pytest.raises(IndexError):
         ds.get_example(2)
     allc = COCOMaskLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017')

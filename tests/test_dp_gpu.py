@@ -1,0 +1,40 @@
+"""Data parallelism on the real training chain: two ranks with ONE image each (gloo, both on the one
+GPU of the test box - RCCL refuses two ranks on a device) against a single process that computes the same step as
+g(img0) + g(img1):
+
+  * SUM semantics with the un-scaled learning rate (train.py:117-121): the all-reduced gradient
+    buffer of both ranks equals the sum of the two single-image gradients, bit for bit (deterministic kernels);
+  * replicas that start from DIFFERENT seeds are made equal by the rank-0 broadcast in enable_data_parallel();
+  * after 3 steps both ranks hold identical parameters, equal to the single-process emulation.
+
+(A 2-rank batch-1 step is NOT a 1-rank batch-2 step - BatchNorm statistics and the loss normalisers are per rank, in the
+reference too - so the emulation evaluates the two images separately.)  The child processes are started by
+tests/conftest.py before this process touches the GPU (tests/dp/launcher.py) and only read back here."""
+import os
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_data_parallel_equals_sum_of_single_image_steps():
+    out = os.environ.get('MRCNN_DP_TEST_DIR')
+    if not out:
+        pytest.skip('the data-parallel workers are started by tests/conftest.py when pytest runs with -m gpu')
+    t0 = time.time()
+    while not os.path.exists(os.path.join(out, 'done')):
+        assert time.time() - t0 < 900, 'data-parallel workers did not finish'
+        time.sleep(1.0)
+    log = open(os.path.join(out, 'log.txt')).read()
+    assert open(os.path.join(out, 'done')).read() == '0', log[-4000:]
+    r0, r1, emu = (torch.load(os.path.join(out, f)) for f in ('dp_rank0.pt', 'dp_rank1.pt', 'emu.pt'))
+    assert not torch.equal(r0['p0'], r1['p0'])                  # the ranks really started from different replicas ...
+    assert torch.equal(r0['p0'], emu['p0'])                     # ... and rank 0's is the emulation's
+    assert abs(r0['loss0'] - emu['losses'][0]) == 0 and abs(r1['loss0'] - emu['losses'][1]) == 0
+    assert torch.equal(r0['grads'], r1['grads'])
+    assert torch.equal(r0['grads'], emu['grads'])               # SUM of the two ranks' gradients, no scaling
+    assert float(emu['grads'].abs().max()) > 0
+    assert torch.equal(r0['params'], r1['params'])
+    assert torch.equal(r0['params'], emu['params'])

@@ -1,0 +1,168 @@
+"""Full-size parity: the REAL ResNet-50-FPN Mask R-CNN (80 classes, full width and depth) - not the
+reduced test network - against the float64 oracle (oracle/model.py) on whole images:
+
+  (i)   activations p2..p6, RPN locs / scores, box-head and mask-head outputs <= 1e-3 of their tensor scale
+        (BASELINE.json north_star: "conv activations and losses within 1e-3 relative fp32");
+  (ii)  every parameter gradient < max(1e-3, 3 x floor), floor = the SAME oracle evaluated in float32 on the CPU against
+        its float64 self: the float32 noise of this network (training-mode BatchNorm over a few hundred pixels, ReLU /
+        max-pool decisions on values within rounding of a tie), which no float32 implementation can beat;
+  (iii) the layer with the largest recorded error (res5/b2/conv2/W, profiles/r01_full_width_parity.txt) in isolation:
+        the oracle's own x and gy of that layer through mrcnn_conv2d_bwd_filter_f32 <= 2e-5;
+for the direct kernels, Winograd F(2x2,3x3) and the shipped 'auto' tile choice (F(4x4,3x3) where cheaper).
+The per-tensor table is written to gpurun_out/ (committed copy: profiles/r02_full_width_parity_*.txt)."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+
+from chainer_maskrcnn import _hip  # noqa: E402
+from chainer_maskrcnn._hip import nn as hnn  # noqa: E402
+from chainer_maskrcnn.model.maskrcnn import MaskRCNN  # noqa: E402
+from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss  # noqa: E402
+from chainer_maskrcnn.utils.synthetic import make_batch  # noqa: E402
+
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODES = {'direct': (100000, 1 << 30, 0), 'winograd_f2': (256, 2048, 2), 'auto': (256, 2048, 0)}
+NAMES = ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
+TAP = 'extractor/resnet/res5/b2'
+_cache = {}
+
+
+def _model():
+    if 'm' not in _cache:
+        m = MaskRCNN(n_fg_class=80, device=DEV, seed=5)
+        chain = FPNMaskRCNNTrainChain(m, mask_loss_fun=calc_mask_loss, mask_rows='all')
+        chain.keep_outputs = True
+        _cache['m'] = (m, chain)
+    return _cache['m']
+
+
+def _targets(chain):
+    t = {k: v.cpu().numpy() for k, v in chain.targets.items() if torch.is_tensor(v)}
+    t['gt_rpn_loc'], t['gt_rpn_label'] = (x.cpu().numpy() for x in chain.rpn_targets)
+    t['mask_rois_xy5'], t['mask_levels'], t['mask_label'] = (x.cpu().numpy() for x in chain.mask_inputs)
+    return t
+
+
+def _oracle(m, t, img4, dtype, tap=None):
+    """One oracle step (forward + backward) in `dtype` on the device's sampled targets."""
+    om.set_dtype(dtype)
+    try:
+        ps = m.ps
+        params = {n: ps.p(n).detach().cpu().to(dtype).requires_grad_(True) for n in ps.names()}
+        o = om.OracleStep(params, tuple(len(s) for s in m.extractor.stages), m.head.n_class, m.head.LOC0, tap=tap)
+        out = o.losses(img4.to(dtype), t)
+        sum(out[k] for k in NAMES).backward()
+        grads = {n: (params[n].grad if params[n].grad is not None else torch.zeros_like(params[n])).double() for n in ps.names()}
+        return o, out, grads
+    finally:
+        om.set_dtype(torch.float64)
+
+
+def _same_targets(a, b):
+    return a is not None and all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def _rel(got, want):
+    want = want.detach().double()
+    return float((got.detach().double().cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+
+
+def _run(S, mode):
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    m, chain = _model()
+    b = make_batch(11, 1, S, S, G=6)
+    b['bboxes'][:, :, 2:] = np.minimum(b['bboxes'][:, :, 2:], [S, S])
+    bt = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
+    _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(*MODES[mode]))
+    try:
+        chain.proposal_target_creator.set_seed(21)
+        chain.anchor_target_creator.set_seed(22)
+        loss = chain(bt['imgs'], bt['bboxes'], bt['labels'], bt['masks'], 1.0)
+        outs = {k: ([f.clone() for f in v] if k == 'features' else v.clone()) for k, v in chain.outputs.items()}
+        loss.backward()
+        obs = {k: float(v) for k, v in chain.observation.items()}
+        t = _targets(chain)
+        img4 = torch.cat([bt['imgs'].cpu().permute(0, 2, 3, 1), torch.zeros((1, S, S, 1))], -1)
+        key = ('oracle', S)
+        if not (key in _cache and _same_targets(_cache[key]['t'], t)):      # proposals can differ between conv paths
+            t0 = time.time()
+            o64, out64, g64 = _oracle(m, t, img4, torch.float64, tap=TAP)
+            _, out32, g32 = _oracle(m, t, img4, torch.float32)
+            h1, y2 = o64.taps[TAP + '/conv2']
+            _cache[key] = dict(t=t, out=out64, g64=g64, g32=g32, tap=(h1.detach(), y2.grad.detach()), secs=time.time() - t0)
+        c = _cache[key]
+        # ---- (i) activations
+        want, acts = c['out'], {}
+        for l, (f, w) in enumerate(zip(outs['features'], want['feats'])):
+            acts['p%d' % (l + 2)] = _rel(f, w)
+        acts['rpn_locs'] = _rel(outs['locs'], want['locs'])
+        acts['rpn_scores'] = _rel(outs['scores'], want['scores'])
+        nc, l0 = m.head.n_class, m.head.LOC0
+        acts['roi_scores'] = _rel(outs['box'][:, :nc], want['box'][:, :nc])
+        acts['roi_cls_locs'] = _rel(outs['box'][:, l0:l0 + 4], want['box'][:, l0:l0 + 4])
+        acts['mask'] = _rel(outs['mask'][..., :nc - 1], want['mask'][..., :nc - 1])
+        losses = {k: abs(obs[k] - float(want[k].detach())) / max(abs(float(want[k].detach())), 1e-3) for k in NAMES}
+        # ---- (ii) gradients against the float64 oracle, with the float32 oracle's own error as the noise floor
+        ps = m.ps
+        gmax = max(float(g.abs().max()) for g in c['g64'].values())
+        rows = []
+        for n in ps.names():
+            w64 = c['g64'][n]
+            scale = max(float(w64.abs().max()), 1e-3 * gmax)
+            err = float((ps.g(n).cpu().double() - w64).abs().max()) / scale
+            floor = float((c['g32'][n] - w64).abs().max()) / scale
+            rows.append((n, err, floor))
+        # ---- (iii) the worst layer of round 1 in isolation: oracle x, gy -> device filter gradient
+        h1, gy2 = c['tap']
+        wname = TAP + '/conv2/W'
+        gw, _ = hnn.conv2d_bwd_filter_raw(h1.float().contiguous().to(DEV), gy2.float().contiguous().to(DEV),
+                                          tuple(ps.p(wname).shape), 1, 1, False)
+        iso = _rel(gw, c['g64'][wname])
+    finally:
+        _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048, 0))
+    # ---- report
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out_dir, exist_ok=True)
+    errs = sorted(r[1] for r in rows)
+    flo = sorted(r[2] for r in rows)
+    q = lambda v, f: v[int(f * (len(v) - 1))]
+    with open(os.path.join(out_dir, 'full_width_parity_%d_%s.txt' % (S, mode)), 'w') as f:
+        f.write('# full ResNet-50-FPN Mask R-CNN, one %dx%d image, conv path %s; oracle float64 + float32 took %.0f s\n' % (S, S, mode, c['secs']))
+        f.write('# activations, max |device - fp64 oracle| / max |oracle|: %s\n' % ', '.join('%s %.2e' % kv for kv in acts.items()))
+        f.write('# losses, relative: %s\n' % ', '.join('%s %.2e' % kv for kv in losses.items()))
+        f.write('# isolated %s filter gradient (oracle x, gy -> mrcnn_conv2d_bwd_filter_f32): %.2e\n' % (wname, iso))
+        f.write('# gradient error quantiles  device: median %.2e 90%% %.2e max %.2e | float32 oracle (floor): median %.2e 90%% %.2e max %.2e\n'
+                % (q(errs, .5), q(errs, .9), errs[-1], q(flo, .5), q(flo, .9), flo[-1]))
+        f.write('# %-48s %10s %10s %8s\n' % ('parameter', 'device', 'fp32floor', 'ratio'))
+        for n, e, fl in rows:
+            f.write('%-50s %10.3e %10.3e %8.2f\n' % (n, e, fl, e / max(fl, 1e-12)))
+    return acts, losses, rows, iso
+
+
+def _check(S, mode):
+    acts, losses, rows, iso = _run(S, mode)
+    for k, v in acts.items():
+        assert v <= 1e-3, ('activation', k, v)
+    for k, v in losses.items():
+        assert v <= 1e-4, ('loss', k, v)
+    assert iso <= 2e-5, ('isolated res5/b2/conv2 filter gradient', iso)
+    bad = [(n, e, fl) for n, e, fl in rows if not e < max(1e-3, 3 * fl)]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize('mode', ['direct', 'winograd_f2', 'auto'])
+def test_full_width_512(mode):
+    _check(512, mode)
+
+
+def test_full_width_1024_auto():
+    """BASELINE.json configs[2]'s image size with the shipped (benchmarked) kernel selection."""
+    _check(1024, 'auto')

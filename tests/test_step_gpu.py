@@ -166,14 +166,149 @@ def test_reference_api_surface():
     assert roi_indices.shape == (R,) and R <= 2000
 
 
-@pytest.mark.parametrize('tile', [2])
+@pytest.mark.parametrize('tile', [2, 4, 0])
 def test_step_matches_oracle_with_winograd_everywhere(tile):
     """The same whole-step parity check with the Winograd thresholds lowered so that every 3x3 / stride-1 layer of the
-    small test network (ResNet conv2's, FPN, RPN, box and mask heads) takes the F(2x2,3x3) / F(4x4,3x3) kernels in all
-    three passes."""
+    small test network (ResNet conv2's, FPN, RPN, box and mask heads) takes the F(2x2,3x3) (tile 2) / F(4x4,3x3) (tile 4)
+    kernels, or the shipped per-layer choice between the two (tile 0 = what bench.py runs), in all three passes."""
     from chainer_maskrcnn import _hip
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(32, 64, tile))
     try:
         test_step_losses_and_gradients_match_oracle('all')
     finally:
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048, 0))
+
+
+def _user_mask_loss(roi_cls_mask, gt_roi_mask, xp, gt_roi_label):
+    """The body of the reference's train.py:50-58, verbatim up to the module that provides sigmoid_cross_entropy
+    (chainer.functions there, chainer_maskrcnn.functions here).  No ``fused_kind`` tag: the chain must CALL it."""
+    from chainer_maskrcnn import functions as F
+    roi_mask = roi_cls_mask[xp.arange(
+        roi_cls_mask.shape[0]), gt_roi_label - 1]
+    return F.sigmoid_cross_entropy(roi_mask[:gt_roi_mask.shape[0]],
+                                   gt_roi_mask)
+
+
+def _user_keypoint_loss(roi_cls_mask, gt_roi_mask, xp, gt_roi_label, num_keypoints=17):
+    """train_keypoints.py:21-27 verbatim (same substitution)."""
+    from chainer_maskrcnn import functions as F
+    num_positives = gt_roi_mask.shape[0]
+    roi_mask = roi_cls_mask[:num_positives].reshape(
+        (num_positives * num_keypoints, -1))
+    gt_roi_mask = gt_roi_mask.reshape((-1,))
+    return F.softmax_cross_entropy(roi_mask, gt_roi_mask)
+
+
+@pytest.mark.parametrize('kind', ['mask', 'keypoint'])
+def test_user_supplied_mask_loss_fun_matches_fused_kernel(kind):
+    """VERDICT r1 item 6 / ADVICE: FPNMaskRCNNTrainChain accepts an arbitrary callable like the reference
+    (train.py:98, fpn_maskrcnn_train_chain.py:103-104).  A user-written copy of the reference's loss function, run through
+    the generic path (HIP-backed select / sigmoid CE / softmax CE under torch autograd), must give the fused kernel's loss
+    and parameter gradients; the exported calc_mask_loss / calc_keypoint_loss are real callables too."""
+    if kind == 'mask':
+        mk = lambda f: FPNMaskRCNNTrainChain(MaskRCNN(n_fg_class=80, device=DEV, seed=7, _test_shrink=dict(stages=STAGES, width_div=2)),
+                                             mask_loss_fun=f, mask_rows='all')
+        b = _batch()
+        args = (b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+        fused_fun, user_fun = calc_mask_loss, _user_mask_loss
+    else:
+        mk = lambda f: FPNMaskRCNNTrainChain(MaskRCNN(n_fg_class=1, n_keypoints=17, n_mask_convs=2, head_arch='fpn_keypoint', device=DEV,
+                                                      seed=11, _test_shrink=dict(stages=(1, 1, 1, 1), width_div=2)),
+                                             mask_loss_fun=f, binary_mask=False, mask_rows='all')
+        b = make_batch(5, 2, 128, 160, G=3, n_fg_class=1, n_keypoints=17)
+        b['bboxes'][:, :, 2:] = np.minimum(b['bboxes'][:, :, 2:], [128, 160])
+        b = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
+        args = (b['imgs'], b['bboxes'], b['labels'], b['keypoints'], 1.0)
+        fused_fun, user_fun = calc_keypoint_loss, _user_keypoint_loss
+    res = {}
+    for name, f in (('fused', fused_fun), ('user', user_fun)):
+        chain = mk(f)
+        assert chain.mask_loss_kind == ('generic' if name == 'user' else chain.mask_loss_kind)
+        chain.proposal_target_creator.set_seed(5)
+        chain.anchor_target_creator.set_seed(9)
+        loss = chain(*args)
+        loss.backward()
+        res[name] = (float(chain.observation['mask_loss']), float(loss.detach()), chain.faster_rcnn.ps.grads.clone())
+    assert abs(res['user'][0] - res['fused'][0]) <= 1e-6 * max(abs(res['fused'][0]), 1.0), (res['user'][0], res['fused'][0])
+    assert abs(res['user'][1] - res['fused'][1]) <= 1e-6 * max(abs(res['fused'][1]), 1.0)
+    gf, gu = res['fused'][2], res['user'][2]
+    # same arithmetic per row; the generic path orders the mask rows positives-first without padding rows, so the
+    # filter-gradient sums run in another order: compare at float32 summation noise
+    assert float((gf - gu).abs().max()) <= 2e-5 * float(gf.abs().max())
+    # loss scaling: (loss * k).backward() scales every gradient by k (the upstream gradient is honoured)
+    chain = mk(fused_fun)
+    chain.proposal_target_creator.set_seed(5)
+    chain.anchor_target_creator.set_seed(9)
+    (chain(*args) * 4.0).backward()
+    assert float((chain.faster_rcnn.ps.grads - 4.0 * gf).abs().max()) <= 1e-5 * 4.0 * float(gf.abs().max())
+
+
+def test_exported_loss_functions_are_callable():
+    """calc_mask_loss / calc_keypoint_loss called directly (outside the chain) on device tensors."""
+    from chainer_maskrcnn.functions.loss import MaskLogits, XP
+    from chainer_maskrcnn._hip import ops
+    rs = np.random.RandomState(0)
+    R, C, S, n_pos = 12, 5, 6, 4
+    x = torch.from_numpy(rs.standard_normal((R, C, S, S)).astype(np.float32)).to(DEV).requires_grad_(True)
+    gt = torch.from_numpy(rs.randint(-1, 2, (n_pos, S, S)).astype(np.int32)).to(DEV)
+    lab = torch.from_numpy(np.array([1, 3, 5, 2] + [0] * (R - n_pos), np.int32)).to(DEV)
+    loss = calc_mask_loss(x.as_subclass(MaskLogits), gt, XP(x.device), lab)
+    loss.backward()
+    xn, gn, ln = x.detach().cpu().numpy().astype(np.float64), gt.cpu().numpy(), lab.cpu().numpy()
+    sel = xn[np.arange(n_pos), ln[:n_pos] - 1]
+    valid = gn != -1
+    want = (np.maximum(sel, 0) - sel * gn + np.log1p(np.exp(-np.abs(sel))))[valid].sum() / valid.sum()
+    assert abs(float(loss) - want) < 1e-5
+    gwant = np.zeros_like(xn)
+    gwant[np.arange(n_pos), ln[:n_pos] - 1] = np.where(valid, (1 / (1 + np.exp(-sel)) - gn) / valid.sum(), 0)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gwant, atol=1e-6)
+    K = 3
+    xk = torch.from_numpy(rs.standard_normal((R, K, S, S)).astype(np.float32)).to(DEV).requires_grad_(True)
+    gk = torch.from_numpy(rs.randint(-1, S * S, (n_pos, K)).astype(np.int32)).to(DEV)
+    lk = calc_keypoint_loss(xk.as_subclass(MaskLogits), gk, XP(xk.device), lab, num_keypoints=K)
+    lk.backward()
+    xr = xk.detach().cpu().double().numpy()[:n_pos].reshape(n_pos * K, -1)
+    tr = gk.cpu().numpy().reshape(-1)
+    lse = np.log(np.exp(xr - xr.max(1, keepdims=True)).sum(1)) + xr.max(1)
+    v = tr != -1
+    assert abs(float(lk) - (lse[v] - xr[v, tr[v]]).sum() / v.sum()) < 1e-5
+    assert float(xk.grad[n_pos:].abs().max()) == 0.0
+
+
+def test_ragged_batch_padding_rows_are_ignored():
+    """dataset/loader.py pads ragged batches with zero boxes / label -1 and train.py passes no counts.
+    The chain must count the valid rows itself (#label >= 0, on the device); a zero box treated as a gt would make every
+    inside anchor positive (ChainerCV's gt-argmax rule)."""
+    from chainer_maskrcnn._hip import ops
+    m, chain = _build('positives')
+    b = _batch(G=3)
+    bb, lab, mk = b['bboxes'].clone(), b['labels'].clone(), b['masks'].clone()
+    bb[1, 1:] = 0
+    lab[1, 1:] = -1
+    mk[1, 1:] = 0
+    chain.use_aux_stream = False
+    chain(b['imgs'], bb, lab, mk, 1.0)                       # only to learn the key shapes
+    A = chain.rpn_out['anchors'].shape[0]
+    roi_cap = chain.rpn_out['rois'].shape[0] // 2
+    pk = ops.random_keys((2, roi_cap + 3), 77, DEV)
+    ak = ops.random_keys((2, A), 78, DEV)
+    chain.sampler_keys = (pk, ak)
+    snap = lambda: ({k: v.clone() for k, v in chain.targets.items() if torch.is_tensor(v)}, [x.clone() for x in chain.rpn_targets],
+                    float(chain.observation['loss']))
+    chain(b['imgs'], bb, lab, mk, 1.0)                       # counts derived from the labels
+    t_auto, r_auto, l_auto = snap()
+    chain(b['imgs'], bb, lab, mk, 1.0, n_gt=torch.tensor([3, 1], dtype=torch.int32, device=DEV))
+    t_exp, r_exp, l_exp = snap()
+    assert l_auto == l_exp
+    for k in t_auto:
+        assert torch.equal(t_auto[k], t_exp[k]), k
+    assert torch.equal(r_auto[1], r_exp[1]) and torch.equal(r_auto[0], r_exp[0])
+    # image 1 alone, un-padded (one gt), gives the same anchor targets as its padded row of the batch
+    loc1, lab1 = chain.anchor_target_creator(bb[1:2, :1].contiguous(), chain.rpn_out['anchors'], (128, 160), keys=ak[1:2].contiguous())
+    assert torch.equal(lab1[0], r_auto[1][1]) and torch.equal(loc1[0], r_auto[0][1])
+    n_pos_anchor = int((r_auto[1][1] == 1).sum())
+    assert 1 <= n_pos_anchor <= 128
+    # and no padded gt row was sampled as a RoI: every sampled source index of image 1 is a proposal or gt row 0
+    src = t_auto['sample_src'][256:256 + int(t_auto['n_sampled'][1])]
+    n_roi1 = int(chain.rpn_out['n_rois'][1])
+    assert int(src.max()) <= n_roi1

@@ -115,7 +115,46 @@ def test_proposal_target_reference_golden_candidate_sets():
                 hits += 1
                 assert ref[tuple(r)][0] == l
                 np.testing.assert_allclose(loc, ref[tuple(r)][1], atol=2e-4)
-        assert hits >= n_pos * 0      # (random subsets differ; the positives' labels above are what is pinned)
+        # fewer than 64 foreground candidates: both samplers take them all; otherwise the random subsets overlap
+        assert hits >= (n_pos if n_pos < 64 else 1)
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2, 3])
+def test_proposal_target_reference_order_equals_reference_golden(ci):
+    """Reference-order mode: the host draws np.random.choice exactly like utils/proposal_target_creator.py:63-78 (same
+    NumPy seed as the golden run), the device consumes the draw order => ALL FIVE outputs equal the reference's own,
+    row for row (sample_roi, sample_levels, gt_roi_label, gt_roi_mask bit-exact; gt_roi_loc involves log())"""
+    from chainer_maskrcnn.utils.proposal_target_creator import ProposalTargetCreator
+    d = np.load(os.path.join(GOLDEN, 'ptc_reference.npz'))
+    shape = tuple(d['c%d_in_mask_shape' % ci])
+    mask = np.unpackbits(d['c%d_in_mask' % ci], axis=-1)[..., :shape[-1]].reshape(shape)
+    roi, bbox, label = d['c%d_in_roi' % ci], d['c%d_in_bbox' % ci], d['c%d_in_label' % ci]
+    ptc = ProposalTargetCreator([32, 64, 128, 256, 512])
+    rs = np.random.RandomState(int(d['c%d_in_np_seed' % ci]))
+    out = ptc(_t(roi), _t(bbox), _t(label), _t(mask.astype(np.uint8)), _t(d['c%d_in_levels' % ci]), mask_size=28,
+              binary_mask=True, random_state=rs)
+    sample_roi, sample_levels, gt_roi_loc, gt_roi_label, gt_roi_mask = [o.cpu().numpy() for o in out]
+    np.testing.assert_array_equal(sample_roi, d['c%d_out_sample_roi' % ci])
+    np.testing.assert_array_equal(sample_levels, d['c%d_out_sample_levels' % ci])
+    np.testing.assert_array_equal(gt_roi_label, d['c%d_out_gt_roi_label' % ci])
+    np.testing.assert_array_equal(gt_roi_mask, d['c%d_out_gt_roi_mask' % ci])
+    np.testing.assert_allclose(gt_roi_loc, d['c%d_out_gt_roi_loc' % ci], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('ci', [0, 1])
+def test_keypoint_proposal_target_reference_order_with_inplace_quirk(ci):
+    """Same for the keypoint variant, including the reference's in-place mutation of the gt keypoints (App. B-11):
+    gt_roi_mask (flat 56x56 indices / -1) equals the reference's output row for row."""
+    from chainer_maskrcnn.utils.proposal_target_creator import ProposalTargetCreator
+    d = np.load(os.path.join(GOLDEN, 'ptc_keypoint_reference.npz'))
+    ptc = ProposalTargetCreator([32, 64, 128, 256, 512])
+    rs = np.random.RandomState(int(d['c%d_in_np_seed' % ci]))
+    out = ptc(_t(d['c%d_in_roi' % ci]), _t(d['c%d_in_bbox' % ci]), _t(d['c%d_in_label' % ci]), _t(d['c%d_in_kp' % ci]),
+              _t(d['c%d_in_levels' % ci]), mask_size=56, binary_mask=False, random_state=rs, inplace_kp_quirk=True)
+    sample_roi, sample_levels, gt_roi_loc, gt_roi_label, gt_roi_mask = [o.cpu().numpy() for o in out]
+    np.testing.assert_array_equal(sample_roi, d['c%d_out_sample_roi' % ci])
+    np.testing.assert_array_equal(gt_roi_label, d['c%d_out_gt_roi_label' % ci])
+    np.testing.assert_array_equal(gt_roi_mask, d['c%d_out_gt_roi_mask' % ci])
 
 
 @pytest.mark.parametrize('ci', [0, 1, 2, 3])
