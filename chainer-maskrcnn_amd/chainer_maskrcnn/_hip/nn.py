@@ -23,7 +23,8 @@ class _prof(object):
     def __init__(self, kind, n_out_pix, KH, KW, cin, cout, geom=None):
         self.on = PROFILE is not None
         if self.on:
-            executed = lib().mrcnn_conv2d_executed_macs(*geom) if geom is not None else n_out_pix * KH * KW * cin * cout
+            pass_ = {'fwd': 0, 'bwd_data': 1, 'bwd_filter': 2}[kind]
+            executed = lib().mrcnn_conv2d_executed_macs(*geom, pass_) if geom is not None else n_out_pix * KH * KW * cin * cout
             if LOGICAL is not None:
                 cin, cout = LOGICAL
             self.rec = [kind, n_out_pix * KH * KW * cin * cout, torch.cuda.Event(enable_timing=True),

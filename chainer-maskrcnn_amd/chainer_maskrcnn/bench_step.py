@@ -20,6 +20,10 @@ def bench_step(args, rank, world):
     torch.cuda.set_device(dev)
     N, H, W = 2, 1024, 1024
     mask_rows = getattr(args, 'mask_rows', 'all')
+    tiles = os.environ.get('MRCNN_WINO_PASS_TILES')       # e.g. "2,0,0": forward F(2x2) (strict gradient parity), measurement knob
+    if tiles:
+        from chainer_maskrcnn._hip import lib, check
+        check(lib().mrcnn_conv2d_set_winograd_pass_tiles(*[int(v) for v in tiles.split(',')]))
     model = MaskRCNN(n_fg_class=80, device=dev, seed=1234)
     chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows=mask_rows)
     opt = MomentumSGD(lr=1e-3, momentum=0.9).setup(chain)
@@ -199,7 +203,7 @@ def _replay_split(recs, n_prof, dev):
                 e1.record()
                 torch.cuda.synchronize()
                 tot[mask] += e0.elapsed_time(e1) / 3 * 1e-3 * cnt
-            exe += 2.0 * lib().mrcnn_conv2d_executed_macs(*g) * cnt
+            exe += 2.0 * lib().mrcnn_conv2d_executed_macs(*g, {'fwd': 0, 'bwd_data': 1, 'bwd_filter': 2}[kind]) * cnt
             vb = lib().mrcnn_conv2d_winograd_v_bytes(*g)
             if vb:          # transforms stream: activation in + transformed operand out, GEMM result in + activation out
                 wb = lib().mrcnn_conv2d_winograd_w_bytes(*g)

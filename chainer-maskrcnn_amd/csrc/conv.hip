@@ -864,20 +864,34 @@ int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes
 constexpr int WINO_ROWS = 128;          // Tp = T rounded up to this: a GEMM tile never straddles two k
 
 int g_wino_min_channels = 256, g_wino_min_pixels = 2048, g_wino_tile = 0;      // tile 0 = automatic, 2 or 4 = forced
+// Per pass (PASS_FWD / PASS_BWD_DATA / PASS_BWD_FILTER) override of the tile: 0 = follow g_wino_tile, 2 / 4 = forced,
+// -1 = the pass never takes the Winograd path.  F(4x4,3x3) amplifies float32 rounding by ~|A|^2 |B|^2 |G|^2: harmless on
+// activations (measured 1.5e-4 of the tensor scale on the full network) but visible in gradients of layers whose own
+// float32 noise floor is low (no BatchNorm behind them) - mrcnn_conv2d_set_winograd_pass_tiles.
+// Default {2, 0, 0}: the FORWARD pass stays on F(2x2,3x3) (or the direct kernel below its threshold).  Measured on the full
+// network (profiles/r02_winograd_pass_probe.txt): F(4x4) in forward keeps activations within 2.2e-4 of their scale, but the
+// losses' curvature (smooth-L1 with sigma 3, softmax) turns those 1e-4 activation errors into parameter-gradient errors
+// of up to 2e-2 in the layers without BatchNorm (rpn/conv, FPN laterals) - 100x their float32 noise floor - whereas F(4x4)
+// in the two BACKWARD passes leaves every gradient at the floor.  {0, 0, 0} = F(4x4) wherever cheaper, +8 % images/s.
+enum { PASS_FWD = 0, PASS_BWD_DATA = 1, PASS_BWD_FILTER = 2 };
+int g_wino_pass_tile[3] = {2, 0, 0};
 
-int wino_m(int H, int W) {
+int wino_m(int H, int W, int pass) {
+    const int pt = g_wino_pass_tile[pass];
+    if (pt == 2 || pt == 4) return pt;
     if (g_wino_tile == 2 || g_wino_tile == 4) return g_wino_tile;
     const long long c2 = 16ll * ((H + 1) / 2) * ((W + 1) / 2), c4 = 36ll * ((H + 3) / 4) * ((W + 3) / 4);
     return c4 < c2 ? 4 : 2;
 }
-bool wino_ok(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+bool wino_ok(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int pass) {
+    if (g_wino_pass_tile[pass] < 0) return false;
     if (KH != 3 || KW != 3 || stride != 1 || pad != 1) return false;
     // measured on gfx950 (tools/conv_bench.py): with >= 256 channels the GEMMs are deep enough (K >= 256) to win from
     // 2048 pixels up; at 128 channels Winograd ties the direct kernel, at 64 it loses; below 2048 pixels the four launches
     // are latency-bound
     // F(4x4) does 4x fewer multiplications, so it pays from a quarter of the channels F(2x2) needs (measured: 64 -> 64 on
     // 256^2 maps 95 -> 78 us, 128 -> 128 on 128^2 83 -> 62 us; with F(2x2) the same layers lose)
-    const int minc = wino_m(H, W) == 4 ? std::max(BK, g_wino_min_channels / 4) : g_wino_min_channels;
+    const int minc = wino_m(H, W, pass) == 4 ? std::max(BK, g_wino_min_channels / 4) : g_wino_min_channels;
     if (Cin % BK || Cout % BK || Cin < minc || Cout < minc) return false;
     if ((long long)N * H * W < g_wino_min_pixels) return false;
     const long long T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
@@ -885,18 +899,18 @@ bool wino_ok(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
     return 16 * Tp < (1ll << 24) && 16 * Tp * std::max(Cin, Cout) < (1ll << 30);    // limits of the GEMM kernel's offsets
 }
 struct WinoGeom { int m, a, nk, th, tw; long long T, Tp; };
-WinoGeom wino_geom(int N, int H, int W) {
+WinoGeom wino_geom(int N, int H, int W, int pass) {
     WinoGeom g;
-    g.m = wino_m(H, W); g.a = g.m + 2; g.nk = g.a * g.a;
+    g.m = wino_m(H, W, pass); g.a = g.m + 2; g.nk = g.a * g.a;
     g.th = (H + g.m - 1) / g.m; g.tw = (W + g.m - 1) / g.m;
     g.T = (long long)N * g.th * g.tw;
     g.Tp = (g.T + WINO_ROWS - 1) / WINO_ROWS * WINO_ROWS;
     return g;
 }
 struct WinoLayout { size_t u, v, m, inner, total; WinoGeom g; };
-WinoLayout wino_layout(int N, int H, int W, int Cin, int Cout) {
+WinoLayout wino_layout(int N, int H, int W, int Cin, int Cout, int pass) {
     WinoLayout L;
-    L.g = wino_geom(N, H, W);
+    L.g = wino_geom(N, H, W, pass);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t o = 0;
     L.u = o; o += al((size_t)L.g.nk * Cout * Cin * 4);
@@ -906,7 +920,7 @@ WinoLayout wino_layout(int N, int H, int W, int Cin, int Cout) {
     L.total = o;
     return L;
 }
-size_t wino_ws_bytes(int N, int H, int W, int Cin, int Cout) { return wino_layout(N, H, W, Cin, Cout).total; }
+size_t wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int pass) { return wino_layout(N, H, W, Cin, Cout, pass).total; }
 
 // ---- the 1-D transforms (T = float or V4) --------------------------------------------------------------------------
 struct V4 { float x, y, z, w; };
@@ -1278,7 +1292,7 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restric
 struct WinoFLayout { size_t v, w, slabs, du, total; WinoGeom g; int ksplit, kchunk; };
 WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
     WinoFLayout L;
-    L.g = wino_geom(N, H, W);
+    L.g = wino_geom(N, H, W, PASS_BWD_FILTER);
     ConvP p = make_p(1, 1, (int)L.g.Tp, Cin, Cout, 1, 1, 1, 0);
     p.wbatch_rows = (int)L.g.Tp; p.wbatch_n = L.g.nk;
     filter_plan(p, L.ksplit, L.kchunk);
@@ -1325,7 +1339,7 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
 int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, int Cin, int Cout, bool transposed,
               const float *bias, int relu, int accumulate, const float *relu_x, void *ws, size_t ws_bytes, hipStream_t st,
               float *v_keep, float *w_keep = nullptr, float *gbias = nullptr, int gbias_accumulate = 0) {
-    const WinoLayout L = wino_layout(N, H, W, Cin, Cout);
+    const WinoLayout L = wino_layout(N, H, W, Cin, Cout, transposed ? PASS_BWD_DATA : PASS_FWD);
     const WinoGeom &g = L.g;
     char *base = (char *)ws;
     float *U = (float *)(base + L.u), *V = v_keep ? v_keep : (float *)(base + L.v), *Mb = (float *)(base + L.m);
@@ -1381,8 +1395,9 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
     // tail split: at most one round of workgroup slots of partial 128x128 tiles (<= 4 workgroups per CU)
     const size_t tail = (size_t)4 * g_cus() * 128 * 128 * sizeof(float);
     size_t bytes = std::max((size_t)need * 16 * sizeof(float), tail);
-    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad))           // same call serves forward (Cin->Cout) and backward-data (Cout->Cin)
-        bytes = std::max(bytes, std::max(wino_ws_bytes(N, H, W, Cin, Cout), wino_ws_bytes(N, H, W, Cout, Cin)));
+    // the same query serves forward (Cin->Cout) and backward-data (Cout->Cin)
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD)) bytes = std::max(bytes, wino_ws_bytes(N, H, W, Cin, Cout, PASS_FWD));
+    if (wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad, PASS_BWD_DATA)) bytes = std::max(bytes, wino_ws_bytes(N, H, W, Cout, Cin, PASS_BWD_DATA));
     return bytes;
 }
 
@@ -1395,17 +1410,27 @@ extern "C" int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pi
     return 0;
 }
 
+extern "C" int mrcnn_conv2d_set_winograd_pass_tiles(int fwd, int bwd_data, int bwd_filter) {
+    const int t[3] = {fwd, bwd_data, bwd_filter};
+    for (int i = 0; i < 3; ++i)
+        if (t[i] != -1 && t[i] != 0 && t[i] != 2 && t[i] != 4)
+            return mrcnn::fail_arg(MRCNN_E_INVALID, "set_winograd_pass_tiles: each of -1 (direct), 0 (follow the global tile), 2, 4");
+    for (int i = 0; i < 3; ++i) g_wino_pass_tile[i] = t[i];
+    return 0;
+}
+
 extern "C" int mrcnn_conv2d_set_debug_skip(int mask) {
     if (mask < 0 || mask > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_debug_skip: mask in [0,3]");
     g_debug_skip = mask;
     return 0;
 }
 
-extern "C" long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
-    // multiply-accumulates the MFMA pipes actually execute for one pass (forward, backward-data or backward-filter)
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
-    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) {
-        const WinoGeom g = wino_geom(N, H, W);
+extern "C" long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int pass) {
+    // multiply-accumulates the MFMA pipes actually execute for one pass (0 forward, 1 backward-data, 2 backward-filter)
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || pass < 0 || pass > 2) return 0;
+    const bool wk = pass == PASS_BWD_DATA ? wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad, pass) : wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, pass);
+    if (wk) {
+        const WinoGeom g = wino_geom(N, H, W, pass);
         return (long long)g.nk * g.Tp * Cin * Cout;
     }
     const long long Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
@@ -1414,8 +1439,8 @@ extern "C" long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, in
 
 extern "C" size_t mrcnn_conv2d_winograd_v_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
-    if (!wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) return 0;
-    const WinoGeom g = wino_geom(N, H, W);
+    if (!wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD)) return 0;
+    const WinoGeom g = wino_geom(N, H, W, PASS_FWD);
     return (size_t)g.nk * g.Tp * Cin * sizeof(float);
 }
 
@@ -1423,7 +1448,7 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
                                     int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                                     float *wino_v, void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
-    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cin, Cout))
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cin, Cout, PASS_FWD))
         return wino_conv(x, w, y, N, H, W, Cin, Cout, false, bias, relu, 0, nullptr, ws, ws_bytes, (hipStream_t)stream, wino_v);
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     p.a = x; p.b = w; p.c = y; p.bias = bias; p.relu = relu;
@@ -1435,8 +1460,10 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
 
 extern "C" size_t mrcnn_conv2d_winograd_w_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
-    if (!wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) return 0;
-    const WinoGeom g = wino_geom(N, H, W);
+    // the shared transform of gy needs the backward-data and backward-filter passes on the same tile
+    if (!wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad, PASS_BWD_DATA) || !wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_BWD_FILTER)) return 0;
+    const WinoGeom g = wino_geom(N, H, W, PASS_BWD_DATA);
+    if (g.m != wino_geom(N, H, W, PASS_BWD_FILTER).m) return 0;
     return (size_t)g.nk * g.Tp * Cout * sizeof(float);
 }
 
@@ -1451,7 +1478,7 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
     if (relu_x && accumulate) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: relu_x with accumulate");
-    if (wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cout, Cin))
+    if (wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad, PASS_BWD_DATA) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cout, Cin, PASS_BWD_DATA))
         return wino_conv(gy, w, gx, N, H, W, Cout, Cin, true, nullptr, 0, accumulate, relu_x, ws, ws_bytes, (hipStream_t)stream, nullptr,
                          wino_w, wino_w ? gbias : nullptr, gbias_accumulate);
     if (wino_w || gbias) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: wino_w / gbias only on the Winograd path (mrcnn_conv2d_winograd_w_bytes() > 0)");
@@ -1471,7 +1498,7 @@ extern "C" size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, i
     const size_t wsz = (size_t)Cout * KH * KW * Cin * sizeof(float);
     const size_t P = (size_t)N * p.Ho * p.Wo;
     const size_t bias_part = (size_t)col_plan((int)P, Cout).nblk * Cout * sizeof(float);
-    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) return wino_filter_layout(N, H, W, Cin, Cout).total + bias_part + 256;
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_BWD_FILTER)) return wino_filter_layout(N, H, W, Cin, Cout).total + bias_part + 256;
     return wsz * ksplit + bias_part + 256;     // slabs are also used for ksplit == 1 when accumulating
 }
 
@@ -1484,8 +1511,11 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     if (!ws || ws_bytes < need) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "conv2d_bwd_filter: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
-    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad)) {
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_BWD_FILTER)) {
         const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
+        // the forward pass's transformed input is reusable only when that pass ran Winograd on the same tile
+        if (wino_v && !(wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD) && wino_geom(N, H, W, PASS_FWD).m == L.g.m)) wino_v = nullptr;
+        if (wino_w && mrcnn_conv2d_winograd_w_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad) == 0) wino_w = nullptr;
         if (int e = wino_bwd_filter(x, gy, gw, N, H, W, Cin, Cout, accumulate, ws, st, wino_v, wino_w)) return e;
         if (gbias) {
             float *bias_part = (float *)((char *)ws + L.total);

@@ -20,6 +20,7 @@
 // (ballot + readlane), streaming gy rows through L1/L2.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -56,7 +57,9 @@ struct Samp {
 
 // One axis of one sample: c = (start + p*bin) + ((i+0.5)*bin)/grid, in exactly this order.
 __device__ __forceinline__ Samp axis_sample(float start, float bin, int p, int i, int grid, int size) {
-    float c = (start + (float)p * bin) + (((float)i + 0.5f) * bin) / (float)grid;
+    // x / 2.0f == x * 0.5f bit for bit (barring subnormals): the common sampling ratio avoids the correctly-rounded divide
+    const float t = ((float)i + 0.5f) * bin;
+    float c = (start + (float)p * bin) + (grid == 2 ? t * 0.5f : t / (float)grid);
     bool valid = !(c < -1.0f || c > (float)size);
     c = fmaxf(c, 0.0f);
     int lo = (int)c, hi;
@@ -94,7 +97,17 @@ struct Levels {
     int L;
 };
 
+// q = v / d, r = v % d for 0 <= v < 2^24 with inv = 1.0f / d: float estimate + one correction each way (exact); the
+// tile decode of a workgroup would otherwise spend ~100 instructions in four 32-bit integer divisions.
+__device__ __forceinline__ void divmod_u24(int v, int d, int &q, int &r) {
+    q = (int)((float)v * (1.0f / (float)d));
+    r = v - q * d;
+    if (r >= d) { r -= d; ++q; }
+    if (r < 0) { r += d; --q; }
+}
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ float readlane_f(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -147,6 +160,145 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_nhwc(Levels lv, const flo
         }
         float4 o = make_float4(acc.x / cnt, acc.y / cnt, acc.z / cnt, acc.w / cnt);
         *reinterpret_cast<float4 *>(yo + c4 * 4) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward, NHWC, one wave per (roi, ph) ROW of bins (the default for sampling grids with PW * grid <= 64).
+// The per-bin kernel above spends ~550 VALU instructions per bin, most of them the coordinate arithmetic that all 64
+// lanes repeat; it is VALU-bound at a quarter of the HBM rate.  Here the geometry is done once per row: lane t computes
+// the x sample (pw = t / gw, ix = t % gw) with the same axis_sample() (bit-identical indices and weights), the y samples
+// are wave-uniform, and the tap loop reads cell offsets and weights from SGPRs (v_readlane): a tap is one buffer load with
+// a scalar offset + the bit-exact ((w1 f1 + w2 f2) + w3 f3) + w4 f4 update.  Workgroup -> row order is XCD-banded so
+// that the rows of one RoI (which share their taps' cache lines) run on one XCD's L2.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_roi_align_fwd_rows(Levels lv, const float *__restrict__ rois,
+                                                            const int32_t *__restrict__ levels, int R, int N, int C, int PH, int PW,
+                                                            int sr, float *__restrict__ y, int chunk) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk) return;
+    const int row_id = wg * 4 + wave;                  // (r, ph)
+    if (row_id >= R * PH) return;
+    int r, ph;
+    divmod_u24(row_id, PH, r, ph);
+    int l = levels ? levels[r] : 0;
+    l = __builtin_amdgcn_readfirstlane(min(max(l, 0), lv.L - 1));
+    const int H = lv.H[l], W = lv.W[l];
+    const RoiGeom g = roi_geom(rois + (size_t)r * 5, lv.scale[l], PH, PW, sr);
+    const int gh = __builtin_amdgcn_readfirstlane(g.gh), gw = __builtin_amdgcn_readfirstlane(g.gw);
+    const int gn = __builtin_amdgcn_readfirstlane(g.n);
+    const bool bad = gn < 0 || gn >= N;
+    // x samples: lane t = pw * gw + ix (host guarantees PW * gw <= 64 for fixed grids; adaptive grids are checked here)
+    const int tpw = lane / max(gw, 1), tix = lane - tpw * max(gw, 1);
+    const Samp sxl = axis_sample(g.x1f, g.bw, min(tpw, PW - 1), tix, gw, W);
+    const int cnt_i = gh * gw;
+    const float cnt = (float)cnt_i;
+    const bool pow2 = (cnt_i & (cnt_i - 1)) == 0;
+    const float inv = 1.0f / cnt;                      // exact when cnt is a power of two: x * inv == x / cnt bit for bit
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)(lv.x[l] + (size_t)(bad ? 0 : gn) * H * W * C), 0,
+                                                        (unsigned)((size_t)H * W * C * 4), 0x00020000);
+    float *yo = y + (size_t)row_id * PW * C;
+    const unsigned OOB = 0xFFFFFFFFu;
+    if (gh == 2 && gw == 2) {
+        // The common 2x2 grid, branch-free and software-pipelined: the 16 taps of bin pw+1 are in flight while bin pw is
+        // reduced (measured 33.4 us on configs[1] against 36.2 us single-buffered at twice the occupancy).  A void sample has weight 0 and an out-of-range offset (the load returns 0): adding its exact +0 is
+        // the same as skipping it, so the result stays bit-identical to the reference loop.
+        const Samp sy0 = axis_sample(g.y1f, g.bh, ph, 0, 2, H), sy1 = axis_sample(g.y1f, g.bh, ph, 1, 2, H);
+        int yl[2] = {__builtin_amdgcn_readfirstlane(sy0.lo), __builtin_amdgcn_readfirstlane(sy1.lo)};
+        int yh[2] = {__builtin_amdgcn_readfirstlane(sy0.hi), __builtin_amdgcn_readfirstlane(sy1.hi)};
+        const float wyl[2] = {sgpr_f(sy0.wl), sgpr_f(sy1.wl)}, wyh[2] = {sgpr_f(sy0.wh), sgpr_f(sy1.wh)};
+        const unsigned cell = (unsigned)C * 4u;
+        for (int cb = 0; cb < C; cb += 256) {
+            const bool act = cb + lane * 4 < C;
+            const unsigned vlane = (act && !bad) ? (unsigned)(cb + lane * 4) * 4u : OOB;
+            float4 tapA[16], tapB[16];
+            auto issue = [&](int pw, float4 (&tap)[16]) {
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix) {
+                        const int t = min(pw, PW - 1) * 2 + ix;
+                        const int xlo = __builtin_amdgcn_readlane(sxl.lo, t), xhi = __builtin_amdgcn_readlane(sxl.hi, t);
+                        const bool ok = xlo >= 0 && yl[iy] >= 0 && pw < PW;
+                        const unsigned vo = ok ? vlane : OOB;
+                        const unsigned rlo = (unsigned)(max(yl[iy], 0) * W) * cell, rhi = (unsigned)(max(yh[iy], 0) * W) * cell;
+                        const unsigned clo = (unsigned)max(xlo, 0) * cell, chi = (unsigned)max(xhi, 0) * cell;
+                        const int b = (iy * 2 + ix) * 4;
+                        { const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, rlo + clo, 0); __builtin_memcpy(&tap[b + 0], &v, 16); }
+                        { const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, rlo + chi, 0); __builtin_memcpy(&tap[b + 1], &v, 16); }
+                        { const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, rhi + clo, 0); __builtin_memcpy(&tap[b + 2], &v, 16); }
+                        { const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, rhi + chi, 0); __builtin_memcpy(&tap[b + 3], &v, 16); }
+                    }
+            };
+            auto reduce = [&](int pw, const float4 (&tap)[16]) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix) {
+                        const int t = pw * 2 + ix;
+                        const float wxl = readlane_f(sxl.wl, t), wxh = readlane_f(sxl.wh, t);
+                        const float w1 = wyl[iy] * wxl, w2 = wyl[iy] * wxh, w3 = wyh[iy] * wxl, w4 = wyh[iy] * wxh;
+                        const int b = (iy * 2 + ix) * 4;
+                        const float4 f1 = tap[b], f2 = tap[b + 1], f3 = tap[b + 2], f4 = tap[b + 3];
+                        acc.x += ((w1 * f1.x + w2 * f2.x) + w3 * f3.x) + w4 * f4.x;
+                        acc.y += ((w1 * f1.y + w2 * f2.y) + w3 * f3.y) + w4 * f4.y;
+                        acc.z += ((w1 * f1.z + w2 * f2.z) + w3 * f3.z) + w4 * f4.z;
+                        acc.w += ((w1 * f1.w + w2 * f2.w) + w3 * f3.w) + w4 * f4.w;
+                    }
+                const float4 o = make_float4(acc.x * 0.25f, acc.y * 0.25f, acc.z * 0.25f, acc.w * 0.25f);    // == acc / 4 exactly
+                if (act) *reinterpret_cast<float4 *>(yo + (size_t)pw * C + cb + lane * 4) = o;
+            };
+            issue(0, tapA);
+#pragma nounroll
+            for (int pw = 0; pw < PW; pw += 2) {
+                issue(pw + 1, tapB);
+                reduce(pw, tapA);
+                if (pw + 1 < PW) {
+                    issue(pw + 2, tapA);
+                    reduce(pw + 1, tapB);
+                }
+            }
+        }
+        return;
+    }
+    for (int cb = 0; cb < C; cb += 256) {
+        const bool act = cb + lane * 4 < C;
+        const unsigned vlane = (act && !bad) ? (unsigned)(cb + lane * 4) * 4u : OOB;
+        for (int pw = 0; pw < PW; ++pw) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int iy = 0; iy < gh; ++iy) {
+                const Samp sy = axis_sample(g.y1f, g.bh, ph, iy, gh, H);
+                const int ylo = __builtin_amdgcn_readfirstlane(sy.lo), yhi = __builtin_amdgcn_readfirstlane(sy.hi);
+                if (ylo < 0) continue;
+                const float wyl = sgpr_f(sy.wl), wyh = sgpr_f(sy.wh);
+                const unsigned rlo = (unsigned)(ylo * W) * (unsigned)C * 4u, rhi = (unsigned)(yhi * W) * (unsigned)C * 4u;
+                for (int ix = 0; ix < gw; ++ix) {
+                    const int t = pw * gw + ix;
+                    const int xlo = __builtin_amdgcn_readlane(sxl.lo, t), xhi = __builtin_amdgcn_readlane(sxl.hi, t);
+                    if (xlo < 0) continue;
+                    const float wxl = readlane_f(sxl.wl, t), wxh = readlane_f(sxl.wh, t);
+                    const unsigned clo = (unsigned)xlo * (unsigned)C * 4u, chi = (unsigned)xhi * (unsigned)C * 4u;
+                    float4 f1, f2, f3, f4;
+                    { const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vlane, rlo + clo, 0); __builtin_memcpy(&f1, &v, 16); }
+                    { const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vlane, rlo + chi, 0); __builtin_memcpy(&f2, &v, 16); }
+                    { const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vlane, rhi + clo, 0); __builtin_memcpy(&f3, &v, 16); }
+                    { const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vlane, rhi + chi, 0); __builtin_memcpy(&f4, &v, 16); }
+                    const float w1 = wyl * wxl, w2 = wyl * wxh, w3 = wyh * wxl, w4 = wyh * wxh;
+                    // ((w1*f1 + w2*f2) + w3*f3) + w4*f4, no contraction: matches the oracle bit for bit
+                    acc.x += ((w1 * f1.x + w2 * f2.x) + w3 * f3.x) + w4 * f4.x;
+                    acc.y += ((w1 * f1.y + w2 * f2.y) + w3 * f3.y) + w4 * f4.y;
+                    acc.z += ((w1 * f1.z + w2 * f2.z) + w3 * f3.z) + w4 * f4.z;
+                    acc.w += ((w1 * f1.w + w2 * f2.w) + w3 * f3.w) + w4 * f4.w;
+                }
+            }
+            float4 o;
+            if (pow2) o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+            else o = make_float4(acc.x / cnt, acc.y / cnt, acc.z / cnt, acc.w / cnt);
+            if (act) *reinterpret_cast<float4 *>(yo + (size_t)pw * C + cb + lane * 4) = o;
+        }
     }
 }
 
@@ -400,6 +552,322 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward, NHWC, owner-computes PATCHES with fully independent waves (the default; the tile kernel above is kept as
+// variant 1 for A/B).  One wave owns a 4x4 patch of gradient-map cells x 256 channels for the whole kernel: 64
+// accumulator VGPRs, no workgroup barrier anywhere, every phase is private to the wave (wave-private LDS regions), so
+// the 16 waves of a CU are in different phases at any time and the memory pipe never idles behind a barrier:
+//   1. scan: lanes test 64 RoIs at a time against the patch (4 x 64 RoIs of loads in flight), candidates are compacted
+//      in ascending RoI order into the wave's LDS list (geometry + index);
+//   2. per candidate, lanes = (axis, bin) compute the summed sample weights of that bin on the patch's 4 rows / 4 columns
+//      ONCE (bilinear weights are separable) with the forward's axis_sample() (bit-identical indices), ballots give the
+//      non-empty bins; lanes = (ph, pw) then append (gy row, wy[4], wx[4]) entries for the bin pairs that touch the patch;
+//   3. drain: entries are wave-uniform, so a row of the patch whose weight is zero is skipped with a scalar branch
+//      (a bin touches ~2 of the 4 rows); gy rows stream with 2*DEPTH loads in flight;
+//   4. the 16 cells are written once at the end (zeros where nothing lands; += old value when accumulating).
+// Sums are in fixed (RoI, ph, pw) order: bit-reproducible.
+// ------------------------------------------------------------------------------------------
+constexpr int W2_DEPTH = 2;       // 2 * W2_DEPTH gy rows in flight per wave during a drain
+constexpr int W2_SEG = 512;       // RoIs per segment: their boxes and bin geometry sit in the workgroup's LDS table
+
+template <int QC>
+struct WaveQueue {
+    float4 wy[QC], wx[QC];
+    int row[QC];
+};
+
+template <int PBT>
+struct WaveLds {
+    static constexpr int QC = PBT == 8 ? 112 : 96;      // the queue is drained when it cannot take another 64-entry unit
+    WaveQueue<QC> q;
+    unsigned short idx[W2_SEG];                // candidates of the segment (positions in the segment table), ascending
+    float4 tab[(64 / (2 * PBT))][2][PBT];      // one table pass: (slot, axis, bin) -> 4 weights
+};
+
+// gy rows are fetched with buffer loads: the row offset is wave-uniform (an SGPR soffset), the per-lane part (lane * 16 B)
+// is one constant VGPR, so the 2*DEPTH loads in flight cost no address registers.  The queue itself is read from LDS
+// ONCE per 64 entries with lane = entry (9 VGPRs); entry j's row and weights then come from v_readlane - no LDS round
+// trip inside the entry loop.
+__device__ __forceinline__ float readlane_fs(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+template <int QC, int DEPTH>
+__device__ __forceinline__ void drain_wave_queue(const WaveQueue<QC> &q, int n, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned row_bytes,
+                                                 float4 (&acc)[PT][PT], int lane) {
+#pragma nounroll
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int m = min(64, n - e0);
+        const int qi = min(e0 + lane, QC - 1);
+        const int qrow = q.row[qi];
+        const float4 qwy = q.wy[qi], qwx = q.wx[qi];
+        auto ldrow = [&](int j) -> float4 {
+            const unsigned so = (unsigned)__builtin_amdgcn_readlane(qrow, j < m ? j : 0) * row_bytes;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so, 0);
+            float4 f;
+            __builtin_memcpy(&f, &v, 16);
+            return f;
+        };
+        float4 buf[2 * DEPTH];
+#pragma unroll
+        for (int d = 0; d < 2 * DEPTH; ++d) buf[d] = ldrow(d);
+#pragma nounroll
+        for (int j = 0; j < m; j += 2 * DEPTH) {
+#pragma unroll
+            for (int d = 0; d < 2 * DEPTH; ++d) {
+                if (j + d < m) {
+                    const int e = j + d;
+                    // weights are >= 0, so "== 0.0f" is an integer test of the SGPR (scalar ALU, not a VALU compare)
+                    const int wyb[PT] = {__builtin_amdgcn_readlane(__float_as_int(qwy.x), e), __builtin_amdgcn_readlane(__float_as_int(qwy.y), e),
+                                         __builtin_amdgcn_readlane(__float_as_int(qwy.z), e), __builtin_amdgcn_readlane(__float_as_int(qwy.w), e)};
+                    const float wx[PT] = {readlane_fs(qwx.x, e), readlane_fs(qwx.y, e), readlane_fs(qwx.z, e), readlane_fs(qwx.w, e)};
+#pragma unroll
+                    for (int i = 0; i < PT; ++i) {
+                        if (wyb[i] != 0) {               // wave-uniform: scalar compare + branch
+                            const float wyi = __int_as_float(wyb[i]);
+#pragma unroll
+                            for (int k = 0; k < PT; ++k) {
+                                const float c = wyi * wx[k];
+                                MRCNN_FMA4(acc[i][k], c, buf[d])
+                            }
+                        }
+                    }
+                }
+                buf[d] = ldrow(j + d + 2 * DEPTH);          // refill this slot for the next round
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+}
+
+// STAMP: diagnostic build only (mrcnn_debug_roi_align_bwd_stamps): s_memtime at the phase boundaries of every wave goes
+// to `stamps` (12 x u64 per wave: start, scan done [last], build done [accumulated build cycles in slot 2], drain cycles
+// [slot 3], before stores, end, s_memrealtime at start, at end); nothing is computed from them.
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+template <int PBT, int DEPTH, bool STAMP = false>
+__global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels lv, const float *__restrict__ gy,
+                                                                        const float *__restrict__ rois,
+                                                                        const int32_t *__restrict__ levels, int R, int N, int C,
+                                                                        int PH, int PW, int sr, int chunk, int accumulate,
+                                                                        unsigned long long *__restrict__ stamps = nullptr) {
+    unsigned long long st0 = 0, st_scan = 0, st_drain = 0, st_tmp = 0, st_rt0 = 0, st_pre = 0, st_tab = 0, st_cnt = 0;
+    if (STAMP) { st0 = stamp_now(); st_rt0 = __builtin_amdgcn_s_memrealtime(); }
+    using LDS = WaveLds<PBT>;
+    constexpr int QC = LDS::QC;
+    constexpr int SPP = 64 / (2 * PBT);          // RoIs (slots) per table pass: 4 (7x7 pooling) or 2 (14x14)
+    constexpr int CH = (PBT * PBT) / 64;         // 64-bin chunks per RoI: 1 (7x7) or 4 (14x14)
+    __shared__ __attribute__((aligned(16))) LDS lds_all[BWD_WAVES];
+    // Segment table, shared by the 4 waves (the only cooperative part of the kernel: each wave fills a quarter, one
+    // barrier): box = (y1f, y1f + rh + 1, x1f, x1f + rw + 1), empty for RoIs of another level / image / split;
+    // geo = (x1f, y1f, bw, bh).  The geometry (two correctly-rounded divisions per RoI) is computed once per workgroup.
+    // Every sample coordinate c of a RoI lies strictly inside (y1f, y1f + rh) (by >= rh / (2 PH grid), far more than
+    // float rounding), it touches cells floor(c) and floor(c) + 1 (c < 0 clamps to cell 0), so the RoI can only touch
+    // cell rows k with y1f - 1 < k <= y1f + rh + 1: a patch [py0, py0 + 4) is a candidate iff y1f < py0 + 4 and
+    // y1f + rh + 1 >= py0.  Conservative (the exact weights decide), and half the candidates of a +-2 margin.
+    __shared__ float4 sBox[W2_SEG], sGeo[W2_SEG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    LDS &lds = lds_all[wave];
+    // The RoI rows of the first segment do not depend on the tile: their loads go out first and fly while the tile is
+    // decoded from the kernel arguments (a chain of dependent scalar loads, ~2 us when every workgroup starts at once).
+    const auto rs_roi = __builtin_amdgcn_make_buffer_rsrc((void *)rois, 0, (unsigned)R * 20u, 0x00020000);
+    const auto rs_lvl = __builtin_amdgcn_make_buffer_rsrc((void *)levels, 0, levels ? (unsigned)R * 4u : 0u, 0x00020000);
+    constexpr int FILL = W2_SEG / BWD_THREADS;
+    float rv0[FILL][5];
+    int lv0[FILL];
+    auto load_rois = [&](int seg, float (&rv)[FILL][5], int (&lvv)[FILL]) {
+#pragma unroll
+        for (int h2 = 0; h2 < FILL; ++h2) {
+            const int i = seg + tid + h2 * BWD_THREADS;
+            const unsigned o = i < R ? (unsigned)i : 0x0FFFFFFFu;        // * 20 / * 4 stays out of range -> 0
+            lvv[h2] = __builtin_amdgcn_raw_buffer_load_b32(rs_lvl, o * 4u, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) rv[h2][k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_roi, o * 20u + 4u * k, 0, 0));
+        }
+    };
+    load_rois(0, rv0, lv0);
+    const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);       // XCD-banded tile order (speed only)
+    if ((int)(blockIdx.x >> 3) >= chunk || tile_id >= lv.tile_begin[lv.L]) return;      // whole workgroup
+    int l = 0;
+    while (l + 1 < lv.L && tile_id >= lv.tile_begin[l + 1]) ++l;
+    int t = tile_id - lv.tile_begin[l];
+    const int nsplit = lv.split[l];
+    int zsplit = 0, n, tyi, txi;
+    if (nsplit > 1) divmod_u24(t, nsplit, t, zsplit);
+    divmod_u24(t, lv.tiles_x[l] * lv.tiles_y[l], n, t);
+    divmod_u24(t, lv.tiles_x[l], tyi, txi);
+    const int py0 = tyi * TH + (wave >> 1) * PT, px0 = txi * TW + (wave & 1) * PT;
+    const int H = lv.H[l], W = lv.W[l];
+    const int nrow = min(PT, H - py0), ncol = min(PT, W - px0);
+    const bool live = nrow > 0 && ncol > 0;      // a wave whose patch lies outside the map only helps to fill the table
+    const float scale = lv.scale[l];
+    float *gxb = (nsplit > 1 ? lv.slab[l] + (size_t)zsplit * N * H * W * C : lv.gx[l]) + (size_t)n * H * W * C;
+    if (nsplit > 1) accumulate = 0;
+    const float inv_cnt = 1.0f / (float)(sr * sr);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // All global traffic goes through buffer descriptors with 32-bit offsets (the host guarantees every tensor of this
+    // launch is < 4 GiB): wave-uniform parts ride in the SGPR soffset, a false predicate turns into an out-of-range
+    // offset (the load returns 0) - no divergent branch and no 64-bit address arithmetic in the kernel.
+    const auto rs_gy = __builtin_amdgcn_make_buffer_rsrc((void *)gy, 0, (unsigned)((size_t)R * PH * PW * C * 4), 0x00020000);
+    const auto rs_gx = __builtin_amdgcn_make_buffer_rsrc((void *)gxb, 0, (unsigned)((size_t)H * W * C * 4), 0x00020000);
+    const unsigned row_bytes = (unsigned)C * 4u;
+    const unsigned OOB = 0xFFFFFFFFu;
+    const unsigned patch_off = (unsigned)(((size_t)py0 * W + px0) * C * 4);
+    const float fy0 = (float)py0, fy1 = (float)(py0 + PT), fx0 = (float)px0, fx1 = (float)(px0 + PT);
+
+    auto fill_table = [&](int seg, float (&rv)[FILL][5], int (&lvv)[FILL]) {
+#pragma unroll
+        for (int h2 = 0; h2 < FILL; ++h2) {
+            const int e = tid + h2 * BWD_THREADS, i = seg + e;
+            const RoiGeom g = roi_geom(rv[h2], scale, PH, PW, sr);
+            bool mine = i < R && min(max(lvv[h2], 0), lv.L - 1) == l && g.n == n;
+            if (nsplit > 1) mine = mine && (i % nsplit == zsplit);       // wave-uniform condition: no division otherwise
+            sBox[e] = mine ? make_float4(g.y1f, g.y1f + g.rh + 1.0f, g.x1f, g.x1f + g.rw + 1.0f)
+                           : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+            sGeo[e] = make_float4(g.x1f, g.y1f, g.bw, g.bh);
+        }
+    };
+    if (STAMP) { st_tmp = stamp_now(); st_pre = st_tmp - st0; }
+    fill_table(0, rv0, lv0);
+#pragma nounroll
+    for (int cb = 0; cb < C; cb += CCH) {
+        const bool act = cb + lane * 4 < C;
+        const unsigned vlane = act ? (unsigned)(cb + lane * 4) * 4u : OOB;        // byte offset of this lane's 4 channels
+        float4 acc[PT][PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int k = 0; k < PT; ++k) acc[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (accumulate && live) {
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int k = 0; k < PT; ++k)
+                    if (i < nrow && k < ncol) {          // wave-uniform
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_gx, vlane, patch_off + (unsigned)((i * W + k) * C) * 4u, 0);
+                        __builtin_memcpy(&acc[i][k], &v, 16);
+                    }
+        }
+        int qn = 0;
+#pragma nounroll
+        for (int seg = 0; seg < R; seg += W2_SEG) {
+            // ---- segment table: thread tid fills entries tid and tid + 256
+            if (STAMP && !(seg == 0 && cb == 0)) st_tmp = stamp_now();
+            if (seg > 0) __syncthreads();                // every wave is done with the previous segment's table
+            if (!(seg == 0 && cb == 0)) {                // (the first table was filled before the accumulators existed)
+                float rv1[FILL][5];
+                int lv1[FILL];
+                load_rois(seg, rv1, lv1);
+                fill_table(seg, rv1, lv1);
+            }
+            __syncthreads();
+            if (!live) continue;
+            // ---- scan the table: 4 compares per (lane, RoI); candidates compacted in ascending RoI order
+            int nlist = 0;
+            const int seg_n = min(W2_SEG, R - seg);
+#pragma unroll
+            for (int g2 = 0; g2 < W2_SEG / 64; ++g2) {
+                if (g2 * 64 >= seg_n) break;
+                const float4 bx = sBox[g2 * 64 + lane];
+                const bool f = bx.x < fy1 && bx.y >= fy0 && bx.z < fx1 && bx.w >= fx0;
+                const unsigned long long bal = __ballot(f);
+                if (f) lds.idx[nlist + __popcll(bal & lt_mask)] = (unsigned short)(g2 * 64 + lane);
+                nlist += __popcll(bal);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (STAMP) st_scan += stamp_now() - st_tmp;
+            // ---- list units (RoI, 64-bin chunk): table pass at the start of every batch of SPP RoIs, then queue entries;
+            //      the queue is drained whenever it cannot take another unit (accumulators stay in registers)
+            const int units = nlist * CH;
+            unsigned long long nzb = 0;
+#pragma nounroll
+            for (int u = 0; u < units; ++u) {
+                if (qn + 64 > QC) {
+                    __builtin_amdgcn_wave_barrier();
+                    if (STAMP) st_tmp = stamp_now();
+                    drain_wave_queue<QC, DEPTH>(lds.q, qn, rs_gy, vlane, row_bytes, acc, lane);
+                    if (STAMP) st_drain += stamp_now() - st_tmp;
+                    __builtin_amdgcn_wave_barrier();
+                    qn = 0;
+                }
+                const int li = u / CH, ch = u - li * CH;
+                const int sl = li % SPP;
+                if (STAMP) st_cnt += 1;
+                if (ch == 0 && sl == 0) {
+                    unsigned long long st_t0 = 0;
+                    if (STAMP) { st_t0 = stamp_now(); st_cnt += 1 << 16; }
+                    // table pass for the batch of SPP RoIs starting at list item li: lane = (slot, axis, bin)
+                    const int slot = lane / (2 * PBT), axis = (lane / PBT) & 1, bin = lane % PBT;
+                    const bool tv = li + slot < nlist && bin < (axis ? PW : PH);
+                    const float4 ge = sGeo[lds.idx[min(li + slot, nlist - 1)]];
+                    float w[PT] = {0.f, 0.f, 0.f, 0.f};
+                    const int size = axis ? W : H, t0 = axis ? px0 : py0;
+                    const float start = axis ? ge.x : ge.y, bsz = axis ? ge.z : ge.w;
+                    for (int i2 = 0; i2 < sr; ++i2) {
+                        const Samp sp = axis_sample(start, bsz, bin, i2, sr, size);
+                        const int dl = sp.lo - t0, dh = sp.hi - t0;
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) {
+                            w[j] += (tv && sp.lo >= 0 && dl == j) ? sp.wl : 0.0f;
+                            w[j] += (tv && sp.hi >= 0 && dh == j) ? sp.wh : 0.0f;
+                        }
+                    }
+                    const float sc = axis == 0 ? inv_cnt : 1.0f;
+#pragma unroll
+                    for (int j = 0; j < PT; ++j) w[j] *= sc;
+                    lds.tab[slot][axis][bin] = make_float4(w[0], w[1], w[2], w[3]);
+                    nzb = __ballot(w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f);
+                    __builtin_amdgcn_wave_barrier();
+                    if (STAMP) st_tab += stamp_now() - st_t0;
+                }
+                // queue pass of unit (list item li, chunk ch): lane = (ph, pw)
+                const unsigned ym = (unsigned)(nzb >> (sl * 2 * PBT)) & ((1u << PBT) - 1u);
+                const unsigned xm = (unsigned)(nzb >> (sl * 2 * PBT + PBT)) & ((1u << PBT) - 1u);
+                if (ym && xm) {
+                    const int r = seg + __builtin_amdgcn_readfirstlane((int)lds.idx[li]);
+                    const int ph = (PBT == 8) ? (lane >> 3) : (ch * 4 + (lane >> 4));
+                    const int pw = (PBT == 8) ? (lane & 7) : (lane & 15);
+                    const bool in = ((ym >> ph) & 1u) && ((xm >> pw) & 1u);
+                    const unsigned long long bal = __ballot(in);
+                    if (in) {
+                        const int pos = qn + __popcll(bal & lt_mask);
+                        lds.q.wy[pos] = lds.tab[sl][0][ph];
+                        lds.q.wx[pos] = lds.tab[sl][1][pw];
+                        lds.q.row[pos] = (r * PH + ph) * PW + pw;
+                    }
+                    qn += __popcll(bal);
+                }
+            }
+        }
+        if (!live) continue;
+        __builtin_amdgcn_wave_barrier();
+        if (STAMP) st_tmp = stamp_now();
+        drain_wave_queue<QC, DEPTH>(lds.q, qn, rs_gy, vlane, row_bytes, acc, lane);
+        if (STAMP) st_drain += stamp_now() - st_tmp;
+        unsigned long long st_store = 0;
+        if (STAMP) st_store = stamp_now();
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int k = 0; k < PT; ++k)
+                if (i < nrow && k < ncol)                // wave-uniform
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const __attribute__((ext_vector_type(4))) unsigned *>(&acc[i][k]), rs_gx,
+                                                           vlane, patch_off + (unsigned)((i * W + k) * C) * 4u, 0);
+        if (STAMP && stamps && lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long st_end = stamp_now();
+            unsigned long long *o = stamps + ((size_t)blockIdx.x * BWD_WAVES + wave) * 12;
+            o[8] = st_pre; o[9] = st_tab; o[10] = st_cnt; o[11] = (unsigned long long)qn;
+            o[0] = st0; o[1] = st_scan; o[2] = st_store - st0 - st_scan - st_drain; o[3] = st_drain; o[4] = st_store; o[5] = st_end;
+            o[6] = st_rt0; o[7] = __builtin_amdgcn_s_memrealtime();
+        }
+        if (cb + CCH < C) __syncthreads();               // the next channel block refills the segment table
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic (any layout through strides, any pooled size / sampling): reference-layout fallback.
 // ------------------------------------------------------------------------------------------
 struct Strides4 {
@@ -559,6 +1027,23 @@ size_t bwd_ws_bytes(const int *Hs, const int *Ws, int L, int N, int C) {
     return b;
 }
 
+// Forward: rows kernel when the x samples of a row fit one wave (fixed sampling grid, PW * grid <= 64) and every level is
+// within 32-bit buffer offsets; else the one-wave-per-bin kernel.
+void launch_fwd(Levels &lv, const float *rois, const int32_t *levels, int R, int N, int C, int PH, int PW, int sr, float *y,
+                hipStream_t st) {
+    bool rows_ok = sr > 0 && PW * sr <= 64 && (long long)R * PH < (1 << 24);
+    for (int l = 0; l < lv.L; ++l) rows_ok = rows_ok && (unsigned long long)lv.H[l] * lv.W[l] * C * 4ull < (1ull << 32);
+    if (rows_ok) {
+        const int wgs = mrcnn::cdiv((long long)R * PH, 4), chunk = mrcnn::cdiv(wgs, 8);
+        hipLaunchKernelGGL(k_roi_align_fwd_rows, dim3(chunk * 8), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW, sr, y, chunk);
+    } else {
+        const long long waves = (long long)R * PH * PW;
+        hipLaunchKernelGGL(k_roi_align_fwd_nhwc, dim3(mrcnn::cdiv(waves, 4)), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW, sr, y);
+    }
+}
+
+int g_bwd_variant = 2;          // 2 = independent waves (default), 1 = the barrier-synchronised tile kernel (A/B)
+
 int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, const int32_t *levels, int R,
                      int C, int PH, int PW, int sr, int accumulate, void *ws, size_t ws_bytes, hipStream_t st) {
     int total = 0;
@@ -581,7 +1066,15 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
     }
     lv.tile_begin[lv.L] = total;
     const int chunk = mrcnn::cdiv(total, 8);
-    if (PH <= 8 && PW <= 8)
+    bool waves_ok = g_bwd_variant == 2 && (unsigned long long)R * PH * PW * C * 4ull < (1ull << 32) && R < (1 << 27) && total < (1 << 24);
+    for (int l = 0; l < lv.L; ++l) waves_ok = waves_ok && (unsigned long long)lv.H[l] * lv.W[l] * C * 4ull < (1ull << 32);
+    if (waves_ok && PH <= 8 && PW <= 8)
+        hipLaunchKernelGGL((k_roi_align_bwd_waves<8, W2_DEPTH>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
+                           PH, PW, sr, chunk, accumulate);
+    else if (waves_ok)
+        hipLaunchKernelGGL((k_roi_align_bwd_waves<16, W2_DEPTH>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
+                           PH, PW, sr, chunk, accumulate);
+    else if (PH <= 8 && PW <= 8)
         hipLaunchKernelGGL(k_roi_align_bwd_nhwc<8>, dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois,
                            levels, R, N, C, PH, PW, sr, chunk, accumulate);
     else
@@ -609,9 +1102,7 @@ extern "C" int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C,
     if (layout == MRCNN_LAYOUT_NHWC && (C % 4) == 0) {
         Levels lv{};
         lv.L = 1; lv.x[0] = x; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
-        const long long waves = (long long)R * PH * PW;
-        hipLaunchKernelGGL(k_roi_align_fwd_nhwc, dim3(mrcnn::cdiv(waves, 4)), dim3(256), 0, st, lv, rois,
-                           (const int32_t *)nullptr, R, N, C, PH, PW, sampling_ratio, y);
+        launch_fwd(lv, rois, nullptr, R, N, C, PH, PW, sampling_ratio, y, st);
     } else {
         const long long total = (long long)R * C * PH * PW;
         hipLaunchKernelGGL(k_roi_align_fwd_generic, dim3(mrcnn::cdiv(total, 256)), dim3(256), 0, st, x,
@@ -666,9 +1157,7 @@ extern "C" int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs
     Levels lv{};
     if (int e = fill_levels(lv, xs, nullptr, Hs, Ws, scales, L)) return e;
     if (R == 0) return 0;
-    const long long waves = (long long)R * PH * PW;
-    hipLaunchKernelGGL(k_roi_align_fwd_nhwc, dim3(mrcnn::cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, lv,
-                       rois, levels, R, N, C, PH, PW, sampling_ratio, y);
+    launch_fwd(lv, rois, levels, R, N, C, PH, PW, sampling_ratio, y, (hipStream_t)stream);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -689,6 +1178,31 @@ extern "C" int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, c
 extern "C" size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int L, int N, int C) {
     if (!Hs || !Ws || L <= 0 || L > MRCNN_MAX_LEVELS || N <= 0 || C <= 0) return 0;
     return bwd_ws_bytes(Hs, Ws, L, N, C);
+}
+
+// Diagnostic: configs-style single-level backward with phase stamps (see k_roi_align_bwd_waves<.., STAMP>); stamps =
+// (grid workgroups x 4 waves x 8) u64, grid = 8 * ceil(tiles / 8).  Not part of the product path.
+extern "C" int mrcnn_debug_roi_align_bwd_stamps(const float *gy, int N, int C, int H, int W, const float *rois, int R, int PH,
+                                                int PW, float spatial_scale, int sampling_ratio, float *gx,
+                                                unsigned long long *stamps, void *stream) {
+    if (!gy || !rois || !gx || !stamps || PH > 8 || PW > 8 || !fast_bwd_ok(C, PH, PW, sampling_ratio, R))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_roi_align_bwd_stamps: bad arguments (7x7-class pooling only)");
+    Levels lv{};
+    lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
+    lv.tiles_x[0] = mrcnn::cdiv(W, TW); lv.tiles_y[0] = mrcnn::cdiv(H, TH); lv.split[0] = 1; lv.tile_begin[0] = 0;
+    const int total = lv.tiles_x[0] * lv.tiles_y[0] * N;
+    lv.tile_begin[1] = total;
+    const int chunk = mrcnn::cdiv(total, 8);
+    hipLaunchKernelGGL((k_roi_align_bwd_waves<8, W2_DEPTH, true>), dim3(chunk * 8), dim3(BWD_THREADS), 0, (hipStream_t)stream, lv, gy, rois,
+                       (const int32_t *)nullptr, R, N, C, PH, PW, sampling_ratio, chunk, 0, stamps);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_roi_align_set_bwd_variant(int variant) {
+    if (variant != 1 && variant != 2) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_set_bwd_variant: 1 or 2");
+    g_bwd_variant = variant;
+    return 0;
 }
 
 extern "C" int mrcnn_roi_align_sample_tables(const float *rois, int R, int H, int W, int PH, int PW,

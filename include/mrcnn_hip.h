@@ -97,6 +97,16 @@ int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, const int *H
                                 int sampling_ratio, int accumulate, void *ws, size_t ws_bytes, void *stream);
 size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int L, int N, int C);
 
+/* Process-wide choice of the fast backward kernel: 2 (default) = one independent wave per 4x4 cell patch, no workgroup
+ * barriers; 1 = the barrier-synchronised 8x8 tile kernel of round 1 (kept for A/B measurements).  Same results contract. */
+int mrcnn_roi_align_set_bwd_variant(int variant);
+
+/* Diagnostic build of the backward kernel with s_memtime stamps at the phase boundaries of every wave (tools/roi_stamps.py;
+ * measurement only).  stamps: 12 x u64 per wave, (8 * ceil(tiles / 8)) workgroups x 4 waves. */
+int mrcnn_debug_roi_align_bwd_stamps(const float *gy, int N, int C, int H, int W, const float *rois, int R, int PH, int PW,
+                                     float spatial_scale, int sampling_ratio, float *gx, unsigned long long *stamps,
+                                     void *stream);
+
 /* Verification hook for the "ROIAlign indices bit-exact" contract: dumps, for every RoI and
  * both axes, the integer corner cells and float weights of every sample exactly as the
  * kernels compute them (same __device__ function).  Shapes as oracle.roi_align.
@@ -128,12 +138,19 @@ int mrcnn_roi_align_sample_tables(const float *rois, int R, int H, int W, int PH
 size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 /* Multiply-accumulates the MFMA pipes execute for ONE pass (forward, backward-data or backward-filter) of this layer:
  * N*Ho*Wo*KH*KW*Cin*Cout for the direct kernels, (m+2)^2 * tiles * Cin * Cout (2.25x / 4x fewer) where the 3x3 /
- * stride 1 / pad 1 layer takes the Winograd F(m x m,3x3) path (>= 256 channels, >= 2048 pixels).  For roofline accounting. */
-long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+ * stride 1 / pad 1 layer takes the Winograd F(m x m,3x3) path (>= 256 channels, >= 2048 pixels) in that pass (pass: 0 forward,
+ * 1 backward-data, 2 backward-filter).  For roofline accounting. */
+long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int pass);
 /* Process-wide selection of the Winograd path: thresholds (defaults 256 channels, 2048 pixels: measured break-even on
  * gfx950) and output tile (0 = per layer, whichever of F(2x2,3x3) / F(4x4,3x3) needs fewer multiplications; 2 or 4 =
  * forced).  Lowering the thresholds is how the tests run whole small networks through the Winograd kernels. */
 int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels, int tile);
+/* Per-pass override of the Winograd tile (forward, backward-data, backward-filter): 0 = follow the global tile above,
+ * 2 / 4 = forced, -1 = that pass never takes the Winograd path.  Default (2, 0, 0): F(4x4,3x3) amplifies float32 rounding
+ * far more than F(2x2,3x3); in the forward pass that shows up as parameter-gradient errors of up to 2e-2 (100x the float32
+ * noise floor) through the curvature of the losses, in the backward passes it does not (profiles/r02_winograd_pass_probe.txt).
+ * (0, 0, 0) = F(4x4) wherever it is cheaper in every pass: activations still within 2.2e-4, +8 % images/s. */
+int mrcnn_conv2d_set_winograd_pass_tiles(int fwd, int bwd_data, int bwd_filter);
 /* Measurement knob for bench.py's roofline split (never set on a product path): bit 0 skips the MFMA GEMM launches of
  * the convolution calls, bit 1 skips every other kernel they launch (Winograd transforms, slab / tail / column sums).
  * Outputs are garbage while a bit is set; 0 restores normal operation. */

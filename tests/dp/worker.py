@@ -52,10 +52,11 @@ def run_dp(rank, world, port, out):
         model = MaskRCNN(n_fg_class=80, device=DEV, seed=7 + 13 * rank, _test_shrink=SHRINK)
         chain = make_chain(model, rank)
         opt = make_opt(chain)
+        res = {'p_init': model.ps.params.cpu().clone()}       # this rank's own initialisation
         opt.enable_data_parallel(bucket_bytes=1 << 20)        # several buckets on the small test network
         assert len(opt.sync.buckets) > 3
         batch = image(rank)
-        res = {'p0': model.ps.params.cpu().clone()}
+        res['p0'] = model.ps.params.cpu().clone()             # after the rank-0 broadcast
         for s in range(STEPS):
             opt.update(chain, *batch, 1.0)
             if s == 0:

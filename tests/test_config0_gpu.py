@@ -112,8 +112,9 @@ def test_predict_800x800_matches_oracle():
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     m = _model()
     m.use_preset('evaluate')
-    keep = m.score_thresh
+    keep = (m.score_thresh, m.min_size, m.max_size)
     m.score_thresh = 0.0135            # random weights: class probabilities sit around 1/81 = 0.0123
+    m.min_size, m.max_size = 800, 1333  # the network input of configs[0] is 800x800: prepare scales 600 -> 800
     try:
         rs = np.random.RandomState(2)
         img = np.floor(rs.rand(3, 600, 600) * 256).astype(np.float32)
@@ -158,5 +159,5 @@ def test_predict_800x800_matches_oracle():
             diff = (want != mk[:k]).sum() / max(int(want.sum()), 1)
             assert diff <= 2e-3, diff           # pixels whose sigmoid sits within float32 rounding of the 127/255 threshold
     finally:
-        m.score_thresh = keep
+        m.score_thresh, m.min_size, m.max_size = keep
         m.use_preset('visualize')

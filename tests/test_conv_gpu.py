@@ -132,18 +132,24 @@ def test_conv_backward_data_fused_relu_mask(case):
 # 3x3 / stride 1 / pad 1 layers with >= 2048 pixels and >= 256 channels take the Winograd F(2x2,3x3) path (filter,
 # input and output transforms + one batched 1x1 GEMM launch).  Tolerance 3e-5 of the tensor scale: the transforms add a
 # few ulp to the direct kernel's error; odd sizes exercise the clipped edge tiles and the padded GEMM rows.
-@pytest.mark.parametrize('tile,tol', [(2, 3e-5), (4, 3e-4)])
+# Per-pass tiles (mrcnn_conv2d_set_winograd_pass_tiles): (0,0,0) = every pass follows the global tile (both tiles are covered
+# in all three passes); 'mixed' = the shipped default, forward F(2x2) + backward F(4x4): the forward's transformed input
+# cannot be reused by the filter-gradient pass then (different tile) and the library must notice.
+@pytest.mark.parametrize('tile,tol,pass_tiles', [(2, 3e-5, (0, 0, 0)), (4, 3e-4, (0, 0, 0)), (4, 3e-4, (2, 0, 0)), (2, 3e-4, (4, -1, 4))],
+                         ids=['f2', 'f4', 'shipped', 'fwd4_bwd_direct_wgrad4'])
 @pytest.mark.parametrize('case', [(2, 48, 48, 256, 256), (1, 67, 63, 256, 288), (3, 40, 36, 320, 256), (16, 14, 14, 256, 256)])
-def test_conv_winograd_forward_and_backward_data(case, tile, tol):
+def test_conv_winograd_forward_and_backward_data(case, tile, tol, pass_tiles):
     from chainer_maskrcnn import _hip
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048, tile))
+    _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(*pass_tiles))
     try:
-        _winograd_case(case, tol)
+        _winograd_case(case, tol, shared_gy=(pass_tiles == (0, 0, 0)))
     finally:
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048, 0))
+        _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))
 
 
-def _winograd_case(case, tol):
+def _winograd_case(case, tol, shared_gy=True):
     N, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(31 + sum(case))
     x = torch.randn((N, H, W, Cin), generator=g)
@@ -184,13 +190,15 @@ def _winograd_case(case, tol):
     assert v is not None
     gw3, _ = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True, wino_v=v)
     assert torch.equal(gw, gw3)
-    # one read of gy: the data-gradient call also emits the filter-gradient operand and the bias gradient
-    gb4 = torch.zeros((Cout,), device=DEV)
-    gx4, wt = hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (N, H, W, Cin), 1, 1, emit_w=True, gb=gb4)
-    assert torch.equal(gx4, gx)
-    gw4, _ = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, False, wino_v=v, wino_w=wt)
-    assert torch.equal(gw, gw4)
-    assert (gb4.cpu().double() - gbref).abs().max().item() / gbref.abs().max().item() < 2e-5
+    if shared_gy:   # one read of gy: the data-gradient call also emits the filter-gradient operand and the bias gradient
+        gb4 = torch.zeros((Cout,), device=DEV)
+        gx4, wt = hnn.conv2d_bwd_data_raw(gy.to(DEV), w.to(DEV), (N, H, W, Cin), 1, 1, emit_w=True, gb=gb4)
+        assert torch.equal(gx4, gx)
+        gw4, _ = hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, False, wino_v=v, wino_w=wt)
+        assert torch.equal(gw, gw4)
+        assert (gb4.cpu().double() - gbref).abs().max().item() / gbref.abs().max().item() < 2e-5
+    else:           # the backward passes run other tiles than the forward: no shared transform is offered
+        assert hnn.winograd_w_bytes((N, H, W, Cin), tuple(w.shape), 1, 1) == 0
     errw = (gw.cpu().double() - wref).abs().max().item() / wref.abs().max().item()
     print('winograd errors: fwd %.2e filter-grad %.2e' % (err, errw))
     assert errw < tol, errw

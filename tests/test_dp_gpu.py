@@ -30,8 +30,9 @@ def test_two_rank_data_parallel_equals_sum_of_single_image_steps():
     log = open(os.path.join(out, 'log.txt')).read()
     assert open(os.path.join(out, 'done')).read() == '0', log[-4000:]
     r0, r1, emu = (torch.load(os.path.join(out, f)) for f in ('dp_rank0.pt', 'dp_rank1.pt', 'emu.pt'))
-    assert not torch.equal(r0['p0'], r1['p0'])                  # the ranks really started from different replicas ...
-    assert torch.equal(r0['p0'], emu['p0'])                     # ... and rank 0's is the emulation's
+    assert not torch.equal(r0['p_init'], r1['p_init'])          # the ranks really started from different replicas ...
+    assert torch.equal(r0['p0'], r1['p0']) and torch.equal(r0['p0'], r0['p_init'])      # ... the broadcast made them rank 0's
+    assert torch.equal(r0['p0'], emu['p0'])                     # ... which is the emulation's
     assert abs(r0['loss0'] - emu['losses'][0]) == 0 and abs(r1['loss0'] - emu['losses'][1]) == 0
     assert torch.equal(r0['grads'], r1['grads'])
     assert torch.equal(r0['grads'], emu['grads'])               # SUM of the two ranks' gradients, no scaling

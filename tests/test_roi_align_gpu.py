@@ -63,10 +63,19 @@ def test_forward_matches_oracle(layout, C, P, sr):
     np.testing.assert_array_equal(got.cpu().numpy(), want)      # bit-exact
 
 
+@pytest.fixture(params=[2, 1], ids=['waves', 'tiles'])
+def bwd_variant(request):
+    """Both fast backward kernels: 2 = independent waves on 4x4 patches (default), 1 = barrier-synchronised 8x8 tiles (the
+    fallback for tensors beyond the 32-bit buffer offsets of variant 2)."""
+    _hip.check(_hip.lib().mrcnn_roi_align_set_bwd_variant(request.param))
+    yield request.param
+    _hip.check(_hip.lib().mrcnn_roi_align_set_bwd_variant(2))
+
+
 @pytest.mark.parametrize('layout', ['nhwc', 'nchw'])
 @pytest.mark.parametrize('C,P,sr', [(8, 7, 2), (256, 7, 2), (12, 14, 2), (8, 3, 1), (8, 5, 0), (6, 7, 2),
                                     (260, 7, 2)])
-def test_backward_matches_oracle(layout, C, P, sr):
+def test_backward_matches_oracle(layout, C, P, sr, bwd_variant):
     rs = np.random.RandomState(100 + C + P)
     N, H, W, scale = 2, 21, 30, 0.125
     x = rs.standard_normal((N, C, H, W)).astype(np.float32)
@@ -83,8 +92,9 @@ def test_backward_matches_oracle(layout, C, P, sr):
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * np.abs(gy).max() * 4)
 
 
-def test_backward_many_rois_on_one_tile_and_segments():
-    """> SLOTS (32) RoIs on one tile => multi-round read-modify-write; R > LISTCAP (1024) => segments."""
+def test_backward_many_rois_on_one_tile_and_segments(bwd_variant):
+    """Hundreds of RoIs on one tile => queue overflow drains / multi-round read-modify-write; R = 1500 => three 512-RoI segment
+    tables (variant 2) / two 1024-RoI segments (variant 1)."""
     rs = np.random.RandomState(7)
     N, C, H, W, scale, P = 1, 8, 16, 16, 0.25, 7
     R = 1500
@@ -156,7 +166,7 @@ def test_config2_full_size_properties_and_sampled_parity():
 
 
 @pytest.mark.parametrize('P', [7, 14])
-def test_fpn_backward_coarse_levels_split_matches_oracle(P):
+def test_fpn_backward_coarse_levels_split_matches_oracle(P, bwd_variant):
     """Multi-level backward with most RoIs on the coarse levels (what map_rois_to_fpn_levels produces): the
     RoI-split path (several workgroups per tile + ordered slab sum) against the per-level oracle, with and
     without accumulation, bit-reproducible run to run, and equal (to rounding) to the unsplit path."""

@@ -1,0 +1,21 @@
+"""One configs[1] ROIAlign forward + backward pair for rocprofv3 --pmc passes (few launches, no timing)."""
+import os, sys
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R_, 'chainer-maskrcnn_amd')); sys.path.insert(0, R_)
+import torch
+from chainer_maskrcnn import _hip
+from tests.util import config2_inputs
+dev = torch.device('cuda:0')
+lib = _hip.lib()
+x, yx, gy = config2_inputs()
+N, C, H, W = x.shape
+R, _, PH, PW = gy.shape
+xt = torch.from_numpy(x).to(dev).contiguous(memory_format=torch.channels_last)
+rois_xy = torch.from_numpy(yx[:, [0, 2, 1, 4, 3]].copy()).to(dev)
+gyt = torch.from_numpy(gy).to(dev).contiguous(memory_format=torch.channels_last)
+y = torch.empty((R, C, PH, PW), device=dev).contiguous(memory_format=torch.channels_last)
+gx = torch.empty_like(xt)
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+    _hip.check(lib.mrcnn_roi_align_fwd_f32(_hip.ptr(xt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW, 0.25, 2, _hip.ptr(y), _hip.stream_ptr()))
+    _hip.check(lib.mrcnn_roi_align_bwd_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW, 0.25, 2, _hip.ptr(gx), _hip.stream_ptr()))
+torch.cuda.synchronize()
