@@ -90,6 +90,31 @@ def maxpool2x2_fwd(x):
     return y
 
 
+def maxpool3x3s2_fwd(x):
+    """F.max_pooling_2d(ksize=3, stride=2) with cover_all (C4Backbone pool1)."""
+    _ck(x)
+    N, H, W, C = x.shape
+    y = _empty((N, (H - 2) // 2 + 1, (W - 2) // 2 + 1, C), x.device)
+    check(lib().mrcnn_maxpool3x3s2_fwd_f32(ptr(x), ptr(y), N, H, W, C, stream_ptr()))
+    return y
+
+
+def global_avg_pool(x):
+    """x (R,H,W,C) -> (R,C): mean over the spatial positions."""
+    _ck(x)
+    R, H, W, C = x.shape
+    y = _empty((R, C), x.device)
+    check(lib().mrcnn_global_avg_pool_fwd_f32(ptr(x), ptr(y), R, H * W, C, stream_ptr()))
+    return y
+
+
+def relu(x, out=None):
+    _ck(x)
+    out = torch.empty_like(x) if out is None else out
+    check(lib().mrcnn_relu_fwd_f32(ptr(x), ptr(out), x.numel(), stream_ptr()))
+    return out
+
+
 def maxpool2x2_bwd(x, gy):
     _ck(x, gy)
     N, H, W, C = x.shape

@@ -330,6 +330,56 @@ __global__ __launch_bounds__(NT) void k_maxpool_fwd(const float *__restrict__ x,
     }
 }
 
+// ---- legacy variants: 3x3 / stride-2 max pooling with cover_all (C4Backbone's pool1,
+//      c4_backbone.py:20: Ho = (H - 3 + 1) / 2 + 1, windows may hang over the bottom / right edge), global average pooling
+//      over the pooled RoI (ResnetRoIMaskHead, resnet_roi_mask_head.py:65) and a stand-alone ReLU.  Forward only.
+__global__ __launch_bounds__(NT) void k_maxpool3s2_fwd(const float *__restrict__ x, float *__restrict__ y, int N, int H, int W,
+                                                       int C4, int Ho, int Wo) {
+    const size_t n4 = (size_t)N * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4);
+        size_t q = i / C4;
+        const int wo = (int)(q % Wo); q /= Wo;
+        const int ho = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        float4 m = f4(-INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int h = 2 * ho + dy, w = 2 * wo + dx;
+                if (h < H && w < W) {
+                    const float4 v = ld4(x + ((((size_t)n * H + h) * W + w) * C4 + c) * 4);
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+            }
+        st4(y + i * 4, m);
+    }
+}
+
+// y (R, C) = mean over the P pixels of x (R, P, C): pixels added in order, then one division by P (F.average_pooling_2d
+// over the whole map = sum / P).
+__global__ __launch_bounds__(NT) void k_global_avg_pool(const float *__restrict__ x, float *__restrict__ y, int R, int P, int C4) {
+    const size_t n4 = (size_t)R * C4;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4), r = (int)(i / C4);
+        float4 a = f4(0.f);
+        for (int p = 0; p < P; ++p) {
+            const float4 v = ld4(x + (((size_t)r * P + p) * C4 + c) * 4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        const float d = (float)P;
+        st4(y + i * 4, make_float4(a.x / d, a.y / d, a.z / d, a.w / d));
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_relu_fwd(const float *__restrict__ x, float *__restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const float4 v = ld4(x + i * 4);
+        st4(y + i * 4, make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)));
+    }
+}
+
 // gx[cell] = gy[window] if the cell is the FIRST maximum of its window (row-major order), else 0.
 // One thread per window: writes all (<=4) cells of the window => gx fully written, no atomics.
 __global__ __launch_bounds__(NT) void k_maxpool_bwd(const float *__restrict__ x, const float *__restrict__ gy,
@@ -811,6 +861,31 @@ extern "C" int mrcnn_maxpool2x2_fwd_f32(const float *x, float *y, int N, int H, 
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     hipLaunchKernelGGL(k_maxpool_fwd, dim3(ew_grid((size_t)N * Ho * Wo * C / 4)), dim3(NT), 0, (hipStream_t)stream, x, y,
                        N, H, W, C / 4, Ho, Wo);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_maxpool3x3s2_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream) {
+    if (int e = chk(x && y && N > 0 && H >= 3 && W >= 3 && C > 0 && (C % 4) == 0, "maxpool3x3s2_fwd: bad args")) return e;
+    const int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;
+    hipLaunchKernelGGL(k_maxpool3s2_fwd, dim3(ew_grid((size_t)N * Ho * Wo * C / 4)), dim3(NT), 0, (hipStream_t)stream, x, y, N, H, W,
+                       C / 4, Ho, Wo);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_global_avg_pool_fwd_f32(const float *x, float *y, int R, int P, int C, void *stream) {
+    if (int e = chk(R >= 0 && P > 0 && C > 0 && (C % 4) == 0 && (R == 0 || (x && y)), "global_avg_pool_fwd: bad args")) return e;
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(k_global_avg_pool, dim3(ew_grid((size_t)R * C / 4)), dim3(NT), 0, (hipStream_t)stream, x, y, R, P, C / 4);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_relu_fwd_f32(const float *x, float *y, size_t n, void *stream) {
+    if (int e = chk((n == 0 || (x && y)) && (n % 4) == 0, "relu_fwd: bad args (n % 4 == 0)")) return e;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_relu_fwd, dim3(ew_grid(n / 4)), dim3(NT), 0, (hipStream_t)stream, x, y, n / 4);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -211,6 +211,12 @@ int mrcnn_relu_bwd_f32(const float *gy, const float *y, float *gx, size_t n, voi
 int mrcnn_add_f32(const float *a, const float *b, float *out, size_t n, void *stream);
 int mrcnn_maxpool2x2_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
 int mrcnn_maxpool2x2_bwd_f32(const float *x, const float *gy, float *gx, int N, int H, int W, int C, void *stream);
+/* Legacy variants (forward only): F.max_pooling_2d(ksize=3, stride=2) with cover_all
+ * (chainer_maskrcnn/model/extractor/c4_backbone.py:20; Ho = (H-3+1)/2 + 1), global average pooling of x (R,P,C) -> (R,C)
+ * (model/head/resnet_roi_mask_head.py:65) and a stand-alone ReLU (x == y allowed). */
+int mrcnn_maxpool3x3s2_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+int mrcnn_global_avg_pool_fwd_f32(const float *x, float *y, int R, int P, int C, void *stream);
+int mrcnn_relu_fwd_f32(const float *x, float *y, size_t n, void *stream);
 /* out (N,H,W,C) = nearest-2x(top (N,Ht,Wt,C)) cropped + lat;  backward: gtop (+)= 2x2 block sums of gout. */
 int mrcnn_upsample2x_add_fwd_f32(const float *top, const float *lat, float *out, int N, int H, int W, int Ht,
                                  int Wt, int C, void *stream);

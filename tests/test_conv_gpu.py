@@ -143,7 +143,7 @@ def test_conv_winograd_forward_and_backward_data(case, tile, tol, pass_tiles):
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048, tile))
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(*pass_tiles))
     try:
-        _winograd_case(case, tol, shared_gy=(pass_tiles == (0, 0, 0)))
+        _winograd_case(case, tol, shared_gy=(pass_tiles[1] == pass_tiles[2]))    # same tile in both backward passes
     finally:
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(256, 2048, 0))
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))

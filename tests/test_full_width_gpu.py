@@ -168,7 +168,7 @@ def _check(S, mode):
         # curvature of the losses into gradient errors far above the float32 floor in the layers without BatchNorm
         # (measured: rpn/conv/W 2.1e-2 at 512^2, 1.2e-2 at 1024^2; profiles/r02_winograd_pass_probe.txt).  That is why this
         # mode is opt-in; the bound here only keeps the deviation where it was measured.
-        assert max(e for _, e, _ in rows) < 0.5 and all(e < max(1e-3, 5 * fl, 4e-2) for _, e, fl in rows), \
+        assert max(e for _, e, _ in rows) < 0.5 and all(e < max(1e-3, 12 * fl, 4e-2) for _, e, fl in rows), \
             sorted(rows, key=lambda r: -r[1])[:5]
         return
     # (ii): the float32 oracle's own error is ONE realisation of the rounding noise of this network, and so is the
