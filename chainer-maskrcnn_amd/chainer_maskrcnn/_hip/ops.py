@@ -322,6 +322,14 @@ def rpn_proposals(locs, scores, anchors, img_size, min_size, n_pre, n_post, nms_
     return dict(rois=rois, roi_indices=idx, levels=lev, n_rois=cnt, sorted_anchor=dbg[0], keep=dbg[1], n_pre=dbg[2])
 
 
+def softmax2(scores):
+    """(..., 2) class scores -> softmax probabilities (the fg score of ChainerCV's single-level RPN)."""
+    _ck(scores)
+    out = torch.empty_like(scores)
+    check(lib().mrcnn_softmax2_f32(ptr(scores), ptr(out), scores.numel() // 2, stream_ptr()))
+    return out
+
+
 def nms(boxes, thresh, max_keep=None):
     """Greedy NMS in the given order; returns (keep (max_keep,) int32 padded, n_keep (1,) int32)."""
     _ck(boxes)

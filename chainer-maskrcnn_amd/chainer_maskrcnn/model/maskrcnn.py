@@ -3,9 +3,10 @@
 Mirror of chainer_maskrcnn/model/maskrcnn.py:23-155,261-276 (constructor :26-133, __call__ :135-155,
 prepare :261-276) and of the ChainerCV ``FasterRCNN`` base-class attributes the train chain and
 train.py rely on (loc_normalize_mean/std, use_preset, n_class).  Only the
-combination the reference can actually train is built: backbone 'fpn' with head_arch 'fpn' or
-'fpn_keypoint' (README.md:39); the other strings raise ValueError like the reference does for unknown
-names.  ``predict`` / ``_suppress`` are SURVEY.md section 8f "next" rows.
+combination the reference can actually train is backbone 'fpn' with head_arch 'fpn' or 'fpn_keypoint'
+(README.md:39) - that is the hot path.  The legacy variants (backbone 'c4' / 'darknet', head_arch 'res5' / 'light';
+SURVEY.md section 8 f-4) construct like in the reference and run forward through ``forward_legacy``.
+``predict`` / ``_suppress`` are SURVEY.md section 8f "next" rows.
 """
 import numpy as np
 import torch
@@ -34,13 +35,36 @@ class MaskRCNN(object):
                 anchor_scales=self.extractor.anchor_scales, feat_strides=self.extractor.feat_strides,
                 in_channels=self.extractor.out_channels, mid_channels=self.extractor.out_channels,
                 proposal_creator_params=proposal_creator_params, ps=self.ps)
-        elif backbone in ('c4', 'darknet'):
-            raise ValueError('backbone %r is outside the MI355X hot path (SURVEY.md section 2.1); only \'fpn\' is built'
-                             % backbone)
+        elif backbone == 'c4':          # legacy (maskrcnn.py:60-69): ResNet-50 C4 + ChainerCV's single-level RPN
+            from .extractor.c4_backbone import C4Backbone
+            from .rpn.region_proposal_network import RegionProposalNetwork
+            self.extractor = C4Backbone(pretrained_model, ps=self.ps, **shrink)
+            wd = shrink.get('width_div', 1)
+            self.rpn = RegionProposalNetwork(1024 // wd, 516 // wd, ratios=ratios, anchor_scales=anchor_scales,
+                                             feat_stride=self.feat_stride, initialW=rpn_initialW,
+                                             proposal_creator_params=proposal_creator_params, ps=self.ps)
+        elif backbone == 'darknet':     # legacy (maskrcnn.py:70-75)
+            from .extractor.darknet import Darknet
+            self.extractor = Darknet(ps=self.ps)
+            self.rpn = MultilevelRegionProposalNetwork(
+                anchor_scales=self.extractor.anchor_scales, feat_strides=self.extractor.feat_strides, in_channels=256,
+                proposal_creator_params={'n_test_pre_nms': 50, 'n_test_post_nms': 10}, ps=self.ps)
         else:
             raise ValueError('unknown backbone: {}'.format(backbone))
         c = self.extractor.out_channels
-        if head_arch == 'fpn':
+        self.head_arch = head_arch
+        if head_arch == 'res5':         # legacy (maskrcnn.py:81-89)
+            from .head.resnet_roi_mask_head import ResnetRoIMaskHead
+            self.head = ResnetRoIMaskHead(n_fg_class + 1, roi_size=7, spatial_scale=1. / self.feat_stride,
+                                          loc_initialW=loc_initialW, score_initialW=score_initialW, mask_initialW=0.01,
+                                          ps=self.ps, width_div=shrink.get('width_div', 1))
+            self.predict_mask = True
+        elif head_arch == 'light':      # legacy (maskrcnn.py:91-98)
+            from .head.light_roi_mask_head import LightRoIMaskHead
+            self.head = LightRoIMaskHead(n_fg_class + 1, roi_size=7, loc_initialW=loc_initialW, score_initialW=score_initialW,
+                                         mask_initialW=0.01, ps=self.ps, in_channels=c)
+            self.predict_mask = True
+        elif head_arch == 'fpn':
             self.head = FPNRoIMaskHead(n_fg_class + 1, roi_size_box=7, roi_size_mask=14, loc_initialW=loc_initialW,
                                        score_initialW=score_initialW, mask_initialW=0.01, ps=self.ps, in_channels=c,
                                        fc_channels=1024 // shrink.get('width_div', 1))
@@ -54,8 +78,6 @@ class MaskRCNN(object):
                                            loc_initialW=loc_initialW, score_initialW=score_initialW, mask_initialW=0.01,
                                            ps=self.ps, in_channels=c, fc_channels=1024 // shrink.get('width_div', 1))
             self.predict_mask = False
-        elif head_arch in ('res5', 'light'):
-            raise ValueError('head_arch %r is outside the MI355X hot path (SURVEY.md section 2.1)' % head_arch)
         else:
             raise ValueError('unknown head archtecture specified. {}'.format(head_arch))
         # FasterRCNN base-class state
@@ -84,8 +106,26 @@ class MaskRCNN(object):
         """(N,3,H,W) float32 images on the device -> the extractor's (N,H,W,4) operand."""
         return ops.image_nchw3_to_nhwc4(x.contiguous())
 
+    def forward_legacy(self, x, scale=1.):
+        """The legacy wiring (backbone 'c4' / 'darknet' with head 'res5' / 'light'): extractor -> RPN -> head with the
+        signature those heads have, ``head(h, rois, roi_indices, spatial_scale)``.  The reference's own ``__call__`` cannot
+        drive them (it passes the FPN head's arguments, maskrcnn.py:148-154, and unpacks six RPN outputs where ChainerCV's
+        RPN returns five) - upstream they were driven by the legacy MaskRCNNTrainChain, which is broken."""
+        img_size = tuple(x.shape[2:])
+        h = self.extractor(self.to_nhwc4(x))
+        self.rpn.train = self.train
+        out = self.rpn(h, img_size, scale)
+        rpn_locs, rpn_scores, rois, roi_indices = out[:4]
+        self.head.train = self.train
+        scale_ = self.extractor.spatial_scales[0] if hasattr(self.extractor, 'spatial_scales') else 1. / self.feat_stride
+        res = self.head(h, rois, roi_indices, scale_)
+        return tuple(res) + (rois, roi_indices)
+
     def __call__(self, x, scale=1.):
         """Reference forward (:135-155).  x (N,3,H,W) on the device."""
+        if self.head_arch in ('res5', 'light'):
+            raise TypeError('MaskRCNN.__call__ passes the FPN head signature (maskrcnn.py:148-154), which the %r head does not '
+                            'have - the reference fails here too; use forward_legacy()' % self.head_arch)
         img_size = tuple(x.shape[2:])
         h = self.extractor(self.to_nhwc4(x))
         self.rpn.train = self.train

@@ -46,6 +46,7 @@ struct ConvP {
     int N, H, W, Cin;     // input tensor (x / gx)
     int Ho, Wo, Cout;     // output tensor (y / gy)
     int KH, KW, stride, pad;
+    int pad_w;            // FWD only: horizontal padding (== pad except for the rectangular kernels of mrcnn_conv2d_fwd_rect_f32)
     int relu;
     int accumulate;       // BWD_DATA: gx += result
     int smallc;           // Cin == 4: the K axis is (tap, 4 channels) flattened, one 16-B chunk per tap
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             divmod_small(v ? m : 0, PW_, invW, q, w_);
             divmod_small(q, PH_, invH, n_, h_);
             a_h0[i] = (MODE == MODE_FWD) ? h_ * p.stride - p.pad : h_ + p.pad;
-            a_w0[i] = (MODE == MODE_FWD) ? w_ * p.stride - p.pad : w_ + p.pad;
+            a_w0[i] = (MODE == MODE_FWD) ? w_ * p.stride - p.pad_w : w_ + p.pad;
             a_off[i] = ((n_ * srcH + a_h0[i]) * srcW + a_w0[i]) * srcC;
         }
     }
@@ -745,7 +746,7 @@ int check_conv(const void *a, const void *b, const void *c, int N, int H, int W,
 
 ConvP make_p(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     ConvP p{};
-    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pad_w = pad;
     p.Ho = conv_out(H, KH, stride, pad);
     p.Wo = conv_out(W, KW, stride, pad);
     p.ksplit = 1;
@@ -1456,6 +1457,25 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
     p.M = N * p.Ho * p.Wo; p.Ng = Cout;
     const int nsteps = p.smallc ? (KH * KW + 7) / 8 : KH * KW * (Cin / BK);
     return run_data_conv<MODE_FWD>(p, nsteps, Cout, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Forward convolution with a rectangular kernel and per-axis padding (the 15x1 / 1x15 separable pairs of LightRoIMaskHead,
+// model/head/light_roi_mask_head.py:29-44).  Same kernel as mrcnn_conv2d_fwd_f32 (never the Winograd path).
+extern "C" int mrcnn_conv2d_fwd_rect_f32(const float *x, const float *w, const float *bias, float *y, int N, int H, int W,
+                                         int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int relu, void *ws,
+                                         size_t ws_bytes, void *stream) {
+    if (pad_h < 0 || pad_w < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "conv2d_fwd_rect: negative padding");
+    // sizes and limits are validated for the larger of the two paddings (a superset of the real output)
+    if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, std::max(pad_h, pad_w))) return e;
+    if (conv_out(H, KH, stride, pad_h) <= 0 || conv_out(W, KW, stride, pad_w) <= 0 || Cin == 4)
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "conv2d_fwd_rect: empty output (or the 4-channel image layer)");
+    ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad_h);
+    p.pad_w = pad_w;
+    p.Wo = conv_out(W, KW, stride, pad_w);
+    p.a = x; p.b = w; p.c = y; p.bias = bias; p.relu = relu;
+    p.bytes_a = (unsigned)((size_t)N * H * W * Cin * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
+    p.M = N * p.Ho * p.Wo; p.Ng = Cout;
+    return run_data_conv<MODE_FWD>(p, KH * KW * (Cin / BK), Cout, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" size_t mrcnn_conv2d_winograd_w_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {

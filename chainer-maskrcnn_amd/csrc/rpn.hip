@@ -419,6 +419,29 @@ extern "C" int mrcnn_nms_f32(const float *boxes, int n, float thresh, int max_ke
     return 0;
 }
 
+// ChainerCV's single-level RegionProposalNetwork ranks proposals by the SOFTMAX foreground probability of the two
+// class scores (the multi-level RPN of this repo's reference uses the raw foreground logit): out (M,2) = softmax(in (M,2)).
+namespace {
+__global__ __launch_bounds__(256) void k_softmax2(const float *__restrict__ in, float *__restrict__ out, size_t M) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const float a = in[2 * i], b = in[2 * i + 1];
+    const float m = fmaxf(a, b);
+    const float ea = expf(a - m), eb = expf(b - m);
+    const float s = ea + eb;
+    out[2 * i] = ea / s;
+    out[2 * i + 1] = eb / s;
+}
+}  // namespace
+
+extern "C" int mrcnn_softmax2_f32(const float *in, float *out, size_t M, void *stream) {
+    if (M > 0 && (!in || !out)) return mrcnn::fail_arg(MRCNN_E_INVALID, "softmax2: null pointer");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(k_softmax2, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, M);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int mrcnn_map_rois_to_fpn_levels_f32(const float *rois, int R, int k_min, int k_max, float *levels,
                                                 void *stream) {
     if (R == 0) return 0;

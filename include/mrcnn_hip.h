@@ -162,6 +162,12 @@ size_t mrcnn_conv2d_winograd_v_bytes(int N, int H, int W, int Cin, int Cout, int
 int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                          float *wino_v, void *ws, size_t ws_bytes, void *stream);
+/* Forward with a rectangular kernel and per-axis padding: the (15,1) / (1,15) separable pairs of the Light-Head R-CNN
+ * head (chainer_maskrcnn/model/head/light_roi_mask_head.py:29-44).  Workspace as mrcnn_conv2d_workspace_bytes() of the
+ * same geometry with pad = max(pad_h, pad_w). */
+int mrcnn_conv2d_fwd_rect_f32(const float *x, const float *w, const float *bias, float *y, int N, int H, int W, int Cin,
+                              int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int relu, void *ws,
+                              size_t ws_bytes, void *stream);
 /* relu_x (nullable, same shape as gx): the layer's input when it is the output of a ReLU; gx is then zeroed where
  * relu_x <= 0, i.e. the ReLU backward of the layer below is fused into this epilogue (not with accumulate). */
 /* wino_w (nullable, mrcnn_conv2d_winograd_w_bytes() bytes; only where that is > 0): the Winograd path reads gy ONCE
@@ -322,6 +328,9 @@ size_t mrcnn_nms_workspace_bytes(int n);
 int mrcnn_nms_f32(const float *boxes, int n, float thresh, int max_keep, int32_t *keep, int32_t *n_keep,
                   void *ws, size_t ws_bytes, void *stream);
 int mrcnn_map_rois_to_fpn_levels_f32(const float *rois, int R, int k_min, int k_max, float *levels, void *stream);
+/* out (M,2) = softmax over the 2 class scores of in (M,2): ChainerCV's single-level RegionProposalNetwork (the 'c4'
+ * backbone, chainer_maskrcnn/model/maskrcnn.py:60-69) ranks its proposals by the foreground PROBABILITY. */
+int mrcnn_softmax2_f32(const float *in, float *out, size_t M, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Target creators (targets.hip).  Replace chainer_maskrcnn/utils/proposal_target_creator.py:26-137
