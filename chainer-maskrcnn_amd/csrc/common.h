@@ -40,8 +40,14 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 constexpr int kWave = 64;  // gfx950 wavefront
 
 namespace mrcnn {
-// Device radix sort of 64-bit keys (sort.hip; rocPRIM device primitive, the only library call in
-// the library).  tmp == nullptr: returns the temporary-storage size in *tmp_bytes.
-int sort_u64(const unsigned long long *in, unsigned long long *out, size_t n, bool descending, void *tmp,
-             size_t *tmp_bytes, hipStream_t st, unsigned end_bit = 64);
+// Hand-written selection / sorting of unsigned 64-bit keys (sort.hip; no library): segments = images.
+// select_kth: kth[seg * kth_stride] = the kreq[seg * kreq_stride]-th largest (descending) or smallest key of the segment (radix select,
+// 11 bits per launch); top_k_sorted: the (up to) cap largest keys carrying valid_bit, in descending order (select + compact
+// + bitonic sort in LDS; cap <= 16384).  Keys must be < 2^key_bits; workspaces from the *_ws_bytes queries.
+size_t select_ws_bytes(int nseg, int key_bits);
+int select_kth(const unsigned long long *keys, int nseg, size_t seg_len, int key_bits, bool descending, const unsigned *kreq,
+               int kreq_stride, unsigned long long *kth, int kth_stride, void *ws, hipStream_t st);
+size_t topk_ws_bytes(int nseg, int key_bits, int cap);
+int top_k_sorted(const unsigned long long *keys, int nseg, size_t seg_len, int key_bits, unsigned long long valid_bit, int cap,
+                 unsigned long long *out, size_t out_stride, void *ws, hipStream_t st);
 }  // namespace mrcnn

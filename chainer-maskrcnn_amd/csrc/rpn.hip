@@ -94,11 +94,12 @@ __global__ __launch_bounds__(256) void k_decode(const float *__restrict__ locs, 
 // Gather the first n_pre sorted boxes; n_valid[n] = min(n_pre, #valid).
 __global__ __launch_bounds__(256) void k_gather_sorted(const u64 *__restrict__ keys_sorted, const float *__restrict__ boxes,
                                                        int A, int n_pre, float *__restrict__ sboxes,
-                                                       int32_t *__restrict__ sidx, int32_t *__restrict__ n_valid, int ib) {
+                                                       int32_t *__restrict__ sidx, int32_t *__restrict__ n_valid, int ib,
+                                                       int ks_stride) {
     const int n = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pre || i >= A) return;
-    const u64 *ks = keys_sorted + (size_t)n * A;
+    const u64 *ks = keys_sorted + (size_t)n * ks_stride;
     const u64 vbit = 1ull << (ib + 32);
     const u64 k = ks[i];
     if (!(k & vbit)) return;
@@ -293,16 +294,16 @@ PropLayout prop_layout(int N, int A, int n_pre, int n_post) {
     L.nblk = (n_pre + 63) / 64;
     L.boxes = o; o += al((size_t)N * A * 16);
     L.keys = o; o += al((size_t)N * A * 8);
-    L.keys_sorted = o; o += al((size_t)N * A * 8);
+    L.keys_sorted = o; o += al((size_t)N * (n_pre + 1) * 8);     // the n_pre best keys per image, descending (+ a zero)
     L.sboxes = o; o += al((size_t)N * n_pre * 16);
     L.sidx = o; o += al((size_t)N * n_pre * 4);
     L.n_valid = o; o += al((size_t)N * 4);
     L.mask = o; o += al((size_t)N * n_pre * L.nblk * 8);
     L.keep = o; o += al((size_t)N * n_post * 4);
-    size_t tb = 0;
-    mrcnn::sort_u64(nullptr, nullptr, (size_t)A * N, true, nullptr, &tb, nullptr);        // one sort over all images
-    L.sort_tmp_bytes = tb;
-    L.sort_tmp = o; o += al(tb);
+    int ib = 1;
+    while ((1ll << ib) < A) ++ib;
+    L.sort_tmp_bytes = mrcnn::topk_ws_bytes(N, 33 + ib, n_pre);
+    L.sort_tmp = o; o += al(L.sort_tmp_bytes);
     L.total = o;
     return L;
 }
@@ -357,26 +358,17 @@ extern "C" int mrcnn_rpn_proposals_f32(const float *locs, const float *scores, c
     int32_t *sidx = (int32_t *)(w + L.sidx), *n_valid = (int32_t *)(w + L.n_valid), *keep = (int32_t *)(w + L.keep);
     u64 *mask = (u64 *)(w + L.mask);
     const long long total = (long long)N * A;
-    int ib = 1, nbits = 0;
+    int ib = 1;
     while ((1ll << ib) < A) ++ib;
-    while ((1ll << nbits) < N) ++nbits;
-    const int batched = (33 + ib + nbits <= 64);       // all images in ONE radix sort (a sort is ~16 tiny launches)
     hipLaunchKernelGGL(k_decode, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, locs, scores,
-                       anchors, N, A, img_h, img_w, min_size, boxes, keys, ib, batched);
+                       anchors, N, A, img_h, img_w, min_size, boxes, keys, ib, 0);
     MRCNN_LAUNCH_CHECK();
-    if (batched) {
-        size_t tb = L.sort_tmp_bytes;
-        if (int e = mrcnn::sort_u64(keys, keys_sorted, (size_t)total, true, w + L.sort_tmp, &tb, st, 33 + ib + nbits)) return e;
-    } else {
-        for (int n = 0; n < N; ++n) {
-            size_t tb = L.sort_tmp_bytes;
-            if (int e = mrcnn::sort_u64(keys + (size_t)n * A, keys_sorted + (size_t)n * A, (size_t)A, true, w + L.sort_tmp, &tb, st,
-                                        33 + ib)) return e;
-        }
-    }
+    // argsort()[::-1][:n_pre] per image: radix select of the n_pre-th key + compaction + bitonic sort in LDS (sort.hip)
+    if (int e = mrcnn::top_k_sorted(keys, N, (size_t)A, 33 + ib, 1ull << (ib + 32), n_pre, keys_sorted, (size_t)n_pre + 1, w + L.sort_tmp, st))
+        return e;
     MRCNN_HIP_TRY(hipMemsetAsync(n_valid, 0, sizeof(int32_t) * N, st));
     hipLaunchKernelGGL(k_gather_sorted, dim3(mrcnn::cdiv(n_pre, 256), N), dim3(256), 0, st, keys_sorted, boxes, A, n_pre,
-                       sboxes, sidx, n_valid, ib);
+                       sboxes, sidx, n_valid, ib, n_pre + 1);
     MRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_nms_mask, dim3(L.nblk, L.nblk, N), dim3(64), 0, st, sboxes, n_valid, n_pre, L.nblk, nms_thresh, mask);
     MRCNN_LAUNCH_CHECK();

@@ -1,19 +1,241 @@
-// 64-bit key radix sort used by the proposal path (top-12000 by score) and by the anchor / proposal
-// samplers (k smallest random keys).  Composite keys are unique, so the result is deterministic.
+// Selection and sorting of 64-bit keys for the proposal path and the samplers - hand-written for gfx950, no library.
+//
+//   select_kth   per segment (image), the k-th largest (or smallest) of `seg_len` unsigned 64-bit keys, k read from device
+//                memory: most-significant-digit radix select, 11 bits per level.  One launch per level: every
+//                workgroup first resolves the previous level from that level's 2048-bin histogram (redundantly - 8 KB of
+//                L2-resident counters - instead of a separate scan launch), then histograms the next digit of the keys
+//                that still match the prefix (LDS counters, one integer atomicAdd per non-empty bin and workgroup).
+//                Integer atomics only: the result does not depend on arrival order.
+//   top_k_sorted the proposal path's "argsort()[::-1][:n_pre]" (utils/proposal_creator.py:144-148): select the n_pre-th
+//                largest composite key, compact the keys >= it (at most n_pre, keys are unique), sort them descending in
+//                LDS (bitonic, one workgroup per image, <= 16384 keys = 128 KB of the CU's 160 KB).
+// Replaces the device radix sort of ALL 261,888 keys per image that round 1 called from rocPRIM: 5 + 2 launches that
+// read the keys instead of ~16 that read and write them.
 #include "common.h"
-#include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
+#include <algorithm>
 
 namespace mrcnn {
-int sort_u64(const unsigned long long *in, unsigned long long *out, size_t n, bool descending, void *tmp,
-             size_t *tmp_bytes, hipStream_t st, unsigned end_bit) {
-    hipError_t e;          // keys only differ in bits [0, end_bit): fewer radix passes for narrow composite keys
-    if (descending) e = rocprim::radix_sort_keys_desc(tmp, *tmp_bytes, in, out, n, 0, end_bit, st);
-    else e = rocprim::radix_sort_keys(tmp, *tmp_bytes, in, out, n, 0, end_bit, st);
-    if (e != hipSuccess) {
-        set_error("rocprim radix sort failed: %s", hipGetErrorString(e));
-        return (int)e;
+namespace {
+
+typedef unsigned long long u64;
+constexpr int RS_BITS = 11, RS_BINS = 1 << RS_BITS;      // digit width
+constexpr int RS_THREADS = 256;
+
+struct SelState {          // per segment, in the workspace
+    u64 prefix;            // digits resolved so far (in place, lower bits zero)
+    unsigned k;            // rank still to find inside the matching keys (1-based)
+    unsigned pad;
+};
+
+// Resolve one level from its histogram: digit d with (keys with a better digit) < k <= (those + hist[d]); `descending`
+// walks the bins from the top.  All threads of the block return the same (d, k').
+__device__ __forceinline__ void resolve_level(const unsigned *__restrict__ hist, unsigned k, bool descending, unsigned *sscan, int &d_out,
+                                              unsigned &k_out) {
+    const int t = threadIdx.x;
+    constexpr int PER = RS_BINS / RS_THREADS;           // 8 consecutive bins (in walk order) per thread
+    unsigned c[PER], tot = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int w = t * PER + j;                        // position in walk order
+        c[j] = hist[descending ? RS_BINS - 1 - w : w];
+        tot += c[j];
     }
+    sscan[t] = tot;
+    __syncthreads();
+    // exclusive prefix of the per-thread totals (256 values: serial per thread over LDS is fine at this size)
+    unsigned before = 0;
+    for (int i = 0; i < t; ++i) before += sscan[i];
+    __shared__ int s_d;
+    __shared__ unsigned s_k;
+    if (t == 0) { s_d = descending ? 0 : RS_BINS - 1; s_k = 1; }      // k beyond the population: the extreme digit
+    __syncthreads();
+    unsigned run = before;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (k > run && k <= run + c[j]) {
+            const int w = t * PER + j;
+            s_d = descending ? RS_BINS - 1 - w : w;
+            s_k = k - run;
+        }
+        run += c[j];
+    }
+    __syncthreads();
+    d_out = s_d;
+    k_out = s_k;
+    __syncthreads();
+}
+
+// level l examines bits [top - 11(l+1), top - 11 l) of the key, top = number of significant key bits rounded up to a
+// multiple of 11 (keys are < 2^top).
+__global__ __launch_bounds__(RS_THREADS) void k_select_level(const u64 *__restrict__ keys, size_t seg_len, int level, int top,
+                                                             bool descending, const unsigned *__restrict__ kreq, int kreq_stride,
+                                                             SelState *__restrict__ state, unsigned *__restrict__ hist) {
+    __shared__ unsigned sh[RS_BINS];
+    __shared__ unsigned sscan[RS_THREADS];
+    const int seg = blockIdx.y, nseg = gridDim.y, t = threadIdx.x;
+    u64 prefix = 0;
+    unsigned k = kreq[(size_t)seg * kreq_stride];
+    if (level > 0) {
+        // double-buffered records: level l reads half (l & 1), written by level l-1, and writes half ((l & 1) ^ 1)
+        const SelState st = state[(size_t)nseg * (level & 1) + seg];
+        int d;
+        resolve_level(hist + ((size_t)(level - 1) * nseg + seg) * RS_BINS, st.k, descending, sscan, d, k);
+        prefix = st.prefix | ((u64)d << (top - RS_BITS * level));
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && t == 0)            // record for the next level (every block of the segment computes the same)
+        state[(size_t)nseg * ((level & 1) ^ 1) + seg] = SelState{prefix, k, 0};
+    for (int i = t; i < RS_BINS; i += RS_THREADS) sh[i] = 0;
+    __syncthreads();
+    const int shift = top - RS_BITS * (level + 1);
+    const u64 hi_mask = level == 0 ? 0ull : ~0ull << (top - RS_BITS * level);
+    const u64 *ks = keys + (size_t)seg * seg_len;
+    for (size_t i = (size_t)blockIdx.x * RS_THREADS + t; i < seg_len; i += (size_t)gridDim.x * RS_THREADS) {
+        const u64 key = ks[i];
+        if ((key & hi_mask) == prefix) atomicAdd(&sh[(unsigned)(key >> shift) & (RS_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    unsigned *gh = hist + ((size_t)level * nseg + seg) * RS_BINS;
+    for (int i = t; i < RS_BINS; i += RS_THREADS)
+        if (sh[i]) atomicAdd(&gh[i], sh[i]);
+}
+
+// Last step: resolve the final level -> kth[seg] = the selected key.
+__global__ __launch_bounds__(RS_THREADS) void k_select_final(int levels, int top, bool descending, const SelState *__restrict__ state,
+                                                             const unsigned *__restrict__ hist, u64 *__restrict__ kth, int kth_stride) {
+    __shared__ unsigned sscan[RS_THREADS];
+    const int seg = blockIdx.x, nseg = gridDim.x;
+    const SelState st = state[(size_t)nseg * (levels & 1) + seg];
+    int d;
+    unsigned k;
+    resolve_level(hist + ((size_t)(levels - 1) * nseg + seg) * RS_BINS, st.k, descending, sscan, d, k);
+    if (threadIdx.x == 0) kth[(size_t)seg * kth_stride] = st.prefix | ((u64)d << (top - RS_BITS * levels));
+}
+
+// keys >= kth[seg] that carry `valid_bit` are appended (order arbitrary) to cand[seg][...]; count[seg] = how many.
+__global__ __launch_bounds__(RS_THREADS) void k_compact_ge(const u64 *__restrict__ keys, size_t seg_len, const u64 *__restrict__ kth,
+                                                           u64 valid_bit, int cap, u64 *__restrict__ cand, unsigned *__restrict__ count) {
+    const int seg = blockIdx.y;
+    const u64 T = kth[seg];
+    const u64 *ks = keys + (size_t)seg * seg_len;
+    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < seg_len; i += (size_t)gridDim.x * RS_THREADS) {
+        const u64 key = ks[i];
+        const bool take = key >= T && (key & valid_bit);
+        // wave-aggregated append: one atomic per wave
+        const u64 bal = __ballot(take);
+        if (bal) {
+            const int lane = threadIdx.x & 63;
+            unsigned base = 0;
+            if (lane == __builtin_ctzll(bal)) base = atomicAdd(&count[seg], (unsigned)__popcll(bal));
+            base = __shfl(base, __builtin_ctzll(bal));
+            const unsigned pos = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            if (take && pos < (unsigned)cap) cand[(size_t)seg * cap + pos] = key;
+        }
+    }
+}
+
+// One workgroup per segment: bitonic sort (descending) of the compacted keys in LDS; out[seg][0 .. seg_out) = sorted keys,
+// zero beyond the count.  NP = power of two >= cap.
+template <int NP>
+__global__ __launch_bounds__(1024) void k_sort_desc_lds(const u64 *__restrict__ cand, const unsigned *__restrict__ count, int cap,
+                                                        u64 *__restrict__ out, size_t out_stride, int seg_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *s = reinterpret_cast<u64 *>(smem_raw);
+    const int seg = blockIdx.x, t = threadIdx.x;
+    const int n = min((int)count[seg], cap);
+    for (int i = t; i < NP; i += 1024) s[i] = i < n ? cand[(size_t)seg * cap + i] : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= NP; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < NP; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const u64 a = s[i], b = s[ixj];
+                    const bool down = (i & k) == 0;             // descending overall
+                    if ((a < b) == down) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = t; i < seg_out; i += 1024) out[(size_t)seg * out_stride + i] = i < NP ? s[i] : 0ull;
+}
+
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+int levels_for(int key_bits) { return (key_bits + RS_BITS - 1) / RS_BITS; }
+
+}  // namespace
+
+// Workspace of select_kth: histograms of every level + double-buffered state.
+size_t select_ws_bytes(int nseg, int key_bits) {
+    return al256((size_t)levels_for(key_bits) * nseg * RS_BINS * sizeof(unsigned)) + al256((size_t)2 * nseg * sizeof(SelState));
+}
+
+// kth[seg * kth_stride] = the kreq[seg * kreq_stride]-th largest (descending) / smallest key of segment seg.  keys < 2^key_bits.
+int select_kth(const u64 *keys, int nseg, size_t seg_len, int key_bits, bool descending, const unsigned *kreq, int kreq_stride, u64 *kth,
+               int kth_stride, void *ws, hipStream_t st) {
+    const int levels = levels_for(key_bits), top = levels * RS_BITS;
+    unsigned *hist = (unsigned *)ws;
+    SelState *state = (SelState *)((char *)ws + al256((size_t)levels * nseg * RS_BINS * sizeof(unsigned)));
+    MRCNN_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)levels * nseg * RS_BINS * sizeof(unsigned), st));
+    const int blocks = (int)std::max<size_t>(1, std::min<size_t>((seg_len + RS_THREADS * 8 - 1) / (RS_THREADS * 8), 256));
+    for (int l = 0; l < levels; ++l) {
+        hipLaunchKernelGGL(k_select_level, dim3(blocks, nseg), dim3(RS_THREADS), 0, st, keys, seg_len, l, top, descending, kreq, kreq_stride,
+                           state, hist);
+        MRCNN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_select_final, dim3(nseg), dim3(RS_THREADS), 0, st, levels, top, descending, state, hist, kth, kth_stride);
+    MRCNN_LAUNCH_CHECK();
     return 0;
 }
+
+namespace {
+__global__ void k_fill_u32(unsigned *p, unsigned v, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+}  // namespace
+void fill_u32(unsigned *p, unsigned v, int n, hipStream_t st) { hipLaunchKernelGGL(k_fill_u32, dim3((n + 255) / 256), dim3(256), 0, st, p, v, n); }
+
+size_t topk_ws_bytes(int nseg, int key_bits, int cap) {
+    return select_ws_bytes(nseg, key_bits) + al256((size_t)nseg * 8) + al256((size_t)nseg * 4) + al256((size_t)nseg * cap * 8) + al256((size_t)nseg * 4);
+}
+
+// out[seg][0 .. cap) = the (up to) cap largest keys of segment seg that carry valid_bit, in descending order, zero-filled
+// beyond their number.  cap <= 16384.  keys are unique (composite keys), < 2^key_bits.
+int top_k_sorted(const u64 *keys, int nseg, size_t seg_len, int key_bits, u64 valid_bit, int cap, u64 *out, size_t out_stride, void *ws,
+                 hipStream_t st) {
+    if (cap <= 0 || cap > 16384) {
+        set_error("top_k_sorted: cap %d not in [1, 16384]", cap);
+        return MRCNN_E_UNSUPPORTED;
+    }
+    char *w = (char *)ws;
+    size_t o = select_ws_bytes(nseg, key_bits);
+    u64 *kth = (u64 *)(w + o); o += al256((size_t)nseg * 8);
+    unsigned *kreq = (unsigned *)(w + o); o += al256((size_t)nseg * 4);
+    u64 *cand = (u64 *)(w + o); o += al256((size_t)nseg * cap * 8);
+    unsigned *count = (unsigned *)(w + o);
+    fill_u32(kreq, (unsigned)cap, nseg, st);              // k = cap for every segment
+    MRCNN_HIP_TRY(hipMemsetAsync(count, 0, (size_t)nseg * 4, st));
+    if (int e = select_kth(keys, nseg, seg_len, key_bits, true, kreq, 1, kth, 1, ws, st)) return e;
+    const int blocks = (int)std::max<size_t>(1, std::min<size_t>((seg_len + RS_THREADS * 8 - 1) / (RS_THREADS * 8), 256));
+    hipLaunchKernelGGL(k_compact_ge, dim3(blocks, nseg), dim3(RS_THREADS), 0, st, keys, seg_len, kth, valid_bit, cap, cand, count);
+    MRCNN_LAUNCH_CHECK();
+    const int seg_out = (int)std::min<size_t>(out_stride, (size_t)cap + 1);     // one zero after the keys when there is room
+    int np = 64;
+    while (np < cap) np <<= 1;
+    const size_t lds = (size_t)np * 8;
+#define SORT_CASE(NPV)                                                                                                      \
+    case NPV:                                                                                                               \
+        MRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_desc_lds<NPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_sort_desc_lds<NPV>), dim3(nseg), dim3(1024), lds, st, cand, count, cap, out, out_stride, seg_out);    \
+        break;
+    switch (np) {
+        SORT_CASE(64) SORT_CASE(128) SORT_CASE(256) SORT_CASE(512) SORT_CASE(1024) SORT_CASE(2048) SORT_CASE(4096) SORT_CASE(8192)
+        SORT_CASE(16384)
+    }
+#undef SORT_CASE
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace mrcnn

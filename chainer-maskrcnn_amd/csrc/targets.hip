@@ -352,16 +352,32 @@ __global__ __launch_bounds__(256) void k_at_label(const float *__restrict__ anch
     }
 }
 
-__global__ __launch_bounds__(256) void k_at_disable(const u64 *__restrict__ sorted, int A, const int *__restrict__ counts,
-                                                    int n_sample, int n_pos_max, int32_t *__restrict__ label) {
-    const int img = blockIdx.y;
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= A) return;
+// Sub-sampling (AnchorTargetCreator: at most n_pos_max positives, n_sample in total): the kept anchors of a class are
+// the ones with the smallest (random key, index).  With the composite keys of k_at_label (positives sort before negatives,
+// unlabelled anchors last) those are the keys <= the keep_p-th smallest key (positives) / <= the (np + keep_n)-th smallest
+// key (negatives): two radix selects (sort.hip) instead of a sort of all A keys.
+__global__ void k_at_ranks(const int *__restrict__ counts, int N, int n_sample, int n_pos_max, unsigned *__restrict__ kreq) {
+    const int img = blockIdx.x * 64 + threadIdx.x;
+    if (img >= N) return;
     const int np = counts[img * 2], nn = counts[img * 2 + 1];
     const int keep_p = min(np, n_pos_max), keep_n = min(nn, n_sample - keep_p);
-    if (r >= np + nn) return;
-    const bool drop = r < np ? (r >= keep_p) : (r - np >= keep_n);
-    if (drop) label[(size_t)img * A + (int)(sorted[(size_t)img * A + r] & 0x7FFFFFFFull)] = -1;
+    kreq[img * 2] = (unsigned)max(keep_p, 1);                 // rank 0 is not a rank: the class is then skipped below
+    kreq[img * 2 + 1] = (unsigned)max(np + keep_n, 1);
+}
+
+__global__ __launch_bounds__(256) void k_at_disable(const u64 *__restrict__ skeys, int A, const int *__restrict__ counts,
+                                                    const u64 *__restrict__ kth, int n_sample, int n_pos_max,
+                                                    int32_t *__restrict__ label) {
+    const int img = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= A) return;
+    const int lab = label[(size_t)img * A + a];
+    if (lab < 0) return;
+    const int np = counts[img * 2], nn = counts[img * 2 + 1];
+    const int keep_p = min(np, n_pos_max), keep_n = min(nn, n_sample - keep_p);
+    const u64 key = skeys[(size_t)img * A + a];
+    const bool drop = lab == 1 ? (keep_p <= 0 || key > kth[img * 2]) : (keep_n <= 0 || key > kth[img * 2 + 1]);
+    if (drop) label[(size_t)img * A + a] = -1;
 }
 
 __global__ __launch_bounds__(256) void k_at_loc(const float *__restrict__ anchors, int A, const float *__restrict__ gt_boxes,
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(256) void k_at_loc(const float *__restrict__ anchor
 }
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
-struct ATLayout { size_t max_iou, argmax, gtmax, counts, skeys, sorted, tmp, tmp_bytes, total; };
+struct ATLayout { size_t max_iou, argmax, gtmax, counts, skeys, kreq, kth, tmp, tmp_bytes, total; };
 ATLayout at_layout(int N, int A) {
     ATLayout L{};
     size_t o = 0;
@@ -387,11 +403,10 @@ ATLayout at_layout(int N, int A) {
     L.gtmax = o; o += al((size_t)N * AT_GCAP * 4);
     L.counts = o; o += al((size_t)N * 2 * 4);
     L.skeys = o; o += al((size_t)N * A * 8);
-    L.sorted = o; o += al((size_t)N * A * 8);
-    size_t tb = 0;
-    mrcnn::sort_u64(nullptr, nullptr, (size_t)A, false, nullptr, &tb, nullptr);
-    L.tmp_bytes = tb;
-    L.tmp = o; o += al(tb);
+    L.kreq = o; o += al((size_t)N * 2 * 4);
+    L.kth = o; o += al((size_t)N * 2 * 8);
+    L.tmp_bytes = mrcnn::select_ws_bytes(N, 64);
+    L.tmp = o; o += al(L.tmp_bytes);
     L.total = o;
     return L;
 }
@@ -479,7 +494,8 @@ extern "C" int mrcnn_anchor_target_f32(const float *anchors, int A, const float 
     float *max_iou = (float *)(w + L.max_iou);
     int32_t *argmax = (int32_t *)(w + L.argmax);
     int *gtmax = (int *)(w + L.gtmax), *counts = (int *)(w + L.counts);
-    u64 *skeys = (u64 *)(w + L.skeys), *sorted = (u64 *)(w + L.sorted);
+    u64 *skeys = (u64 *)(w + L.skeys), *kth = (u64 *)(w + L.kth);
+    unsigned *kreq = (unsigned *)(w + L.kreq);
     MRCNN_HIP_TRY(hipMemsetAsync(w + L.gtmax, 0, (L.counts - L.gtmax) + al((size_t)N * 2 * 4), st));
     const dim3 grid(mrcnn::cdiv(A, 256), N);
     hipLaunchKernelGGL(k_at_iou, grid, dim3(256), 0, st, anchors, A, gt_boxes, n_gt, gt_cap, img_h, img_w, max_iou, argmax, gtmax);
@@ -488,11 +504,14 @@ extern "C" int mrcnn_anchor_target_f32(const float *anchors, int A, const float 
                        do_sample ? keys : (const uint32_t *)max_iou, pos_iou_thresh, neg_iou_thresh, gt_rpn_label, skeys, counts);
     MRCNN_LAUNCH_CHECK();
     if (do_sample) {
-        for (int n = 0; n < N; ++n) {
-            size_t tb = L.tmp_bytes;
-            if (int e = mrcnn::sort_u64(skeys + (size_t)n * A, sorted + (size_t)n * A, (size_t)A, false, w + L.tmp, &tb, st)) return e;
-        }
-        hipLaunchKernelGGL(k_at_disable, grid, dim3(256), 0, st, sorted, A, counts, n_sample, (int)(pos_ratio * n_sample), gt_rpn_label);
+        const int n_pos_max = (int)(pos_ratio * n_sample);
+        hipLaunchKernelGGL(k_at_ranks, dim3(mrcnn::cdiv(N, 64)), dim3(64), 0, st, counts, N, n_sample, n_pos_max, kreq);
+        MRCNN_LAUNCH_CHECK();
+        // kth[img][0] = the keep_p-th smallest key, kth[img][1] = the (np + keep_n)-th smallest key (the two selects share
+        // the workspace: the second starts after the first has finished on this stream)
+        for (int c = 0; c < 2; ++c)
+            if (int e = mrcnn::select_kth(skeys, N, (size_t)A, 64, false, kreq + c, 2, kth + c, 2, w + L.tmp, st)) return e;
+        hipLaunchKernelGGL(k_at_disable, grid, dim3(256), 0, st, skeys, A, counts, kth, n_sample, n_pos_max, gt_rpn_label);
         MRCNN_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_at_loc, grid, dim3(256), 0, st, anchors, A, gt_boxes, gt_cap, argmax, gt_rpn_loc);
