@@ -134,30 +134,98 @@ __global__ __launch_bounds__(RS_THREADS) void k_compact_ge(const u64 *__restrict
     }
 }
 
-// One workgroup per segment: bitonic sort (descending) of the compacted keys in LDS; out[seg][0 .. seg_out) = sorted keys,
-// zero beyond the count.  NP = power of two >= cap.
+// One workgroup per segment: bitonic sort (descending) of the compacted keys; out[seg][0 .. seg_out) = sorted keys, zero
+// beyond the count.  NP = power of two >= cap, NP = 1024 * E: thread t holds E keys in REGISTERS; a compare-exchange step
+// of distance 2^p is done inside a thread when index bit p is one of the thread's LB = log2(E) "local" bits, and the keys
+// change owners through LDS only when the next steps need other local bits ("layout" = which LB index bits are local: a
+// stage of the network walks p = s-1 .. 0 in groups of LB bits).  For NP = 16384: 32 exchanges through LDS instead of the
+// 105 barrier-separated LDS passes of the textbook form (measured 247 us -> see DESIGN.md).  LDS index i is padded by one
+// slot every 32 (8-byte slots: the blocked layout would otherwise put a wave on two banks).
 template <int NP>
 __global__ __launch_bounds__(1024) void k_sort_desc_lds(const u64 *__restrict__ cand, const unsigned *__restrict__ count, int cap,
                                                         u64 *__restrict__ out, size_t out_stride, int seg_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *s = reinterpret_cast<u64 *>(smem_raw);
+    constexpr int T = NP >= 1024 ? 1024 : NP;           // active threads
+    constexpr int E = NP / T;                            // keys per thread (1, 2, 4, 8 or 16)
+    constexpr int LB = E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : 4;
+    constexpr int NBITS = __builtin_ctz(NP);
     const int seg = blockIdx.x, t = threadIdx.x;
     const int n = min((int)count[seg], cap);
-    for (int i = t; i < NP; i += 1024) s[i] = i < n ? cand[(size_t)seg * cap + i] : 0ull;
-    __syncthreads();
-    for (int k = 2; k <= NP; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < NP; i += 1024) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const u64 a = s[i], b = s[ixj];
-                    const bool down = (i & k) == 0;             // descending overall
-                    if ((a < b) == down) { s[i] = b; s[ixj] = a; }
+    auto phys = [](int i) { return i + (i >> 5); };
+    // index of local element e of thread t when the local bits are [b, b + LB)
+    auto index_of = [](int t_, int e, int b) { return ((t_ >> b) << (b + LB)) | (e << b) | (t_ & ((1 << b) - 1)); };
+    u64 v[E];
+    const bool active = t < T;
+    int b = 0;                                           // current layout
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = index_of(t, e, 0);
+            v[e] = i < n ? cand[(size_t)seg * cap + i] : 0ull;
+        }
+    }
+    for (int sbit = 1; sbit <= NBITS; ++sbit) {          // stage: sorted runs of length 2^sbit
+        int p = sbit - 1;
+        while (p >= 0) {
+            const int nb = LB == 0 ? p : min(max(p - (LB - 1), 0), NBITS - LB);      // layout whose local bits contain p
+            if (LB == 0 || nb != b) {
+                // ---- change owners through LDS (every key written at its index, read back in the new layout)
+                __syncthreads();
+                if (active) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) s[phys(index_of(t, e, b))] = v[e];
+                }
+                __syncthreads();
+                if (LB == 0) {
+                    // one key per thread: the partner is read from LDS
+                    if (active) {
+                        const int i = t, ixj = i ^ (1 << p);
+                        const u64 a = v[0], o = s[phys(ixj)];
+                        const bool down = (i & (1 << sbit)) == 0;
+                        const bool lower = i < ixj;
+                        // descending run: the lower index keeps the larger key
+                        const bool take_max = (lower == down);
+                        v[0] = take_max ? (a > o ? a : o) : (a < o ? a : o);
+                    }
+                    --p;
+                    continue;
+                }
+                b = nb;
+                if (active) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) v[e] = s[phys(index_of(t, e, b))];
                 }
             }
-            __syncthreads();
+            // ---- all steps whose bit lies in the local window [b, b + LB) and is <= p
+            const int lo = b;
+#pragma unroll
+            for (int q = LB - 1; q >= 0; --q) {
+                const int bit = lo + q;
+                if (bit > p || bit < 0) continue;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int e2 = e ^ (1 << q);
+                    if (e2 > e) {
+                        const int i = index_of(t, e, b);
+                        const bool down = (i & (1 << sbit)) == 0 || sbit == NBITS;      // the last stage sorts the whole array descending
+                        const u64 x = v[e], y = v[e2];
+                        const bool sw = down ? (x < y) : (x > y);
+                        v[e] = sw ? y : x;
+                        v[e2] = sw ? x : y;
+                    }
+                }
+            }
+            p = lo - 1;
         }
-    for (int i = t; i < seg_out; i += 1024) out[(size_t)seg * out_stride + i] = i < NP ? s[i] : 0ull;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[phys(index_of(t, e, b))] = v[e];
+    }
+    __syncthreads();
+    for (int i = t; i < seg_out; i += 1024) out[(size_t)seg * out_stride + i] = i < NP ? s[phys(i)] : 0ull;
 }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -223,7 +291,7 @@ int top_k_sorted(const u64 *keys, int nseg, size_t seg_len, int key_bits, u64 va
     const int seg_out = (int)std::min<size_t>(out_stride, (size_t)cap + 1);     // one zero after the keys when there is room
     int np = 64;
     while (np < cap) np <<= 1;
-    const size_t lds = (size_t)np * 8;
+    const size_t lds = (size_t)(np + np / 32 + 1) * 8;
 #define SORT_CASE(NPV)                                                                                                      \
     case NPV:                                                                                                               \
         MRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_desc_lds<NPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \

@@ -78,12 +78,16 @@ def _rpn_case(seed, N, feat_shapes, exact):
     return anchors, locs, scores
 
 
-@pytest.mark.parametrize('n_pre,n_post', [(12000, 2000), (600, 100)])
-def test_proposals_end_to_end_bit_exact(n_pre, n_post):
+# The top-n_pre selection is a radix select + an in-LDS bitonic sort whose shape depends on n_pre: 8192 keys (8 per thread),
+# 1024 (1 per thread, partner through LDS), 4096 (4 per thread), 128 (fewer threads than the block), and - with the larger
+# pyramid, A = 23,025 anchors - the training size: 12,000 of them in a 16,384-key sort (16 per thread).
+@pytest.mark.parametrize('n_pre,n_post,big', [(12000, 2000, False), (600, 100, False), (3000, 300, False), (100, 20, False),
+                                              (12000, 2000, True)])
+def test_proposals_end_to_end_bit_exact(n_pre, n_post, big):
     N = 2
-    feat = [(40, 48), (20, 24), (10, 12), (5, 6), (3, 3)]
+    feat = [(72, 80), (36, 40), (18, 20), (9, 10), (5, 5)] if big else [(40, 48), (20, 24), (10, 12), (5, 6), (3, 3)]
     anchors, locs, scores = _rpn_case(1, N, feat, exact=True)
-    img_size = (160, 192)
+    img_size = (288, 320) if big else (160, 192)
     o = ops.rpn_proposals(torch.from_numpy(locs).to(DEV), torch.from_numpy(scores).to(DEV), torch.from_numpy(anchors).to(DEV),
                           img_size, 16.0, n_pre, n_post, 0.7, debug=True)
     pc = ProposalCreator(n_train_pre_nms=n_pre, n_train_post_nms=n_post)
