@@ -45,7 +45,7 @@ def roialign_inputs(seed_shift=0):
 def _pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_roialign_pmc_traffic.json')))
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_roialign_pmc_traffic.json')))
         return d[kernel]['hbm_bytes']
     except Exception:
         return None
@@ -99,13 +99,14 @@ def bench_roialign(args, rank, world):
         'config': {'workload': 'configs[1] roi_align_2d fwd+bwd microbench: 512 RoIs, x=(1,256,200,272) NHWC, '
                                '7x7, sampling 2x2, spatial_scale 0.25', 'rois_per_step': R * world,
                    'parallelism': 'independent batch per rank, no collective'},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_roi_align_bwd_nhwc', 'achieved': round(bwd_gbps, 2),
+        'roofline': {'bound': 'hbm', 'kernel': 'k_roi_align_bwd_waves', 'achieved': round(bwd_gbps, 2),
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(bwd_gbps / HBM_PEAK_GBPS, 4),
-                     'traffic': _pmc_traffic('k_roi_align_bwd_nhwc'), 'algorithmic_bytes_per_launch': algo_bytes,
+                     'traffic': _pmc_traffic('k_roi_align_bwd_waves'), 'algorithmic_bytes_per_launch': algo_bytes,
                      'avg_launch_us': round(bwd_avg_s * 1e6, 3), 'median_launch_us': round(float(np.median(bwd_ms)) * 1e3, 3)},
         'roi_align_fwd': {'avg_launch_us': round(fwd_avg_s * 1e6, 3),
                           'achieved_GBps': round(algo_bytes / fwd_avg_s / 1e9, 2),
-                          'frac': round(algo_bytes / fwd_avg_s / 1e9 / HBM_PEAK_GBPS, 4)},
+                          'frac': round(algo_bytes / fwd_avg_s / 1e9 / HBM_PEAK_GBPS, 4), 'kernel': 'k_roi_align_fwd_rows',
+                          'traffic': _pmc_traffic('k_roi_align_fwd_rows')},
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_roialign(x, yx, gy, algo_bytes)

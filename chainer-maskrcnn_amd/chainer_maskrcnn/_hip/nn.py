@@ -28,7 +28,8 @@ class _prof(object):
             if LOGICAL is not None:
                 cin, cout = LOGICAL
             self.rec = [kind, n_out_pix * KH * KW * cin * cout, torch.cuda.Event(enable_timing=True),
-                        torch.cuda.Event(enable_timing=True), (n_out_pix, KH, cin, cout), executed, geom]
+                        torch.cuda.Event(enable_timing=True), (n_out_pix, KH, cin, cout), executed, geom,
+                        winograd_pass_tiles()]      # the per-pass tiles in force for THIS call (layers may bracket their own)
 
     def __enter__(self):
         if self.on:
@@ -60,6 +61,18 @@ def workspace(nbytes, device):
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+def winograd_pass_tiles():
+    """(forward, backward-data, backward-filter) Winograd tile settings of the process (mrcnn_conv2d_set_winograd_pass_tiles)."""
+    import ctypes
+    t = (ctypes.c_int * 3)()
+    check(lib().mrcnn_conv2d_get_winograd_pass_tiles(t))
+    return (t[0], t[1], t[2])
+
+
+def set_winograd_pass_tiles(fwd, bwd_data, bwd_filter):
+    check(lib().mrcnn_conv2d_set_winograd_pass_tiles(int(fwd), int(bwd_data), int(bwd_filter)))
 
 
 def conv_out(n, k, s, p):

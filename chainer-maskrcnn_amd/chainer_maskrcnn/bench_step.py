@@ -85,6 +85,24 @@ def bench_step(args, rank, world):
         alt = N * 5 / (time.perf_counter() - t1)
         chain.mask_rows = 'all'
 
+    # opt-in mode: F(4x4) Winograd in the forward pass of the ResNet conv2 layers too (activations still <= 2.2e-4 of
+    # scale, but the gradients of the layers fed by c4 / c5 move by up to 2e-2: profiles/r02_winograd_layer_probe.txt) -
+    # reported, never `value`
+    fast = None
+    if world == 1 and not tiles:
+        from chainer_maskrcnn._hip import lib, check
+        check(lib().mrcnn_conv2d_set_winograd_pass_tiles(0, 0, 0))
+        for _ in range(2):
+            opt.update(chain, imgs, bb, lab, masks, 1.0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            opt.update(chain, imgs, bb, lab, masks, 1.0)
+        torch.cuda.synchronize()
+        fast = N * 5 / (time.perf_counter() - t1)
+        check(lib().mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))
+        opt.update(chain, imgs, bb, lab, masks, 1.0)
+
     # roofline of the dominant kernel family (k_conv_igemm): instrumented steps, HIP events around every launch
     hnn.PROFILE = []
     chain.use_aux_stream = False      # instrumented steps: one stream, every conv launch bracketed by events
@@ -138,6 +156,10 @@ def bench_step(args, rank, world):
     }
     if alt is not None:
         out['config']['images_per_sec_mask_branch_on_positive_rows_only'] = round(alt, 3)
+    if fast is not None:
+        out['config']['images_per_sec_opt_in_winograd_f4_forward'] = round(fast, 3)
+    out['config']['winograd_tiles_fwd_bwddata_bwdfilter'] = tiles or ('2,0,0 (0 = F(4x4) where the layer is large enough, else F(2x2)); the FPN / '
+                                                                      'RPN / head convolutions run their forward pass with 0')
     if dp_report is not None:
         out['config']['allreduce_rank0'] = dp_report
     return out, model, dev
@@ -176,14 +198,16 @@ def _replay_split(recs, n_prof, dev):
     HBM_PEAK = 8000.0
     geoms = {}
     for rec in recs:
-        geoms[(rec[0], rec[6])] = geoms.get((rec[0], rec[6]), 0) + 1
+        geoms[(rec[0], rec[6], rec[7])] = geoms.get((rec[0], rec[6], rec[7]), 0) + 1
     tot = {1: 0.0, 2: 0.0}
     exe, aux_bytes = 0.0, 0.0
     keep = hnn.PROFILE
     hnn.PROFILE = None
+    base = hnn.winograd_pass_tiles()
     try:
-        for (kind, g), cnt in geoms.items():
+        for (kind, g, tiles), cnt in geoms.items():
             cnt = cnt / n_prof
+            hnn.set_winograd_pass_tiles(*tiles)         # the call's own tiles (FPN / RPN / head layers bracket theirs)
             N, H, W, Cin, Cout, KH, KW, stride, pad = g
             Ho, Wo = hnn.conv_out(H, KH, stride, pad), hnn.conv_out(W, KW, stride, pad)
             x = torch.empty((N, H, W, Cin), device=dev).normal_()
@@ -211,6 +235,7 @@ def _replay_split(recs, n_prof, dev):
                 aux_bytes += cnt * ({'fwd': ain + vb + wb + aout, 'bwd_data': aout + wb + vb + ain, 'bwd_filter': aout + wb}[kind])
     finally:
         check(lib().mrcnn_conv2d_set_debug_skip(0))
+        hnn.set_winograd_pass_tiles(*base)
         hnn.PROFILE = keep
     gemm = {'TFLOPs': round(exe / tot[2] / 1e12, 3), 'frac': round(exe / tot[2] / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
             'ms_per_step': round(tot[2] * 1e3, 3)}

@@ -39,9 +39,9 @@ class FeaturePyramidNetwork(object):
         fc = 256 // d
         self.out_channels = fc
         self.toplayer = Conv(self.ps, p + 'toplayer', 2048 // d, fc, 1)
-        self.conv_p4 = Conv(self.ps, p + 'conv_p4', fc, fc, 3, 1, 1)
-        self.conv_p3 = Conv(self.ps, p + 'conv_p3', fc, fc, 3, 1, 1)
-        self.conv_p2 = Conv(self.ps, p + 'conv_p2', fc, fc, 3, 1, 1)
+        self.conv_p4 = Conv(self.ps, p + 'conv_p4', fc, fc, 3, 1, 1, fwd_tile=0)
+        self.conv_p3 = Conv(self.ps, p + 'conv_p3', fc, fc, 3, 1, 1, fwd_tile=0)
+        self.conv_p2 = Conv(self.ps, p + 'conv_p2', fc, fc, 3, 1, 1, fwd_tile=0)
         self.conv_p6 = Conv(self.ps, p + 'conv_p6', fc, fc, 1, 2, 0)
         self.lat_p4 = Conv(self.ps, p + 'lat_p4', 1024 // d, fc, 1)
         self.lat_p3 = Conv(self.ps, p + 'lat_p3', 512 // d, fc, 1)

@@ -61,7 +61,7 @@ class FPNRoIMaskHead(object):
         self.n_class, self.roi_size_box, self.roi_size_mask = n_class, roi_size_box, roi_size_mask
         c = in_channels
         p = prefix + '/'
-        self.conv1 = Conv(self.ps, p + 'conv1', c, c, 3, 1, 1, relu=True)
+        self.conv1 = Conv(self.ps, p + 'conv1', c, c, 3, 1, 1, relu=True, fwd_tile=0)
         self.fc1 = Conv(self.ps, p + 'fc1', c * roi_size_box * roi_size_box, fc_channels, relu=True)
         self.fc2 = Conv(self.ps, p + 'fc2', fc_channels, fc_channels, relu=True)
         # fused [score | loc] linear layer
@@ -74,7 +74,7 @@ class FPNRoIMaskHead(object):
                             init=lambda shape: (lambda rs: np.concatenate([si(rs), li(rs)], 0)))
         mi = 0.01 if mask_initialW is None else mask_initialW
         names = mask_conv_names or ['mask%d' % (i + 1) for i in range(n_mask_convs)]
-        self.mask_convs = [Conv(self.ps, p + nm, c, c, 3, 1, 1, relu=True) for nm in names]
+        self.mask_convs = [Conv(self.ps, p + nm, c, c, 3, 1, 1, relu=True, fwd_tile=0) for nm in names]
         self.mask_out_channels = (n_class - 1) if mask_out_channels is None else mask_out_channels
         self.upsample2x = upsample2x
         # deconv1: W (Cin, Cout, 2, 2) in Chainer == 1x1 conv weight ((a*2+b)*Cout + o, Cin); bias added by the shuffle

@@ -45,7 +45,7 @@ class MultilevelRegionProposalNetwork(object):
         self.n_anchor = A = self.anchor_bases[0].shape[0]
         self.ps = ps if ps is not None else ParamStore()
         init = None if initialW is None else normal(initialW)
-        self.conv = Conv(self.ps, prefix + '/conv', in_channels, mid_channels, 3, 1, 1, relu=True, init=init)
+        self.conv = Conv(self.ps, prefix + '/conv', in_channels, mid_channels, 3, 1, 1, relu=True, init=init, fwd_tile=0)
         # channels [0,4A) = loc (a*4+k), [4A,6A) = score (a*2+c): the reference's `loc` and `score` links fused
         self.head = Conv(self.ps, prefix + '/loc_score', mid_channels, 6 * A, 1, 1, 0, init=init)
         self.train = True

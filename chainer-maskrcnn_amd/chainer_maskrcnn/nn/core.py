@@ -31,6 +31,35 @@ FILTER_GRAD_ON_SIDE_STREAM = True
 # reads per step but the filter gradient then starts after the data gradient (less overlap): same-box A/B 26.80 vs 26.68
 # ms/step (tools/ab_step.py), so it is off.
 WINOGRAD_SHARED_GY_TRANSFORM = False
+# Per-layer Winograd tile of the FORWARD pass.  Measured on the full network (profiles/r02_winograd_layer_probe.txt): the
+# F(4x4,3x3) forward transform costs gradient accuracy ONLY in the ResNet conv2 layers (their 1e-4 output error passes
+# through training-mode BatchNorm and moves c4 / c5, hence the lateral / RPN gradients, by up to 2e-2); in the layers
+# behind the backbone - FPN smoothing convolutions, the RPN convolution, the box / mask / keypoint head convolutions -
+# every gradient stays at the float32 noise floor.  Those layers are built with fwd_tile=0 ("F(4x4) where the map is large
+# enough"); while the process-wide forward setting is the shipped 2 their forward AND backward calls are bracketed with
+# that value (the library reads the setting on the host at call time, and the filter-gradient pass reuses the forward's
+# transformed input only when both used the same tile).  LAYER_TILE_HINTS = False: every layer follows the process-wide
+# setting.  FWD_TILE_RULE: callable(layer name) -> tile or None, overrides the hints (measurement, tools/wino_error_probe.py).
+LAYER_TILE_HINTS = True
+FWD_TILE_RULE = None
+
+
+class _layer_tiles(object):
+    def __init__(self, conv):
+        self.t = FWD_TILE_RULE(conv.name) if FWD_TILE_RULE is not None else (conv.fwd_tile if LAYER_TILE_HINTS else None)
+        self.keep = None
+
+    def __enter__(self):
+        if self.t is None:
+            return
+        cur = hnn.winograd_pass_tiles()
+        if cur[0] == 2 and cur[0] != self.t:
+            self.keep = cur
+            hnn.set_winograd_pass_tiles(self.t, cur[1], cur[2])
+
+    def __exit__(self, *a):
+        if self.keep is not None:
+            hnn.set_winograd_pass_tiles(*self.keep)
 
 
 def join_side_stream(device):
@@ -111,8 +140,8 @@ class Conv(object):
     """
 
     def __init__(self, ps, name, cin, cout, k=1, stride=1, pad=0, bias=True, relu=False, init=None,
-                 cin_p=None, cout_p=None, cout_index=None):
-        self.ps, self.name = ps, name
+                 cin_p=None, cout_p=None, cout_index=None, fwd_tile=None):
+        self.ps, self.name, self.fwd_tile = ps, name, fwd_tile
         self.cin, self.cout, self.k, self.stride, self.pad, self.relu = cin, cout, k, stride, pad, relu
         self.cin_p = cin_p or (4 if cin <= 4 else pad_to(cin, 32))
         self.cout_p = cout_p or pad_to(cout, 32)
@@ -141,8 +170,9 @@ class Conv(object):
         relu = self.relu if relu is None else relu
         hnn.LOGICAL = (self.cin, self.cout)
         # training: layers on the Winograd path keep their transformed input for the filter-gradient pass
-        y, v = hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu, keep_v=True) if TRAIN else \
-            (hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu), None)
+        with _layer_tiles(self):
+            y, v = hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu, keep_v=True) if TRAIN else \
+                (hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu), None)
         hnn.LOGICAL = None
         return y, (x, y if relu else None, v)
 
@@ -152,6 +182,10 @@ class Conv(object):
         gy_masked: the producer of gy already applied this layer's ReLU mask (the layer above ran with mask_gx).
         mask_gx: this layer's input is itself a ReLU output - zero gx where x <= 0 in the data-gradient epilogue,
         which is the ReLU backward of the layer below (call that layer with gy_masked=True)."""
+        with _layer_tiles(self):
+            return self._bwd(ctx, gy, need_gx, gx_acc, accumulate_params, gy_masked, mask_gx)
+
+    def _bwd(self, ctx, gy, need_gx, gx_acc, accumulate_params, gy_masked, mask_gx):
         x, y, v = ctx
         if y is not None and not gy_masked:
             gy = ops.relu_bwd(gy, y)

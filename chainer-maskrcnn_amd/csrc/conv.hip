@@ -1420,6 +1420,12 @@ extern "C" int mrcnn_conv2d_set_winograd_pass_tiles(int fwd, int bwd_data, int b
     return 0;
 }
 
+extern "C" int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3) {
+    if (!tiles3) return mrcnn::fail_arg(MRCNN_E_INVALID, "get_winograd_pass_tiles: null output");
+    for (int i = 0; i < 3; ++i) tiles3[i] = g_wino_pass_tile[i];
+    return 0;
+}
+
 extern "C" int mrcnn_conv2d_set_debug_skip(int mask) {
     if (mask < 0 || mask > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_debug_skip: mask in [0,3]");
     g_debug_skip = mask;

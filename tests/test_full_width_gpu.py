@@ -24,6 +24,7 @@ pytestmark = pytest.mark.gpu
 
 from chainer_maskrcnn import _hip  # noqa: E402
 from chainer_maskrcnn._hip import nn as hnn  # noqa: E402
+from chainer_maskrcnn.nn import core  # noqa: E402
 from chainer_maskrcnn.model.maskrcnn import MaskRCNN  # noqa: E402
 from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss  # noqa: E402
 from chainer_maskrcnn.utils.synthetic import make_batch  # noqa: E402
@@ -33,7 +34,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # name -> (Winograd thresholds (min channels, min pixels, tile), per-pass tiles (forward, backward-data, backward-filter))
 MODES = {'direct': ((100000, 1 << 30, 0), (0, 0, 0)),
          'winograd_f2': ((256, 2048, 2), (0, 0, 0)),
-         'shipped': ((256, 2048, 0), (2, 0, 0)),        # the library default: forward F(2x2), backward F(4x4) where cheaper
+         # the shipped configuration: backward F(4x4) where cheaper; forward F(2x2) in the ResNet, F(4x4) where cheaper in the
+         # FPN / RPN / head convolutions (nn/core.py LAYER_TILE_HINTS, profiles/r02_winograd_layer_probe.txt)
+         'shipped': ((256, 2048, 0), (2, 0, 0)),
+         'uniform_f2_forward': ((256, 2048, 0), (2, 0, 0), False),   # the same without the per-layer hints
          'fast': ((256, 2048, 0), (0, 0, 0))}           # F(4x4) in the forward pass too (opt-in)
 DEFAULT = MODES['shipped']
 NAMES = ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
@@ -89,6 +93,7 @@ def _run(S, mode):
     bt = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(*MODES[mode][0]))
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(*MODES[mode][1]))
+    core.LAYER_TILE_HINTS = MODES[mode][2] if len(MODES[mode]) > 2 else True
     try:
         chain.proposal_target_creator.set_seed(21)
         chain.anchor_target_creator.set_seed(22)
@@ -136,6 +141,7 @@ def _run(S, mode):
     finally:
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(*DEFAULT[0]))
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(*DEFAULT[1]))
+        core.LAYER_TILE_HINTS = True
     # ---- report
     out_dir = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out_dir, exist_ok=True)
@@ -182,7 +188,7 @@ def _check(S, mode):
     assert ratios[len(ratios) // 2] <= 1.3, ratios[len(ratios) // 2]
 
 
-@pytest.mark.parametrize('mode', ['direct', 'winograd_f2', 'shipped', 'fast'])
+@pytest.mark.parametrize('mode', ['direct', 'winograd_f2', 'uniform_f2_forward', 'shipped', 'fast'])
 def test_full_width_512(mode):
     _check(512, mode)
 
