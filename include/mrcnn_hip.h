@@ -147,10 +147,14 @@ long long mrcnn_conv2d_executed_macs(int N, int H, int W, int Cin, int Cout, int
 int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels, int tile);
 /* Per-pass override of the Winograd tile (forward, backward-data, backward-filter): 0 = follow the global tile above,
  * 2 / 4 = forced, -1 = that pass never takes the Winograd path.  Default (2, 0, 0): F(4x4,3x3) amplifies float32 rounding
- * far more than F(2x2,3x3); in the forward pass that shows up as parameter-gradient errors of up to 2e-2 (100x the float32
- * noise floor) through the curvature of the losses, in the backward passes it does not (profiles/r02_winograd_pass_probe.txt).
- * (0, 0, 0) = F(4x4) wherever it is cheaper in every pass: activations still within 2.2e-4, +8 % images/s. */
+ * far more than F(2x2,3x3).  In the forward pass of the ResNet conv2 layers that shows up as parameter-gradient errors of
+ * up to 2e-2 (300x the float32 noise floor) in the layers fed by c4 / c5; in the backward passes, and in the forward pass of
+ * the layers behind the backbone, it does not (profiles/r02_winograd_pass_probe.txt, r02_winograd_layer_probe.txt) - the
+ * host layer therefore brackets the calls of its FPN / RPN / head convolutions with (0, ., .) (nn/core.py: Conv(fwd_tile=0)).
+ * (0, 0, 0) = F(4x4) wherever it is cheaper in every pass of every layer: activations still within 2.2e-4 of their scale.
+ * The setting is read on the host when a convolution entry point is called.  The getter writes the three current values. */
 int mrcnn_conv2d_set_winograd_pass_tiles(int fwd, int bwd_data, int bwd_filter);
+int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3);
 /* Measurement knob for bench.py's roofline split (never set on a product path): bit 0 skips the MFMA GEMM launches of
  * the convolution calls, bit 1 skips every other kernel they launch (Winograd transforms, slab / tail / column sums).
  * Outputs are garbage while a bit is set; 0 restores normal operation. */
