@@ -80,14 +80,17 @@ class BatchLoader(object):
     """Endless iterator of device batches.  ``rank``/``world`` shard the (seeded, per-epoch) permutation."""
 
     def __init__(self, dataset, transform, batch_size=1, shuffle=True, seed=0, rank=0, world=1, num_workers=4,
-                 prefetch=4, max_gt=None, keypoints=False, device=None, skip_empty=True):
+                 prefetch=4, max_gt=None, keypoints=False, device=None, skip_empty=True, start_ticket=0):
         self.dataset, self.transform = dataset, transform
         self.bs, self.shuffle, self.seed, self.rank, self.world = batch_size, shuffle, seed, rank, world
         self.max_gt, self.keypoints, self.device, self.skip_empty = max_gt, keypoints, device, skip_empty
         self._idx = queue.Queue(maxsize=prefetch * batch_size * 2)
         self._out = {}
         self._cv = threading.Condition()
-        self._next_put, self._next_get = 0, 0
+        # start_ticket: resume - the first `start_ticket` examples of the (seeded) sequence are skipped without being
+        # decoded; `ticket` (examples consumed so far) is what a trainer checkpoint stores
+        self._start = int(start_ticket)
+        self._next_put, self._next_get = self._start, self._start
         self._stop = False
         self._threads = [threading.Thread(target=self._feed, daemon=True)]
         self._threads += [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, num_workers))]
@@ -104,6 +107,9 @@ class BatchLoader(object):
         while not self._stop:
             order = np.random.RandomState(self.seed + epoch).permutation(n) if self.shuffle else np.arange(n)
             for i in order[self.rank::self.world]:
+                if ticket < self._start:
+                    ticket += 1
+                    continue
                 while not self._stop:
                     try:
                         self._idx.put((ticket, int(i)), timeout=0.1)
@@ -146,6 +152,11 @@ class BatchLoader(object):
 
     def __iter__(self):
         return self
+
+    @property
+    def ticket(self):
+        """Examples consumed so far (pass as start_ticket to continue the same sequence)."""
+        return self._next_get
 
     def _next_device_batch(self):
         """transform = RawTransform: raw uint8 images / masks are uploaded at their original size and resized on the GPU

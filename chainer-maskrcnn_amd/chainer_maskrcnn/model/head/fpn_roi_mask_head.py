@@ -138,6 +138,7 @@ class FPNRoIMaskHead(object):
         composed = getattr(self, '_composed', None)
         self._composed = None                      # valid for one forward pass: the parameters change every step
         wm, bm, ev = composed if composed is not None else self.compose_deconv(h.device)
+        self._composed = None                      # (compose_deconv parks its result there for the train chain's early call)
         cur = torch.cuda.current_stream(h.device)
         cur.wait_event(ev)                         # composed on another stream at the start of the step
         wm.record_stream(cur)

@@ -150,6 +150,36 @@ class MomentumSGD(object):
                 else:
                     torch.distributed.broadcast(b, src=0)
 
+    # ---- trainer state (checkpoint / resume) -----------------------------------------------------
+    def state_dict(self):
+        """Everything a bit-identical continuation needs: parameters, momentum, BatchNorm running statistics, the
+        update count, the hyper-parameters and the device-resident sampler seeds of the train chain."""
+        ps = self.ps
+        d = {'params': ps.params.detach().cpu(), 'momentum': ps.momentum.detach().cpu(),
+             'buffers': {k: v.detach().cpu() for k, v in ps.buffers.items()},
+             't': self.t, 'lr': self.lr, 'sgd_momentum': self.momentum, 'weight_decay': self.weight_decay, 'samplers': {}}
+        for name in ('proposal_target_creator', 'anchor_target_creator'):
+            c = getattr(self.target, name, None)
+            if c is not None:
+                d['samplers'][name] = {'seed': c.seed, 'state': None if c._state is None else c._state.detach().cpu()}
+        return d
+
+    def load_state_dict(self, d):
+        ps = self.ps
+        if tuple(d['params'].shape) != tuple(ps.params.shape):
+            raise ValueError('trainer state is for a different model: %r parameters, this model has %r'
+                             % (tuple(d['params'].shape), tuple(ps.params.shape)))
+        ps.params.copy_(d['params'])
+        ps.momentum.copy_(d['momentum'])
+        for k, v in d['buffers'].items():
+            ps.buffers[k].copy_(v)
+        self.t, self.lr, self.momentum, self.weight_decay = d['t'], d['lr'], d['sgd_momentum'], d['weight_decay']
+        for name, st in d.get('samplers', {}).items():
+            c = getattr(self.target, name, None)
+            if c is not None:
+                c.seed = st['seed']
+                c._state = None if st['state'] is None else st['state'].to(ps.params.device)
+
     def update(self, lossfun=None, *args, **kwds):
         """Chainer semantics: with ``lossfun`` -> loss = lossfun(*args); backward; update.  Without: update only."""
         loss = None

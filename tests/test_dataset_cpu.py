@@ -231,3 +231,25 @@ def test_batch_loader_order_sharding_and_padding(tiny_coco):
         idx = perm[0::2][k % 2] if k < 2 else None
         assert batch['imgs'][0, :, :shapes[idx][1], :shapes[idx][2]].shape == shapes[idx]
     assert not np.array_equal(r0[0]['imgs'].shape, ()) and r1[0]['imgs'].shape[0] == 1
+
+
+def test_batch_loader_resumes_at_a_ticket(tiny_coco):
+    """Trainer checkpoints store BatchLoader.ticket; a loader built with start_ticket continues the same sequence."""
+    root = str(tiny_coco)
+    ds = COCOMaskLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017')
+    tf = transforms.Transform(_Sizes())
+    ld = BatchLoader(ds, tf, batch_size=1, shuffle=True, seed=3, num_workers=2, max_gt=3)
+    full = [next(ld) for _ in range(8)]
+    assert ld.ticket >= 8
+    ld.close()
+    ld = BatchLoader(ds, tf, batch_size=1, shuffle=True, seed=3, num_workers=2, max_gt=3)
+    for _ in range(3):
+        next(ld)
+    t = ld.ticket
+    ld.close()
+    ld = BatchLoader(ds, tf, batch_size=1, shuffle=True, seed=3, num_workers=2, max_gt=3, start_ticket=t)
+    rest = [next(ld) for _ in range(5)]
+    ld.close()
+    for x, y in zip(full[3:], rest):
+        np.testing.assert_array_equal(x['imgs'], y['imgs'])
+        np.testing.assert_array_equal(x['bboxes'], y['bboxes'])

@@ -51,6 +51,11 @@ def build_parser(keypoints=False):
     parser.add_argument('--log-interval', type=int, default=100)
     parser.add_argument('--snapshot-interval', type=int, default=5000)
     parser.add_argument('--lr-shift-interval', type=int, default=0, help='iterations between lr x0.1 (reference: 2 epochs)')
+    parser.add_argument('--resume', default='', help='trainer_<iteration>.pt written next to the NPZ snapshots: parameters, momentum, '
+                                                     'BN statistics, sampler seeds, iteration and lr - continues bit-identically')
+    parser.add_argument('--profile', type=int, nargs=2, default=None, metavar=('FIRST', 'LAST'),
+                        help='bracket iterations FIRST..LAST with roctx ranges (step / forward+backward / update) for '
+                             '`rocprofv3 --marker-trace --kernel-trace -- python3 train.py ...`')
     return parser
 
 
@@ -97,6 +102,7 @@ def run(args, keypoints=False):
     keys = ('loss', 'rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
     acc = {k: 0.0 for k in keys}
     loader = None
+    resume = torch.load(args.resume, map_location='cpu', weights_only=False) if args.resume else None
     if not args.synthetic:          # train.py:111-126: COCOMaskLoader(category_filter=labels, data_type='2017') + Transform
         from chainer_maskrcnn.dataset.coco_dataset import COCOMaskLoader, COCOKeypointsLoader
         from chainer_maskrcnn.dataset.transforms import RawTransform
@@ -108,27 +114,48 @@ def run(args, keypoints=False):
             data = COCOMaskLoader(anno_dir=args.anno_dir, img_dir=args.img_dir, data_type=args.data_type, category_filter=labels)
             tf = RawTransform(faster_rcnn)
         loader = BatchLoader(data, tf, batch_size=bs, shuffle=True, seed=1234, rank=rank, world=world,
-                             num_workers=args.num_workers, max_gt=args.max_gt or None, keypoints=keypoints, device=dev)
+                             num_workers=args.num_workers, max_gt=args.max_gt or None, keypoints=keypoints, device=dev,
+                             start_ticket=resume['loader_ticket'] if resume else 0)
     pool = []
+    if loader is None:
+        for j in range(8):
+            b = make_batch((j + 1) * world + rank, bs, H, W, G=8, n_fg_class=n_fg, n_keypoints=K)
+            pool.append([torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')])
+    first_it = 1
+    if resume is not None:
+        optimizer.load_state_dict(resume['optimizer'])
+        first_it = resume['iteration'] + 1
+    rtx = _Roctx() if args.profile else None
     t0 = time.time()
-    for it in range(1, args.iteration + 1):
+    for it in range(first_it, args.iteration + 1):
         if loader is not None:
             b = next(loader)
             batch = [b[k] for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')]
             scale = float(b['scales'][0])
         else:           # a small pool of device-resident synthetic batches, cycled (generating one per step is host-bound)
-            if len(pool) < 8:
-                b = make_batch((len(pool) + 1) * world + rank, bs, H, W, G=8, n_fg_class=n_fg, n_keypoints=K)
-                pool.append([torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')])
             batch = pool[it % len(pool)]
             scale = 1.0
-        optimizer.update(model, *batch, scale)
+        if rtx is not None and args.profile[0] <= it <= args.profile[1]:
+            with rtx.range('step %d' % it):
+                with rtx.range('forward+backward'):
+                    if optimizer.sync is not None:
+                        optimizer.sync.begin()
+                    loss = model(*batch, scale)
+                    model.unit_upstream = True
+                    try:
+                        loss.backward()
+                    finally:
+                        model.unit_upstream = False
+                with rtx.range('all-reduce wait + sgd'):
+                    optimizer.update()
+        else:
+            optimizer.update(model, *batch, scale)
         if it % args.log_interval == 0 or it == args.iteration:       # one device->host sync per log interval
             obs = {k: float(v) for k, v in model.observation.items()}
             if any(not np.isfinite(v) for v in obs.values()):
                 raise FloatingPointError('non-finite loss at iteration %d: %r' % (it, obs))
             entry = {'iteration': it, 'lr': optimizer.lr, 'elapsed_time': time.time() - t0,
-                     'images/sec': it * bs * world / (time.time() - t0)}
+                     'images/sec': (it - first_it + 1) * bs * world / (time.time() - t0)}
             entry.update({'main/' + k: v for k, v in obs.items()})
             if rank == 0:
                 log.write(json.dumps(entry) + '\n')
@@ -138,8 +165,37 @@ def run(args, keypoints=False):
             optimizer.lr *= 0.1                                       # ExponentialShift('lr', 0.1), train.py:139-140
         if rank == 0 and it % args.snapshot_interval == 0:
             save_npz(os.path.join(args.out, 'model_%d.npz' % it), faster_rcnn)      # snapshot_object, train.py:134-137
+            torch.save({'iteration': it, 'optimizer': optimizer.state_dict(), 'loader_ticket': loader.ticket if loader is not None else 0},
+                       os.path.join(args.out, 'trainer_%d.pt' % it))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+class _Roctx(object):
+    """roctx ranges through libroctx64 (ROCm's marker API; rocprofv3 --marker-trace shows them over the kernel trace)."""
+
+    def __init__(self):
+        import ctypes
+        self.lib = None
+        for name in ('librocprofiler-sdk-roctx.so', 'libroctx64.so'):
+            try:
+                self.lib = ctypes.CDLL(name)
+                break
+            except OSError:
+                continue
+        if self.lib is None:
+            raise RuntimeError('--profile: neither librocprofiler-sdk-roctx.so nor libroctx64.so can be loaded')
+
+    def range(self, name):
+        rtx = self
+
+        class _R(object):
+            def __enter__(self_):
+                rtx.lib.roctxRangePushA(name.encode())
+
+            def __exit__(self_, *a):
+                rtx.lib.roctxRangePop()
+        return _R()
 
 
 def save_npz(path, faster_rcnn):
