@@ -301,9 +301,10 @@ def rpn_unpack_grad(glocs, gscores, head_shape, A, a_off):
     return ghead
 
 
-def rpn_proposals(locs, scores, anchors, img_size, min_size, n_pre, n_post, nms_thresh, debug=False):
-    """locs (N,A,4), scores (N,A,2), anchors (A,4).  Returns dict of padded device outputs."""
-    _ck(locs, scores, anchors)
+def rpn_proposals(locs, scores, anchors, img_size, min_size, n_pre, n_post, nms_thresh, debug=False, per_image=None):
+    """locs (N,A,4), scores (N,A,2), anchors (A,4).  Returns dict of padded device outputs.
+    per_image: optional (N,3) f32 device tensor (h, w, min_size * scale) - every image clipped / filtered with its own."""
+    _ck(locs, scores, anchors, per_image)
     N, A, _ = locs.shape
     dev = locs.device
     rois = _empty((N * n_post, 4), dev)
@@ -316,7 +317,7 @@ def rpn_proposals(locs, scores, anchors, img_size, min_size, n_pre, n_post, nms_
         dbg = [torch.full((N * npre,), -1, dtype=i32, device=dev), _empty((N * n_post,), dev, i32), _empty((N,), dev, i32)]
     ws = workspace(lib().mrcnn_rpn_proposals_workspace_bytes(N, A, n_pre, n_post), dev)
     check(lib().mrcnn_rpn_proposals_f32(ptr(locs), ptr(scores), ptr(anchors), N, A, float(img_size[0]),
-                                        float(img_size[1]), float(min_size), n_pre, n_post, float(nms_thresh), ptr(rois),
+                                        float(img_size[1]), float(min_size), ptr(per_image), n_pre, n_post, float(nms_thresh), ptr(rois),
                                         ptr(idx), ptr(lev), ptr(cnt), ptr(dbg[0]), ptr(dbg[1]), ptr(dbg[2]), ptr(ws),
                                         ws.numel(), stream_ptr()))
     return dict(rois=rois, roi_indices=idx, levels=lev, n_rois=cnt, sorted_anchor=dbg[0], keep=dbg[1], n_pre=dbg[2])
@@ -410,9 +411,10 @@ def count_valid_labels(labels):
 
 
 def anchor_target(anchors, gt_boxes, n_gt, img_size, keys=None, n_sample=256, pos_iou_thresh=0.7, neg_iou_thresh=0.3,
-                  pos_ratio=0.5):
-    """anchors (A,4), gt_boxes (N,gt_cap,4), keys (N,A) u32 or None (= no subsampling).  Returns (loc (N,A,4), label (N,A))."""
-    _ck(anchors, gt_boxes, n_gt, keys)
+                  pos_ratio=0.5, per_image_hw=None):
+    """anchors (A,4), gt_boxes (N,gt_cap,4), keys (N,A) u32 or None (= no subsampling).  Returns (loc (N,A,4), label (N,A)).
+    per_image_hw: optional (N,2) f32 device tensor - each image's own size for the inside test."""
+    _ck(anchors, gt_boxes, n_gt, keys, per_image_hw)
     A = anchors.shape[0]
     N, gt_cap, _ = gt_boxes.shape
     dev = anchors.device
@@ -420,7 +422,7 @@ def anchor_target(anchors, gt_boxes, n_gt, img_size, keys=None, n_sample=256, po
     label = _empty((N, A), dev, i32)
     ws = workspace(lib().mrcnn_anchor_target_workspace_bytes(N, A), dev)
     check(lib().mrcnn_anchor_target_f32(ptr(anchors), A, ptr(gt_boxes), ptr(n_gt), gt_cap, N, float(img_size[0]),
-                                        float(img_size[1]), ptr(keys), n_sample, pos_iou_thresh, neg_iou_thresh, pos_ratio,
+                                        float(img_size[1]), ptr(per_image_hw), ptr(keys), n_sample, pos_iou_thresh, neg_iou_thresh, pos_ratio,
                                         int(keys is not None), ptr(loc), ptr(label), ptr(ws), ws.numel(), stream_ptr()))
     return loc, label
 

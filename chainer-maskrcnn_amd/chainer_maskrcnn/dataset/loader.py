@@ -24,7 +24,8 @@ def collate(examples, max_gt=None, keypoints=False, size_multiple=64):
     W = max(e[0].shape[2] for e in examples)
     H, W = -(-H // size_multiple) * size_multiple, -(-W // size_multiple) * size_multiple
     out = {'imgs': np.zeros((N, 3, H, W), np.float32), 'bboxes': np.zeros((N, G, 4), np.float32),
-           'labels': np.full((N, G), -1, np.int32), 'scales': np.zeros((N,), np.float32)}
+           'labels': np.full((N, G), -1, np.int32), 'scales': np.zeros((N,), np.float32),
+           'sizes': np.zeros((N, 2), np.float32)}      # each image's own (h, w) inside the zero-padded batch tensor
     if keypoints:
         K = examples[0][3].shape[1] if examples[0][3].ndim == 3 else 17
         out['keypoints'] = np.zeros((N, G, K, 3), np.float32)
@@ -37,6 +38,7 @@ def collate(examples, max_gt=None, keypoints=False, size_multiple=64):
         out['bboxes'][i, :g] = bbox[:g]
         out['labels'][i, :g] = label[:g]
         out['scales'][i] = scale
+        out['sizes'][i] = (h, w)
         if keypoints:
             out['keypoints'][i, :g] = extra[:g]
         else:
@@ -174,6 +176,7 @@ class BatchLoader(object):
         bboxes = np.zeros((N, G, 4), np.float32)
         labels = np.full((N, G), -1, np.int32)
         scales = np.zeros((N,), np.float32)
+        sizes = np.zeros((N, 2), np.float32)
         slot = self._ring.next_slot()
         with torch.cuda.stream(self._stream):
             st = self._stream.cuda_stream
@@ -183,7 +186,7 @@ class BatchLoader(object):
             keep = []
             for i, (img, bbox, label, ext, scale, (oh, ow)) in enumerate(exs):
                 g = min(G, bbox.shape[0])
-                bboxes[i, :g], labels[i, :g], scales[i] = bbox[:g], label[:g], scale
+                bboxes[i, :g], labels[i, :g], scales[i], sizes[i] = bbox[:g], label[:g], scale, (oh, ow)
                 raw = self._ring.upload(slot, 'img%d' % i, img, dev)
                 check(lib().mrcnn_image_resize_u8_f32(ptr(raw), img.shape[0], img.shape[1], ptr(imgs[i]), oh, ow, H, W, 255.0, st))
                 keep.append(raw)
@@ -195,7 +198,7 @@ class BatchLoader(object):
                     keep.append(m)
             out = {'imgs': imgs, 'bboxes': self._ring.upload(slot, 'bboxes', bboxes, dev),
                    'labels': self._ring.upload(slot, 'labels', labels, dev),
-                   'keypoints' if self.keypoints else 'masks': extra, 'scales': scales}
+                   'keypoints' if self.keypoints else 'masks': extra, 'scales': scales, 'sizes': sizes}
             slot['event'] = torch.cuda.Event()
             slot['event'].record(self._stream)
         cur = torch.cuda.current_stream(dev)

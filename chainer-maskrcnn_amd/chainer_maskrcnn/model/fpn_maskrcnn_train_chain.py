@@ -17,6 +17,7 @@ What is different in mechanism:
   * the mask branch runs on the (<= 64 per image) positive rows only by default - identical loss and
     gradients; ``mask_rows='all'`` evaluates all sampled rows like the reference.
 """
+import numpy as np
 import torch
 
 from chainer_maskrcnn._hip import ops
@@ -35,8 +36,8 @@ class AnchorTargetCreator(object):
         self.seed = seed
         self._state = None
 
-    def __call__(self, bbox, anchor, img_size, n_gt=None, keys=None):
-        """bbox (N,G,4) (or (G,4)), anchor (A,4) -> (loc (N,A,4), label (N,A))."""
+    def __call__(self, bbox, anchor, img_size, n_gt=None, keys=None, per_image_hw=None):
+        """bbox (N,G,4) (or (G,4)), anchor (A,4) -> (loc (N,A,4), label (N,A)).  per_image_hw (N,2): each image's own size."""
         if bbox.dim() == 2:
             bbox = bbox[None]
         N, G, _ = bbox.shape
@@ -47,7 +48,7 @@ class AnchorTargetCreator(object):
                 self._state = ops.seed_state(self.seed, bbox.device)
             keys = ops.random_keys_dev((N, anchor.shape[0]), self._state)
         return ops.anchor_target(anchor, bbox.contiguous(), n_gt, img_size, keys, self.n_sample, self.pos_iou_thresh,
-                                 self.neg_iou_thresh, self.pos_ratio)
+                                 self.neg_iou_thresh, self.pos_ratio, per_image_hw=per_image_hw)
 
 
 class _LossHandle(torch.autograd.Function):
@@ -127,16 +128,23 @@ class FPNMaskRCNNTrainChain(object):
         return self._aux[key]
 
     # ------------------------------------------------------------------------------------------
-    def __call__(self, imgs, bboxes, labels, masks, scale, n_gt=None):
+    def __call__(self, imgs, bboxes, labels, masks, scale, n_gt=None, img_sizes=None):
+        """scale: the Transform's resize factor - a number, or one per image (host array or device tensor).  img_sizes:
+        optional (N,2) (h, w) of every image inside the zero-padded batch tensor (dataset/loader.py 'sizes'); with either,
+        proposals are clipped to / anchors tested against each image's OWN size and min_size * its own scale, which is
+        what the reference's batch-1-per-process step does (fpn_maskrcnn_train_chain.py:60-70)."""
         m = self.faster_rcnn
         n = bboxes.shape[0]
         if self.strict_batch1 and n != 1:
             raise ValueError('Currently only batch size 1 is supported. n={}'.format(n))
-        if torch.is_tensor(scale):
+        if torch.is_tensor(scale) and scale.numel() == 1:
             scale = float(scale.reshape(-1)[0].item())
         dev = imgs.device
         _, _, H, W = imgs.shape
         img_size = (H, W)
+        per_hw = None
+        if img_sizes is not None:
+            per_hw = (img_sizes if torch.is_tensor(img_sizes) else torch.from_numpy(np.asarray(img_sizes, np.float32))).to(dev, torch.float32).contiguous()
         i32 = torch.int32
         bboxes = bboxes.contiguous()
         labels = labels.to(i32).contiguous()
@@ -163,13 +171,13 @@ class FPNMaskRCNNTrainChain(object):
             A_ = anchors.shape[0]
             aux.wait_stream(main)
             with torch.cuda.stream(aux):
-                br1['loc'], br1['label'] = self.anchor_target_creator(bboxes, anchors, img_size, n_gt=n_gt, keys=ak)
+                br1['loc'], br1['label'] = self.anchor_target_creator(bboxes, anchors, img_size, n_gt=n_gt, keys=ak, per_image_hw=per_hw)
                 _, br1['g_locs'] = ops.smooth_l1(locs.view(n * A_, 4), 4, br1['loc'].view(n * A_, 4), br1['label'].view(-1),
                                                  n * A_, self.rpn_sigma, out=losses[0])
                 _, br1['g_scores'] = ops.softmax_ce(scores.view(n * A_, 2), br1['label'].view(-1), n * A_, 2, (1, 2, 0, 1),
                                                     out=losses[1])
 
-        r = m.rpn.forward_padded(features, img_size, scale, after_heads=rpn_loss_branch)
+        r = m.rpn.forward_padded(features, per_hw if per_hw is not None else img_size, scale, after_heads=rpn_loss_branch, batch_size=img_size)
         A = r['anchors'].shape[0]
         gt_rpn_loc, gt_rpn_label, g_locs, g_scores = br1['loc'], br1['label'], br1['g_locs'], br1['g_scores']
         # Branch 2 (main stream): proposals -> sampled RoIs and targets

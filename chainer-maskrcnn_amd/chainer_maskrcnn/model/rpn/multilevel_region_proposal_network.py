@@ -59,7 +59,29 @@ class MultilevelRegionProposalNetwork(object):
             self._anchor_cache[key] = torch.from_numpy(np.concatenate(a, axis=0)).to(device)
         return self._anchor_cache[key]
 
-    def forward_padded(self, xs, img_size, scale=1., debug=False, after_heads=None):
+    @staticmethod
+    def per_image_params(N, img_size, scale, min_size, dev):
+        """(N,3) f32 device tensor (h, w, min_size * scale) when the images of the batch differ in size or scale, else None.
+        img_size: (H, W) or an (N,2) array / tensor of each image's own size inside the padded batch; scale: a number or N
+        numbers (host or device).  No device->host copy is made."""
+        sizes = img_size if torch.is_tensor(img_size) else np.asarray(img_size, np.float32)
+        per_size = sizes.ndim == 2
+        per_scale = (torch.is_tensor(scale) and scale.numel() > 1) or (not torch.is_tensor(scale) and np.ndim(scale) > 0 and np.size(scale) > 1)
+        if not per_size and not per_scale:
+            return None
+        out = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        if per_size:
+            out[:, :2] = (sizes if torch.is_tensor(sizes) else torch.from_numpy(np.ascontiguousarray(sizes))).to(dev, torch.float32)
+        else:
+            out[:, 0], out[:, 1] = float(sizes[0]), float(sizes[1])
+        if per_scale:
+            sc = scale if torch.is_tensor(scale) else torch.from_numpy(np.asarray(scale, np.float32))
+            out[:, 2] = sc.to(dev, torch.float32).reshape(N) * float(min_size)
+        else:
+            out[:, 2] = float(min_size) * float(scale)
+        return out
+
+    def forward_padded(self, xs, img_size, scale=1., debug=False, after_heads=None, batch_size=None):
         """xs: NHWC pyramid levels.  Returns a dict: locs (N,A,4), scores (N,A,2), anchors (A,4) and the
         padded proposal outputs of ops.rpn_proposals (rois, roi_indices, levels, n_rois).
         ``after_heads(locs, scores, anchors)`` is called once the head outputs are enqueued and BEFORE the proposal
@@ -85,8 +107,11 @@ class MultilevelRegionProposalNetwork(object):
         pl = self.proposal_layer
         n_pre = pl.n_train_pre_nms if self.train else pl.n_test_pre_nms
         n_post = pl.n_train_post_nms if self.train else pl.n_test_post_nms
-        out = ops.rpn_proposals(locs, scores, anchors, img_size, pl.min_size * scale, n_pre, n_post, pl.nms_thresh,
-                                debug=debug)
+        per_image = self.per_image_params(N, img_size, scale, pl.min_size, dev)
+        if per_image is not None:       # the scalar arguments are unused then; pass the padded size
+            img_size, scale = (batch_size or (xs[0].shape[1] * self.feat_strides[0], xs[0].shape[2] * self.feat_strides[0])), 1.0
+        out = ops.rpn_proposals(locs, scores, anchors, img_size, pl.min_size * float(scale), n_pre, n_post, pl.nms_thresh,
+                                debug=debug, per_image=per_image)
         out.update(locs=locs, scores=scores, anchors=anchors, n_post=n_post)
         return out
 

@@ -67,11 +67,15 @@ __device__ __forceinline__ unsigned orderable(float f) {     // monotone float -
 
 __global__ __launch_bounds__(256) void k_decode(const float *__restrict__ locs, const float *__restrict__ scores,
                                                 const float *__restrict__ anchors, int N, int A, float img_h, float img_w,
-                                                float min_size, float *__restrict__ boxes, u64 *__restrict__ keys, int ib,
-                                                int batched) {
+                                                float min_size, const float *__restrict__ per_image, float *__restrict__ boxes,
+                                                u64 *__restrict__ keys, int ib, int batched) {
     const long long total = (long long)N * A;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int a = (int)(i % A);
+        if (per_image) {            // ragged batch: every image is clipped to its OWN size and filtered with its own min_size * scale
+            const int n = (int)(i / A);
+            img_h = per_image[3 * n]; img_w = per_image[3 * n + 1]; min_size = per_image[3 * n + 2];
+        }
         const float4 an = *reinterpret_cast<const float4 *>(anchors + (size_t)a * 4);
         const float4 l = *reinterpret_cast<const float4 *>(locs + (size_t)i * 4);
         const float h = an.z - an.x, w = an.w - an.y;
@@ -338,8 +342,8 @@ extern "C" size_t mrcnn_rpn_proposals_workspace_bytes(int N, int A, int n_pre, i
 }
 
 extern "C" int mrcnn_rpn_proposals_f32(const float *locs, const float *scores, const float *anchors, int N, int A,
-                                       float img_h, float img_w, float min_size, int n_pre, int n_post,
-                                       float nms_thresh, float *rois, int32_t *roi_indices, float *levels,
+                                       float img_h, float img_w, float min_size, const float *per_image, int n_pre,
+                                       int n_post, float nms_thresh, float *rois, int32_t *roi_indices, float *levels,
                                        int32_t *n_rois, int32_t *dbg_sorted_anchor, int32_t *dbg_keep,
                                        int32_t *dbg_n_pre, void *ws, size_t ws_bytes, void *stream) {
     if (!locs || !scores || !anchors || !rois || !roi_indices || !levels || !n_rois || !ws)
@@ -361,7 +365,7 @@ extern "C" int mrcnn_rpn_proposals_f32(const float *locs, const float *scores, c
     int ib = 1;
     while ((1ll << ib) < A) ++ib;
     hipLaunchKernelGGL(k_decode, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, locs, scores,
-                       anchors, N, A, img_h, img_w, min_size, boxes, keys, ib, 0);
+                       anchors, N, A, img_h, img_w, min_size, per_image, boxes, keys, ib, 0);
     MRCNN_LAUNCH_CHECK();
     // argsort()[::-1][:n_pre] per image: radix select of the n_pre-th key + compaction + bitonic sort in LDS (sort.hip)
     if (int e = mrcnn::top_k_sorted(keys, N, (size_t)A, 33 + ib, 1ull << (ib + 32), n_pre, keys_sorted, (size_t)n_pre + 1, w + L.sort_tmp, st))

@@ -285,10 +285,11 @@ __device__ __forceinline__ bool anchor_inside(const float4 a, float img_h, float
 
 __global__ __launch_bounds__(256) void k_at_iou(const float *__restrict__ anchors, int A, const float *__restrict__ gt_boxes,
                                                 const int32_t *__restrict__ n_gt, int gt_cap, float img_h, float img_w,
-                                                float *__restrict__ max_iou, int32_t *__restrict__ argmax,
-                                                int *__restrict__ gt_max_bits) {
+                                                const float *__restrict__ per_image_hw, float *__restrict__ max_iou,
+                                                int32_t *__restrict__ argmax, int *__restrict__ gt_max_bits) {
     __shared__ float4 sg[AT_GCAP];
     const int img = blockIdx.y;
+    if (per_image_hw) { img_h = per_image_hw[2 * img]; img_w = per_image_hw[2 * img + 1]; }     // ragged batch: own size
     const int G = min(min(n_gt[img], gt_cap), AT_GCAP);
     for (int g = threadIdx.x; g < G; g += 256) sg[g] = *reinterpret_cast<const float4 *>(gt_boxes + ((size_t)img * gt_cap + g) * 4);
     __syncthreads();
@@ -479,8 +480,8 @@ extern "C" size_t mrcnn_anchor_target_workspace_bytes(int N, int A) {
 }
 
 extern "C" int mrcnn_anchor_target_f32(const float *anchors, int A, const float *gt_boxes, const int32_t *n_gt, int gt_cap,
-                                       int N, float img_h, float img_w, const uint32_t *keys, int n_sample,
-                                       float pos_iou_thresh, float neg_iou_thresh, float pos_ratio, int do_sample,
+                                       int N, float img_h, float img_w, const float *per_image_hw, const uint32_t *keys,
+                                       int n_sample, float pos_iou_thresh, float neg_iou_thresh, float pos_ratio, int do_sample,
                                        float *gt_rpn_loc, int32_t *gt_rpn_label, void *ws, size_t ws_bytes,
                                        void *stream) {
     if (!anchors || !gt_boxes || !n_gt || !gt_rpn_loc || !gt_rpn_label || !ws || (do_sample && !keys))
@@ -498,7 +499,7 @@ extern "C" int mrcnn_anchor_target_f32(const float *anchors, int A, const float 
     unsigned *kreq = (unsigned *)(w + L.kreq);
     MRCNN_HIP_TRY(hipMemsetAsync(w + L.gtmax, 0, (L.counts - L.gtmax) + al((size_t)N * 2 * 4), st));
     const dim3 grid(mrcnn::cdiv(A, 256), N);
-    hipLaunchKernelGGL(k_at_iou, grid, dim3(256), 0, st, anchors, A, gt_boxes, n_gt, gt_cap, img_h, img_w, max_iou, argmax, gtmax);
+    hipLaunchKernelGGL(k_at_iou, grid, dim3(256), 0, st, anchors, A, gt_boxes, n_gt, gt_cap, img_h, img_w, per_image_hw, max_iou, argmax, gtmax);
     MRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_at_label, grid, dim3(256), 0, st, anchors, A, gt_boxes, n_gt, gt_cap, max_iou, argmax, gtmax,
                        do_sample ? keys : (const uint32_t *)max_iou, pos_iou_thresh, neg_iou_thresh, gt_rpn_label, skeys, counts);

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 2
+#define MRCNN_ABI_VERSION 3
 
 enum {
     MRCNN_OK = 0,
@@ -317,6 +317,9 @@ int mrcnn_loss_total_f32(const float *losses, int n, float *out, void *stream);
  *   rois (N*n_post,4) yx, zero padded;  roi_indices (N*n_post) = image or -1;  levels f32;  n_rois (N)
  *   dbg_* (nullable): anchor index of each pre-NMS box in sort order (N*n_pre), NMS keep list
  *   (N*n_post, indices into the sort order), pre-NMS count (N).
+ *   per_image (nullable, device, (N,3) f32 = h, w, min_size * scale): a padded batch of images of different sizes - every
+ *   image's boxes are clipped to its own size and filtered with its own scaled min_size, as the reference (batch 1 per
+ *   process, rpn/...:156-164: img_size and scale of THAT image) does; null = img_h / img_w / min_size for all.
  * ---------------------------------------------------------------------------------------- */
 int mrcnn_rpn_pack_f32(const float *head, int N, int HW, int Cp, int A, float *locs, float *scores, int a_off,
                        int Atot, void *stream);
@@ -324,7 +327,7 @@ int mrcnn_rpn_unpack_grad_f32(const float *glocs, const float *gscores, int N, i
                               float *ghead, int a_off, int Atot, void *stream);
 size_t mrcnn_rpn_proposals_workspace_bytes(int N, int A, int n_pre, int n_post);
 int mrcnn_rpn_proposals_f32(const float *locs, const float *scores, const float *anchors, int N, int A,
-                            float img_h, float img_w, float min_size, int n_pre, int n_post, float nms_thresh,
+                            float img_h, float img_w, float min_size, const float *per_image, int n_pre, int n_post, float nms_thresh,
                             float *rois, int32_t *roi_indices, float *levels, int32_t *n_rois,
                             int32_t *dbg_sorted_anchor, int32_t *dbg_keep, int32_t *dbg_n_pre, void *ws,
                             size_t ws_bytes, void *stream);
@@ -366,9 +369,11 @@ int mrcnn_keypoint_target_f32(const float *keypoints, int N, int gt_cap, int K, 
 /* n_gt[i] = number of labels[i, :] >= 0: the per-image gt counts of a padded batch (Chainer concat_examples pads with
  * -1; dataset/loader.py does the same), valid rows first.  Used when the caller passes no counts (train.py:117-125). */
 int mrcnn_count_valid_labels_i32(const int32_t *labels, int N, int G, int32_t *n_gt, void *stream);
+/* per_image_hw (nullable, device, (N,2) f32): each image's own (h, w) for the "anchor inside the image" test of a padded
+ * batch; null = img_h / img_w for all images. */
 size_t mrcnn_anchor_target_workspace_bytes(int N, int A);
 int mrcnn_anchor_target_f32(const float *anchors, int A, const float *gt_boxes, const int32_t *n_gt, int gt_cap,
-                            int N, float img_h, float img_w, const uint32_t *keys, int n_sample,
+                            int N, float img_h, float img_w, const float *per_image_hw, const uint32_t *keys, int n_sample,
                             float pos_iou_thresh, float neg_iou_thresh, float pos_ratio, int do_sample,
                             float *gt_rpn_loc, int32_t *gt_rpn_label, void *ws, size_t ws_bytes, void *stream);
 

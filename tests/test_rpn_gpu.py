@@ -107,6 +107,31 @@ def test_proposals_end_to_end_bit_exact(n_pre, n_post, big):
         np.testing.assert_array_equal(o['levels'].cpu().numpy().reshape(N, n_post)[i, :nk], ob.map_rois_to_fpn_levels(want))
 
 
+def test_proposals_per_image_size_and_scale_equal_separate_calls():
+    """A padded batch of two images of different sizes / resize factors: with per_image (h, w, min_size * scale) every
+    image's proposals are bitwise those of a batch-1 call with its own size - and they are checked against the oracle's
+    ProposalCreator called the way the reference calls it (rpn/multilevel_region_proposal_network.py:156-164: that
+    image's img_size and scale)."""
+    N, n_pre, n_post = 2, 3000, 300
+    feat = [(40, 48), (20, 24), (10, 12), (5, 6), (3, 3)]
+    anchors, locs, scores = _rpn_case(4, N, feat, exact=True)
+    sizes = np.array([[160, 192], [117, 150]], np.float32)
+    scales = np.array([1.0, 1.75], np.float32)
+    per = torch.from_numpy(np.concatenate([sizes, (16.0 * scales)[:, None]], 1).astype(np.float32)).to(DEV)
+    dl, ds, da = (torch.from_numpy(v).to(DEV) for v in (locs, scores, anchors))
+    o = ops.rpn_proposals(dl, ds, da, (160, 192), 16.0, n_pre, n_post, 0.7, per_image=per)
+    for i in range(N):
+        one = ops.rpn_proposals(dl[i:i + 1].contiguous(), ds[i:i + 1].contiguous(), da, tuple(sizes[i]), 16.0 * float(scales[i]), n_pre, n_post, 0.7)
+        nk = int(one['n_rois'][0].item())
+        assert nk == int(o['n_rois'][i].item())
+        got = o['rois'].cpu().numpy().reshape(N, n_post, 4)[i]
+        np.testing.assert_array_equal(got, one['rois'].cpu().numpy())
+        want = ProposalCreator(n_train_pre_nms=n_pre, n_train_post_nms=n_post)(locs[i], scores[i, :, 1], anchors, tuple(sizes[i]), scale=float(scales[i]))
+        np.testing.assert_array_equal(got[:nk], want)
+        assert got[:nk, 2].max() <= sizes[i, 0] and got[:nk, 3].max() <= sizes[i, 1]
+    assert not np.array_equal(o['rois'].cpu().numpy(), ops.rpn_proposals(dl, ds, da, (160, 192), 16.0, n_pre, n_post, 0.7)['rois'].cpu().numpy())
+
+
 def test_proposals_random_scales_decode_tolerance():
     """exp() differs by <= 2 ulp between NumPy and the device: boxes compared with tolerance."""
     N = 1

@@ -263,7 +263,7 @@ def test_exported_loss_functions_are_callable():
     sel = xn[np.arange(n_pos), ln[:n_pos] - 1]
     valid = gn != -1
     want = (np.maximum(sel, 0) - sel * gn + np.log1p(np.exp(-np.abs(sel))))[valid].sum() / valid.sum()
-    assert abs(float(loss) - want) < 1e-5
+    assert abs(float(loss.detach()) - want) < 1e-5
     gwant = np.zeros_like(xn)
     gwant[np.arange(n_pos), ln[:n_pos] - 1] = np.where(valid, (1 / (1 + np.exp(-sel)) - gn) / valid.sum(), 0)
     np.testing.assert_allclose(x.grad.cpu().numpy(), gwant, atol=1e-6)
@@ -317,3 +317,36 @@ def test_ragged_batch_padding_rows_are_ignored():
     src = t_auto['sample_src'][256:256 + int(t_auto['n_sampled'][1])]
     n_roi1 = int(chain.rpn_out['n_rois'][1])
     assert int(src.max()) <= n_roi1
+
+
+def test_padded_batch_uses_each_images_own_size_and_scale():
+    """dataset/loader.py hands over 'scales' (N,) and 'sizes' (N,2): the chain clips proposals to / tests anchors against
+    each image's own size and filters with min_size * its own scale (the reference step is batch 1 per process:
+    fpn_maskrcnn_train_chain.py:60-70).  Image 0 of the batch must see exactly what a scalar call with its size sees."""
+    m, chain = _build('positives')
+    b = _batch(G=3)
+    chain.use_aux_stream = False
+    chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+    A = chain.rpn_out['anchors'].shape[0]
+    from chainer_maskrcnn._hip import ops
+    ak = ops.random_keys((2, A), 78, DEV)
+    sizes = np.array([[128, 160], [100, 131]], np.float32)
+    scales = np.array([1.0, 1.6], np.float32)
+    bb = b['bboxes'].clone()
+    bb[1] = torch.minimum(bb[1], torch.tensor([100., 131., 100., 131.], device=DEV))
+    chain.sampler_keys = (None, ak)
+    chain(b['imgs'], bb, b['labels'], b['masks'], scales, img_sizes=sizes)
+    rois = chain.rpn_out['rois'].reshape(2, -1, 4)
+    n1 = int(chain.rpn_out['n_rois'][1])
+    assert float(rois[1, :n1, 2].max()) <= 100 and float(rois[1, :n1, 3].max()) <= 131
+    hw = rois[1, :n1, 2:] - rois[1, :n1, :2]
+    assert float(hw.min()) >= chain.faster_rcnn.rpn.proposal_layer.min_size * 1.6
+    lab_batch = chain.rpn_targets[1].clone()
+    rois0 = rois[0].clone()
+    # image 1's anchor labels = a batch-1 call with its own size; image 0 is untouched by image 1's smaller size
+    loc1, lab1 = chain.anchor_target_creator(bb[1:2].contiguous(), chain.rpn_out['anchors'], (100, 131), keys=ak[1:2].contiguous())
+    assert torch.equal(lab1[0], lab_batch[1])
+    chain(b['imgs'], bb, b['labels'], b['masks'], 1.0)
+    assert torch.equal(chain.rpn_out['rois'].reshape(2, -1, 4)[0], rois0)
+    assert not torch.equal(chain.rpn_targets[1][1], lab_batch[1])
+    chain.sampler_keys = None

@@ -258,3 +258,28 @@ def test_anchor_target_labels_and_sampling(seed, G):
         got = label[i].cpu().numpy()
         np.testing.assert_array_equal(got, wlab)
         assert (got == 1).sum() <= 128 and (got >= 0).sum() <= 256
+
+
+def test_anchor_target_per_image_sizes_equal_separate_calls():
+    """Padded batch, images of different sizes: the 'anchor inside the image' test uses each image's OWN size
+    (AnchorTargetCreator is called with that image's img_size in the reference, fpn_maskrcnn_train_chain.py:81)."""
+    rs = np.random.RandomState(3)
+    feat = [(48, 64), (24, 32), (12, 16), (6, 8), (3, 4)]
+    anchors = ob.fpn_anchors(feat)
+    A = anchors.shape[0]
+    sizes = np.array([[192, 256], [150, 201]], np.float32)
+    N, gt_cap = 2, 8
+    gt = np.zeros((N, gt_cap, 4), np.float32)
+    n_gt = np.array([5, 3], np.int32)
+    for i in range(N):
+        c = rs.uniform(0.2, 0.8, (n_gt[i], 2)) * sizes[i]
+        hw = np.exp(rs.uniform(np.log(16), np.log(90), (n_gt[i], 2)))
+        gt[i, :n_gt[i]] = np.concatenate([np.maximum(c - hw / 2, 0), np.minimum(c + hw / 2, sizes[i])], 1)
+    keys = rs.randint(0, 2 ** 32, (N, A), dtype=np.uint64).astype(np.uint32)
+    loc, label = ops.anchor_target(_t(anchors), _t(gt), _t(n_gt), (192, 256), keys=_t(keys.view(np.int32)), per_image_hw=_t(sizes))
+    for i in range(N):
+        wl, wlab = ot.anchor_targets_from_keys(gt[i, :n_gt[i]], anchors, tuple(sizes[i]), keys[i])
+        np.testing.assert_array_equal(label[i].cpu().numpy(), wlab)
+        np.testing.assert_allclose(loc[i].cpu().numpy(), wl, rtol=1e-5, atol=1e-5)
+    padded = ops.anchor_target(_t(anchors), _t(gt), _t(n_gt), (192, 256), keys=_t(keys.view(np.int32)))[1]
+    assert not np.array_equal(padded[1].cpu().numpy(), label[1].cpu().numpy())

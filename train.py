@@ -131,16 +131,18 @@ def run(args, keypoints=False):
         if loader is not None:
             b = next(loader)
             batch = [b[k] for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks')]
-            scale = float(b['scales'][0])
+            # every image keeps its own resize factor and its own size inside the padded batch (the reference runs batch 1
+            # per process, so its img_size / scale are always those of THE image: fpn_maskrcnn_train_chain.py:60-70)
+            scale, sizes = b['scales'], b['sizes']
         else:           # a small pool of device-resident synthetic batches, cycled (generating one per step is host-bound)
             batch = pool[it % len(pool)]
-            scale = 1.0
+            scale, sizes = 1.0, None
         if rtx is not None and args.profile[0] <= it <= args.profile[1]:
             with rtx.range('step %d' % it):
                 with rtx.range('forward+backward'):
                     if optimizer.sync is not None:
                         optimizer.sync.begin()
-                    loss = model(*batch, scale)
+                    loss = model(*batch, scale, img_sizes=sizes)
                     model.unit_upstream = True
                     try:
                         loss.backward()
@@ -149,7 +151,7 @@ def run(args, keypoints=False):
                 with rtx.range('all-reduce wait + sgd'):
                     optimizer.update()
         else:
-            optimizer.update(model, *batch, scale)
+            optimizer.update(model, *batch, scale, img_sizes=sizes)
         if it % args.log_interval == 0 or it == args.iteration:       # one device->host sync per log interval
             obs = {k: float(v) for k, v in model.observation.items()}
             if any(not np.isfinite(v) for v in obs.values()):
