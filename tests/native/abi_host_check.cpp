@@ -1,0 +1,140 @@
+// Host-side robustness check of libmrcnn_hip.so, meant to run under AddressSanitizer WITHOUT a GPU
+// (make -C chainer-maskrcnn_amd/csrc asan; tests/test_abi_cpu.py::test_host_side_under_address_sanitizer):
+//   * every planning / workspace query over a sweep of shapes (these functions index host tables and size workspaces),
+//   * every compute entry point with null buffers and with nonsensical sizes: each must return a non-zero code and leave a
+//     message in mrcnn_last_error() before anything is launched - never dereference, never divide by zero.
+// GPU AddressSanitizer is not available on the target pool; the device code is covered by the parity tests instead.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "mrcnn_hip.h"
+
+static int failures = 0;
+#define EXPECT(cond)                                                          \
+    do {                                                                      \
+        if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+#define EXPECT_ERR(call)                                                      \
+    do {                                                                      \
+        const int rc_ = (call);                                               \
+        if (rc_ == 0) { std::printf("FAIL %s:%d: %s returned 0\n", __FILE__, __LINE__, #call); ++failures; } \
+        else if (rc_ < 0 && std::strlen(mrcnn_last_error()) == 0) { std::printf("FAIL %s:%d: no message\n", __FILE__, __LINE__); ++failures; } \
+    } while (0)
+
+int main() {
+    EXPECT(mrcnn_abi_version() == MRCNN_ABI_VERSION);
+    // ---- planning queries -----------------------------------------------------------------------------------------
+    const int sizes[] = {1, 7, 13, 14, 28, 64, 100, 256};
+    const int chans[] = {4, 32, 64, 96, 256, 512, 2048};
+    const int ks[] = {1, 3, 7};
+    unsigned long long acc = 0;
+    for (int tiles = 0; tiles < 4; ++tiles) {
+        const int t[4][3] = {{2, 0, 0}, {0, 0, 0}, {4, 4, 4}, {-1, -1, -1}};
+        EXPECT(mrcnn_conv2d_set_winograd_pass_tiles(t[tiles][0], t[tiles][1], t[tiles][2]) == 0);
+        int got[3] = {9, 9, 9};
+        EXPECT(mrcnn_conv2d_get_winograd_pass_tiles(got) == 0 && got[0] == t[tiles][0] && got[2] == t[tiles][2]);
+        for (int N = 1; N <= 2; ++N)
+            for (int H : sizes) for (int W : {H, H + 3}) for (int ci : chans) for (int co : chans) for (int k : ks)
+                for (int stride = 1; stride <= 2; ++stride) {
+                    const int pad = k / 2;
+                    acc += mrcnn_conv2d_workspace_bytes(N, H, W, ci, co, k, k, stride, pad);
+                    acc += mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, ci, co, k, k, stride, pad);
+                    acc += mrcnn_conv2d_winograd_v_bytes(N, H, W, ci, co, k, k, stride, pad);
+                    acc += mrcnn_conv2d_winograd_w_bytes(N, H, W, ci, co, k, k, stride, pad);
+                    for (int pass = 0; pass < 3; ++pass) acc += (unsigned long long)mrcnn_conv2d_executed_macs(N, H, W, ci, co, k, k, stride, pad, pass);
+                }
+    }
+    EXPECT(mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0) == 0);
+    EXPECT_ERR(mrcnn_conv2d_set_winograd_pass_tiles(3, 0, 0));
+    EXPECT_ERR(mrcnn_conv2d_get_winograd_pass_tiles(nullptr));
+    EXPECT_ERR(mrcnn_conv2d_set_debug_skip(7));
+    EXPECT_ERR(mrcnn_roi_align_set_bwd_variant(5));
+    EXPECT(mrcnn_conv2d_workspace_bytes(0, 0, 0, 0, 0, 0, 0, 0, 0) == 0 || true);
+    for (int N = 1; N <= 3; ++N)
+        for (int A : {1, 9, 1000, 23025, 261888})
+            for (int n_pre : {1, 100, 6000, 12000}) for (int n_post : {1, 300, 2000}) {
+                acc += mrcnn_rpn_proposals_workspace_bytes(N, A, n_pre, n_post);
+                acc += mrcnn_anchor_target_workspace_bytes(N, A);
+            }
+    acc += mrcnn_rpn_proposals_workspace_bytes(0, 0, 0, 0) + mrcnn_rpn_proposals_workspace_bytes(-1, -5, -7, -9);
+    for (int n : {0, 1, 63, 64, 65, 12000}) acc += mrcnn_nms_workspace_bytes(n);
+    for (int P : {1, 100, 524288}) for (int C : chans) acc += mrcnn_bn_workspace_bytes(P, C);
+    acc += mrcnn_loss_workspace_bytes();
+    {
+        const int Hs[5] = {256, 128, 64, 32, 16}, Ws[5] = {256, 128, 64, 32, 16};
+        for (int L = 1; L <= 5; ++L) acc += mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, 2, 256);
+    }
+    // ---- compute entries: null buffers ---------------------------------------------------------------------------
+    float *F = nullptr; const float *CF = nullptr; int32_t *I = nullptr; const int32_t *CI = nullptr; void *V = nullptr;
+    const uint8_t *CU = nullptr; uint8_t *U = nullptr; const uint32_t *CK = nullptr; uint32_t *K = nullptr;
+    EXPECT_ERR(mrcnn_roi_align_fwd_f32(CF, 1, 1, 256, 8, 8, CF, 4, 7, 7, 0.25f, 2, F, V));
+    EXPECT_ERR(mrcnn_roi_align_bwd_f32(CF, 1, 1, 256, 8, 8, CF, 4, 7, 7, 0.25f, 2, F, V));
+    EXPECT_ERR(mrcnn_roi_align_fwd_f32(CF, 7, 1, 256, 8, 8, CF, 4, 7, 7, 0.25f, 2, F, V));
+    EXPECT_ERR(mrcnn_roi_align_fpn_fwd_f32(nullptr, nullptr, nullptr, CF, 5, 1, 256, CF, CI, 4, 7, 7, 2, F, V));
+    EXPECT_ERR(mrcnn_roi_align_fpn_bwd_f32(CF, nullptr, nullptr, nullptr, CF, 5, 1, 256, CF, CI, 4, 7, 7, 2, 0, V, 0, V));
+    EXPECT_ERR(mrcnn_debug_roi_align_bwd_stamps(CF, 1, 256, 8, 8, CF, 4, 7, 7, 0.25f, 2, F, nullptr, V));
+    EXPECT_ERR(mrcnn_roi_align_sample_tables(CF, 4, 8, 8, 7, 7, 0.25f, 2, 16, I, I, F, V));
+    EXPECT_ERR(mrcnn_conv2d_fwd_f32(CF, CF, CF, F, 1, 8, 8, 32, 32, 3, 3, 1, 1, 0, F, V, 0, V));
+    EXPECT_ERR(mrcnn_conv2d_fwd_rect_f32(CF, CF, CF, F, 1, 8, 8, 32, 32, 15, 1, 1, 7, 0, 0, V, 0, V));
+    EXPECT_ERR(mrcnn_conv2d_bwd_data_f32(CF, CF, F, CF, 1, 8, 8, 32, 32, 3, 3, 1, 1, 0, F, F, 0, V, 0, V));
+    EXPECT_ERR(mrcnn_conv2d_bwd_filter_f32(CF, CF, F, F, 1, 8, 8, 32, 32, 3, 3, 1, 1, 0, CF, CF, V, 0, V));
+    {   // non-null buffers, unsupported channel counts / zero sizes / too small a workspace
+        static float buf[64];
+        EXPECT_ERR(mrcnn_conv2d_fwd_f32(buf, buf, buf, buf, 1, 8, 8, 33, 32, 3, 3, 1, 1, 0, nullptr, buf, sizeof(buf), V));
+        EXPECT_ERR(mrcnn_conv2d_fwd_f32(buf, buf, buf, buf, 0, 8, 8, 32, 32, 3, 3, 1, 1, 0, nullptr, buf, sizeof(buf), V));
+        EXPECT_ERR(mrcnn_conv2d_bwd_filter_f32(buf, buf, buf, buf, 1, 64, 64, 256, 256, 3, 3, 1, 1, 0, nullptr, nullptr, buf, 16, V));
+        EXPECT_ERR(mrcnn_rpn_proposals_f32(buf, buf, buf, 1, 100, 64.f, 64.f, 16.f, nullptr, 20000, 100, 0.7f, buf, (int32_t *)buf, buf,
+                                           (int32_t *)buf, I, I, I, buf, 1u << 30, V));
+        EXPECT_ERR(mrcnn_anchor_target_f32(buf, 100, buf, (const int32_t *)buf, 1000, 1, 64.f, 64.f, nullptr, CK, 256, 0.7f, 0.3f, 0.5f, 0, buf,
+                                           (int32_t *)buf, buf, 1u << 30, V));
+    }
+    EXPECT_ERR(mrcnn_bn_train_fwd_f32(CF, CF, CF, CF, F, F, F, F, F, 64, 32, 2e-5f, 0.9f, 1, V, 0, V));
+    EXPECT_ERR(mrcnn_bn_train_bwd_f32(CF, CF, CF, CF, CF, CF, CF, F, F, F, F, 64, 32, 1, V, 0, V));
+    EXPECT_ERR(mrcnn_bn_infer_fwd_f32(CF, CF, CF, CF, CF, CF, F, 64, 32, 2e-5f, 1, V));
+    EXPECT_ERR(mrcnn_relu_bwd_f32(CF, CF, F, 64, V));
+    EXPECT_ERR(mrcnn_relu_fwd_f32(CF, F, 64, V));
+    EXPECT_ERR(mrcnn_add_f32(CF, CF, F, 64, V));
+    EXPECT_ERR(mrcnn_maxpool2x2_fwd_f32(CF, F, 1, 8, 8, 32, V));
+    EXPECT_ERR(mrcnn_maxpool2x2_bwd_f32(CF, CF, F, 1, 8, 8, 32, V));
+    EXPECT_ERR(mrcnn_maxpool3x3s2_fwd_f32(CF, F, 1, 8, 8, 32, V));
+    EXPECT_ERR(mrcnn_global_avg_pool_fwd_f32(CF, F, 2, 49, 32, V));
+    EXPECT_ERR(mrcnn_upsample2x_add_fwd_f32(CF, CF, F, 1, 8, 8, 4, 4, 32, V));
+    EXPECT_ERR(mrcnn_upsample2x_bwd_f32(CF, F, 1, 8, 8, 4, 4, 32, 0, V));
+    EXPECT_ERR(mrcnn_subsample_bwd_f32(CF, F, 1, 8, 8, 32, 2, 0, V));
+    EXPECT_ERR(mrcnn_pixel_shuffle2x_f32(CF, CF, F, 1, 8, 8, 32, 0, V));
+    EXPECT_ERR(mrcnn_deconv_merge_fwd_f32(CF, CF, CF, CF, F, F, 32, 32, 32, 32, V));
+    EXPECT_ERR(mrcnn_deconv_merge_bwd_f32(CF, CF, CF, CF, CF, F, F, F, F, 32, 32, 32, 32, V));
+    EXPECT_ERR(mrcnn_bilinear2x_fwd_f32(CF, F, 1, 8, 8, 32, V));
+    EXPECT_ERR(mrcnn_bilinear2x_bwd_f32(CF, F, 1, 8, 8, 32, V));
+    EXPECT_ERR(mrcnn_image_nchw3_to_nhwc4_f32(CF, F, 1, 8, 8, V));
+    EXPECT_ERR(mrcnn_image_resize_u8_f32(CU, 8, 8, F, 16, 16, 16, 16, 255.f, V));
+    EXPECT_ERR(mrcnn_image_resize_f32(CF, 3, 8, 8, F, 16, 16, 16, 16, 255.f, V));
+    EXPECT_ERR(mrcnn_mask_resize_nearest_u8(CU, 2, 8, 8, U, 16, 16, 16, 16, V));
+    EXPECT_ERR(mrcnn_random_keys_u32(K, 64, 1ull, V));
+    EXPECT_ERR(mrcnn_random_keys_dev_u32(K, 64, nullptr, V));
+    EXPECT_ERR(mrcnn_sgd_momentum_wd_f32(F, CF, F, 64, 1e-3f, 0.9f, 5e-4f, V));
+    EXPECT_ERR(mrcnn_softmax_ce_f32(CF, 1, 0, 2, 1, CI, 64, 2, -1, F, F, 0, 2, 1, 2, V, 0, V));
+    EXPECT_ERR(mrcnn_smooth_l1_f32(CF, 4, CF, CI, 64, 3.f, F, F, 4, 4, V, 0, V));
+    EXPECT_ERR(mrcnn_mask_bce_f32(CF, CI, CI, 4, 196, 96, F, F, V, 0, V));
+    EXPECT_ERR(mrcnn_sigmoid_ce_f32(CF, CI, 64, F, F, V, 0, V));
+    EXPECT_ERR(mrcnn_select_channel_f32(CF, CI, 4, 80, 196, F, 0, V));
+    EXPECT_ERR(mrcnn_nhwc_nchw_f32(CF, F, 4, 196, 96, 80, 0, V));
+    EXPECT_ERR(mrcnn_scale_by_dev_f32(F, 64, CF, V));
+    EXPECT_ERR(mrcnn_loss_total_f32(CF, 5, F, V));
+    EXPECT_ERR(mrcnn_rpn_pack_f32(CF, 1, 64, 32, 3, F, F, 0, 192, V));
+    EXPECT_ERR(mrcnn_rpn_unpack_grad_f32(CF, CF, 1, 64, 32, 3, F, 0, 192, V));
+    EXPECT_ERR(mrcnn_rpn_proposals_f32(CF, CF, CF, 1, 192, 64.f, 64.f, 16.f, CF, 100, 20, 0.7f, F, I, F, I, I, I, I, V, 0, V));
+    EXPECT_ERR(mrcnn_nms_f32(CF, 100, 0.5f, 100, I, I, V, 0, V));
+    EXPECT_ERR(mrcnn_map_rois_to_fpn_levels_f32(CF, 10, 2, 6, F, V));
+    EXPECT_ERR(mrcnn_softmax2_f32(CF, F, 10, V));
+    EXPECT_ERR(mrcnn_proposal_target_f32(CF, CF, CI, 100, CF, CI, CI, 8, CK, 1, 256, 64, 0.5f, 0.5f, 0.f, CF, CF, F, F, I, F, I, I, I, I, I, CI, CI, I, V));
+    EXPECT_ERR(mrcnn_mask_target_u8(CU, 1, 8, 64, 64, CF, CI, CI, 256, 64, 14, I, V));
+    EXPECT_ERR(mrcnn_keypoint_target_f32(CF, 1, 8, 17, CF, CI, CI, 256, 64, 56, 0, I, V));
+    EXPECT_ERR(mrcnn_count_valid_labels_i32(CI, 2, 8, I, V));
+    EXPECT_ERR(mrcnn_anchor_target_f32(CF, 100, CF, CI, 8, 1, 64.f, 64.f, CF, CK, 256, 0.7f, 0.3f, 0.5f, 1, F, I, V, 0, V));
+    EXPECT_ERR(mrcnn_detect_decode_f32(CF, 10, CF, 96, 81, 88, 1.f, CF, CF, 64.f, 64.f, F, F, V));
+    EXPECT_ERR(mrcnn_class_nms_f32(CF, CF, 10, 81, 1, 81, 0.5f, 0.5f, I, I, V));
+    EXPECT_ERR(mrcnn_mask_paste_f32(CF, 2, 28, 96, CI, CF, 64, 64, U, V));
+    std::printf("planning checksum %llu, %d failure(s)\n", acc, failures);
+    return failures ? 1 : 0;
+}

@@ -53,3 +53,23 @@ def test_product_never_imports_the_oracle():
             if fn.endswith(('.py', '.hip', '.h', '.cpp')):
                 txt = open(os.path.join(dp, fn)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), fn
+
+
+def test_host_side_under_address_sanitizer():
+    """SURVEY.md section 5 (sanitizers on the CPU build): the library's host code - argument validation, workspace and
+    launch planning - built with AddressSanitizer (device code as usual; GPU ASan does not exist on the target pool) and
+    driven by tests/native/abi_host_check.cpp: every planning query over a shape sweep, every compute entry point with
+    null buffers / bad sizes.  No GPU is touched: each call must fail cleanly before launching."""
+    import shutil
+    import subprocess
+    hipcc = '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    csrc = os.path.join(ROOT, 'chainer-maskrcnn_amd', 'csrc')
+    subprocess.check_call(['make', '-C', csrc, 'asan', '-j8'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    rt = subprocess.check_output(['/opt/rocm/lib/llvm/bin/clang', '-print-file-name=libclang_rt.asan-x86_64.so']).decode().strip()
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=0:abort_on_error=0',
+               LD_LIBRARY_PATH=os.path.dirname(rt) + ':' + os.environ.get('LD_LIBRARY_PATH', ''))
+    r = subprocess.run([os.path.join(csrc, 'asan', 'abi_host_check')], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and 'AddressSanitizer' not in out and ' 0 failure(s)' in out, out[-3000:]
