@@ -10,6 +10,8 @@ Workloads
             BASELINE.json's metric), whole job (sum over ranks; ranks run independent batches).
   step      BASELINE.json configs[2]: full ResNet50-FPN Mask R-CNN training step, bs=2/GPU,
             1024x1024 (images/sec) - selected automatically once the training path is built.
+  keypoint  BASELINE.json configs[4] per-GPU shape: the Keypoint R-CNN step of train_keypoints.py
+            (17 keypoints, 56x56 heat maps), same batch / image size; a secondary line, never the default.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, measured with HIP
 events inside the timed region on the launch stream; `cpu_baseline` is the NumPy oracle timed
@@ -190,7 +192,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
-    ap.add_argument('--workload', default='auto', choices=['auto', 'roialign', 'step'])
+    ap.add_argument('--workload', default='auto', choices=['auto', 'roialign', 'step', 'keypoint'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mask-rows', default='all', choices=['positives', 'all'])
     ap.add_argument('--graph', type=int, default=0, help='capture the step into a HIP graph (single GPU; measured slower than eager multi-stream launches on ROCm 7.2, so off by default)')
@@ -213,13 +215,14 @@ def main():
                 workload = 'step'
         except ImportError:
             pass
-    if workload == 'step':
+    args.keypoints = workload == 'keypoint'
+    if workload in ('step', 'keypoint'):
         from chainer_maskrcnn.bench_step import bench_step
         args.steps = args.steps or 20
         args.warmup = 3 if args.warmup is None else args.warmup
         args.mask_rows = args.mask_rows
         out, model, dev = bench_step(args, rank, world)
-        if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        if world == 1 and rank == 0 and not args.no_cpu_baseline and not args.keypoints:
             out['cpu_baseline'] = cpu_baseline_step(model, dev)
         if rank == 0:       # second half of BASELINE.json's metric: ROIAlign backward HBM GB/s on configs[1]
             ra = argparse.Namespace(steps=100, warmup=10, no_cpu_baseline=True)

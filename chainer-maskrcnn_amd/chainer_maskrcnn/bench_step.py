@@ -12,7 +12,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense p
 
 def bench_step(args, rank, world):
     from chainer_maskrcnn.model.maskrcnn import MaskRCNN
-    from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss
+    from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss, calc_keypoint_loss
     from chainer_maskrcnn.optimizers import MomentumSGD, WeightDecay
     from chainer_maskrcnn.utils.synthetic import make_batch
     from chainer_maskrcnn._hip import nn as hnn
@@ -24,14 +24,19 @@ def bench_step(args, rank, world):
     if tiles:
         from chainer_maskrcnn._hip import lib, check
         check(lib().mrcnn_conv2d_set_winograd_pass_tiles(*[int(v) for v in tiles.split(',')]))
-    model = MaskRCNN(n_fg_class=80, device=dev, seed=1234)
-    chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows=mask_rows)
+    keypoints = bool(getattr(args, 'keypoints', False))
+    if keypoints:       # BASELINE.json configs[4] per-GPU shape: train_keypoints.py's model (1 class, 17 keypoints, 8 mask convs, 56x56 maps)
+        model = MaskRCNN(n_fg_class=1, n_keypoints=17, head_arch='fpn_keypoint', device=dev, seed=1234)
+        chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_keypoint_loss, binary_mask=False, mask_rows=mask_rows)
+    else:
+        model = MaskRCNN(n_fg_class=80, device=dev, seed=1234)
+        chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows=mask_rows)
     opt = MomentumSGD(lr=1e-3, momentum=0.9).setup(chain)
     opt.add_hook(WeightDecay(0.0005))
     if world > 1:
         opt.enable_data_parallel()
-    b = make_batch(100 + rank, N, H, W, G=8)
-    imgs, bb, lab, masks = (torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'masks'))
+    b = make_batch(100 + rank, N, H, W, G=8, n_fg_class=1 if keypoints else 80, n_keypoints=17 if keypoints else None)
+    imgs, bb, lab, masks = (torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks'))
 
     graphed = None
     mode = 'eager launches'
@@ -131,8 +136,11 @@ def bench_step(args, rank, world):
         'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs[2] ResNet50-FPN Mask R-CNN full fwd+bwd+SGD step, batch 2/GPU, 1024x1024, fp32, '
-                               '8 gt boxes/image, 2000 proposals -> 256 sampled RoIs/image, mask branch on %s rows'
+        'config': {'workload': ('configs[4] per-GPU shape: Keypoint R-CNN (train_keypoints.py: 1 class, 17 keypoints, 8 mask convs, 56x56 heat '
+                                'maps) full fwd+bwd+SGD step, batch 2/GPU, 1024x1024, fp32, 8 gt boxes/image, keypoint branch on %s rows'
+                                if keypoints else
+                                'configs[2] ResNet50-FPN Mask R-CNN full fwd+bwd+SGD step, batch 2/GPU, 1024x1024, fp32, '
+                                '8 gt boxes/image, 2000 proposals -> 256 sampled RoIs/image, mask branch on %s rows')
                                % ('the <=64 positive' if mask_rows == 'positives' else 'all 256 sampled'),
                    'global_batch': N * world, 'launch_mode': mode, 'parallelism': 'dp%d: RCCL all-reduce of the flat gradient buffer in 25 MB '
                    'buckets on a side stream' % world if world > 1 else 'single GPU', 'final_loss': round(loss, 4)},

@@ -3,13 +3,15 @@ reduced test network - against the float64 oracle (oracle/model.py) on whole ima
 
   (i)   activations p2..p6, RPN locs / scores, box-head and mask-head outputs <= 1e-3 of their tensor scale
         (BASELINE.json north_star: "conv activations and losses within 1e-3 relative fp32");
-  (ii)  every parameter gradient < max(1e-3, 3 x floor), floor = the SAME oracle evaluated in float32 on the CPU against
-        its float64 self: the float32 noise of this network (training-mode BatchNorm over a few hundred pixels, ReLU /
+  (ii)  every parameter gradient < max(1e-3, 6 x floor) (see _check), floor = the SAME oracle evaluated in float32 on the CPU
+        against its float64 self - the larger of two float32 realisations (oneDNN convolutions / plain im2col ones, i.e. two
+        summation orders): the float32 noise of this network (training-mode BatchNorm over a few hundred pixels, ReLU /
         max-pool decisions on values within rounding of a tie), which no float32 implementation can beat;
   (iii) the layer with the largest recorded error (res5/b2/conv2/W, profiles/r01_full_width_parity.txt) in isolation:
         the oracle's own x and gy of that layer through mrcnn_conv2d_bwd_filter_f32 <= 2e-5;
-for the direct kernels, Winograd F(2x2,3x3), the shipped configuration (forward F(2x2), backward passes F(4x4) where
-cheaper) and the opt-in 'fast' configuration (F(4x4) in the forward pass too: activation / loss bars only, see _check).
+for the direct kernels, Winograd F(2x2,3x3), the shipped configuration (backward passes F(4x4) where cheaper; forward
+F(2x2) in the ResNet, F(4x4) behind it) and the opt-in 'fast' configuration (F(4x4) in the ResNet's forward pass too:
+activation / loss bars only, see _check) - and for the Keypoint R-CNN of train_keypoints.py (configs[4]) as shipped.
 The per-tensor table is written to gpurun_out/ (committed copy: profiles/r02_full_width_parity_*.txt)."""
 import os
 import time
@@ -26,7 +28,7 @@ from chainer_maskrcnn import _hip  # noqa: E402
 from chainer_maskrcnn._hip import nn as hnn  # noqa: E402
 from chainer_maskrcnn.nn import core  # noqa: E402
 from chainer_maskrcnn.model.maskrcnn import MaskRCNN  # noqa: E402
-from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss  # noqa: E402
+from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss, calc_keypoint_loss  # noqa: E402
 from chainer_maskrcnn.utils.synthetic import make_batch  # noqa: E402
 
 DEV = 'cuda:0'
@@ -45,13 +47,18 @@ TAP = 'extractor/resnet/res5/b2'
 _cache = {}
 
 
-def _model():
-    if 'm' not in _cache:
-        m = MaskRCNN(n_fg_class=80, device=DEV, seed=5)
-        chain = FPNMaskRCNNTrainChain(m, mask_loss_fun=calc_mask_loss, mask_rows='all')
+def _model(keypoints=False):
+    key = 'mk' if keypoints else 'm'
+    if key not in _cache:
+        if keypoints:       # train_keypoints.py's model: 1 class, 17 keypoints, 8 mask convs, 56x56 heat maps
+            m = MaskRCNN(n_fg_class=1, n_keypoints=17, head_arch='fpn_keypoint', device=DEV, seed=5)
+            chain = FPNMaskRCNNTrainChain(m, mask_loss_fun=calc_keypoint_loss, binary_mask=False, mask_rows='all')
+        else:
+            m = MaskRCNN(n_fg_class=80, device=DEV, seed=5)
+            chain = FPNMaskRCNNTrainChain(m, mask_loss_fun=calc_mask_loss, mask_rows='all')
         chain.keep_outputs = True
-        _cache['m'] = (m, chain)
-    return _cache['m']
+        _cache[key] = (m, chain)
+    return _cache[key]
 
 
 def _targets(chain):
@@ -61,13 +68,14 @@ def _targets(chain):
     return t
 
 
-def _oracle(m, t, img4, dtype, tap=None):
+def _oracle(m, t, img4, dtype, tap=None, keypoints=False):
     """One oracle step (forward + backward) in `dtype` on the device's sampled targets."""
     om.set_dtype(dtype)
     try:
         ps = m.ps
         params = {n: ps.p(n).detach().cpu().to(dtype).requires_grad_(True) for n in ps.names()}
-        o = om.OracleStep(params, tuple(len(s) for s in m.extractor.stages), m.head.n_class, m.head.LOC0, tap=tap)
+        kw = dict(mask_conv_names=['mask_convs/%d' % i for i in range(len(m.head.mask_convs))], n_keypoints=17) if keypoints else {}
+        o = om.OracleStep(params, tuple(len(s) for s in m.extractor.stages), m.head.n_class, m.head.LOC0, tap=tap, **kw)
         out = o.losses(img4.to(dtype), t)
         sum(out[k] for k in NAMES).backward()
         grads = {n: (params[n].grad if params[n].grad is not None else torch.zeros_like(params[n])).double() for n in ps.names()}
@@ -85,10 +93,10 @@ def _rel(got, want):
     return float((got.detach().double().cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-30)
 
 
-def _run(S, mode):
+def _run(S, mode, keypoints=False):
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    m, chain = _model()
-    b = make_batch(11, 1, S, S, G=6)
+    m, chain = _model(keypoints)
+    b = make_batch(11, 1, S, S, G=6, n_fg_class=1 if keypoints else 80, n_keypoints=17 if keypoints else None)
     b['bboxes'][:, :, 2:] = np.minimum(b['bboxes'][:, :, 2:], [S, S])
     bt = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(*MODES[mode][0]))
@@ -97,19 +105,24 @@ def _run(S, mode):
     try:
         chain.proposal_target_creator.set_seed(21)
         chain.anchor_target_creator.set_seed(22)
-        loss = chain(bt['imgs'], bt['bboxes'], bt['labels'], bt['masks'], 1.0)
+        loss = chain(bt['imgs'], bt['bboxes'], bt['labels'], bt['keypoints' if keypoints else 'masks'], 1.0)
         outs = {k: ([f.clone() for f in v] if k == 'features' else v.clone()) for k, v in chain.outputs.items()}
         loss.backward()
         obs = {k: float(v) for k, v in chain.observation.items()}
         t = _targets(chain)
         img4 = torch.cat([bt['imgs'].cpu().permute(0, 2, 3, 1), torch.zeros((1, S, S, 1))], -1)
-        key = ('oracle', S)
+        key = ('oracle', S, keypoints)
         if not (key in _cache and _same_targets(_cache[key]['t'], t)):      # proposals can differ between conv paths
             t0 = time.time()
-            o64, out64, g64 = _oracle(m, t, img4, torch.float64, tap=TAP)
-            _, out32, g32 = _oracle(m, t, img4, torch.float32)
+            o64, out64, g64 = _oracle(m, t, img4, torch.float64, tap=TAP, keypoints=keypoints)
+            _, out32, g32 = _oracle(m, t, img4, torch.float32, keypoints=keypoints)
+            # a SECOND float32 realisation of the same step (other convolution kernels => other summation order): a single
+            # realisation under-estimates the rounding noise of individual tensors by up to 40x (head/fc1/W of the
+            # keypoint model: floor 3.7e-4, 3.4e-3 or 1.5e-2 depending on the sampled RoIs of the run)
+            with torch.backends.mkldnn.flags(enabled=False):
+                _, _, g32b = _oracle(m, t, img4, torch.float32, keypoints=keypoints)
             h1, y2 = o64.taps[TAP + '/conv2']
-            _cache[key] = dict(t=t, out=out64, g64=g64, g32=g32, tap=(h1.detach(), y2.grad.detach()), secs=time.time() - t0)
+            _cache[key] = dict(t=t, out=out64, g64=g64, g32=g32, g32b=g32b, tap=(h1.detach(), y2.grad.detach()), secs=time.time() - t0)
         c = _cache[key]
         # ---- (i) activations
         want, acts = c['out'], {}
@@ -120,7 +133,8 @@ def _run(S, mode):
         nc, l0 = m.head.n_class, m.head.LOC0
         acts['roi_scores'] = _rel(outs['box'][:, :nc], want['box'][:, :nc])
         acts['roi_cls_locs'] = _rel(outs['box'][:, l0:l0 + 4], want['box'][:, l0:l0 + 4])
-        acts['mask'] = _rel(outs['mask'][..., :nc - 1], want['mask'][..., :nc - 1])
+        mc = m.head.mask_out_channels
+        acts['mask'] = _rel(outs['mask'][..., :mc], want['mask'][..., :mc])
         losses = {k: abs(obs[k] - float(want[k].detach())) / max(abs(float(want[k].detach())), 1e-3) for k in NAMES}
         # ---- (ii) gradients against the float64 oracle, with the float32 oracle's own error as the noise floor
         ps = m.ps
@@ -130,7 +144,7 @@ def _run(S, mode):
             w64 = c['g64'][n]
             scale = max(float(w64.abs().max()), 1e-3 * gmax)
             err = float((ps.g(n).cpu().double() - w64).abs().max()) / scale
-            floor = float((c['g32'][n] - w64).abs().max()) / scale
+            floor = max(float((c['g32'][n] - w64).abs().max()), float((c['g32b'][n] - w64).abs().max())) / scale
             rows.append((n, err, floor))
         # ---- (iii) the worst layer of round 1 in isolation: oracle x, gy -> device filter gradient
         h1, gy2 = c['tap']
@@ -148,8 +162,9 @@ def _run(S, mode):
     errs = sorted(r[1] for r in rows)
     flo = sorted(r[2] for r in rows)
     q = lambda v, f: v[int(f * (len(v) - 1))]
-    with open(os.path.join(out_dir, 'full_width_parity_%d_%s.txt' % (S, mode)), 'w') as f:
-        f.write('# full ResNet-50-FPN Mask R-CNN, one %dx%d image, conv path %s; oracle float64 + float32 took %.0f s\n' % (S, S, mode, c['secs']))
+    with open(os.path.join(out_dir, 'full_width_parity_%d_%s%s.txt' % (S, mode, '_keypoint' if keypoints else '')), 'w') as f:
+        f.write('# full ResNet-50-FPN %s R-CNN, one' % ('Keypoint' if keypoints else 'Mask'))
+        f.write(' %dx%d image, conv path %s; oracle float64 + float32 took %.0f s\n' % (S, S, mode, c['secs']))
         f.write('# activations, max |device - fp64 oracle| / max |oracle|: %s\n' % ', '.join('%s %.2e' % kv for kv in acts.items()))
         f.write('# losses, relative: %s\n' % ', '.join('%s %.2e' % kv for kv in losses.items()))
         f.write('# isolated %s filter gradient (oracle x, gy -> mrcnn_conv2d_bwd_filter_f32): %.2e\n' % (wname, iso))
@@ -161,8 +176,8 @@ def _run(S, mode):
     return acts, losses, rows, iso
 
 
-def _check(S, mode):
-    acts, losses, rows, iso = _run(S, mode)
+def _check(S, mode, keypoints=False):
+    acts, losses, rows, iso = _run(S, mode, keypoints)
     for k, v in acts.items():
         assert v <= 1e-3, ('activation', k, v)          # BASELINE.json north_star: conv activations within 1e-3 relative
     for k, v in losses.items():
@@ -196,3 +211,9 @@ def test_full_width_512(mode):
 def test_full_width_1024_shipped():
     """BASELINE.json configs[2]'s image size with the shipped (benchmarked) kernel selection."""
     _check(1024, 'shipped')
+
+
+def test_full_width_keypoint_512_shipped():
+    """BASELINE.json configs[4]'s model at full width (train_keypoints.py: 1 class, 17 keypoints, 8 keypoint convolutions,
+    56x56 heat maps, softmax cross-entropy over positions), one 512x512 image, shipped kernel selection: the same bars."""
+    _check(512, 'shipped', keypoints=True)

@@ -1,0 +1,34 @@
+"""Per-queue (HIP stream) busy time of one step from a rocprofv3 kernel trace of bench.py (steps delimited by k_sgd):
+which stream is the critical path, and how much of the other streams' work hides under it."""
+import csv, glob, collections, re, sys
+f = sorted(glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv'))[-1]
+rows = list(csv.DictReader(open(f)))
+ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r['Queue_Id']) for r in rows)
+sg = [e for e in ev if 'k_sgd' in e[2]]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+t0, t1 = sg[k][1], sg[k + 1][1]
+ks = [e for e in ev if e[0] >= t0 and e[1] <= t1]
+print('step wall %.2f ms, %d kernels' % ((t1 - t0) / 1e6, len(ks)))
+byq = collections.defaultdict(list)
+for e in ks: byq[e[3]].append(e)
+for q, es in sorted(byq.items(), key=lambda kv: -sum(e[1] - e[0] for e in kv[1])):
+    busy = sum(e[1] - e[0] for e in es)
+    print('queue %s: %4d kernels, busy %.2f ms, first start +%.2f ms, last end +%.2f ms' % (q, len(es), busy / 1e6, (es[0][0] - t0) / 1e6, (max(e[1] for e in es) - t0) / 1e6))
+# timeline in 1-ms bins: busy fraction per queue
+nb = int((t1 - t0) / 1e6) + 1
+qs = sorted(byq)
+print('ms   ' + ' '.join('%8s' % ('q' + q) for q in qs) + '   any')
+for b in range(nb):
+    a, z = t0 + b * 1e6, t0 + (b + 1) * 1e6
+    row = []
+    for q in qs:
+        row.append(sum(max(0, min(e[1], z) - max(e[0], a)) for e in byq[q]) / 1e6)
+    # union
+    segs = sorted((max(e[0], a), min(e[1], z)) for e in ks if e[1] > a and e[0] < z)
+    u = 0; cs = ce = None
+    for s, e in segs:
+        if ce is None: cs, ce = s, e
+        elif s > ce: u += ce - cs; cs, ce = s, e
+        else: ce = max(ce, e)
+    if ce is not None: u += ce - cs
+    print('%3d  ' % b + ' '.join('%8.2f' % v for v in row) + '  %5.2f' % (u / 1e6))
