@@ -148,37 +148,67 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ sboxe
     mask[((size_t)img * n_pre + i) * nblk + cb] = bits;
 }
 
-// One 1024-thread workgroup per image walks the boxes in order, 64 at a time.  Wave 0 resolves the intra-chunk
-// dependency on the diagonal 64x64 block with scalar bit operations (the next chunk's diagonal words are already in
-// flight); then ALL threads OR the mask rows of the boxes kept in the chunk into the removed set with independent,
-// coalesced loads (one round of memory latency per chunk instead of one per kept box).  The removed set is maintained
-// for a WINDOW of NMS_WIN chunks ahead only: the walk stops at n_post kept boxes, which with few suppressions is after
-// n_post/64 chunks, so rows are not ORed into words that are never reached; when the walk does cross into the next window
-// every box kept so far is applied to that window's words first.
+// One 1024-thread workgroup per image walks the boxes in order.  The walk is a dependency chain (a box is kept iff no
+// earlier KEPT box overlaps it), so what matters is the latency of one link.  Round 1 paid a memory round trip and two
+// barriers per 64-box chunk (~5 us); here wave 0 - the resolver - holds, for the NMS_SC chunks of a super-chunk, the mask
+// words of the next NMS_LA column blocks in registers (lane = box): it resolves the chunks back to back with scalar bit
+// operations on the diagonal words, ORs the rows of the boxes it keeps into the following words with wave reductions
+// (no memory access on the chain), and publishes the kept list.  The other 15 waves then OR those boxes' rows into the
+// removed set for the words BEYOND the resolver's look-ahead while the resolver is already on the next super-chunk: one
+// barrier per super-chunk, the memory latency off the critical path.  The removed set is maintained for a WINDOW of
+// NMS_WIN words ahead only (the walk stops at n_post kept boxes, with few suppressions after n_post/64 chunks); when the
+// walk approaches the window's end every box kept so far is applied to the next window's words first.
 constexpr int NMS_RED_THREADS = 1024;
 constexpr int NMS_WIN = 48;
+constexpr int NMS_SC = 4;           // chunks per super-chunk
+constexpr int NMS_LA = 8;           // column blocks the resolver holds per box: its super-chunk's own NMS_SC and the next NMS_SC
+
+__device__ __forceinline__ u64 wave_or_u64(u64 v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        lo |= (unsigned)__shfl_xor((int)lo, o, 64);
+        hi |= (unsigned)__shfl_xor((int)hi, o, 64);
+    }
+    return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+}
+
 __global__ __launch_bounds__(NMS_RED_THREADS) void k_nms_reduce(const u64 *__restrict__ mask, const int32_t *__restrict__ n_valid,
                                                                 int n_pre, int nblk, int n_post, int32_t *__restrict__ keep,
                                                                 int32_t *__restrict__ n_keep) {
     constexpr int MAXW = 256;      // up to 16384 boxes
+    constexpr int HELPERS = NMS_RED_THREADS - 64;
     __shared__ u64 rem[MAXW];
-    __shared__ int s_list[64];
-    __shared__ int s_cnt, s_kept;
+    __shared__ int s_list[2][NMS_SC * 64];
+    __shared__ int s_cnt[2];
+    __shared__ int s_kept;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = n_valid[img];
     const u64 *mk = mask + (size_t)img * n_pre * nblk;
     int32_t *kp = keep + (size_t)img * n_post;
     for (int w = tid; w < MAXW; w += NMS_RED_THREADS) rem[w] = 0ull;
-    if (tid == 0) { s_kept = 0; s_cnt = 0; }
+    if (tid == 0) { s_kept = 0; s_cnt[0] = 0; s_cnt[1] = 0; }
     __syncthreads();
     const int nb = (n + 63) / 64;
-    u64 Dn = (wave == 0 && lane < n) ? mk[(size_t)lane * nblk] : 0ull;       // diagonal word of chunk 0
-    int wend = min(nb, NMS_WIN);      // rem[] is complete for words < wend
-    for (int c = 0; c < nb; ++c) {
-        int kept = s_kept;
-        if (kept >= n_post) break;
-        if (c >= wend) {              // open the next window (block-uniform): apply every kept box to its words
-            const int wnew = min(nb, wend + NMS_WIN), Wn = wnew - wend, total = kept * Wn;
+    int wend = min(nb, NMS_WIN);      // rem[] receives the helpers' contributions for words < wend
+    // resolver registers: X[j][w] = row of box (g + j) * 64 + lane, column block g + w (only w >= j is ever used: the mask
+    // kernel writes the upper triangle)
+    u64 X[NMS_SC][NMS_LA];
+    auto load_x = [&](int g) {
+#pragma unroll
+        for (int j = 0; j < NMS_SC; ++j)
+#pragma unroll
+            for (int w = 0; w < NMS_LA; ++w) {
+                const int box = (g + j) * 64 + lane, word = g + w;
+                X[j][w] = (w >= j && box < n && word < nb) ? mk[(size_t)box * nblk + word] : 0ull;
+            }
+    };
+    if (wave == 0) load_x(0);
+    int kept_before = 0;
+    for (int g = 0, s = 0; g < nb; g += NMS_SC, ++s) {
+        const int buf = s & 1;
+        if (wend < nb && g + NMS_SC + NMS_LA > wend) {      // block-uniform: open the next window
+            const int wnew = min(nb, wend + NMS_WIN), Wn = wnew - wend, total = kept_before * Wn;
             for (int idx = tid; idx < total; idx += 4 * NMS_RED_THREADS) {
                 u64 v[4];
                 int w[4];
@@ -198,49 +228,84 @@ __global__ __launch_bounds__(NMS_RED_THREADS) void k_nms_reduce(const u64 *__res
             wend = wnew;
         }
         if (wave == 0) {
-            const u64 D = Dn;
-            const int inext = (c + 1) * 64 + lane;
-            Dn = (c + 1 < nb && inext < n) ? mk[(size_t)inext * nblk + (c + 1)] : 0ull;   // prefetch
-            const int cnt = min(64, n - c * 64);
-            const u64 remc = rem[c];      // wave-uniform value: make that provable (scalar loop below)
-            u64 alive = ~(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(remc >> 32)) << 32) |
-                          (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)remc));
-            if (cnt < 64) alive &= (1ull << cnt) - 1ull;
-            const unsigned dlo = (unsigned)D, dhi = (unsigned)(D >> 32);
-            int k = 0;
-            while (alive && kept < n_post) {
-                const int b = __builtin_ctzll(alive);
-                const u64 Db = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
-                               (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, b);
-                alive &= ~Db;
-                alive &= ~(1ull << b);
-                if (lane == 0) { kp[kept] = c * 64 + b; s_list[k] = b; }
-                ++kept; ++k;
-            }
-            if (lane == 0) { s_cnt = k; s_kept = kept; }
-        }
-        __syncthreads();
-        const int K = s_cnt, Wd = wend - c - 1;
-        if (K > 0 && Wd > 0 && s_kept < n_post) {
-            // four independent loads in flight per thread (the loop is latency-bound: ~12 rounds per chunk otherwise)
-            const int total = K * Wd;
-            for (int idx = tid; idx < total; idx += 4 * NMS_RED_THREADS) {
-                u64 v[4];
-                int w[4];
+            // ---- resolver: NMS_SC chunks back to back, everything in registers / LDS words that are already final
+            u64 racc[NMS_LA];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int id = idx + j * NMS_RED_THREADS;
-                    const bool ok = id < total;
-                    const int q = ok ? id / Wd : 0;
-                    w[j] = c + 1 + (ok ? id - q * Wd : 0);
-                    v[j] = ok ? mk[(size_t)(c * 64 + s_list[q]) * nblk + w[j]] : 0ull;
+            for (int w = 0; w < NMS_LA; ++w) racc[w] = 0ull;
+            int kept = kept_before, k = 0;
+#pragma unroll
+            for (int j = 0; j < NMS_SC; ++j) {
+                const int c = g + j;
+                if (c < nb && kept < n_post) {              // wave-uniform
+                    const int cnt = min(64, n - c * 64);
+                    const u64 remc = rem[c];                 // wave-uniform value: make that provable (scalar loop below)
+                    u64 alive = ~((((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(remc >> 32)) << 32) |
+                                   (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)remc)) | racc[j]);
+                    if (cnt < 64) alive &= (1ull << cnt) - 1ull;
+                    const unsigned dlo = (unsigned)X[j][j], dhi = (unsigned)(X[j][j] >> 32);
+                    // Only a box whose diagonal word is non-zero can change the fate of a later box of the chunk, and in
+                    // score order such boxes are rare: the dependency chain visits those alone (ascending), every other
+                    // live box is kept without a step of its own.
+                    const u64 nz = __ballot((dlo | dhi) != 0u);
+                    u64 pend = alive & nz;
+                    while (pend) {
+                        const int b = __builtin_ctzll(pend);
+                        const u64 Db = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                                       (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, b);
+                        alive &= ~Db;
+                        pend &= ~Db;
+                        pend &= ~(1ull << b);
+                    }
+                    // the boxes still alive are kept, in index order, up to n_post in total
+                    const int rank = __popcll(alive & ((1ull << lane) - 1ull));
+                    const bool take = ((alive >> lane) & 1ull) && kept + rank < n_post;
+                    const u64 keptmask = __ballot(take);
+                    if (take) {
+                        kp[kept + rank] = c * 64 + lane;
+                        s_list[buf][k + rank] = c * 64 + lane;
+                    }
+                    const int nk = __popcll(keptmask);
+                    kept += nk; k += nk;
+                    const bool mine = (keptmask >> lane) & 1ull;
+#pragma unroll
+                    for (int w = j + 1; w < NMS_LA; ++w) racc[w] |= wave_or_u64(mine ? X[j][w] : 0ull);
                 }
+            }
+            // the look-ahead words beyond this super-chunk: merged into the removed set (the helpers may be adding to the
+            // same words for older boxes: atomics)
+            if (lane == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (v[j]) atomicOr(&rem[w[j]], v[j]);
+                for (int w = NMS_SC; w < NMS_LA; ++w)
+                    if (g + w < nb && racc[w]) atomicOr(&rem[g + w], racc[w]);
+                s_cnt[buf] = k;
+                s_kept = kept;
+            }
+            if (g + NMS_SC < nb && kept < n_post) load_x(g + NMS_SC);      // in flight across the barrier
+        } else if (s > 0) {
+            // ---- helpers: the boxes kept in the PREVIOUS super-chunk, words beyond the resolver's look-ahead
+            const int pb = buf ^ 1, K = s_cnt[pb], w0 = (g - NMS_SC) + NMS_LA, Wd = wend - w0;
+            if (K > 0 && Wd > 0) {
+                const int total = K * Wd;
+                for (int idx = tid - 64; idx < total; idx += 8 * HELPERS) {
+                    u64 v[8];
+                    int w[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int id = idx + j * HELPERS;
+                        const bool ok = id < total;
+                        const int q = ok ? id / Wd : 0;
+                        w[j] = w0 + (ok ? id - q * Wd : 0);
+                        v[j] = ok ? mk[(size_t)s_list[pb][q] * nblk + w[j]] : 0ull;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (v[j]) atomicOr(&rem[w[j]], v[j]);
+                }
             }
         }
         __syncthreads();
+        kept_before = s_kept;
+        if (kept_before >= n_post) break;
     }
     if (tid == 0) n_keep[img] = s_kept;
 }
