@@ -135,15 +135,23 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ sboxe
     u64 bits = 0ull;
     const int jmax = min(64, n - cb * 64);
     for (int j = 0; j < jmax; ++j) {
-        if (cb * 64 + j <= i) continue;
         const float4 c = cbox[j];
         const float top = fmaxf(b.x, c.x), left = fmaxf(b.y, c.y);
         const float bottom = fminf(b.z, c.z), right = fminf(b.w, c.w);
         const float hgt = fmaxf(bottom - top, 0.f), wid = fmaxf(right - left, 0.f);
         const float ai = hgt * wid;
         const float area_j = (c.z - c.x) * (c.w - c.y);
-        const float iou = ai / ((area_i + area_j) - ai);
-        if (iou >= thresh) bits |= 1ull << j;
+        const float u = (area_i + area_j) - ai;
+        // iou >= thresh with the correctly-rounded division of the reference is decided WITHOUT the division (a dozen
+        // instructions) whenever ai is outside a 4e-7 band around thresh * u: fl(ai / u) >= thresh <=> ai / u >= thresh (1 - 6e-8 ..),
+        // and thresh * u is known to 6e-8.  Inside the band - and for u <= 0, where the sign rules of the division decide -
+        // the wave falls back to the exact expression (rare: a whole-wave branch).
+        const float p = thresh * u;
+        const bool sure_yes = u > 0.f && ai > p * 1.0000004f;
+        const bool sure_no = u > 0.f && ai < p * 0.9999996f;
+        bool hit = sure_yes;
+        if (__any(!sure_yes && !sure_no)) hit = (ai / u) >= thresh;
+        if (hit && cb * 64 + j > i) bits |= 1ull << j;
     }
     mask[((size_t)img * n_pre + i) * nblk + cb] = bits;
 }

@@ -113,24 +113,50 @@ __global__ __launch_bounds__(RS_THREADS) void k_select_final(int levels, int top
 }
 
 // keys >= kth[seg] that carry `valid_bit` are appended (order arbitrary) to cand[seg][...]; count[seg] = how many.
+// A workgroup takes tiles of RS_THREADS * 8 keys: all 8 loads of a thread are issued first, the survivors of the tile are
+// counted through ballots + LDS, and ONE returning atomic per tile reserves their slots (a returning atomic per wave and
+// iteration serialised the kernel on the latency of the counter: 43 us for 2 x 261,888 keys).
 __global__ __launch_bounds__(RS_THREADS) void k_compact_ge(const u64 *__restrict__ keys, size_t seg_len, const u64 *__restrict__ kth,
                                                            u64 valid_bit, int cap, u64 *__restrict__ cand, unsigned *__restrict__ count) {
+    constexpr int PER = 8, NW = RS_THREADS / 64;
+    __shared__ unsigned s_wave[NW][PER];
+    __shared__ unsigned s_base;
     const int seg = blockIdx.y;
     const u64 T = kth[seg];
     const u64 *ks = keys + (size_t)seg * seg_len;
-    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < seg_len; i += (size_t)gridDim.x * RS_THREADS) {
-        const u64 key = ks[i];
-        const bool take = key >= T && (key & valid_bit);
-        // wave-aggregated append: one atomic per wave
-        const u64 bal = __ballot(take);
-        if (bal) {
-            const int lane = threadIdx.x & 63;
-            unsigned base = 0;
-            if (lane == __builtin_ctzll(bal)) base = atomicAdd(&count[seg], (unsigned)__popcll(bal));
-            base = __shfl(base, __builtin_ctzll(bal));
-            const unsigned pos = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-            if (take && pos < (unsigned)cap) cand[(size_t)seg * cap + pos] = key;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t tile = (size_t)RS_THREADS * PER;
+    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < seg_len; t0 += (size_t)gridDim.x * tile) {
+        u64 key[PER];
+        bool take[PER];
+        unsigned before[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const size_t i = t0 + (size_t)j * RS_THREADS + threadIdx.x;
+            key[j] = i < seg_len ? ks[i] : 0ull;
         }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            take[j] = key[j] >= T && (key[j] & valid_bit);
+            const u64 bal = __ballot(take[j]);
+            before[j] = (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave[wave][j] = (unsigned)__popcll(bal);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0;
+            for (int w = 0; w < NW; ++w)
+                for (int j = 0; j < PER; ++j) { const unsigned c = s_wave[w][j]; s_wave[w][j] = tot; tot += c; }
+            s_base = tot ? atomicAdd(&count[seg], tot) : 0u;
+        }
+        __syncthreads();
+        const unsigned base = s_base;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const unsigned pos = base + s_wave[wave][j] + before[j];
+            if (take[j] && pos < (unsigned)cap) cand[(size_t)seg * cap + pos] = key[j];
+        }
+        __syncthreads();
     }
 }
 
@@ -141,7 +167,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_compact_ge(const u64 *__restrict
 // stage of the network walks p = s-1 .. 0 in groups of LB bits).  For NP = 16384: 32 exchanges through LDS instead of the
 // 105 barrier-separated LDS passes of the textbook form (measured 247 us -> see DESIGN.md).  LDS index i is padded by one
 // slot every 32 (8-byte slots: the blocked layout would otherwise put a wave on two banks).
-template <int NP>
+// SLICE: blockIdx.y = slice; the workgroup sorts candidates [slice * NP, (slice + 1) * NP) of its segment and writes all NP
+// keys to out[(seg * gridDim.y + slice) * NP ..] (runs for k_merge_runs).
+template <int NP, bool SLICE = false>
 __global__ __launch_bounds__(1024) void k_sort_desc_lds(const u64 *__restrict__ cand, const unsigned *__restrict__ count, int cap,
                                                         u64 *__restrict__ out, size_t out_stride, int seg_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -151,7 +179,8 @@ __global__ __launch_bounds__(1024) void k_sort_desc_lds(const u64 *__restrict__ 
     constexpr int LB = E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : 4;
     constexpr int NBITS = __builtin_ctz(NP);
     const int seg = blockIdx.x, t = threadIdx.x;
-    const int n = min((int)count[seg], cap);
+    const int base = SLICE ? (int)blockIdx.y * NP : 0;
+    const int n = min((int)count[seg], cap) - base;
     auto phys = [](int i) { return i + (i >> 5); };
     // index of local element e of thread t when the local bits are [b, b + LB)
     auto index_of = [](int t_, int e, int b) { return ((t_ >> b) << (b + LB)) | (e << b) | (t_ & ((1 << b) - 1)); };
@@ -162,7 +191,7 @@ __global__ __launch_bounds__(1024) void k_sort_desc_lds(const u64 *__restrict__ 
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int i = index_of(t, e, 0);
-            v[e] = i < n ? cand[(size_t)seg * cap + i] : 0ull;
+            v[e] = i < n ? cand[(size_t)seg * cap + base + i] : 0ull;
         }
     }
     for (int sbit = 1; sbit <= NBITS; ++sbit) {          // stage: sorted runs of length 2^sbit
@@ -225,7 +254,50 @@ __global__ __launch_bounds__(1024) void k_sort_desc_lds(const u64 *__restrict__ 
         for (int e = 0; e < E; ++e) s[phys(index_of(t, e, b))] = v[e];
     }
     __syncthreads();
+    if (SLICE) {
+        u64 *o = out + ((size_t)seg * gridDim.y + blockIdx.y) * NP;
+        for (int i = t; i < NP; i += 1024) o[i] = s[phys(i)];
+        return;
+    }
     for (int i = t; i < seg_out; i += 1024) out[(size_t)seg * out_stride + i] = i < NP ? s[phys(i)] : 0ull;
+}
+
+// Merge of NR descending runs of RUN keys each (k_sort_desc_lds<RUN, true>) by RANK: a key's position in the merged order is
+// its index in its own run + the number of keys of every other run that precede it - binary searches in LDS, where the
+// workgroup holds all NR runs (NR * RUN * 8 bytes <= 128 KB).  Equal keys (only the zero padding) are ordered by run, then
+// by index, so ranks are a permutation.  Workgroup (r, seg) places run r; 2 launches (slices, merge) sort 16,384 keys on 8
+// CUs per segment in ~1/5 of the time ONE workgroup needs for the whole array.
+constexpr int RUN = 2048;
+template <int NR>
+__global__ __launch_bounds__(1024) void k_merge_runs(const u64 *__restrict__ runs, u64 *__restrict__ out, size_t out_stride, int seg_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *s = reinterpret_cast<u64 *>(smem_raw);
+    const int seg = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
+    const u64 *src = runs + (size_t)seg * NR * RUN;
+    for (int i = t; i < NR * RUN; i += 1024) s[i] = src[i];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < RUN / 1024; ++e) {
+        const int idx = t + e * 1024;
+        const u64 x = s[r * RUN + idx];
+        int rank = idx;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            if (q == r) continue;
+            // descending run q: number of keys > x (q after r) or >= x (q before r) = first index whose key fails the test
+            const u64 *rq = s + q * RUN;
+            int lo = 0, hi = RUN;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const u64 y = rq[mid];
+                const bool before = q < r ? (y >= x) : (y > x);
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < seg_out) out[(size_t)seg * out_stride + rank] = x;
+    }
+    if (r == 0 && t == 0 && seg_out > NR * RUN) out[(size_t)seg * out_stride + NR * RUN] = 0ull;
 }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -265,7 +337,10 @@ __global__ void k_fill_u32(unsigned *p, unsigned v, int n) {
 void fill_u32(unsigned *p, unsigned v, int n, hipStream_t st) { hipLaunchKernelGGL(k_fill_u32, dim3((n + 255) / 256), dim3(256), 0, st, p, v, n); }
 
 size_t topk_ws_bytes(int nseg, int key_bits, int cap) {
-    return select_ws_bytes(nseg, key_bits) + al256((size_t)nseg * 8) + al256((size_t)nseg * 4) + al256((size_t)nseg * cap * 8) + al256((size_t)nseg * 4);
+    int np = 64;
+    while (np < cap) np <<= 1;
+    return select_ws_bytes(nseg, key_bits) + al256((size_t)nseg * 8) + al256((size_t)nseg * 4) + al256((size_t)nseg * cap * 8) + al256((size_t)nseg * 4) +
+           al256(np > RUN ? (size_t)nseg * np * 8 : 0);         // sorted runs of the two-launch sort
 }
 
 // out[seg][0 .. cap) = the (up to) cap largest keys of segment seg that carry valid_bit, in descending order, zero-filled
@@ -281,7 +356,8 @@ int top_k_sorted(const u64 *keys, int nseg, size_t seg_len, int key_bits, u64 va
     u64 *kth = (u64 *)(w + o); o += al256((size_t)nseg * 8);
     unsigned *kreq = (unsigned *)(w + o); o += al256((size_t)nseg * 4);
     u64 *cand = (u64 *)(w + o); o += al256((size_t)nseg * cap * 8);
-    unsigned *count = (unsigned *)(w + o);
+    unsigned *count = (unsigned *)(w + o); o += al256((size_t)nseg * 4);
+    u64 *runs = (u64 *)(w + o);
     fill_u32(kreq, (unsigned)cap, nseg, st);              // k = cap for every segment
     MRCNN_HIP_TRY(hipMemsetAsync(count, 0, (size_t)nseg * 4, st));
     if (int e = select_kth(keys, nseg, seg_len, key_bits, true, kreq, 1, kth, 1, ws, st)) return e;
@@ -291,6 +367,23 @@ int top_k_sorted(const u64 *keys, int nseg, size_t seg_len, int key_bits, u64 va
     const int seg_out = (int)std::min<size_t>(out_stride, (size_t)cap + 1);     // one zero after the keys when there is room
     int np = 64;
     while (np < cap) np <<= 1;
+    if (np > RUN) {
+        // more than one run: slices of RUN keys sorted by np / RUN workgroups per segment, then merged by rank
+        const int nr = np / RUN;
+        const size_t lds_a = (size_t)(RUN + RUN / 32 + 1) * 8, lds_b = (size_t)np * 8;
+        MRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_desc_lds<RUN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+        hipLaunchKernelGGL((k_sort_desc_lds<RUN, true>), dim3(nseg, nr), dim3(1024), lds_a, st, cand, count, cap, runs, (size_t)0, 0);
+        MRCNN_LAUNCH_CHECK();
+#define MERGE_CASE(NRV)                                                                                                     \
+    case NRV:                                                                                                               \
+        MRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_runs<NRV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)); \
+        hipLaunchKernelGGL((k_merge_runs<NRV>), dim3(nseg, NRV), dim3(1024), lds_b, st, runs, out, out_stride, seg_out);    \
+        break;
+        switch (nr) { MERGE_CASE(2) MERGE_CASE(4) MERGE_CASE(8) }
+#undef MERGE_CASE
+        MRCNN_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = (size_t)(np + np / 32 + 1) * 8;
 #define SORT_CASE(NPV)                                                                                                      \
     case NPV:                                                                                                               \
