@@ -92,6 +92,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_proposal_target(
                       : *reinterpret_cast<const float4 *>(gb + (size_t)(c - nr) * 4);
     };
     if (tid < 2) scount[tid] = 0;
+    int np2 = 64;                      // the sorts below run over the next power of two >= the candidate count, not PT_CAP
+    while (np2 < nc) np2 <<= 1;
     __syncthreads();
     // IoU max / first argmax
     for (int c = tid; c < nc; c += PT_THREADS) {
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_proposal_target(
     for (int phase = 0; phase < 2; ++phase) {
         // candidate set of this phase -> composite keys (key, index), others = max
         int local = 0;
-        for (int c = tid; c < PT_CAP; c += PT_THREADS) {
+        for (int c = tid; c < np2; c += PT_THREADS) {
             bool in = false;
             if (c < nc && G > 0) {
                 const float m = smax[c];
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_proposal_target(
         __syncthreads();
         const int avail = scount[phase];
         const int want = phase == 0 ? min(n_pos_max, avail) : min(n_sample - n_pos, avail);
-        bitonic_sort(skey, PT_CAP);
+        bitonic_sort(skey, np2);
         if (n_cand && tid == 0) n_cand[img * 2 + phase] = avail;
         const int32_t *order = phase == 0 ? pos_order : neg_order;
         if (order) {
