@@ -702,26 +702,29 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
         __syncthreads();
     }
 }
-constexpr int CSF_CH = 16;       // channels per block of the final stage: C / 16 blocks (a 256-channel layer: 16, not 4)
-__global__ __launch_bounds__(1024) void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int nb, int C,
-                                                       int accumulate) {
-    constexpr int SL = 1024 / CSF_CH;            // 64 slices, each adds every 64th partial in order (4 loads in flight)
-    __shared__ double sa[SL][CSF_CH];
+// Final stage: 256-thread workgroups (4 channels x 64 slices; slice s adds partials s, s + 64, ... in order, four loads in
+// flight, then the 64 slice sums are added in slice order).  Small workgroups on purpose: this kernel runs on the
+// weight-gradient stream beside the data-gradient GEMMs, whose workgroups hold 3 of the 4 wave slots of every SIMD - a
+// 1024-thread workgroup needs a whole CU to drain before it can start (measured: 20-30 us per launch for a 1-MB reduction).
+constexpr int CSF_CH = 4, CSF_SL = 64;
+__global__ __launch_bounds__(CSF_CH * CSF_SL) void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int nb, int C,
+                                                                 int accumulate) {
+    __shared__ double sa[CSF_SL][CSF_CH];
     const int cl = threadIdx.x % CSF_CH, c = blockIdx.x * CSF_CH + cl, slice = threadIdx.x / CSF_CH;
     double a = 0.0;
     if (c < C) {
         int k = slice;
-        for (; k + 3 * SL < nb; k += 4 * SL) {
-            const float v0 = part[(size_t)k * C + c], v1 = part[(size_t)(k + SL) * C + c];
-            const float v2 = part[(size_t)(k + 2 * SL) * C + c], v3 = part[(size_t)(k + 3 * SL) * C + c];
+        for (; k + 3 * CSF_SL < nb; k += 4 * CSF_SL) {
+            const float v0 = part[(size_t)k * C + c], v1 = part[(size_t)(k + CSF_SL) * C + c];
+            const float v2 = part[(size_t)(k + 2 * CSF_SL) * C + c], v3 = part[(size_t)(k + 3 * CSF_SL) * C + c];
             a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
         }
-        for (; k < nb; k += SL) a += (double)part[(size_t)k * C + c];
+        for (; k < nb; k += CSF_SL) a += (double)part[(size_t)k * C + c];
     }
     sa[slice][cl] = a;
     __syncthreads();
     if (slice == 0 && c < C) {
-        for (int k = 1; k < SL; ++k) a += sa[k][cl];
+        for (int k = 1; k < CSF_SL; ++k) a += sa[k][cl];
         out[c] = (float)a + (accumulate ? out[c] : 0.0f);
     }
 }
@@ -1356,7 +1359,7 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
         float *bias_part = wb ? (float *)(base + L.m) : nullptr;          // M is written only after this kernel has finished
         WINO_LAUNCH(k_wino_gy_dual, g, dim3(nblk), in, V, w_keep, bias_part, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
         if (wb) {
-            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cin, CSF_CH)), dim3(1024), 0, st, bias_part, gbias, nblk, Cin, gbias_accumulate);
+            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cin, CSF_CH)), dim3(CSF_CH * CSF_SL), 0, st, bias_part, gbias, nblk, Cin, gbias_accumulate);
             MRCNN_LAUNCH_CHECK();
         } else if (gbias) {       // channel count that does not tile a 256-thread block: the ordinary two-kernel column sum
             const int P = N * H * W;
@@ -1364,7 +1367,7 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
             float *part = (float *)(base + L.m);
             if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, in, part, P, Cin, cp.G, cp.RPI, cp.rows_per_blk);
             MRCNN_LAUNCH_CHECK();
-            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cin, CSF_CH)), dim3(1024), 0, st, part, gbias, cp.nblk, Cin, gbias_accumulate);
+            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cin, CSF_CH)), dim3(CSF_CH * CSF_SL), 0, st, part, gbias, cp.nblk, Cin, gbias_accumulate);
             MRCNN_LAUNCH_CHECK();
         }
     } else
@@ -1551,7 +1554,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
             const ColPlan cp = col_plan(P, Cout);
             if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, gy, bias_part, P, Cout, cp.G, cp.RPI, cp.rows_per_blk);
             MRCNN_LAUNCH_CHECK();
-            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, CSF_CH)), dim3(1024), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
+            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, CSF_CH)), dim3(CSF_CH * CSF_SL), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
             MRCNN_LAUNCH_CHECK();
         }
         return 0;
@@ -1576,7 +1579,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
         const ColPlan cp = col_plan(P, Cout);
         if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, gy, bias_part, P, Cout, cp.G, cp.RPI, cp.rows_per_blk);
         MRCNN_LAUNCH_CHECK();
-        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, CSF_CH)), dim3(1024), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
+        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, CSF_CH)), dim3(CSF_CH * CSF_SL), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
         MRCNN_LAUNCH_CHECK();
     }
     return 0;

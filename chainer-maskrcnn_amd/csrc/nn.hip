@@ -85,11 +85,13 @@ __global__ __launch_bounds__(NT) void k_bn_stats_partial(const float *__restrict
     }
 }
 
-// Sum of the per-block partials of 64 channels by a 1024-thread block: thread (slice s, channel c) adds partials
-// s, s+16, ... in double, the 16 slice sums are then added in slice order (fixed order => bit-reproducible).
-constexpr int FIN_SLICES = 16;
+// Sum of the per-block partials of FIN_CH channels by a 256-thread block: thread (slice s, channel c) adds partials
+// s, s+16, ... in double, the 16 slice sums are then added in slice order (fixed order => bit-reproducible).  256 threads,
+// not 1024: a workgroup of 16 waves cannot start until a whole CU has drained, and these kernels run beside the
+// weight-gradient GEMMs of the other stream.
+constexpr int FIN_SLICES = 16, FIN_CH = 16;
 __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int nblk, int C, int c, int slice,
-                                                double (*sa)[64], double (*sb)[64], double &a, double &b) {
+                                                double (*sa)[FIN_CH], double (*sb)[FIN_CH], double &a, double &b) {
     a = 0.0; b = 0.0;
     if (c < C) {
         int k = slice;
@@ -108,20 +110,20 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
             b += (double)part[(size_t)k * 2 * C + C + c];
         }
     }
-    sa[slice][threadIdx.x & 63] = a;
-    sb[slice][threadIdx.x & 63] = b;
+    sa[slice][threadIdx.x % FIN_CH] = a;
+    sb[slice][threadIdx.x % FIN_CH] = b;
     __syncthreads();
     if (slice == 0) {
-        for (int k = 1; k < FIN_SLICES; ++k) { a += sa[k][threadIdx.x & 63]; b += sb[k][threadIdx.x & 63]; }
+        for (int k = 1; k < FIN_SLICES; ++k) { a += sa[k][threadIdx.x % FIN_CH]; b += sb[k][threadIdx.x % FIN_CH]; }
     }
 }
 
-__global__ __launch_bounds__(1024) void k_bn_stats_final(const float *__restrict__ x, const float *__restrict__ part,
+__global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_stats_final(const float *__restrict__ x, const float *__restrict__ part,
                                                          int nblk, int P, int C, float eps, float decay,
                                                          float *__restrict__ mean, float *__restrict__ invstd,
                                                          float *__restrict__ run_mean, float *__restrict__ run_var) {
-    __shared__ double sa[FIN_SLICES][64], sb[FIN_SLICES][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    __shared__ double sa[FIN_SLICES][FIN_CH], sb[FIN_SLICES][FIN_CH];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, slice = threadIdx.x / FIN_CH;
     double a, b;
     reduce_partials(part, nblk, C, c, slice, sa, sb, a, b);
     if (slice != 0 || c >= C) return;
@@ -241,10 +243,10 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__
     }
 }
 
-__global__ __launch_bounds__(1024) void k_bn_bwd_final(const float *__restrict__ part, int nblk, int C,
+__global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_bwd_final(const float *__restrict__ part, int nblk, int C,
                                                        float *__restrict__ gbeta, float *__restrict__ ggamma) {
-    __shared__ double sa[FIN_SLICES][64], sb[FIN_SLICES][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    __shared__ double sa[FIN_SLICES][FIN_CH], sb[FIN_SLICES][FIN_CH];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, slice = threadIdx.x / FIN_CH;
     double a, b;
     reduce_partials(part, nblk, C, c, slice, sa, sb, a, b);
     if (slice != 0 || c >= C) return;
@@ -807,7 +809,7 @@ extern "C" int mrcnn_bn_train_fwd_f32(const float *x, const float *gamma, const 
     const RedPlan r = red_plan(P, C);
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(r.nblk), dim3(NT), 0, st, x, P, C, r.G, r.RPI, r.rows_per_blk, (float *)ws);
     MRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_stats_final, dim3(mrcnn::cdiv(C, 64)), dim3(1024), 0, st, x, (const float *)ws, r.nblk, P, C,
+    hipLaunchKernelGGL(k_bn_stats_final, dim3(mrcnn::cdiv(C, FIN_CH)), dim3(FIN_SLICES * FIN_CH), 0, st, x, (const float *)ws, r.nblk, P, C,
                        eps, decay, save_mean, save_invstd, running_mean, running_var);
     MRCNN_LAUNCH_CHECK();
     const size_t n4 = (size_t)P * C / 4;
@@ -831,7 +833,7 @@ extern "C" int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const flo
     hipLaunchKernelGGL(k_bn_bwd_partial, dim3(r.nblk), dim3(NT), 0, st, gy, x, y, gamma, beta, save_mean, save_invstd, P, C, r.G,
                        r.RPI, r.rows_per_blk, rmode, (float *)ws);
     MRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(mrcnn::cdiv(C, 64)), dim3(1024), 0, st, (const float *)ws, r.nblk, C, gbeta, ggamma);
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(mrcnn::cdiv(C, FIN_CH)), dim3(FIN_SLICES * FIN_CH), 0, st, (const float *)ws, r.nblk, C, gbeta, ggamma);
     MRCNN_LAUNCH_CHECK();
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, gy, x, y, gamma, save_mean, save_invstd, gbeta,
