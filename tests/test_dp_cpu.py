@@ -48,15 +48,25 @@ def _worker(rank, world, port, n, bucket_bytes, average, q):
 @pytest.mark.parametrize('n,bucket_bytes,average', [(100003, 64 << 10, False), (4096, 1 << 20, False), (50000, 32 << 10, True)])
 def test_bucketed_allreduce_two_ranks(n, bucket_bytes, average):
     ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, bucket_bytes, average, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    outs = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    outs = None
+    for attempt in range(3):       # the rendezvous port is picked, released and re-bound by rank 0: retried if something else took it
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, n, bucket_bytes, average, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            got = [q.get(timeout=120) for _ in procs]
+        except Exception:
+            got = None
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if got is not None and all(p.exitcode == 0 for p in procs):
+            outs = got
+            break
+    assert outs is not None, 'two-rank gloo group failed three times'
     want = torch.arange(n, dtype=torch.float32) * 3            # rank0 (x1) + rank1 (x2): SUM, like the reference
     if average:
         want = want / 2
