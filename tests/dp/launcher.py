@@ -8,22 +8,32 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def main(out):
+def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def main(out):
     w = os.path.join(HERE, 'worker.py')
     log = open(os.path.join(out, 'log.txt'), 'w')
     rc = subprocess.call([sys.executable, w, 'emu', out], stdout=log, stderr=subprocess.STDOUT)
-    procs = [subprocess.Popen([sys.executable, w, 'dp', str(r), '2', str(port), out], stdout=log, stderr=subprocess.STDOUT)
-             for r in range(2)]
-    for p in procs:
-        try:
-            rc |= p.wait(timeout=600)
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rc |= 1
+    for attempt in range(3):       # the rendezvous port is picked and released here, re-bound by rank 0: retried on a collision
+        port = _free_port()
+        procs = [subprocess.Popen([sys.executable, w, 'dp', str(r), '2', str(port), out], stdout=log, stderr=subprocess.STDOUT)
+                 for r in range(2)]
+        rcd = 0
+        for p in procs:
+            try:
+                rcd |= p.wait(timeout=600)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                rcd |= 1
+        if rcd == 0:
+            break
+    rc |= rcd
     open(os.path.join(out, 'done'), 'w').write(str(rc))
 
 
