@@ -70,13 +70,13 @@ def bench_roialign(args, rank, world):
     lib = _hip.lib()
     algo_bytes = 4 * (N * C * H * W + R * C * PH * PW) + 20 * R
 
-    def fwd():
+    def fwd(sr=2):
         _hip.check(lib.mrcnn_roi_align_fwd_f32(_hip.ptr(xt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
-                                               0.25, 2, _hip.ptr(y), _hip.stream_ptr()))
+                                               0.25, sr, _hip.ptr(y), _hip.stream_ptr()))
 
-    def bwd():
+    def bwd(sr=2):
         _hip.check(lib.mrcnn_roi_align_bwd_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
-                                               0.25, 2, _hip.ptr(gx), _hip.stream_ptr()))
+                                               0.25, sr, _hip.ptr(gx), _hip.stream_ptr()))
 
     for _ in range(args.warmup):
         fwd(); bwd()
@@ -88,6 +88,20 @@ def bench_roialign(args, rank, world):
         ev[k][0].record(); fwd(); ev[k][1].record(); bwd(); ev[k][2].record()
     sync_all(world)
     dt = time.perf_counter() - t0
+    # a second run with the ADAPTIVE sampling grid (sampling_ratio 0 = ceil(roi / pooled) samples
+    # per bin; the reference's configuration is 2) - reported, not part of `value`
+    ad = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for _ in range(3):
+        fwd(0); bwd(0)
+    ad[0].record()
+    for _ in range(20):
+        fwd(0)
+    ad[1].record()
+    for _ in range(20):
+        bwd(0)
+    ad[2].record()
+    torch.cuda.synchronize()
+    adaptive = {'fwd_avg_launch_us': round(ad[0].elapsed_time(ad[1]) / 20 * 1e3, 2), 'bwd_avg_launch_us': round(ad[1].elapsed_time(ad[2]) / 20 * 1e3, 2)}
     fwd_ms = np.array([ev[k][0].elapsed_time(ev[k][1]) for k in range(K)])
     bwd_ms = np.array([ev[k][1].elapsed_time(ev[k][2]) for k in range(K)])
     dt = max_over_ranks(dt, world, dev)
@@ -109,6 +123,7 @@ def bench_roialign(args, rank, world):
                           'achieved_GBps': round(algo_bytes / fwd_avg_s / 1e9, 2),
                           'frac': round(algo_bytes / fwd_avg_s / 1e9 / HBM_PEAK_GBPS, 4), 'kernel': 'k_roi_align_fwd_rows',
                           'traffic': _pmc_traffic('k_roi_align_fwd_rows')},
+        'roi_align_adaptive_sampling': adaptive,
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_roialign(x, yx, gy, algo_bytes)

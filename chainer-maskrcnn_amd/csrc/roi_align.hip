@@ -740,16 +740,9 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
         for (int i = 0; i < PT; ++i)
 #pragma unroll
             for (int k = 0; k < PT; ++k) acc[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (accumulate && live) {
-#pragma unroll
-            for (int i = 0; i < PT; ++i)
-#pragma unroll
-                for (int k = 0; k < PT; ++k)
-                    if (i < nrow && k < ncol) {          // wave-uniform
-                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_gx, vlane, patch_off + (unsigned)((i * W + k) * C) * 4u, 0);
-                        __builtin_memcpy(&acc[i][k], &v, 16);
-                    }
-        }
+        // accumulate: the old values are read at the END, and only by patches that received an entry - most patches of the
+        // fine levels are touched by no RoI at all (a step's RoIs sit on the coarse levels) and then cost no traffic
+        bool touched = false;
         int qn = 0;
 #pragma nounroll
         for (int seg = 0; seg < R; seg += W2_SEG) {
@@ -838,6 +831,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
                         lds.q.row[pos] = (r * PH + ph) * PW + pw;
                     }
                     qn += __popcll(bal);
+                    touched = touched || bal != 0ull;
                 }
             }
         }
@@ -848,6 +842,27 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
         if (STAMP) st_drain += stamp_now() - st_tmp;
         unsigned long long st_store = 0;
         if (STAMP) st_store = stamp_now();
+        if (accumulate) {
+            // gx += acc for the patches that received an entry, with no-return float atomics: this wave is the ONLY writer of
+            // its cells (owner-computes), so the result is the single IEEE addition old + acc whatever the hardware's
+            // order - and neither a second set of 16 float4 registers (the 64 accumulators fill the budget) nor a
+            // load -> add -> store round trip is needed.
+            // Idle lanes (C < 256 or a channel tail) are masked off by a real branch: the out-of-range-offset trick of the
+            // loads and stores is NOT safe for atomics (an out-of-range buffer atomic raised a hardware exception).
+            if (touched && act) {
+#pragma unroll
+                for (int i = 0; i < PT; ++i)
+#pragma unroll
+                    for (int k = 0; k < PT; ++k)
+                        if (i < nrow && k < ncol) {      // wave-uniform
+                            const unsigned so = patch_off + (unsigned)((i * W + k) * C) * 4u;
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].x, rs_gx, vlane, so, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].y, rs_gx, vlane + 4u, so, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].z, rs_gx, vlane + 8u, so, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].w, rs_gx, vlane + 12u, so, 0);
+                        }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < PT; ++i)
 #pragma unroll

@@ -51,6 +51,8 @@ def build_parser(keypoints=False):
     parser.add_argument('--log-interval', type=int, default=100)
     parser.add_argument('--snapshot-interval', type=int, default=5000)
     parser.add_argument('--lr-shift-interval', type=int, default=0, help='iterations between lr x0.1 (reference: 2 epochs)')
+    parser.add_argument('--grad-average', type=int, default=0, help='multi GPU: 1 = average the gradients over the ranks (extension); '
+                                                                   '0 = sum them with the un-scaled lr, as the reference does')
     parser.add_argument('--resume', default='', help='trainer_<iteration>.pt written next to the NPZ snapshots: parameters, momentum, '
                                                      'BN statistics, sampler seeds, iteration and lr - continues bit-identically')
     parser.add_argument('--profile', type=int, nargs=2, default=None, metavar=('FIRST', 'LAST'),
@@ -94,7 +96,7 @@ def run(args, keypoints=False):
     optimizer.setup(model)
     optimizer.add_hook(WeightDecay(rate=0.0005))
     if world > 1:
-        optimizer.enable_data_parallel()
+        optimizer.enable_data_parallel(average=bool(args.grad_average))
     bs = args.batch_size
     H, W = args.image_size
     os.makedirs(args.out, exist_ok=True)
