@@ -102,6 +102,23 @@ def conv2d_fwd_raw(x, w, b, stride, pad, relu, keep_v=False):
     return (y, v) if keep_v else y
 
 
+def conv2d_fwd_bnstats_raw(x, w, stride, pad):
+    """Forward convolution (no bias, no ReLU) whose epilogue also produces the BatchNorm statistics partials of its output:
+    returns (y, part (rows, 2, Cout)) - or None when this geometry has no fused-statistics launch (Winograd / split-K / tail
+    split: mrcnn_conv2d_bnstats_rows == 0); the caller then takes the plain path."""
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    rows = lib().mrcnn_conv2d_bnstats_rows(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    if rows == 0:
+        return None
+    assert x.is_contiguous() and w.is_contiguous()
+    y = torch.empty((N, conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad), Cout), dtype=torch.float32, device=x.device)
+    part = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
+    with _prof('fwd', N * y.shape[1] * y.shape[2], KH, KW, Cin, Cout, (N, H, W, Cin, Cout, KH, KW, stride, pad)):
+        check(lib().mrcnn_conv2d_fwd_bnstats_f32(ptr(x), ptr(w), ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, ptr(part), stream_ptr()))
+    return y, part
+
+
 def winograd_w_bytes(x_shape, w_shape, stride, pad):
     N, H, W, Cin = x_shape
     Cout, KH, KW, _ = w_shape

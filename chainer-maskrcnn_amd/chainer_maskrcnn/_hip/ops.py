@@ -44,6 +44,19 @@ def bn_train_fwd(x, gamma, beta, residual=None, relu=False, running_mean=None, r
     return y, mean, invstd
 
 
+def bn_train_fwd_stats(x, part, gamma, beta, residual=None, relu=False, running_mean=None, running_var=None, eps=2e-5, decay=0.9):
+    """bn_train_fwd from the partial statistics (rows, 2, C) the producing convolution's epilogue left (hnn.conv2d_fwd_bnstats_raw)."""
+    _ck(x, part, gamma, beta, residual)
+    C = x.shape[-1]
+    P = x.numel() // C
+    y = torch.empty_like(x)
+    mean = _empty((C,), x.device)
+    invstd = _empty((C,), x.device)
+    check(lib().mrcnn_bn_train_fwd_stats_f32(ptr(x), ptr(part), part.shape[0], ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean),
+                                             ptr(invstd), ptr(running_mean), ptr(running_var), P, C, eps, decay, int(relu), stream_ptr()))
+    return y, mean, invstd
+
+
 def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu=False, want_gres=False, beta=None):
     """y None + beta given (BN + ReLU without residual): the ReLU mask is recomputed from x."""
     _ck(gy, x, y, gamma, mean, invstd, beta)

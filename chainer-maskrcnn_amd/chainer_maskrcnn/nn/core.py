@@ -42,6 +42,8 @@ WINOGRAD_SHARED_GY_TRANSFORM = False
 # setting.  FWD_TILE_RULE: callable(layer name) -> tile or None, overrides the hints (measurement, tools/wino_error_probe.py).
 LAYER_TILE_HINTS = True
 FWD_TILE_RULE = None
+# BatchNorm statistics from the producing convolution's GEMM epilogue (mrcnn_conv2d_fwd_bnstats_f32) where the launch allows
+FUSE_BN_STATS = True
 
 
 class _layer_tiles(object):
@@ -166,9 +168,19 @@ class Conv(object):
     def b(self):
         return self.ps.p(self.name + '/b') if self.has_bias else None
 
-    def fwd(self, x, relu=None):
+    def fwd(self, x, relu=None, bn_stats=False):
+        """bn_stats: the output feeds a training-mode BatchNorm - where the geometry allows, the GEMM epilogue also leaves the
+        statistics partials in ``self.last_bn_part`` (None otherwise) and BatchNorm.fwd skips its statistics pass."""
         relu = self.relu if relu is None else relu
+        self.last_bn_part = None
         hnn.LOGICAL = (self.cin, self.cout)
+        if bn_stats and FUSE_BN_STATS and TRAIN and not relu and not self.has_bias:
+            with _layer_tiles(self):
+                res = hnn.conv2d_fwd_bnstats_raw(x, self.W, self.stride, self.pad)
+            if res is not None:
+                hnn.LOGICAL = None
+                y, self.last_bn_part = res
+                return y, (x, None, None)
         # training: layers on the Winograd path keep their transformed input for the filter-gradient pass
         with _layer_tiles(self):
             y, v = hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu, keep_v=True) if TRAIN else \
@@ -258,14 +270,18 @@ class BatchNorm(object):
         ps.register(name + '/avg_mean', (c,), lambda rs: np.zeros((c,), np.float32), trainable=False)
         ps.register(name + '/avg_var', (c,), lambda rs: np.ones((c,), np.float32), trainable=False)
 
-    def fwd(self, x, relu=False, residual=None):
+    def fwd(self, x, relu=False, residual=None, partials=None):
         gamma, beta = self.ps.p(self.name + '/gamma'), self.ps.p(self.name + '/beta')
         if not TRAIN:
             y = ops.bn_infer_fwd(x, gamma, beta, self.ps.buffers[self.name + '/avg_mean'],
                                  self.ps.buffers[self.name + '/avg_var'], residual, relu)
             return y, None
-        y, mean, invstd = ops.bn_train_fwd(x, gamma, beta, residual, relu, self.ps.buffers[self.name + '/avg_mean'],
-                                           self.ps.buffers[self.name + '/avg_var'])
+        if partials is not None and partials.shape[2] == x.shape[-1]:
+            y, mean, invstd = ops.bn_train_fwd_stats(x, partials, gamma, beta, residual, relu, self.ps.buffers[self.name + '/avg_mean'],
+                                                     self.ps.buffers[self.name + '/avg_var'])
+        else:
+            y, mean, invstd = ops.bn_train_fwd(x, gamma, beta, residual, relu, self.ps.buffers[self.name + '/avg_mean'],
+                                               self.ps.buffers[self.name + '/avg_var'])
         # BN + ReLU without a residual: backward recomputes the ReLU mask from x (bitwise the forward's y), so y is not
         # kept for (or read by) the backward pass
         return y, (x, y if (residual is not None or not relu) else None, mean, invstd, relu)
@@ -304,17 +320,18 @@ class Bottleneck(object):
             self.bn4 = BatchNorm(ps, name + '/bn4', cout)
 
     def fwd(self, x):
-        h1, c1 = self.conv1.fwd(x)
-        a1, b1 = self.bn1.fwd(h1, relu=True)
-        h2, c2 = self.conv2.fwd(a1)
-        a2, b2 = self.bn2.fwd(h2, relu=True)
-        h3, c3 = self.conv3.fwd(a2)
+        h1, c1 = self.conv1.fwd(x, bn_stats=True)
+        a1, b1 = self.bn1.fwd(h1, relu=True, partials=self.conv1.last_bn_part)
+        h2, c2 = self.conv2.fwd(a1, bn_stats=True)
+        a2, b2 = self.bn2.fwd(h2, relu=True, partials=self.conv2.last_bn_part)
+        h3, c3 = self.conv3.fwd(a2, bn_stats=True)
+        p3 = self.conv3.last_bn_part
         if self.project:
-            h4, c4 = self.conv4.fwd(x)
-            r, b4 = self.bn4.fwd(h4)
+            h4, c4 = self.conv4.fwd(x, bn_stats=True)
+            r, b4 = self.bn4.fwd(h4, partials=self.conv4.last_bn_part)
         else:
             r, c4, b4 = x, None, None
-        y, b3 = self.bn3.fwd(h3, relu=True, residual=r)
+        y, b3 = self.bn3.fwd(h3, relu=True, residual=r, partials=p3)
         return y, (c1, b1, c2, b2, c3, b3, c4, b4)
 
     def bwd(self, ctx, gy, gx_acc=None):

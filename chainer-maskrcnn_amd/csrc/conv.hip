@@ -65,6 +65,9 @@ struct ConvP {
     // FWD as the batched GEMM of the Winograd path: GEMM rows [k*wbatch_rows, (k+1)*wbatch_rows) use weight matrix k
     // (b + k*Ng*Cin); wbatch_rows is a multiple of every tile height.  0 = ordinary convolution.
     int wbatch_rows, wbatch_n;   // wbatch_n = number of GEMMs (16 or 36)
+    // FWD, un-split launches only (nullable): BatchNorm statistics of the output from the epilogue.  Row (M tile * 2 + wave
+    // row) of bn_part (rows, 2, Ng) receives the sums and the sums of squares of that wave's BM_/2 output rows, per channel.
+    float *bn_part;
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -462,6 +465,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     float *const et = smem + wave * (32 * EPI_LD);
     const int er = lane >> 3, ec = (lane & 7) * 4;         // read side: rows er + 8j, columns ec..ec+3
     const bool plain = !partial;
+    const bool bn = MODE == MODE_FWD && plain && p.bn_part != nullptr;
+    float4 bsum[TN], bsq[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) { bsum[tn] = make_float4(0.f, 0.f, 0.f, 0.f); bsq[tn] = make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -480,6 +487,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
                 if (!nv || m >= p.M) continue;
                 float *dst = cbase + (size_t)m * ldc + n;
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (MODE == MODE_FWD && bn) {
+                    bsum[tn].x += v.x; bsum[tn].y += v.y; bsum[tn].z += v.z; bsum[tn].w += v.w;
+                    bsq[tn].x = fmaf(v.x, v.x, bsq[tn].x); bsq[tn].y = fmaf(v.y, v.y, bsq[tn].y);
+                    bsq[tn].z = fmaf(v.z, v.z, bsq[tn].z); bsq[tn].w = fmaf(v.w, v.w, bsq[tn].w);
+                }
                 if (MODE == MODE_FWD && p.relu && plain) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (MODE == MODE_BWD_DATA && p.accumulate && plain) {
                     const float4 o = ldg4(dst);
@@ -493,6 +505,26 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
                 *reinterpret_cast<float4 *>(dst) = v;
             }
         }
+    if (MODE == MODE_FWD && bn) {
+        // the 8 lanes with equal (lane & 7) hold the same 4 channels for different rows: butterfly over lane bits 3..5 (fixed
+        // order), lanes 0..7 then write the wave's row of partial statistics
+        const int prow = (m0 / BM_) * 2 + wm;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+            for (int o = 8; o <= 32; o <<= 1) {
+                bsum[tn].x += __shfl_xor(bsum[tn].x, o, 64); bsum[tn].y += __shfl_xor(bsum[tn].y, o, 64);
+                bsum[tn].z += __shfl_xor(bsum[tn].z, o, 64); bsum[tn].w += __shfl_xor(bsum[tn].w, o, 64);
+                bsq[tn].x += __shfl_xor(bsq[tn].x, o, 64); bsq[tn].y += __shfl_xor(bsq[tn].y, o, 64);
+                bsq[tn].z += __shfl_xor(bsq[tn].z, o, 64); bsq[tn].w += __shfl_xor(bsq[tn].w, o, 64);
+            }
+            const int n = n0 + wn * (BN_ / 2) + tn * 32 + ec;
+            if (er == 0 && n < p.Ng) {
+                *reinterpret_cast<float4 *>(p.bn_part + ((size_t)prow * 2) * p.Ng + n) = bsum[tn];
+                *reinterpret_cast<float4 *>(p.bn_part + ((size_t)prow * 2 + 1) * p.Ng + n) = bsq[tn];
+            }
+        }
+    }
 }
 
 // ---- launch planning -------------------------------------------------------------------------------------
@@ -756,6 +788,7 @@ ConvP make_p(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
     p.Wo = conv_out(W, KW, stride, pad);
     p.ksplit = 1;
     p.smallc = (Cin == 4);
+    p.bn_part = nullptr;
     return p;
 }
 
@@ -1468,6 +1501,40 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
     p.M = N * p.Ho * p.Wo; p.Ng = Cout;
     const int nsteps = p.smallc ? (KH * KW + 7) / 8 : KH * KW * (Cin / BK);
     return run_data_conv<MODE_FWD>(p, nsteps, Cout, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Forward convolution of a layer that feeds a training-mode BatchNorm (no bias, no ReLU): the epilogue also leaves the
+// per-channel sums / sums of squares of its output rows in bn_part (rows, 2, Cout) - the statistics pass of BatchNorm
+// (one read of the activation) disappears; mrcnn_bn_train_fwd_stats_f32 finishes from the partials.  rows = 0: this
+// geometry takes a path without the fused statistics (Winograd, split-K or tail-split launches) - call the plain entry.
+static int bnstats_plan(ConvP &p, TileChoice &t, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
+    if ((Cin % BK && Cin != 4) || Cout % BK || Cin == 4) return 0;
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD)) return 0;
+    p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
+    if (p.Ho <= 0 || p.Wo <= 0) return 0;
+    p.M = N * p.Ho * p.Wo; p.Ng = Cout;
+    data_plan<MODE_FWD>(p, t, KH * KW * (Cin / BK));
+    if (p.ksplit > 1 || p.tail_ks) return 0;
+    return mrcnn::cdiv(p.M, t.bm) * 2;
+}
+extern "C" size_t mrcnn_conv2d_bnstats_rows(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    ConvP p;
+    TileChoice t;
+    return (size_t)bnstats_plan(p, t, N, H, W, Cin, Cout, KH, KW, stride, pad);
+}
+extern "C" int mrcnn_conv2d_fwd_bnstats_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH,
+                                            int KW, int stride, int pad, float *bn_part, void *stream) {
+    if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
+    ConvP p;
+    TileChoice t;
+    if (!bn_part || bnstats_plan(p, t, N, H, W, Cin, Cout, KH, KW, stride, pad) == 0)
+        return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_fwd_bnstats: no fused statistics for this geometry (mrcnn_conv2d_bnstats_rows == 0)");
+    p.a = x; p.b = w; p.c = y; p.bias = nullptr; p.relu = 0; p.bn_part = bn_part;
+    p.bytes_a = (unsigned)((size_t)N * H * W * Cin * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
+    launch_conv<MODE_FWD>(p, 1, t, (hipStream_t)stream);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
 }
 
 // Forward convolution with a rectangular kernel and per-axis padding (the 15x1 / 1x15 separable pairs of LightRoIMaskHead,

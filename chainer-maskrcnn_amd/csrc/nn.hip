@@ -119,7 +119,7 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
 }
 
 __global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_stats_final(const float *__restrict__ x, const float *__restrict__ part,
-                                                         int nblk, int P, int C, float eps, float decay,
+                                                         int nblk, int P, int C, float eps, float decay, int shifted,
                                                          float *__restrict__ mean, float *__restrict__ invstd,
                                                          float *__restrict__ run_mean, float *__restrict__ run_var) {
     __shared__ double sa[FIN_SLICES][FIN_CH], sb[FIN_SLICES][FIN_CH];
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_stats_final(const fl
     const double ms = a / P;
     double var = b / P - ms * ms;
     if (var < 0.0) var = 0.0;
-    const float m = (float)((double)x[c] + ms), v = (float)var;
+    // shifted: the partials are sums of (x - K), K = x[0][c] (k_bn_stats_partial); else plain sums (the convolution epilogue)
+    const float m = (float)((shifted ? (double)x[c] : 0.0) + ms), v = (float)var;
     mean[c] = m;
     invstd[c] = 1.0f / sqrtf(v + eps);
     if (run_mean) run_mean[c] = decay * run_mean[c] + (1.0f - decay) * m;
@@ -810,11 +811,29 @@ extern "C" int mrcnn_bn_train_fwd_f32(const float *x, const float *gamma, const 
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(r.nblk), dim3(NT), 0, st, x, P, C, r.G, r.RPI, r.rows_per_blk, (float *)ws);
     MRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_stats_final, dim3(mrcnn::cdiv(C, FIN_CH)), dim3(FIN_SLICES * FIN_CH), 0, st, x, (const float *)ws, r.nblk, P, C,
-                       eps, decay, save_mean, save_invstd, running_mean, running_var);
+                       eps, decay, 1, save_mean, save_invstd, running_mean, running_var);
     MRCNN_LAUNCH_CHECK();
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, x, gamma, beta, save_mean, save_invstd, residual, y,
                        n4, C / 4, relu);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Training-mode BatchNorm forward from the per-row-block partial statistics the producing convolution left behind
+// (mrcnn_conv2d_fwd_bnstats_f32: part (rows, 2, C) = sums, sums of squares): finalize + apply, no statistics pass over x.
+extern "C" int mrcnn_bn_train_fwd_stats_f32(const float *x, const float *part, int rows, const float *gamma, const float *beta,
+                                            const float *residual, float *y, float *save_mean, float *save_invstd,
+                                            float *running_mean, float *running_var, int P, int C, float eps, float decay, int relu,
+                                            void *stream) {
+    if (int e = chk(x && part && gamma && beta && y && save_mean && save_invstd, "bn_train_fwd_stats: null pointer")) return e;
+    if (int e = chk(P > 0 && C > 0 && (C % 4) == 0 && rows > 0, "bn_train_fwd_stats: need P>0, C%4==0, rows>0")) return e;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_stats_final, dim3(mrcnn::cdiv(C, FIN_CH)), dim3(FIN_SLICES * FIN_CH), 0, st, x, part, rows, P, C, eps, decay, 0,
+                       save_mean, save_invstd, running_mean, running_var);
+    MRCNN_LAUNCH_CHECK();
+    const size_t n4 = (size_t)P * C / 4;
+    hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, x, gamma, beta, save_mean, save_invstd, residual, y, n4, C / 4, relu);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 3
+#define MRCNN_ABI_VERSION 4
 
 enum {
     MRCNN_OK = 0,
@@ -169,6 +169,14 @@ int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, floa
 /* Forward with a rectangular kernel and per-axis padding: the (15,1) / (1,15) separable pairs of the Light-Head R-CNN
  * head (chainer_maskrcnn/model/head/light_roi_mask_head.py:29-44).  Workspace as mrcnn_conv2d_workspace_bytes() of the
  * same geometry with pad = max(pad_h, pad_w). */
+/* Convolution feeding a training-mode BatchNorm (no bias, no ReLU: extractor/feature_pyramid_network.py:48-66, Chainer's
+ * ResNet50Layers): the GEMM epilogue also leaves per-channel sums / sums of squares of every block of output rows in
+ * bn_part (rows, 2, Cout); mrcnn_bn_train_fwd_stats_f32 finishes BatchNorm from them without a statistics pass over the
+ * activation.  mrcnn_conv2d_bnstats_rows = rows for this geometry, or 0 when the call would take a path without the
+ * fused statistics (Winograd, split-K, tail split): use the plain entry points then. */
+size_t mrcnn_conv2d_bnstats_rows(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int mrcnn_conv2d_fwd_bnstats_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                 int stride, int pad, float *bn_part, void *stream);
 int mrcnn_conv2d_fwd_rect_f32(const float *x, const float *w, const float *bias, float *y, int N, int H, int W, int Cin,
                               int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int relu, void *ws,
                               size_t ws_bytes, void *stream);
@@ -209,6 +217,9 @@ int mrcnn_bn_train_fwd_f32(const float *x, const float *gamma, const float *beta
  * input);  ggamma, gbeta (C) overwritten.  y may be NULL when relu != 0, the forward had no residual and beta is
  * given: the mask is then recomputed from x as gamma*(x-mean)*invstd + beta > 0 with the forward's exact expression
  * (bitwise the same mask, one HBM stream less).  beta is otherwise unused (nullable). */
+int mrcnn_bn_train_fwd_stats_f32(const float *x, const float *part, int rows, const float *gamma, const float *beta,
+                                 const float *residual, float *y, float *save_mean, float *save_invstd, float *running_mean,
+                                 float *running_var, int P, int C, float eps, float decay, int relu, void *stream);
 int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const float *y, const float *gamma, const float *beta,
                            const float *save_mean, const float *save_invstd, float *gx, float *gres,
                            float *ggamma, float *gbeta, int P, int C, int relu, void *ws, size_t ws_bytes,

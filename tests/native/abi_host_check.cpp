@@ -18,6 +18,7 @@ static int failures = 0;
     do {                                                                      \
         const int rc_ = (call);                                               \
         if (rc_ == 0) { std::printf("FAIL %s:%d: %s returned 0\n", __FILE__, __LINE__, #call); ++failures; } \
+        else if (rc_ > 0) { std::printf("FAIL %s:%d: reached the HIP runtime (code %d) instead of rejecting its arguments: %s\n", __FILE__, __LINE__, rc_, #call); ++failures; } \
         else if (rc_ < 0 && std::strlen(mrcnn_last_error()) == 0) { std::printf("FAIL %s:%d: no message\n", __FILE__, __LINE__); ++failures; } \
     } while (0)
 
@@ -41,6 +42,7 @@ int main() {
                     acc += mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, ci, co, k, k, stride, pad);
                     acc += mrcnn_conv2d_winograd_v_bytes(N, H, W, ci, co, k, k, stride, pad);
                     acc += mrcnn_conv2d_winograd_w_bytes(N, H, W, ci, co, k, k, stride, pad);
+                    acc += mrcnn_conv2d_bnstats_rows(N, H, W, ci, co, k, k, stride, pad);
                     for (int pass = 0; pass < 3; ++pass) acc += (unsigned long long)mrcnn_conv2d_executed_macs(N, H, W, ci, co, k, k, stride, pad, pass);
                 }
     }
@@ -76,14 +78,17 @@ int main() {
     EXPECT_ERR(mrcnn_roi_align_sample_tables(CF, 4, 8, 8, 7, 7, 0.25f, 2, 16, I, I, F, V));
     EXPECT_ERR(mrcnn_conv2d_fwd_f32(CF, CF, CF, F, 1, 8, 8, 32, 32, 3, 3, 1, 1, 0, F, V, 0, V));
     EXPECT_ERR(mrcnn_conv2d_fwd_rect_f32(CF, CF, CF, F, 1, 8, 8, 32, 32, 15, 1, 1, 7, 0, 0, V, 0, V));
+    EXPECT_ERR(mrcnn_conv2d_fwd_bnstats_f32(CF, CF, F, 2, 64, 64, 256, 1024, 1, 1, 1, 0, F, V));
+    EXPECT_ERR(mrcnn_bn_train_fwd_stats_f32(CF, CF, 16, CF, CF, CF, F, F, F, F, F, 64, 32, 2e-5f, 0.9f, 1, V));
     EXPECT_ERR(mrcnn_conv2d_bwd_data_f32(CF, CF, F, CF, 1, 8, 8, 32, 32, 3, 3, 1, 1, 0, F, F, 0, V, 0, V));
     EXPECT_ERR(mrcnn_conv2d_bwd_filter_f32(CF, CF, F, F, 1, 8, 8, 32, 32, 3, 3, 1, 1, 0, CF, CF, V, 0, V));
     {   // non-null buffers, unsupported channel counts / zero sizes / too small a workspace
         static float buf[64];
         EXPECT_ERR(mrcnn_conv2d_fwd_f32(buf, buf, buf, buf, 1, 8, 8, 33, 32, 3, 3, 1, 1, 0, nullptr, buf, sizeof(buf), V));
         EXPECT_ERR(mrcnn_conv2d_fwd_f32(buf, buf, buf, buf, 0, 8, 8, 32, 32, 3, 3, 1, 1, 0, nullptr, buf, sizeof(buf), V));
+        EXPECT_ERR(mrcnn_conv2d_fwd_bnstats_f32(buf, buf, buf, 2, 64, 64, 256, 256, 3, 3, 1, 1, buf, V));       /* Winograd geometry: declined */
         EXPECT_ERR(mrcnn_conv2d_bwd_filter_f32(buf, buf, buf, buf, 1, 64, 64, 256, 256, 3, 3, 1, 1, 0, nullptr, nullptr, buf, 16, V));
-        EXPECT_ERR(mrcnn_rpn_proposals_f32(buf, buf, buf, 1, 100, 64.f, 64.f, 16.f, nullptr, 20000, 100, 0.7f, buf, (int32_t *)buf, buf,
+        EXPECT_ERR(mrcnn_rpn_proposals_f32(buf, buf, buf, 1, 30000, 64.f, 64.f, 16.f, nullptr, 20000, 100, 0.7f, buf, (int32_t *)buf, buf,
                                            (int32_t *)buf, I, I, I, buf, 1u << 30, V));
         EXPECT_ERR(mrcnn_anchor_target_f32(buf, 100, buf, (const int32_t *)buf, 1000, 1, 64.f, 64.f, nullptr, CK, 256, 0.7f, 0.3f, 0.5f, 0, buf,
                                            (int32_t *)buf, buf, 1u << 30, V));

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'libmrcnn_hip.so lacks %s' % n
         assert n in _hip.SIGNATURES, 'ctypes binding lacks %s' % n
     assert set(_hip.SIGNATURES) == set(names)
-    assert lib.mrcnn_abi_version() == 3
+    assert lib.mrcnn_abi_version() == 4
 
 
 def test_argument_errors_do_not_need_a_device():
@@ -65,6 +65,9 @@ def test_host_side_under_address_sanitizer():
     hipcc = '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         pytest.skip('hipcc not available')
+    import torch
+    if torch.cuda.device_count() > 0:       # (does not initialise the device)
+        pytest.skip('host-only check: the driver passes null buffers on purpose and must not run where a GPU could execute a launch')
     csrc = os.path.join(ROOT, 'chainer-maskrcnn_amd', 'csrc')
     subprocess.check_call(['make', '-C', csrc, 'asan', '-j8'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     rt = subprocess.check_output(['/opt/rocm/lib/llvm/bin/clang', '-print-file-name=libclang_rt.asan-x86_64.so']).decode().strip()

@@ -184,3 +184,46 @@ def test_sgd_momentum_weight_decay(n):
     ops.sgd_momentum_wd(pd, gd, vd, float(lr), float(mom), float(wd))
     np.testing.assert_allclose(vd.cpu().numpy(), v2, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(pd.cpu().numpy(), p2, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize('geom', [(2, 64, 64, 256, 1024, 1, 1, 0),       # res4 conv3
+                                  (2, 128, 128, 256, 128, 1, 2, 0),      # strided 1x1 (first block of a stage)
+                                  (2, 200, 272, 64, 64, 3, 1, 1),        # 3x3 below the Winograd channel threshold
+                                  (1, 37, 53, 64, 96, 1, 1, 0)])         # ragged M: the last row block is partial
+def test_bn_statistics_from_the_convolution_epilogue(geom):
+    """SURVEY.md K9: the forward GEMM epilogue leaves per-row-block sums / sums of squares (mrcnn_conv2d_fwd_bnstats_f32);
+    BatchNorm finishes from them (mrcnn_bn_train_fwd_stats_f32).  Against float64: the convolution output is bitwise the
+    plain kernel's, mean / inverse std / BN output within the bars of the two-pass path."""
+    from chainer_maskrcnn._hip import nn as hnn
+    N, H, W, Ci, Co, k, stride, pad = geom
+    rs = np.random.RandomState(7)
+    x = (rs.standard_normal((N, H, W, Ci)) + 0.3).astype(np.float32)
+    w = (rs.standard_normal((Co, k, k, Ci)) * (1.0 / np.sqrt(Ci * k * k))).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, Co).astype(np.float32)
+    beta = rs.standard_normal(Co).astype(np.float32)
+    xt, wt = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
+    res = hnn.conv2d_fwd_bnstats_raw(xt, wt, stride, pad)
+    assert res is not None
+    y, part = res
+    y_plain = hnn.conv2d_fwd_raw(xt, wt, None, stride, pad, False)
+    assert torch.equal(y, y_plain)
+    P = y.numel() // Co
+    assert part.shape[1:] == (2, Co) and part.shape[0] >= -(-P // 128) * 2 - 2
+    yd = y.double().cpu().reshape(P, Co)
+    np.testing.assert_allclose(part[:, 0].double().sum(0).cpu().numpy(), yd.sum(0).numpy(), rtol=1e-5, atol=1e-3)
+    rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+    o, mean, invstd = ops.bn_train_fwd_stats(y, part, torch.from_numpy(gamma).to(DEV), torch.from_numpy(beta).to(DEV), None, True, rm, rv)
+    m64, v64 = yd.mean(0), yd.var(0, unbiased=False)
+    want = torch.relu((yd - m64) / torch.sqrt(v64 + 2e-5) * torch.from_numpy(gamma).double() + torch.from_numpy(beta).double())
+    assert _rel(mean, m64) <= 2e-6 and _rel(invstd, 1.0 / torch.sqrt(v64 + 2e-5)) <= 2e-5
+    assert _rel(o.reshape(P, Co), want) <= 2e-5
+    o2, mean2, invstd2 = ops.bn_train_fwd(y, torch.from_numpy(gamma).to(DEV), torch.from_numpy(beta).to(DEV), None, True)
+    assert _rel(o, o2.double().cpu()) <= 1e-5
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * m64.float().numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_bn_statistics_fusion_declines_winograd_and_split_launches():
+    from chainer_maskrcnn._hip import lib
+    assert lib().mrcnn_conv2d_bnstats_rows(2, 64, 64, 256, 256, 3, 3, 1, 1) == 0        # Winograd layer
+    assert lib().mrcnn_conv2d_bnstats_rows(2, 8, 8, 2048, 512, 1, 1, 1, 0) == 0         # few tiles, long K: split-K
+    assert lib().mrcnn_conv2d_bnstats_rows(2, 64, 64, 256, 1024, 1, 1, 1, 0) > 0
