@@ -1153,45 +1153,63 @@ __global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ M
 }
 
 // W[k][t][c] = (A dy A^T)[k]: the m x m output-gradient tile t, zero outside the image.  Thread = (t, 4 channels).
+// bias_part (nullable): the kernel reads every element of gy exactly once, so the bias gradient's column sums ride along -
+// row blockIdx.x of bias_part (gridDim.x, C) receives the sums of the block's tiles (a block covers 256 / (C/4) whole tiles
+// when C/4 divides 256: the host passes bias_part only then); k_colsum_final adds the rows up.
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_gy(const float *__restrict__ gy, float *__restrict__ Wt, int N, int H, int W, int C,
-                                                 int th, int tw, long long T, long long Tp) {
+                                                 int th, int tw, long long T, long long Tp, float *__restrict__ bias_part) {
     constexpr int A_ = M_ + 2;
+    __shared__ float4 sred[256];
     const int C4 = C / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Tp * C4) return;
-    const int c = (int)(i % C4) * 4;
-    const long long t = i / C4;
-    if (t >= T) {           // padded rows: zero
+    const bool in_range = i < Tp * C4;
+    const int c = in_range ? (int)(i % C4) * 4 : 0;
+    const long long t = in_range ? i / C4 : Tp;
+    V4 bsum = v4zero();
+    if (in_range && t >= T) {           // padded rows: zero
 #pragma unroll
         for (int k = 0; k < A_ * A_; ++k) v4st(Wt + ((size_t)k * Tp + t) * C + c, v4zero());
-        return;
-    }
-    const int tx = (int)(t % tw);
-    const int ty = (int)((t / tw) % th);
-    const int n = (int)(t / ((long long)tw * th));
-    V4 r[A_][M_];           // A y, column by column
+    } else if (in_range) {
+        const int tx = (int)(t % tw);
+        const int ty = (int)((t / tw) % th);
+        const int n = (int)(t / ((long long)tw * th));
+        V4 r[A_][M_];           // A y, column by column
 #pragma unroll
-    for (int b = 0; b < M_; ++b) {
-        const int ww = M_ * tx + b;
-        V4 y[M_], col[A_];
+        for (int b = 0; b < M_; ++b) {
+            const int ww = M_ * tx + b;
+            V4 y[M_], col[A_];
 #pragma unroll
-        for (int a = 0; a < M_; ++a) {
-            const int h = M_ * ty + a;
-            y[a] = (h < H && ww < W) ? v4ld(gy + (((size_t)n * H + h) * W + ww) * C + c) : v4zero();
+            for (int a = 0; a < M_; ++a) {
+                const int h = M_ * ty + a;
+                y[a] = (h < H && ww < W) ? v4ld(gy + (((size_t)n * H + h) * W + ww) * C + c) : v4zero();
+                bsum = bsum + y[a];
+            }
+            wino_a<M_, V4>(y, col, v4zero());
+#pragma unroll
+            for (int q = 0; q < A_; ++q) r[q][b] = col[q];
         }
-        wino_a<M_, V4>(y, col, v4zero());
+        const size_t ks = (size_t)Tp * C;
+        float *o = Wt + (size_t)t * C + c;
 #pragma unroll
-        for (int q = 0; q < A_; ++q) r[q][b] = col[q];
+        for (int q = 0; q < A_; ++q) {
+            V4 row[A_];
+            wino_a<M_, V4>(r[q], row, v4zero());
+#pragma unroll
+            for (int j = 0; j < A_; ++j) v4st(o + (size_t)(q * A_ + j) * ks, row[j]);
+        }
     }
-    const size_t ks = (size_t)Tp * C;
-    float *o = Wt + (size_t)t * C + c;
-#pragma unroll
-    for (int q = 0; q < A_; ++q) {
-        V4 row[A_];
-        wino_a<M_, V4>(r[q], row, v4zero());
-#pragma unroll
-        for (int j = 0; j < A_; ++j) v4st(o + (size_t)(q * A_ + j) * ks, row[j]);
+    if (bias_part) {            // block-uniform
+        sred[threadIdx.x] = make_float4(bsum.x, bsum.y, bsum.z, bsum.w);
+        __syncthreads();
+        if ((int)threadIdx.x < C4) {        // the block's tiles in tile order (fixed => bit-reproducible)
+            float4 a = sred[threadIdx.x];
+            for (int k = threadIdx.x + C4; k < 256; k += C4) {
+                const float4 q = sred[k];
+                a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+            }
+            *reinterpret_cast<float4 *>(bias_part + (size_t)blockIdx.x * C + threadIdx.x * 4) = a;
+        }
     }
 }
 
@@ -1345,8 +1363,10 @@ WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
     return L;
 }
 
+// bias_part / bias_rows (nullable): when the gy transform runs here and its blocks cover whole tiles, it also leaves the
+// bias gradient's partial column sums in bias_part and *bias_rows = their number (else *bias_rows = 0: the caller sums gy)
 int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, int W, int Cin, int Cout, int accumulate, void *ws,
-                    hipStream_t st, const float *v_cached, const float *w_cached) {
+                    hipStream_t st, const float *v_cached, const float *w_cached, float *bias_part = nullptr, int *bias_rows = nullptr) {
     const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
     const WinoGeom &g = L.g;
     char *base = (char *)ws;
@@ -1354,7 +1374,11 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     const float *V = v_cached ? v_cached : Vw;       // the forward pass's transformed input, kept by the caller
     const long long nin = g.Tp * (Cin / 4), nout = g.Tp * (Cout / 4);      // the transform kernels zero the padded rows
     if (!v_cached) WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), x, Vw, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
-    if (!w_cached) WINO_LAUNCH(k_wino_gy, g, dim3((unsigned)((nout + 255) / 256)), gy, Wt, N, H, W, Cout, g.th, g.tw, g.T, g.Tp);
+    const int C4o = Cout / 4;
+    const bool fuse_bias = bias_part && bias_rows && !w_cached && C4o <= 256 && 256 % C4o == 0 && !(g_debug_skip & 2);
+    if (bias_rows) *bias_rows = fuse_bias ? (int)((nout + 255) / 256) : 0;
+    if (!w_cached) WINO_LAUNCH(k_wino_gy, g, dim3((unsigned)((nout + 255) / 256)), gy, Wt, N, H, W, Cout, g.th, g.tw, g.T, g.Tp,
+                               fuse_bias ? bias_part : (float *)nullptr);
     ConvP p = make_p(1, 1, (int)g.Tp, Cin, Cout, 1, 1, 1, 0);
     p.wbatch_rows = (int)g.Tp; p.wbatch_n = g.nk;
     p.ksplit = L.ksplit; p.kchunk = L.kchunk;
@@ -1596,7 +1620,12 @@ extern "C" size_t mrcnn_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, i
     const size_t wsz = (size_t)Cout * KH * KW * Cin * sizeof(float);
     const size_t P = (size_t)N * p.Ho * p.Wo;
     const size_t bias_part = (size_t)col_plan((int)P, Cout).nblk * Cout * sizeof(float);
-    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_BWD_FILTER)) return wino_filter_layout(N, H, W, Cin, Cout).total + bias_part + 256;
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_BWD_FILTER)) {
+        // the gy transform leaves one row of bias-gradient partials per 256-thread block
+        const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
+        const size_t rows = (size_t)((L.g.Tp * (Cout / 4) + 255) / 256);
+        return L.total + std::max(bias_part, rows * Cout * sizeof(float)) + 256;
+    }
     return wsz * ksplit + bias_part + 256;     // slabs are also used for ksplit == 1 when accumulating
 }
 
@@ -1614,14 +1643,19 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
         // the forward pass's transformed input is reusable only when that pass ran Winograd on the same tile
         if (wino_v && !(wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD) && wino_geom(N, H, W, PASS_FWD).m == L.g.m)) wino_v = nullptr;
         if (wino_w && mrcnn_conv2d_winograd_w_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad) == 0) wino_w = nullptr;
-        if (int e = wino_bwd_filter(x, gy, gw, N, H, W, Cin, Cout, accumulate, ws, st, wino_v, wino_w)) return e;
+        float *bias_part = (float *)((char *)ws + L.total);
+        int bias_rows = 0;
+        if (int e = wino_bwd_filter(x, gy, gw, N, H, W, Cin, Cout, accumulate, ws, st, wino_v, wino_w, gbias ? bias_part : nullptr, &bias_rows)) return e;
         if (gbias) {
-            float *bias_part = (float *)((char *)ws + L.total);
-            const int P = N * p.Ho * p.Wo;
-            const ColPlan cp = col_plan(P, Cout);
-            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, gy, bias_part, P, Cout, cp.G, cp.RPI, cp.rows_per_blk);
-            MRCNN_LAUNCH_CHECK();
-            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, CSF_CH)), dim3(CSF_CH * CSF_SL), 0, st, bias_part, gbias, cp.nblk, Cout, accumulate);
+            int nrows = bias_rows;          // partial column sums from the gy transform, or a separate pass over gy
+            if (nrows == 0) {
+                const int P = N * p.Ho * p.Wo;
+                const ColPlan cp = col_plan(P, Cout);
+                if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_partial, dim3(cp.nblk), dim3(256), 0, st, gy, bias_part, P, Cout, cp.G, cp.RPI, cp.rows_per_blk);
+                MRCNN_LAUNCH_CHECK();
+                nrows = cp.nblk;
+            }
+            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_colsum_final, dim3(mrcnn::cdiv(Cout, CSF_CH)), dim3(CSF_CH * CSF_SL), 0, st, bias_part, gbias, nrows, Cout, accumulate);
             MRCNN_LAUNCH_CHECK();
         }
         return 0;
