@@ -102,10 +102,11 @@ def conv2d_fwd_raw(x, w, b, stride, pad, relu, keep_v=False):
     return (y, v) if keep_v else y
 
 
-def conv2d_fwd_bnstats_raw(x, w, stride, pad):
-    """Forward convolution (no bias, no ReLU) whose epilogue also produces the BatchNorm statistics partials of its output:
-    returns (y, part (rows, 2, Cout)) - or None when this geometry has no fused-statistics launch (Winograd / split-K / tail
-    split: mrcnn_conv2d_bnstats_rows == 0); the caller then takes the plain path."""
+def conv2d_fwd_bnstats_raw(x, w, stride, pad, keep_v=False):
+    """Forward convolution (no bias, no ReLU) that also produces the BatchNorm statistics partials of its output (GEMM
+    epilogue, or the output transform of a Winograd layer): returns (y, v, part (rows, 2, Cout)) - or None when this geometry
+    has no fused-statistics launch (split-K / tail split: mrcnn_conv2d_bnstats_rows == 0); the caller then takes the plain
+    path.  v: the Winograd-transformed input when keep_v (as conv2d_fwd_raw)."""
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
     rows = lib().mrcnn_conv2d_bnstats_rows(N, H, W, Cin, Cout, KH, KW, stride, pad)
@@ -114,9 +115,17 @@ def conv2d_fwd_bnstats_raw(x, w, stride, pad):
     assert x.is_contiguous() and w.is_contiguous()
     y = torch.empty((N, conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad), Cout), dtype=torch.float32, device=x.device)
     part = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
+    nb = lib().mrcnn_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    ws = workspace(nb, x.device) if nb else None
+    v = None
+    if keep_v:
+        vb = lib().mrcnn_conv2d_winograd_v_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+        if vb:
+            v = torch.empty((vb // 4,), dtype=torch.float32, device=x.device)
     with _prof('fwd', N * y.shape[1] * y.shape[2], KH, KW, Cin, Cout, (N, H, W, Cin, Cout, KH, KW, stride, pad)):
-        check(lib().mrcnn_conv2d_fwd_bnstats_f32(ptr(x), ptr(w), ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, ptr(part), stream_ptr()))
-    return y, part
+        check(lib().mrcnn_conv2d_fwd_bnstats_f32(ptr(x), ptr(w), ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, ptr(part), ptr(v),
+                                                 ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()))
+    return y, v, part
 
 
 def winograd_w_bytes(x_shape, w_shape, stride, pad):

@@ -176,11 +176,11 @@ class Conv(object):
         hnn.LOGICAL = (self.cin, self.cout)
         if bn_stats and FUSE_BN_STATS and TRAIN and not relu and not self.has_bias:
             with _layer_tiles(self):
-                res = hnn.conv2d_fwd_bnstats_raw(x, self.W, self.stride, self.pad)
+                res = hnn.conv2d_fwd_bnstats_raw(x, self.W, self.stride, self.pad, keep_v=True)
             if res is not None:
                 hnn.LOGICAL = None
-                y, self.last_bn_part = res
-                return y, (x, None, None)
+                y, v, self.last_bn_part = res
+                return y, (x, None, v)
         # training: layers on the Winograd path keep their transformed input for the filter-gradient pass
         with _layer_tiles(self):
             y, v = hnn.conv2d_fwd_raw(x, self.W, self.b, self.stride, self.pad, relu, keep_v=True) if TRAIN else \

@@ -1104,50 +1104,74 @@ __global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x,
 }
 
 // y (m x m pixels of tile t) = A^T M A + bias, then ReLU | + old y (accumulate) | zeroed where relu_x <= 0.
+// bn_part (nullable; the layer feeds a training-mode BatchNorm): row blockIdx.x of bn_part (gridDim.x, 2, C) receives the
+// per-channel sums and sums of squares of the pixels the block wrote (a block covers 256 / (C/4) whole tiles: the host
+// passes bn_part only when C/4 divides 256) - the same partials the GEMM epilogue produces for the direct layers.
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ Mb, float *__restrict__ y, int N, int H, int W, int C,
                                                      int th, int tw, long long T, long long Tp, const float *__restrict__ bias,
-                                                     int relu, int accumulate, const float *__restrict__ relu_x) {
+                                                     int relu, int accumulate, const float *__restrict__ relu_x,
+                                                     float *__restrict__ bn_part) {
     constexpr int A_ = M_ + 2;
+    __shared__ float4 sred[2][256];
     const int C4 = C / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * C4) return;
-    const int c = (int)(i % C4) * 4;
-    const long long t = i / C4;
-    const int tx = (int)(t % tw);
-    const int ty = (int)((t / tw) % th);
-    const int n = (int)(t / ((long long)tw * th));
-    const size_t ks = (size_t)Tp * C;
-    const float *src = Mb + (size_t)t * C + c;
-    V4 s[M_][A_];           // A^T m, column by column
+    V4 bs = v4zero(), bq = v4zero();
+    if (i < T * C4) {
+        const int c = (int)(i % C4) * 4;
+        const long long t = i / C4;
+        const int tx = (int)(t % tw);
+        const int ty = (int)((t / tw) % th);
+        const int n = (int)(t / ((long long)tw * th));
+        const size_t ks = (size_t)Tp * C;
+        const float *src = Mb + (size_t)t * C + c;
+        V4 s[M_][A_];           // A^T m, column by column
 #pragma unroll
-    for (int q = 0; q < A_; ++q) {
-        V4 m[A_], r[M_];
+        for (int q = 0; q < A_; ++q) {
+            V4 m[A_], r[M_];
 #pragma unroll
-        for (int rr = 0; rr < A_; ++rr) m[rr] = v4ld(src + (size_t)(rr * A_ + q) * ks);
-        wino_at<M_, V4>(m, r);
+            for (int rr = 0; rr < A_; ++rr) m[rr] = v4ld(src + (size_t)(rr * A_ + q) * ks);
+            wino_at<M_, V4>(m, r);
 #pragma unroll
-        for (int a = 0; a < M_; ++a) s[a][q] = r[a];
-    }
-    const V4 bv = bias ? v4ld(bias + c) : v4zero();
+            for (int a = 0; a < M_; ++a) s[a][q] = r[a];
+        }
+        const V4 bv = bias ? v4ld(bias + c) : v4zero();
 #pragma unroll
-    for (int a = 0; a < M_; ++a) {
-        V4 row[M_];
-        wino_at<M_, V4>(s[a], row);
-        const int h = M_ * ty + a;
+        for (int a = 0; a < M_; ++a) {
+            V4 row[M_];
+            wino_at<M_, V4>(s[a], row);
+            const int h = M_ * ty + a;
 #pragma unroll
-        for (int b = 0; b < M_; ++b) {
-            const int ww = M_ * tx + b;
-            if (h >= H || ww >= W) continue;
-            V4 v = row[b] + bv;
-            const size_t off = (((size_t)n * H + h) * W + ww) * C + c;
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (accumulate) v = v + v4ld(y + off);
-            if (relu_x) {
-                const V4 xm = v4ld(relu_x + off);
-                v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f; v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
+            for (int b = 0; b < M_; ++b) {
+                const int ww = M_ * tx + b;
+                if (h >= H || ww >= W) continue;
+                V4 v = row[b] + bv;
+                const size_t off = (((size_t)n * H + h) * W + ww) * C + c;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (accumulate) v = v + v4ld(y + off);
+                if (relu_x) {
+                    const V4 xm = v4ld(relu_x + off);
+                    v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f; v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
+                }
+                v4st(y + off, v);
+                bs = bs + v;
+                bq.x = fmaf(v.x, v.x, bq.x); bq.y = fmaf(v.y, v.y, bq.y); bq.z = fmaf(v.z, v.z, bq.z); bq.w = fmaf(v.w, v.w, bq.w);
             }
-            v4st(y + off, v);
+        }
+    }
+    if (bn_part) {              // block-uniform
+        sred[0][threadIdx.x] = make_float4(bs.x, bs.y, bs.z, bs.w);
+        sred[1][threadIdx.x] = make_float4(bq.x, bq.y, bq.z, bq.w);
+        __syncthreads();
+        if ((int)threadIdx.x < C4) {        // the block's tiles in tile order (fixed => bit-reproducible)
+            float4 a = sred[0][threadIdx.x], b2 = sred[1][threadIdx.x];
+            for (int k = threadIdx.x + C4; k < 256; k += C4) {
+                const float4 q = sred[0][k], r = sred[1][k];
+                a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+                b2.x += r.x; b2.y += r.y; b2.z += r.z; b2.w += r.w;
+            }
+            *reinterpret_cast<float4 *>(bn_part + ((size_t)blockIdx.x * 2) * C + threadIdx.x * 4) = a;
+            *reinterpret_cast<float4 *>(bn_part + ((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x * 4) = b2;
         }
     }
 }
@@ -1401,7 +1425,7 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
 // the backward-data filter (then Cin here = the layer's Cout and Cout here = the layer's Cin).
 int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, int Cin, int Cout, bool transposed,
               const float *bias, int relu, int accumulate, const float *relu_x, void *ws, size_t ws_bytes, hipStream_t st,
-              float *v_keep, float *w_keep = nullptr, float *gbias = nullptr, int gbias_accumulate = 0) {
+              float *v_keep, float *w_keep = nullptr, float *gbias = nullptr, int gbias_accumulate = 0, float *bn_part = nullptr) {
     const WinoLayout L = wino_layout(N, H, W, Cin, Cout, transposed ? PASS_BWD_DATA : PASS_FWD);
     const WinoGeom &g = L.g;
     char *base = (char *)ws;
@@ -1437,7 +1461,7 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
     p.wbatch_rows = (int)g.Tp; p.wbatch_n = g.nk;
     if (int e = run_data_conv<MODE_FWD>(p, Cin / BK, Cout, base + L.inner, ws_bytes - L.inner, st)) return e;
     WINO_LAUNCH(k_wino_output, g, dim3((unsigned)((nout + 255) / 256)), Mb, out, N, H, W, Cout, g.th, g.tw, g.T, g.Tp, bias, relu,
-                accumulate, relu_x);
+                accumulate, relu_x, bn_part);
     return 0;
 }
 
@@ -1531,10 +1555,18 @@ extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float 
 // per-channel sums / sums of squares of its output rows in bn_part (rows, 2, Cout) - the statistics pass of BatchNorm
 // (one read of the activation) disappears; mrcnn_bn_train_fwd_stats_f32 finishes from the partials.  rows = 0: this
 // geometry takes a path without the fused statistics (Winograd, split-K or tail-split launches) - call the plain entry.
-static int bnstats_plan(ConvP &p, TileChoice &t, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+static int bnstats_plan(ConvP &p, TileChoice &t, bool &wino, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    wino = false;
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
     if ((Cin % BK && Cin != 4) || Cout % BK || Cin == 4) return 0;
-    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD)) return 0;
+    if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD)) {
+        // Winograd forward: the output transform produces the partials, one row per 256-thread block of whole tiles
+        const int C4 = Cout / 4;
+        if (C4 > 256 || 256 % C4) return 0;
+        wino = true;
+        const WinoGeom g = wino_geom(N, H, W, PASS_FWD);
+        return (int)((g.T * C4 + 255) / 256);
+    }
     p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (p.Ho <= 0 || p.Wo <= 0) return 0;
     p.M = N * p.Ho * p.Wo; p.Ng = Cout;
@@ -1545,15 +1577,23 @@ static int bnstats_plan(ConvP &p, TileChoice &t, int N, int H, int W, int Cin, i
 extern "C" size_t mrcnn_conv2d_bnstats_rows(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     ConvP p;
     TileChoice t;
-    return (size_t)bnstats_plan(p, t, N, H, W, Cin, Cout, KH, KW, stride, pad);
+    bool wino;
+    return (size_t)bnstats_plan(p, t, wino, N, H, W, Cin, Cout, KH, KW, stride, pad);
 }
 extern "C" int mrcnn_conv2d_fwd_bnstats_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH,
-                                            int KW, int stride, int pad, float *bn_part, void *stream) {
+                                            int KW, int stride, int pad, float *bn_part, float *wino_v, void *ws, size_t ws_bytes,
+                                            void *stream) {
     if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     ConvP p;
     TileChoice t;
-    if (!bn_part || bnstats_plan(p, t, N, H, W, Cin, Cout, KH, KW, stride, pad) == 0)
+    bool wino;
+    if (!bn_part || bnstats_plan(p, t, wino, N, H, W, Cin, Cout, KH, KW, stride, pad) == 0)
         return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_fwd_bnstats: no fused statistics for this geometry (mrcnn_conv2d_bnstats_rows == 0)");
+    if (wino) {
+        if (!ws || ws_bytes < wino_ws_bytes(N, H, W, Cin, Cout, PASS_FWD))
+            return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "conv2d_fwd_bnstats: workspace %zu < %zu", ws_bytes, wino_ws_bytes(N, H, W, Cin, Cout, PASS_FWD));
+        return wino_conv(x, w, y, N, H, W, Cin, Cout, false, nullptr, 0, 0, nullptr, ws, ws_bytes, (hipStream_t)stream, wino_v, nullptr, nullptr, 0, bn_part);
+    }
     p.a = x; p.b = w; p.c = y; p.bias = nullptr; p.relu = 0; p.bn_part = bn_part;
     p.bytes_a = (unsigned)((size_t)N * H * W * Cin * 4); p.bytes_b = (unsigned)((size_t)Cout * KH * KW * Cin * 4);
     launch_conv<MODE_FWD>(p, 1, t, (hipStream_t)stream);

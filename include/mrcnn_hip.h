@@ -172,11 +172,12 @@ int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, floa
 /* Convolution feeding a training-mode BatchNorm (no bias, no ReLU: extractor/feature_pyramid_network.py:48-66, Chainer's
  * ResNet50Layers): the GEMM epilogue also leaves per-channel sums / sums of squares of every block of output rows in
  * bn_part (rows, 2, Cout); mrcnn_bn_train_fwd_stats_f32 finishes BatchNorm from them without a statistics pass over the
- * activation.  mrcnn_conv2d_bnstats_rows = rows for this geometry, or 0 when the call would take a path without the
- * fused statistics (Winograd, split-K, tail split): use the plain entry points then. */
+ * activation.  Winograd layers produce the same partials in their output transform (wino_v / ws as for
+ * mrcnn_conv2d_fwd_f32).  mrcnn_conv2d_bnstats_rows = rows for this geometry, or 0 when the call would take a path without
+ * the fused statistics (split-K or tail-split launches): use the plain entry points then. */
 size_t mrcnn_conv2d_bnstats_rows(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int mrcnn_conv2d_fwd_bnstats_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                                 int stride, int pad, float *bn_part, void *stream);
+                                 int stride, int pad, float *bn_part, float *wino_v, void *ws, size_t ws_bytes, void *stream);
 int mrcnn_conv2d_fwd_rect_f32(const float *x, const float *w, const float *bias, float *y, int N, int H, int W, int Cin,
                               int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int relu, void *ws,
                               size_t ws_bytes, void *stream);

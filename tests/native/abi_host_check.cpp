@@ -78,7 +78,7 @@ int main() {
     EXPECT_ERR(mrcnn_roi_align_sample_tables(CF, 4, 8, 8, 7, 7, 0.25f, 2, 16, I, I, F, V));
     EXPECT_ERR(mrcnn_conv2d_fwd_f32(CF, CF, CF, F, 1, 8, 8, 32, 32, 3, 3, 1, 1, 0, F, V, 0, V));
     EXPECT_ERR(mrcnn_conv2d_fwd_rect_f32(CF, CF, CF, F, 1, 8, 8, 32, 32, 15, 1, 1, 7, 0, 0, V, 0, V));
-    EXPECT_ERR(mrcnn_conv2d_fwd_bnstats_f32(CF, CF, F, 2, 64, 64, 256, 1024, 1, 1, 1, 0, F, V));
+    EXPECT_ERR(mrcnn_conv2d_fwd_bnstats_f32(CF, CF, F, 2, 64, 64, 256, 1024, 1, 1, 1, 0, F, F, V, 0, V));
     EXPECT_ERR(mrcnn_bn_train_fwd_stats_f32(CF, CF, 16, CF, CF, CF, F, F, F, F, F, 64, 32, 2e-5f, 0.9f, 1, V));
     EXPECT_ERR(mrcnn_conv2d_bwd_data_f32(CF, CF, F, CF, 1, 8, 8, 32, 32, 3, 3, 1, 1, 0, F, F, 0, V, 0, V));
     EXPECT_ERR(mrcnn_conv2d_bwd_filter_f32(CF, CF, F, F, 1, 8, 8, 32, 32, 3, 3, 1, 1, 0, CF, CF, V, 0, V));
@@ -86,7 +86,8 @@ int main() {
         static float buf[64];
         EXPECT_ERR(mrcnn_conv2d_fwd_f32(buf, buf, buf, buf, 1, 8, 8, 33, 32, 3, 3, 1, 1, 0, nullptr, buf, sizeof(buf), V));
         EXPECT_ERR(mrcnn_conv2d_fwd_f32(buf, buf, buf, buf, 0, 8, 8, 32, 32, 3, 3, 1, 1, 0, nullptr, buf, sizeof(buf), V));
-        EXPECT_ERR(mrcnn_conv2d_fwd_bnstats_f32(buf, buf, buf, 2, 64, 64, 256, 256, 3, 3, 1, 1, buf, V));       /* Winograd geometry: declined */
+        EXPECT_ERR(mrcnn_conv2d_fwd_bnstats_f32(buf, buf, buf, 2, 64, 64, 256, 256, 3, 3, 1, 1, buf, nullptr, buf, 16, V));    /* Winograd: workspace too small */
+        EXPECT_ERR(mrcnn_conv2d_fwd_bnstats_f32(buf, buf, buf, 2, 8, 8, 2048, 512, 1, 1, 1, 0, buf, nullptr, buf, sizeof(buf), V));    /* split-K geometry: declined */
         EXPECT_ERR(mrcnn_conv2d_bwd_filter_f32(buf, buf, buf, buf, 1, 64, 64, 256, 256, 3, 3, 1, 1, 0, nullptr, nullptr, buf, 16, V));
         EXPECT_ERR(mrcnn_rpn_proposals_f32(buf, buf, buf, 1, 30000, 64.f, 64.f, 16.f, nullptr, 20000, 100, 0.7f, buf, (int32_t *)buf, buf,
                                            (int32_t *)buf, I, I, I, buf, 1u << 30, V));

@@ -189,7 +189,9 @@ def test_sgd_momentum_weight_decay(n):
 @pytest.mark.parametrize('geom', [(2, 64, 64, 256, 1024, 1, 1, 0),       # res4 conv3
                                   (2, 128, 128, 256, 128, 1, 2, 0),      # strided 1x1 (first block of a stage)
                                   (2, 200, 272, 64, 64, 3, 1, 1),        # 3x3 below the Winograd channel threshold
-                                  (1, 37, 53, 64, 96, 1, 1, 0)])         # ragged M: the last row block is partial
+                                  (1, 37, 53, 64, 96, 1, 1, 0),          # ragged M: the last row block is partial
+                                  (2, 64, 64, 256, 256, 3, 1, 1),        # Winograd layer: partials from the output transform
+                                  (2, 30, 45, 512, 512, 3, 1, 1)])       # Winograd, ragged tiles
 def test_bn_statistics_from_the_convolution_epilogue(geom):
     """SURVEY.md K9: the forward GEMM epilogue leaves per-row-block sums / sums of squares (mrcnn_conv2d_fwd_bnstats_f32);
     BatchNorm finishes from them (mrcnn_bn_train_fwd_stats_f32).  Against float64: the convolution output is bitwise the
@@ -204,11 +206,11 @@ def test_bn_statistics_from_the_convolution_epilogue(geom):
     xt, wt = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
     res = hnn.conv2d_fwd_bnstats_raw(xt, wt, stride, pad)
     assert res is not None
-    y, part = res
+    y, _, part = res
     y_plain = hnn.conv2d_fwd_raw(xt, wt, None, stride, pad, False)
     assert torch.equal(y, y_plain)
     P = y.numel() // Co
-    assert part.shape[1:] == (2, Co) and part.shape[0] >= -(-P // 128) * 2 - 2
+    assert part.shape[1:] == (2, Co)
     yd = y.double().cpu().reshape(P, Co)
     np.testing.assert_allclose(part[:, 0].double().sum(0).cpu().numpy(), yd.sum(0).numpy(), rtol=1e-5, atol=1e-3)
     rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
@@ -222,8 +224,8 @@ def test_bn_statistics_from_the_convolution_epilogue(geom):
     np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * m64.float().numpy(), rtol=1e-4, atol=1e-6)
 
 
-def test_bn_statistics_fusion_declines_winograd_and_split_launches():
+def test_bn_statistics_fusion_declines_split_launches():
     from chainer_maskrcnn._hip import lib
-    assert lib().mrcnn_conv2d_bnstats_rows(2, 64, 64, 256, 256, 3, 3, 1, 1) == 0        # Winograd layer
+    assert lib().mrcnn_conv2d_bnstats_rows(2, 64, 64, 256, 256, 3, 3, 1, 1) > 0         # Winograd layer: output transform
     assert lib().mrcnn_conv2d_bnstats_rows(2, 8, 8, 2048, 512, 1, 1, 1, 0) == 0         # few tiles, long K: split-K
     assert lib().mrcnn_conv2d_bnstats_rows(2, 64, 64, 256, 1024, 1, 1, 1, 0) > 0

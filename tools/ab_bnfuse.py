@@ -27,8 +27,8 @@ for rnd in range(4):
 core.FUSE_BN_STATS = True
 n = [0, 0]
 orig = hnn.conv2d_fwd_bnstats_raw
-def counting(*a):
-    r = orig(*a); n[0] += 1; n[1] += r is not None; return r
+def counting(*a, **k):
+    r = orig(*a, **k); n[0] += 1; n[1] += r is not None; return r
 hnn.conv2d_fwd_bnstats_raw = counting
 opt.update(chain, *args, 1.0); torch.cuda.synchronize()
 print('BatchNorm convolutions asked: %d, fused: %d' % tuple(n))
