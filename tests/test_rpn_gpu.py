@@ -42,6 +42,26 @@ def test_nms_keep_list_bit_exact(n, thresh):
     np.testing.assert_array_equal(keep.cpu().numpy()[:nk], want)
 
 
+# The walk works in super-chunks of 256 boxes inside windows of 48 chunks (3072 boxes): sizes on and around those
+# boundaries, the largest supported input, sparse boxes (almost nothing suppressed: every chunk keeps 64) and dense ones, and
+# max_keep values that stop the walk inside a chunk, at a chunk end and at a super-chunk end.
+@pytest.mark.parametrize('n,spread,thresh,max_keep', [(255, 400, 0.5, None), (256, 400, 0.5, None), (257, 400, 0.5, None),
+                                                      (3071, 3000, 0.7, None), (3072, 3000, 0.7, None), (3073, 3000, 0.7, None),
+                                                      (6200, 20000, 0.7, None), (16384, 4000, 0.6, None), (16384, 60000, 0.7, 2000),
+                                                      (9000, 2000, 0.7, 1), (9000, 2000, 0.7, 64), (9000, 2000, 0.7, 65),
+                                                      (9000, 2000, 0.7, 256), (9000, 2000, 0.7, 300)])
+def test_nms_walk_boundaries(n, spread, thresh, max_keep):
+    rs = np.random.RandomState(n + (max_keep or 0))
+    b = _rand_boxes(rs, n, float(spread))
+    want = ob.nms(b, thresh)
+    if max_keep:
+        want = want[:max_keep]
+    keep, nk = ops.nms(torch.from_numpy(b).to(DEV), thresh, max_keep=max_keep)
+    nk = int(nk.item())
+    assert nk == len(want)
+    np.testing.assert_array_equal(keep.cpu().numpy()[:nk], want)
+
+
 def test_nms_max_keep_and_empty():
     rs = np.random.RandomState(2)
     b = _rand_boxes(rs, 500)
@@ -82,7 +102,7 @@ def _rpn_case(seed, N, feat_shapes, exact):
 # 1024 (1 per thread, partner through LDS), 4096 (4 per thread), 128 (fewer threads than the block), and - with the larger
 # pyramid, A = 23,025 anchors - the training size: 12,000 of them in a 16,384-key sort (16 per thread).
 @pytest.mark.parametrize('n_pre,n_post,big', [(12000, 2000, False), (600, 100, False), (3000, 300, False), (100, 20, False),
-                                              (12000, 2000, True)])
+                                              (12000, 2000, True), (2048, 300, False), (2049, 300, False), (16384, 2000, True)])
 def test_proposals_end_to_end_bit_exact(n_pre, n_post, big):
     N = 2
     feat = [(72, 80), (36, 40), (18, 20), (9, 10), (5, 5)] if big else [(40, 48), (20, 24), (10, 12), (5, 6), (3, 3)]
