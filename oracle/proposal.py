@@ -1,10 +1,13 @@
 """Oracle: RPN proposal generation (TEST INFRASTRUCTURE - see oracle/__init__.py).
 
-Restates ChainerCV ``ProposalCreator.__call__`` (third-party, not on disk; "parity
-unpinned") as called at model/rpn/multilevel_region_proposal_network.py:156-161.  The
-in-tree mirror of that algorithm is utils/proposal_creator.py:108-169 (dead code in the
-reference but the only on-disk statement of the steps) -- followed line by line below,
-minus ``level_indices``.
+Restates ChainerCV ``ProposalCreator.__call__`` (third-party, not on disk) as called at
+model/rpn/multilevel_region_proposal_network.py:156-161.  The in-tree mirror of that
+algorithm is utils/proposal_creator.py:108-169 (dead code in the reference but the only
+on-disk statement of the steps) -- followed line by line below, minus ``level_indices``.
+Pinning: the CONTROL FLOW is pinned by tests/golden/pc_reference.npz (that in-tree class
+executed in the build container, tests/test_oracle_pins.py); the third-party arithmetic it
+calls (``loc2bbox``, ``non_maximum_suppression``) is this oracle's own restatement -
+"parity unpinned" for those two.
 """
 import numpy as np
 

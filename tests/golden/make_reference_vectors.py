@@ -20,6 +20,11 @@ source is copied -- so that two in-tree reference functions execute:
      indices, keypoint index arithmetic incl. the in-place mutation quirk), not the
      third-party arithmetic.  => ptc_reference.npz, ptc_keypoint_reference.npz
 
+  3. ``ProposalCreator.__call__`` of the in-tree utils/proposal_creator.py:108-169 (the reference's own copy of
+     ChainerCV's ProposalCreator, extended with level indices): ``loc2bbox`` and ``non_maximum_suppression`` are served by
+     this repo's oracle, so the fixture pins the control flow - clip to the image, min_size * scale filter, descending
+     argsort, top n_pre, NMS, top n_post - for train and test presets.  => pc_reference.npz
+
 Only data (inputs + outputs) is stored in the fixtures.
 """
 import os
@@ -63,6 +68,9 @@ def install_placeholders():
     _mod(base + '.utils.proposal_creator', ProposalCreator=object)
     _mod(base + '.utils.bbox2loc', bbox2loc=oboxes.bbox2loc)
     _mod('chainercv.utils.bbox.bbox_iou', bbox_iou=oboxes.bbox_iou)
+    _mod(base + '.utils.loc2bbox', loc2bbox=oboxes.loc2bbox)
+    _mod('chainercv.utils.bbox.non_maximum_suppression',
+         non_maximum_suppression=lambda bbox, thresh, score=None, limit=None: oboxes.nms(bbox, thresh))
     _mod('cv2', resize=lambda a, dsize: otargets.cv2_resize_linear_u8(a, dsize))
 
 
@@ -160,6 +168,33 @@ def main():
         kc['c%d_out_kp_after' % ci] = kp       # in-place mutation quirk (Appendix B-11)
         print('ptc keypoint case', ci, [np.asarray(v).shape for v in out])
     np.savez_compressed(os.path.join(OUT, 'ptc_keypoint_reference.npz'), **kc)
+
+    # ---- 3. ProposalCreator control flow (in-tree utils/proposal_creator.py) ---------------------------------------
+    import chainer
+    from chainer_maskrcnn.utils.proposal_creator import ProposalCreator as RefPC
+    pc = {}
+    for ci, (seed, feat, img, scale, train, n_pre, n_post, min_size) in enumerate([
+            (31, [(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)], (80, 96), 1.0, True, 600, 100, 16),
+            (32, [(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)], (80, 96), 1.6, True, 300, 50, 16),
+            (33, [(24, 16), (12, 8), (6, 4), (3, 2), (2, 1)], (96, 64), 1.0, False, 200, 30, 8),
+            (36, [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)], (64, 64), 0.5, True, 5000, 400, 16)]):
+        rs = np.random.RandomState(seed)
+        anchor = oboxes.fpn_anchors(feat)
+        A = anchor.shape[0]
+        loc = (rs.standard_normal((A, 4)) * 0.4).astype(np.float32)
+        loc[:, 2:] = 0.0                     # dh = dw = 0: exp() plays no part, decoding is exact on every platform
+        score = rs.standard_normal(A).astype(np.float32)
+        assert len(np.unique(score)) == A    # distinct scores: numpy's (unstable) argsort has one answer
+        chainer.config = types.SimpleNamespace(train=train)
+        ref = RefPC(nms_thresh=0.7, n_train_pre_nms=n_pre, n_train_post_nms=n_post, n_test_pre_nms=n_pre,
+                    n_test_post_nms=n_post, min_size=min_size)
+        roi, lev = ref(loc.copy(), score.copy(), anchor.copy(), np.zeros(A, np.int32), img, scale=scale)
+        for k, v in (('loc', loc), ('score', score), ('anchor', anchor), ('img', np.array(img)), ('scale', np.float32(scale)),
+                     ('train', np.int32(train)), ('n_pre', np.int32(n_pre)), ('n_post', np.int32(n_post)), ('min_size', np.int32(min_size))):
+            pc['c%d_in_%s' % (ci, k)] = v
+        pc['c%d_out_roi' % ci] = np.asarray(roi, np.float32)
+        print('proposal creator case', ci, 'anchors', A, '->', roi.shape)
+    np.savez_compressed(os.path.join(OUT, 'pc_reference.npz'), **pc)
 
 
 if __name__ == '__main__':

@@ -148,3 +148,19 @@ def test_proposal_creator_shapes_and_order():
     s = score[dbg['anchor_index']]
     assert np.all(np.diff(s) <= 0)
     assert np.all(roi[:, 2] - roi[:, 0] >= 16) and np.all(roi[:, 3] - roi[:, 1] >= 16)
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2, 3])
+def test_proposal_creator_control_flow_matches_reference(golden_dir, ci):
+    """pc_reference.npz = outputs of the REFERENCE's in-tree ProposalCreator (utils/proposal_creator.py:108-169) executed in
+    the build container (tests/golden/make_reference_vectors.py): clip, min_size * scale filter, descending sort, top n_pre,
+    NMS, top n_post - train and test presets.  The oracle's ProposalCreator (what every device test is compared with) must
+    give the same RoIs bit for bit."""
+    from oracle import proposal as opr
+    d = np.load(os.path.join(golden_dir, 'pc_reference.npz'))
+    g = lambda k: d['c%d_in_%s' % (ci, k)]
+    n_pre, n_post, train = int(g('n_pre')), int(g('n_post')), bool(g('train'))
+    pc = opr.ProposalCreator(n_train_pre_nms=n_pre, n_train_post_nms=n_post, n_test_pre_nms=n_pre, n_test_post_nms=n_post,
+                             min_size=int(g('min_size')))
+    got = pc(g('loc'), g('score'), g('anchor'), tuple(int(v) for v in g('img')), scale=float(g('scale')), train=train)
+    np.testing.assert_array_equal(got, d['c%d_out_roi' % ci])

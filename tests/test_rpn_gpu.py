@@ -152,6 +152,27 @@ def test_proposals_per_image_size_and_scale_equal_separate_calls():
     assert not np.array_equal(o['rois'].cpu().numpy(), ops.rpn_proposals(dl, ds, da, (160, 192), 16.0, n_pre, n_post, 0.7)['rois'].cpu().numpy())
 
 
+@pytest.mark.parametrize('ci', [0, 1, 2, 3])
+def test_proposals_equal_reference_golden(ci):
+    """tests/golden/pc_reference.npz: RoIs produced by the REFERENCE's in-tree ProposalCreator (utils/proposal_creator.py)
+    executed in the build container.  The device's decode -> clip -> filter -> select -> sort -> NMS chain must reproduce them
+    bit for bit (dh = dw = 0 in these cases: no exp() rounding involved)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pc_reference.npz'))
+    g = lambda k: d['c%d_in_%s' % (ci, k)]
+    loc, score, anchor = g('loc'), g('score'), g('anchor')
+    A = anchor.shape[0]
+    scores2 = np.stack([np.zeros(A, np.float32), score], 1)[None]
+    n_pre, n_post = int(g('n_pre')), int(g('n_post'))
+    o = ops.rpn_proposals(torch.from_numpy(loc[None]).to(DEV), torch.from_numpy(scores2).to(DEV), torch.from_numpy(anchor).to(DEV),
+                          tuple(int(v) for v in g('img')), float(g('min_size')) * float(g('scale')), n_pre, n_post, 0.7)
+    want = d['c%d_out_roi' % ci]
+    nk = int(o['n_rois'][0].item())
+    assert nk == len(want)
+    np.testing.assert_array_equal(o['rois'].cpu().numpy()[:nk], want)
+    np.testing.assert_array_equal(o['levels'].cpu().numpy()[:nk], ob.map_rois_to_fpn_levels(want))
+
+
 def test_proposals_random_scales_decode_tolerance():
     """exp() differs by <= 2 ulp between NumPy and the device: boxes compared with tolerance."""
     N = 1
