@@ -45,6 +45,20 @@ def suppress(cls_bbox, prob, n_class, nms_thresh, score_thresh, predict_mask=Tru
     return np.concatenate(idx).astype(np.int64), np.concatenate(lab)
 
 
+def prepare(img, min_size=600, max_size=1000):
+    """MaskRCNN.prepare (maskrcnn.py:261-276): (3,H,W) float32 0..255 -> resized so that the short side is min_size unless the
+    long side would exceed max_size (chainercv.transforms.resize = cv2.resize INTER_LINEAR per channel), then / 255.  The size
+    rule and the scaling are pinned by tests/golden/prepare_reference.npz (the reference method executed in the build
+    container); the interpolation is this oracle's cv2 restatement."""
+    _, H, W = img.shape
+    scale = min_size / min(H, W)
+    if scale * max(H, W) > max_size:
+        scale = max_size / max(H, W)
+    oh, ow = int(H * scale), int(W * scale)
+    out = np.stack([cv2_resize_linear_f32(img[c], (ow, oh)) for c in range(img.shape[0])])
+    return out.astype(np.float32) / 255
+
+
 def cv2_resize_linear_f32(src, dsize):
     """cv2.resize(src, (dw, dh)) for a 2-D float32 image."""
     src = np.asarray(src, F)

@@ -27,6 +27,8 @@ source is copied -- so that two in-tree reference functions execute:
 
 Only data (inputs + outputs) is stored in the fixtures.
 """
+import importlib.abc
+import importlib.machinery
 import os
 import sys
 import types
@@ -42,9 +44,45 @@ from oracle import boxes as oboxes      # noqa: E402
 from oracle import targets as otargets  # noqa: E402
 
 
+class _Dummy(object):
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Dummy()
+
+    def __getattr__(self, n):
+        return _Dummy()
+
+
+class _Placeholder(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return type(name, (_Dummy,), {})
+
+
+class _PlaceholderFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """Any other module of the absent packages (and of the reference's absent ``roi_align`` submodule) imports as an empty
+    placeholder whose attributes are inert classes: enough for ``import chainer_maskrcnn.model.maskrcnn`` to execute its
+    module level, so that MaskRCNN._suppress / MaskRCNN.prepare (plain NumPy control flow) can be called unbound."""
+    ROOTS = ('chainer', 'chainercv', 'chainerui', 'cv2', 'pycocotools', 'cupy')
+
+    def find_spec(self, name, path, target=None):
+        if name.split('.')[0] in self.ROOTS or name.startswith('chainer_maskrcnn.functions.roi_align.'):
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+    def create_module(self, spec):
+        return _Placeholder(spec.name)
+
+    def exec_module(self, m):
+        m.__path__ = []
+
+
 def _mod(name, **attrs):
-    m = types.ModuleType(name)
+    m = _Placeholder(name)
     m.__dict__.update(attrs)
+    m.__path__ = []            # a package: children that are not listed here come from _PlaceholderFinder
     sys.modules[name] = m
     return m
 
@@ -72,6 +110,7 @@ def install_placeholders():
     _mod('chainercv.utils.bbox.non_maximum_suppression',
          non_maximum_suppression=lambda bbox, thresh, score=None, limit=None: oboxes.nms(bbox, thresh))
     _mod('cv2', resize=lambda a, dsize: otargets.cv2_resize_linear_u8(a, dsize))
+    sys.meta_path.insert(0, _PlaceholderFinder())
 
 
 def synth_case(seed, n_roi, G, H, W, keypoints=False):
@@ -195,6 +234,42 @@ def main():
         pc['c%d_out_roi' % ci] = np.asarray(roi, np.float32)
         print('proposal creator case', ci, 'anchors', A, '->', roi.shape)
     np.savez_compressed(os.path.join(OUT, 'pc_reference.npz'), **pc)
+
+    # ---- 4. MaskRCNN._suppress / MaskRCNN.prepare (model/maskrcnn.py:261-312) ---------------------------------------
+    from chainer_maskrcnn.model import maskrcnn as ref_m
+    from oracle import predict as opredict
+    # third-party stand-ins: ChainerCV's NMS with scores (sort by score, keep list in the input's indices) and
+    # chainercv.transforms.resize (= cv2.resize INTER_LINEAR per channel)
+    ref_m.non_maximum_suppression = lambda bbox, thresh, score=None, limit=None: opredict.nms_with_score(bbox, thresh, score)
+    ref_m.resize = lambda img, size: np.stack([opredict.cv2_resize_linear_f32(img[c], (size[1], size[0])) for c in range(img.shape[0])])
+    sp = {}
+    for ci, (seed, R, n_class, predict_mask, score_thresh) in enumerate([(41, 120, 6, True, 0.12), (42, 300, 9, False, 0.05),
+                                                                         (43, 60, 81, True, 0.0123)]):
+        rs = np.random.RandomState(seed)
+        c = rs.uniform(0, 300, (R, 2)); hw = np.exp(rs.uniform(np.log(12), np.log(160), (R, 2)))
+        box = np.concatenate([c - hw / 2, c + hw / 2], 1).astype(np.float32)
+        box[5] = box[2]                                              # duplicates: suppressed whatever the scores
+        raw_cls_bbox = np.tile(box, (1, n_class)).astype(np.float32)      # class-agnostic loc: the same box for every class
+        logits = rs.standard_normal((R, n_class)).astype(np.float32) * 1.5
+        prob = (np.exp(logits) / np.exp(logits).sum(1, keepdims=True)).astype(np.float32)
+        raw_roi = np.tile(box[:, None, :], (1, n_class, 1)).astype(np.float32)
+        raw_level = rs.randint(0, 5, R).astype(np.int32)
+        self_ = types.SimpleNamespace(n_class=n_class, predict_mask=predict_mask, nms_thresh=0.3, score_thresh=score_thresh)
+        bbox, label, score, roi, level = ref_m.MaskRCNN._suppress(self_, raw_cls_bbox, prob, raw_roi, raw_level)
+        for k, v in (('box', box), ('prob', prob), ('level', raw_level), ('n_class', np.int32(n_class)), ('predict_mask', np.int32(predict_mask)),
+                     ('score_thresh', np.float32(score_thresh)), ('nms_thresh', np.float32(0.3))):
+            sp['c%d_in_%s' % (ci, k)] = v
+        for k, v in (('bbox', bbox), ('label', label), ('score', score), ('roi', roi), ('level', level)):
+            sp['c%d_out_%s' % (ci, k)] = np.asarray(v)
+        print('suppress case', ci, 'kept', len(label), 'classes', len(np.unique(label)))
+    np.savez_compressed(os.path.join(OUT, 'suppress_reference.npz'), **sp)
+    pr = {}
+    for ci, (H, W, mn, mx) in enumerate([(48, 64, 60, 100), (50, 140, 60, 100), (80, 80, 80, 133), (33, 50, 60, 100), (120, 70, 60, 100)]):
+        img = np.floor(np.random.RandomState(50 + ci).rand(3, H, W) * 256).astype(np.float32)
+        out = ref_m.MaskRCNN.prepare(types.SimpleNamespace(min_size=mn, max_size=mx), img)
+        pr['c%d_in_img' % ci], pr['c%d_in_min_max' % ci], pr['c%d_out' % ci] = img, np.array([mn, mx]), np.asarray(out)
+        print('prepare case', ci, img.shape, '->', out.shape)
+    np.savez_compressed(os.path.join(OUT, 'prepare_reference.npz'), **pr)
 
 
 if __name__ == '__main__':

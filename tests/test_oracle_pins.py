@@ -164,3 +164,27 @@ def test_proposal_creator_control_flow_matches_reference(golden_dir, ci):
                              min_size=int(g('min_size')))
     got = pc(g('loc'), g('score'), g('anchor'), tuple(int(v) for v in g('img')), scale=float(g('scale')), train=train)
     np.testing.assert_array_equal(got, d['c%d_out_roi' % ci])
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2])
+def test_suppress_control_flow_matches_reference(golden_dir, ci):
+    """suppress_reference.npz = MaskRCNN._suppress of the reference (maskrcnn.py:278-312) executed in the build container with
+    this oracle's NMS as ChainerCV's: per-class loop, score threshold, the skipped last class when masks are predicted, label
+    offsets, concatenation order."""
+    from oracle import predict as op
+    d = np.load(os.path.join(golden_dir, 'suppress_reference.npz'))
+    g = lambda k: d['c%d_in_%s' % (ci, k)]
+    box, prob, level = g('box'), g('prob'), g('level')
+    idx, lab = op.suppress(box, prob, int(g('n_class')), float(g('nms_thresh')), float(g('score_thresh')), predict_mask=bool(g('predict_mask')))
+    np.testing.assert_array_equal(box[idx], d['c%d_out_bbox' % ci])
+    np.testing.assert_array_equal(lab, d['c%d_out_label' % ci])
+    np.testing.assert_array_equal(prob[idx, lab + 1], d['c%d_out_score' % ci])
+    np.testing.assert_array_equal(level[idx], d['c%d_out_level' % ci])
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2, 3, 4])
+def test_prepare_size_rule_matches_reference(golden_dir, ci):
+    from oracle import predict as op
+    d = np.load(os.path.join(golden_dir, 'prepare_reference.npz'))
+    mn, mx = (int(v) for v in d['c%d_in_min_max' % ci])
+    np.testing.assert_array_equal(op.prepare(d['c%d_in_img' % ci], mn, mx), d['c%d_out' % ci])

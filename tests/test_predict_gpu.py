@@ -99,3 +99,36 @@ def test_predict_end_to_end_on_reduced_network():
                     assert np.nonzero(ys[i])[0].min() >= int(b[i, 0]) and np.nonzero(ys[i])[0].max() < int(b[i, 0]) + max(int(b[i, 2] - b[i, 0]), 1)
     assert m.train is True                                           # training mode restored
     assert sum(l.shape[0] for l in labels) > 0
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2])
+def test_suppress_equals_reference_golden(ci):
+    """tests/golden/suppress_reference.npz: MaskRCNN._suppress of the REFERENCE (maskrcnn.py:278-312) executed in the build
+    container.  The device's per-class threshold + NMS (mrcnn_class_nms_f32) and the host concatenation reproduce its
+    boxes, labels, scores and levels exactly."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'suppress_reference.npz'))
+    g = lambda k: d['c%d_in_%s' % (ci, k)]
+    n_class = int(g('n_class'))
+    m = MaskRCNN.__new__(MaskRCNN)              # _suppress only reads these attributes
+    import types
+    m.head = types.SimpleNamespace(n_class=n_class)
+    m.predict_mask, m.score_thresh, m.nms_thresh = bool(g('predict_mask')), float(g('score_thresh')), float(g('nms_thresh'))
+    bbox, label, score, level = m._suppress(_t(g('box')), _t(g('prob')), _t(g('level')))
+    np.testing.assert_array_equal(bbox.cpu().numpy(), d['c%d_out_bbox' % ci])
+    np.testing.assert_array_equal(label.cpu().numpy(), d['c%d_out_label' % ci])
+    np.testing.assert_array_equal(score.cpu().numpy(), d['c%d_out_score' % ci])
+    np.testing.assert_array_equal(level.cpu().numpy(), d['c%d_out_level' % ci])
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2, 3, 4])
+def test_prepare_equals_reference_golden(ci):
+    """tests/golden/prepare_reference.npz: MaskRCNN.prepare of the reference (maskrcnn.py:261-276) executed in the build
+    container (resize = this repo's cv2 restatement): size rule, interpolation and /255 on the device, bit for bit."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'prepare_reference.npz'))
+    m = MaskRCNN.__new__(MaskRCNN)
+    m.min_size, m.max_size = (int(v) for v in d['c%d_in_min_max' % ci])
+    m.device = torch.device(DEV)
+    got = m.prepare(torch.from_numpy(d['c%d_in_img' % ci]).to(DEV))
+    np.testing.assert_array_equal(got.cpu().numpy(), d['c%d_out' % ci])
