@@ -44,7 +44,14 @@ from oracle import boxes as oboxes      # noqa: E402
 from oracle import targets as otargets  # noqa: E402
 
 
-class _Dummy(object):
+class _DummyMeta(type):
+    def __getattr__(cls, n):            # chainer.dataset.DatasetMixin: attribute of a placeholder CLASS
+        if n.startswith('__'):
+            raise AttributeError(n)
+        return _DummyMeta(n, (_Dummy,), {})
+
+
+class _Dummy(object, metaclass=_DummyMeta):
     def __init__(self, *a, **k):
         pass
 
@@ -59,7 +66,7 @@ class _Placeholder(types.ModuleType):
     def __getattr__(self, name):
         if name.startswith('__'):
             raise AttributeError(name)
-        return type(name, (_Dummy,), {})
+        return _DummyMeta(name, (_Dummy,), {})
 
 
 class _PlaceholderFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
@@ -270,6 +277,47 @@ def main():
         pr['c%d_in_img' % ci], pr['c%d_in_min_max' % ci], pr['c%d_out' % ci] = img, np.array([mn, mx]), np.asarray(out)
         print('prepare case', ci, img.shape, '->', out.shape)
     np.savez_compressed(os.path.join(OUT, 'prepare_reference.npz'), **pr)
+
+    # ---- 5. the training Transforms (train.py:21-37, train_keypoints.py:48-68) -----------------------------------------
+    import train as ref_train                      # /root/reference/train.py (REF is first on sys.path)
+    import train_keypoints as ref_train_kp
+    assert os.path.dirname(os.path.abspath(ref_train.__file__)) == REF
+
+    def resize_bbox(bbox, in_size, out_size):      # chainercv.transforms.resize_bbox (third-party stand-in)
+        bbox = bbox.copy()
+        ys, xs = float(out_size[0]) / in_size[0], float(out_size[1]) / in_size[1]
+        bbox[:, 0] = ys * bbox[:, 0]; bbox[:, 2] = ys * bbox[:, 2]
+        bbox[:, 1] = xs * bbox[:, 1]; bbox[:, 3] = xs * bbox[:, 3]
+        return bbox
+
+    def cv2_resize_nearest(im, dsize, interpolation=None):      # cv2.resize(..., INTER_NEAREST) (third-party stand-in)
+        ow, oh = dsize
+        H_, W_ = im.shape
+        sy = np.minimum(np.floor(np.arange(oh) * (1.0 / (oh / H_))).astype(np.int64), H_ - 1)
+        sx = np.minimum(np.floor(np.arange(ow) * (1.0 / (ow / W_))).astype(np.int64), W_ - 1)
+        return im[sy][:, sx]
+    for mod in (ref_train, ref_train_kp):
+        mod.transforms.resize_bbox = resize_bbox
+    ref_train.cv2.resize = cv2_resize_nearest
+    tr = {}
+    for ci, (H, W, G, mn, mx) in enumerate([(48, 64, 3, 60, 100), (50, 140, 2, 60, 100), (90, 70, 4, 60, 100)]):
+        rs = np.random.RandomState(60 + ci)
+        fr = types.SimpleNamespace(prepare=lambda im, mn=mn, mx=mx: ref_m.MaskRCNN.prepare(types.SimpleNamespace(min_size=mn, max_size=mx), im))
+        img = np.floor(rs.rand(3, H, W) * 256).astype(np.float32)
+        tl = rs.uniform(0, [H * 0.6, W * 0.6], (G, 2)); hw = rs.uniform(4, [H * 0.4, W * 0.4], (G, 2))
+        bbox = np.concatenate([tl, tl + hw], 1).astype(np.float32)
+        label = rs.randint(0, 80, G).astype(np.int32)
+        masks = [(rs.rand(H, W) > 0.5).astype(np.uint8) for _ in range(G)]
+        o_img, o_bbox, o_label, o_masks, o_scale = ref_train.Transform(fr)((img.copy(), bbox.copy(), label.copy(), [m_.copy() for m_ in masks]))
+        kps = np.concatenate([rs.uniform(0, [W, H], (G, 17, 2)), rs.randint(0, 3, (G, 17, 1))], 2).astype(np.float32)      # (x, y, v)
+        k_img, k_bbox, k_label, k_kp, k_scale = ref_train_kp.Transform(fr)((img.copy(), bbox.copy(), kps.copy()))
+        for k, v in (('img', img), ('bbox', bbox), ('label', label), ('masks', np.stack(masks)), ('kps', kps), ('min_max', np.array([mn, mx]))):
+            tr['c%d_in_%s' % (ci, k)] = v
+        for k, v in (('img', o_img), ('bbox', o_bbox), ('label', o_label), ('masks', np.stack(o_masks)), ('scale', np.float64(o_scale)),
+                     ('kp_img', k_img), ('kp_bbox', k_bbox), ('kp_label', k_label), ('kp', k_kp), ('kp_scale', np.float64(k_scale))):
+            tr['c%d_out_%s' % (ci, k)] = np.asarray(v)
+        print('transform case', ci, img.shape, '->', o_img.shape, 'scale', o_scale)
+    np.savez_compressed(os.path.join(OUT, 'transform_reference.npz'), **tr)
 
 
 if __name__ == '__main__':

@@ -253,3 +253,30 @@ def test_batch_loader_resumes_at_a_ticket(tiny_coco):
     for x, y in zip(full[3:], rest):
         np.testing.assert_array_equal(x['imgs'], y['imgs'])
         np.testing.assert_array_equal(x['bboxes'], y['bboxes'])
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2])
+def test_transforms_equal_reference_golden(ci):
+    """tests/golden/transform_reference.npz: Transform.__call__ of the reference's train.py:21-37 and train_keypoints.py:48-68
+    EXECUTED in the build container (tests/golden/make_reference_vectors.py; chainercv.transforms.resize_bbox, cv2.resize and the
+    prepare resize are third-party stand-ins there).  This repo's Transform / KeypointTransform give the same image, boxes
+    (maximum corners + 1), labels, nearest-resized masks, (y, x, v) keypoints and scale, bit for bit."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'transform_reference.npz'))
+    g = lambda k: d['c%d_in_%s' % (ci, k)]
+    o = lambda k: d['c%d_out_%s' % (ci, k)]
+
+    class S(object):
+        min_size, max_size = (int(v) for v in g('min_max'))
+    img, bbox, label, masks, scale = transforms.Transform(S())((g('img'), g('bbox'), g('label'), list(g('masks'))))
+    np.testing.assert_array_equal(img, o('img'))
+    np.testing.assert_array_equal(bbox, o('bbox'))
+    np.testing.assert_array_equal(label, o('label'))
+    np.testing.assert_array_equal(masks, o('masks'))
+    assert scale == float(o('scale'))
+    img, bbox, label, kp, scale = transforms.KeypointTransform(S())((g('img'), g('bbox'), g('kps')))
+    np.testing.assert_array_equal(img, o('kp_img'))
+    np.testing.assert_array_equal(bbox, o('kp_bbox'))
+    np.testing.assert_array_equal(label, o('kp_label'))
+    np.testing.assert_array_equal(kp, o('kp'))
+    assert scale == float(o('kp_scale'))
