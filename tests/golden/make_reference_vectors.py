@@ -319,6 +319,76 @@ def main():
         print('transform case', ci, img.shape, '->', o_img.shape, 'scale', o_scale)
     np.savez_compressed(os.path.join(OUT, 'transform_reference.npz'), **tr)
 
+    # ---- 6. the dataset classes (dataset/coco_dataset.py:11-161) on a tiny COCO tree ---------------------------------------
+    # pycocotools.coco.COCO is served by this repo's own COCO index / mask decoder (loaded by file path: the package name
+    # chainer_maskrcnn belongs to the reference in this process), chainercv.utils.read_image by a PIL reader: the fixture
+    # pins the loaders' control flow - category OR-filter, image order, int-truncated boxes, continuous label ids, the
+    # keypoint loader's image filter and the max(1, .) clamp.
+    import importlib.util
+    import json
+    import tempfile
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location('mrcnn_coco_api', os.path.join(ROOT, 'chainer-maskrcnn_amd', 'chainer_maskrcnn', 'dataset', 'coco_api.py'))
+    coco_api = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(coco_api)
+    from chainer_maskrcnn.dataset import coco_dataset as ref_ds
+    ref_ds.COCO = coco_api.COCO
+    ref_ds.read_image = lambda path, color=True: np.asarray(Image.open(path).convert('RGB'), np.float32).transpose(2, 0, 1)
+    rs = np.random.RandomState(70)
+    cats = [{'id': 1, 'name': 'person'}, {'id': 7, 'name': 'train'}, {'id': 16, 'name': 'bird'}, {'id': 90, 'name': 'toothbrush'}]
+    sizes = [(48, 64), (80, 60), (50, 50), (64, 96), (40, 40), (56, 72)]
+    images, imgs, anns, aid = [], [], [], 1
+    for i, (h, w) in enumerate(sizes):
+        imgs.append(rs.randint(0, 256, (h, w, 3)).astype(np.uint8))
+        images.append({'id': 300 - 7 * i, 'file_name': 'im_%d.png' % i, 'height': h, 'width': w})      # ids not in file order
+    def poly_box(x, y, w, h):
+        return [[x, y, x + w, y, x + w, y + h, x, y + h]]
+    def add(img, cat, bbox, seg, kp=None, crowd=0):
+        nonlocal aid
+        a = {'id': aid, 'image_id': images[img]['id'], 'category_id': cat, 'bbox': bbox, 'iscrowd': crowd, 'segmentation': seg}
+        if kp is not None:
+            a['keypoints'], a['num_keypoints'] = kp, sum(1 for v in kp[2::3] if v > 0)
+        anns.append(a); aid += 1
+    kp17 = lambda: [int(v) for v in np.stack([rs.randint(0, 40, 17), rs.randint(0, 40, 17), rs.randint(0, 3, 17)], 1).reshape(-1)]
+    add(0, 1, [10.6, 5.2, 20.9, 30.7], poly_box(10, 5, 21, 31), kp17())
+    add(0, 7, [40, 20, 20, 10], {'size': [48, 64], 'counts': [40 * 48 + 20, 10] + [38, 10] * 19 + [48 * 64 - (40 * 48 + 20) - 10 - 19 * 48]}, crowd=1)
+    add(1, 90, [5, 6, 30, 40], poly_box(5, 6, 30, 40))
+    add(1, 1, [1, 1, 0.4, 0.2], [[1, 1, 2, 1, 2, 2]], [0, 0, 0] * 17)
+    add(2, 7, [0, 0, 50, 50], poly_box(0, 0, 50, 50))
+    add(3, 16, [12.9, 7.1, 33.3, 21.8], [[13, 7, 46, 9, 44, 28, 12, 25]])
+    add(3, 1, [50, 30, 20.5, 25.5], poly_box(50, 30, 20, 25), kp17())
+    add(3, 1, [5, 40, 9.9, 12.2], poly_box(5, 40, 10, 12), kp17())
+    add(5, 90, [20, 20, 8, 30], poly_box(20, 20, 8, 30))
+    ds_json = {'images': images, 'annotations': anns, 'categories': cats}
+    kp_json = {'images': images, 'categories': cats[:1], 'annotations': [a for a in anns if a['category_id'] == 1]}
+    dsg = {'instances_json': np.array(json.dumps(ds_json)), 'keypoints_json': np.array(json.dumps(kp_json))}
+    for i, im in enumerate(imgs):
+        dsg['image_%d' % i] = im
+    with tempfile.TemporaryDirectory() as root:
+        os.makedirs(os.path.join(root, 'annotations')); os.makedirs(os.path.join(root, 'train2017'))
+        for i, im in enumerate(imgs):
+            Image.fromarray(im).save(os.path.join(root, 'train2017', 'im_%d.png' % i))
+        json.dump(ds_json, open(os.path.join(root, 'annotations', 'instances_train2017.json'), 'w'))
+        json.dump(kp_json, open(os.path.join(root, 'annotations', 'person_keypoints_train2017.json'), 'w'))
+        for tag, flt in (('all', None), ('two', ['person', 'toothbrush']), ('bird', ['bird'])):
+            ld = ref_ds.COCOMaskLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017', category_filter=flt)
+            dsg['mask_%s_cat_ids' % tag] = np.array(ld.cat_ids)
+            dsg['mask_%s_files' % tag] = np.array([n for n, _ in ld.img_infos])
+            for j in range(len(ld)):
+                img, bbox, label, masks = ld.get_example(j)
+                dsg['mask_%s_%d_img' % (tag, j)] = np.asarray(img, np.float32)
+                dsg['mask_%s_%d_bbox' % (tag, j)] = np.asarray(bbox, np.float32).reshape(-1, 4)
+                dsg['mask_%s_%d_label' % (tag, j)] = label
+                dsg['mask_%s_%d_masks' % (tag, j)] = np.stack(masks) if len(masks) else np.zeros((0,) + img.shape[1:], np.uint8)
+            print('mask loader', tag, 'cat ids', ld.cat_ids, 'images', [n for n, _ in ld.img_infos])
+        kl = ref_ds.COCOKeypointsLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017')
+        dsg['kp_files'] = np.array([n for n, _ in kl.img_infos])
+        for j in range(len(kl)):
+            img, bbox, kps = kl.get_example(j)
+            dsg['kp_%d_img' % j], dsg['kp_%d_bbox' % j], dsg['kp_%d_kps' % j] = np.asarray(img, np.float32), bbox, kps
+        print('keypoint loader images', [n for n, _ in kl.img_infos])
+    np.savez_compressed(os.path.join(OUT, 'dataset_reference.npz'), **dsg)
+
 
 if __name__ == '__main__':
     main()

@@ -280,3 +280,48 @@ def test_transforms_equal_reference_golden(ci):
     np.testing.assert_array_equal(label, o('kp_label'))
     np.testing.assert_array_equal(kp, o('kp'))
     assert scale == float(o('kp_scale'))
+
+
+def test_loaders_equal_reference_golden(tmp_path):
+    """tests/golden/dataset_reference.npz: COCOMaskLoader / COCOKeypointsLoader of the reference (dataset/coco_dataset.py:11-161)
+    EXECUTED in the build container on a tiny COCO tree (pycocotools' COCO served by this repo's coco_api, read_image by PIL).
+    This repo's loaders - rewritten around the COCO index, not a transcription - must return the same category ids, the same
+    images in the same order and the same examples (int-truncated boxes, continuous labels, decoded masks, keypoints)."""
+    from PIL import Image
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'dataset_reference.npz'))
+    root = str(tmp_path)
+    os.makedirs(root + '/annotations'); os.makedirs(root + '/train2017')
+    open(root + '/annotations/instances_train2017.json', 'w').write(str(d['instances_json']))
+    open(root + '/annotations/person_keypoints_train2017.json', 'w').write(str(d['keypoints_json']))
+    i = 0
+    while 'image_%d' % i in d.files:
+        Image.fromarray(d['image_%d' % i]).save(root + '/train2017/im_%d.png' % i)
+        i += 1
+    # Image ORDER: the reference's is the iteration order of a Python set of image ids (hash order - an accident of the
+    # interpreter); this repo's is ascending image id (a defined order, DESIGN.md section 4).  Examples are matched by file name.
+    for tag, flt in (('all', None), ('two', ['person', 'toothbrush']), ('bird', ['bird'])):
+        ld = COCOMaskLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017', category_filter=flt)
+        assert list(ld.cat_ids) == d['mask_%s_cat_ids' % tag].tolist()
+        ref_files = d['mask_%s_files' % tag].tolist()
+        files = [n for n, _ in ld.img_infos]
+        assert sorted(files) == sorted(ref_files) and len(files) == len(ld)
+        ids = [i_ for _, i_ in ld.img_infos]
+        assert ids == sorted(ids)
+        for j, name in enumerate(files):
+            r = ref_files.index(name)
+            img, bbox, label, masks = ld.get_example(j)
+            np.testing.assert_array_equal(img, d['mask_%s_%d_img' % (tag, r)])
+            np.testing.assert_array_equal(np.asarray(bbox, np.float32).reshape(-1, 4), d['mask_%s_%d_bbox' % (tag, r)])
+            np.testing.assert_array_equal(label, d['mask_%s_%d_label' % (tag, r)])
+            got = np.stack(masks) if len(masks) else np.zeros((0,) + img.shape[1:], np.uint8)
+            np.testing.assert_array_equal(got, d['mask_%s_%d_masks' % (tag, r)])
+    kl = COCOKeypointsLoader(anno_dir=root + '/annotations', img_dir=root, split='train', data_type='2017')
+    ref_files = d['kp_files'].tolist()
+    files = [n for n, _ in kl.img_infos]
+    assert sorted(files) == sorted(ref_files)
+    for j, name in enumerate(files):
+        r = ref_files.index(name)
+        img, bbox, kps = kl.get_example(j)
+        np.testing.assert_array_equal(img, d['kp_%d_img' % r])
+        np.testing.assert_array_equal(bbox, d['kp_%d_bbox' % r])
+        np.testing.assert_array_equal(kps, d['kp_%d_kps' % r])
