@@ -11,6 +11,11 @@ Inputs that are not differentiated (proposals -> sampled RoIs, labels, regressio
 anchor labels) are passed in: their device implementations are pinned separately against
 oracle/proposal.py and oracle/targets.py (tests/test_rpn_gpu.py, tests/test_targets_gpu.py).
 
+PINNED (wiring): tests/test_step_reference_cpu.py compares this module - five losses to 1e-6, p2-p6, RPN outputs and head
+outputs to <= 1e-6 - with a training-step forward executed by the reference's own MaskRCNN / FeaturePyramidNetwork /
+MultilevelRegionProposalNetwork / FPNRoIMaskHead / FPNMaskRCNNTrainChain code on float64 stand-ins of the Chainer primitives
+(tests/golden/make_step_reference.py -> tests/golden/step_reference.npz).  The third-party arithmetic stays unpinned.
+
 Weights use the device's storage convention: conv weight (Cout, KH, KW, Cin) with zero-padded
 channels, activations NHWC; names are the ParamStore names of the product.
 """
