@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-end validation on the GPU box (run through gpurun from the repo root): full -m gpu suite, smoke(), the three bench
+# lines, rocprofv3 kernel statistics of the step and of the ROIAlign workload.  Outputs under gpurun_out/round_end/.
+set -o pipefail
+R=$PWD
+O=$R/gpurun_out/round_end
+mkdir -p $O
+python -m pytest tests -m gpu -q --ignore=tests/test_abi_cpu.py -p no:cacheprovider > $O/gpu_tests.txt 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.txt
+tail -3 $O/gpu_tests.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
+python bench.py > $O/bench_step_n1.json 2> $O/bench_step.err; tail -c 600 $O/bench_step_n1.json
+python bench.py --workload roialign > $O/bench_roialign_n1.json 2> $O/bench_roialign.err
+python bench.py --workload keypoint > $O/bench_keypoint_n1.json 2> $O/bench_keypoint.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/prof_step --output-format csv -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > $O/prof_step.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_roi --output-format csv -- python3 $R/bench.py --workload roialign --no-cpu-baseline > $O/prof_roi.log 2>&1
+cd $R
+for d in prof_step prof_roi; do f=$(ls $O/$d/*/*_kernel_stats.csv 2>/dev/null | tail -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
+python tools/trace_step.py $O/prof_step 5 > $O/step_breakdown.txt 2>&1
+python tools/trace_streams.py $O/prof_step 5 > $O/step_streams.txt 2>&1
+rm -rf $O/prof_step $O/prof_roi
+ls -la $O
