@@ -114,9 +114,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_proposal_target(
         int local = 0;
         for (int c = tid; c < np2; c += PT_THREADS) {
             bool in = false;
-            if (c < nc && G > 0) {
+            if (c < nc) {            // an image without objects (G = 0, max IoU 0): every proposal is a background candidate
                 const float m = smax[c];
-                in = phase == 0 ? (m >= pos_thresh) : (m < neg_hi && m >= neg_lo);
+                in = phase == 0 ? (G > 0 && m >= pos_thresh) : (m < neg_hi && m >= neg_lo);
             }
             // reference-order mode (pos_order / neg_order given): keys are ignored, the sort leaves the candidates in
             // ascending index order and row j takes the candidate of rank order[j] - np.random.choice's draw order
@@ -159,12 +159,15 @@ __global__ __launch_bounds__(PT_THREADS) void k_proposal_target(
             float *r5 = rois_xy5 + (size_t)row * 5;
             r5[0] = (float)img; r5[1] = b.y; r5[2] = b.x; r5[3] = b.w; r5[4] = b.z;
             sample_levels[row] = (int)(c < nr ? roi_levels[(size_t)img * roi_cap + c] : fpn_level(b));
-            float4 loc = bbox2loc(b, gbx);
-            loc.x = (loc.x - mean.x) / stdv.x; loc.y = (loc.y - mean.y) / stdv.y;
-            loc.z = (loc.z - mean.z) / stdv.z; loc.w = (loc.w - mean.w) / stdv.w;
+            float4 loc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (G > 0) {             // (no gt: row 0 is padding, its zero size would give -inf targets)
+                loc = bbox2loc(b, gbx);
+                loc.x = (loc.x - mean.x) / stdv.x; loc.y = (loc.y - mean.y) / stdv.y;
+                loc.z = (loc.z - mean.z) / stdv.z; loc.w = (loc.w - mean.w) / stdv.w;
+            }
             *reinterpret_cast<float4 *>(gt_roi_loc + (size_t)row * 4) = loc;
             gt_roi_label[row] = phase == 0 ? gt_labels[(size_t)img * gt_cap + g] + 1 : 0;
-            gt_assign[row] = g;
+            gt_assign[row] = G > 0 ? g : -1;
             sample_src[row] = c;
         }
         if (phase == 0) n_pos = want;
@@ -384,13 +387,16 @@ __global__ __launch_bounds__(256) void k_at_disable(const u64 *__restrict__ skey
 }
 
 __global__ __launch_bounds__(256) void k_at_loc(const float *__restrict__ anchors, int A, const float *__restrict__ gt_boxes,
-                                                int gt_cap, const int32_t *__restrict__ argmax, float *__restrict__ loc) {
+                                                const int32_t *__restrict__ n_gt, int gt_cap, const int32_t *__restrict__ argmax,
+                                                float *__restrict__ loc) {
     const int img = blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
     if (a >= A) return;
     const int g = argmax[(size_t)img * A + a];
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g >= 0)
+    // an image without objects (n_gt = 0) has no box to regress to: its inside anchors carry argmax 0 = a padding row, whose
+    // zero size would turn into -inf targets (and 0 x inf = NaN in the loss of anchors that are not even positive)
+    if (g >= 0 && g < n_gt[img])
         o = bbox2loc(*reinterpret_cast<const float4 *>(anchors + (size_t)a * 4),
                      *reinterpret_cast<const float4 *>(gt_boxes + ((size_t)img * gt_cap + g) * 4));
     *reinterpret_cast<float4 *>(loc + ((size_t)img * A + a) * 4) = o;
@@ -517,7 +523,7 @@ extern "C" int mrcnn_anchor_target_f32(const float *anchors, int A, const float 
         hipLaunchKernelGGL(k_at_disable, grid, dim3(256), 0, st, skeys, A, counts, kth, n_sample, n_pos_max, gt_rpn_label);
         MRCNN_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_at_loc, grid, dim3(256), 0, st, anchors, A, gt_boxes, gt_cap, argmax, gt_rpn_loc);
+    hipLaunchKernelGGL(k_at_loc, grid, dim3(256), 0, st, anchors, A, gt_boxes, n_gt, gt_cap, argmax, gt_rpn_loc);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -344,6 +344,42 @@ def test_ragged_batch_padding_rows_are_ignored():
     assert int(src.max()) <= n_roi1
 
 
+def test_image_without_objects_is_a_background_only_example():
+    """An image whose every gt row is padding (label -1): the reference's step raises there (ChainerCV's AnchorTargetCreator
+    takes an argmax over an empty axis); here it is a well-defined background-only example - all anchors of the image that
+    are sampled are negatives, all its sampled RoIs are background with no mask target - and the step stays finite."""
+    m, chain = _build('positives')
+    b = _batch(G=3)
+    bb, lab, mk = b['bboxes'].clone(), b['labels'].clone(), b['masks'].clone()
+    bb[1] = 0
+    lab[1] = -1
+    mk[1] = 0
+    loss = chain(b['imgs'], bb, lab, mk, 1.0)
+    loss.backward()
+    obs = {k: float(v) for k, v in chain.observation.items()}
+    assert all(np.isfinite(v) for v in obs.values()), obs
+    assert bool(torch.isfinite(m.ps.grads).all())
+    gt_rpn_loc, gt_rpn_label = chain.rpn_targets
+    assert int((gt_rpn_label[1] == 1).sum()) == 0 and int((gt_rpn_label[1] == 0).sum()) == 256
+    assert int((gt_rpn_label[0] == 1).sum()) >= 1
+    t = chain.targets
+    assert int(t['n_pos'][1]) == 0 and int(t['n_sampled'][1]) >= 1
+    lab1 = t['gt_roi_label'][256:256 + int(t['n_sampled'][1])]
+    assert int(lab1.abs().max()) == 0
+    assert float(t['gt_roi_loc'][256:512].abs().max()) == 0.0 or int(t['n_pos'][1]) == 0
+    # both images without objects: every loss term that needs a positive is exactly zero
+    bb[0] = 0
+    lab[0] = -1
+    mk[0] = 0
+    loss = chain(b['imgs'], bb, lab, mk, 1.0)
+    loss.backward()
+    obs = {k: float(v) for k, v in chain.observation.items()}
+    assert all(np.isfinite(v) for v in obs.values()), obs
+    assert obs['rpn_loc_loss'] == 0.0 and obs['roi_loc_loss'] == 0.0 and obs['mask_loss'] == 0.0
+    assert obs['rpn_cls_loss'] > 0.0 and obs['roi_cls_loss'] > 0.0
+    assert bool(torch.isfinite(m.ps.grads).all())
+
+
 def test_padded_batch_uses_each_images_own_size_and_scale():
     """dataset/loader.py hands over 'scales' (N,) and 'sizes' (N,2): the chain clips proposals to / tests anchors against
     each image's own size and filters with min_size * its own scale (the reference step is batch 1 per process:
