@@ -305,6 +305,58 @@ def test_exported_loss_functions_are_callable():
     assert float(xk.grad[n_pos:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('H,W', [(100, 132), (97, 151), (130, 66)])
+def test_odd_image_sizes_whole_step_matches_oracle(H, W):
+    """Sizes that are not multiples of 64: the stride-2 layers round up, max_pooling_2d covers the last odd row, and the
+    top-down pathway crops F.unpooling_2d's output to the lateral's size (feature_pyramid_network.py:57-66).  Whole step
+    (five losses, every parameter gradient) against the oracle on such tensors, batch 2."""
+    m, chain = _build('positives')
+    b = make_batch(5, 2, H, W, G=3)
+    b['bboxes'][:, :, 2:] = np.minimum(b['bboxes'][:, :, 2:], [H, W])
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
+    chain.keep_outputs = True
+    loss = chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+    loss.backward()
+    obs = {k: float(v) for k, v in chain.observation.items()}
+    ps = m.ps
+    params = {n: ps.p(n).detach().cpu().to(D).requires_grad_(True) for n in ps.names()}
+    t = {k: v.cpu().numpy() for k, v in chain.targets.items() if torch.is_tensor(v)}
+    t['gt_rpn_loc'], t['gt_rpn_label'] = (x.cpu().numpy() for x in chain.rpn_targets)
+    t['mask_rois_xy5'], t['mask_levels'], t['mask_label'] = (x.cpu().numpy() for x in chain.mask_inputs)
+    oracle = OracleStep(params, STAGES, m.head.n_class, m.head.LOC0)
+    img4 = torch.cat([b['imgs'].cpu().permute(0, 2, 3, 1), torch.zeros((2, H, W, 1))], -1).to(D)
+    out = oracle.losses(img4, t)
+    shapes = [tuple(f.shape[1:3]) for f in out['feats']]
+    half = lambda n: (n - 1) // 2 + 1
+    pool = lambda n: -(-(n - 2) // 2) + 1
+    want = [(pool(half(H)), pool(half(W)))]
+    for _ in range(4):
+        want.append((half(want[-1][0]), half(want[-1][1])))
+    assert shapes == want and [tuple(f.shape[1:3]) for f in chain.outputs['features']] == want
+    names = ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
+    for k in names:
+        ok_ = float(out[k].detach())
+        assert abs(obs[k] - ok_) <= 1e-4 * max(abs(ok_), 1e-3), (k, obs[k], ok_)
+    sum(out[k] for k in names).backward()
+    from oracle import model as om
+    om.set_dtype(torch.float32)          # the float32 oracle = this network's own noise floor (see the first test of this file)
+    try:
+        p32 = {n: ps.p(n).detach().cpu().requires_grad_(True) for n in ps.names()}
+        out32 = OracleStep(p32, STAGES, m.head.n_class, m.head.LOC0).losses(img4.float(), t)
+        sum(out32[k] for k in names).backward()
+    finally:
+        om.set_dtype(torch.float64)
+    gmax = max(float(params[n].grad.abs().max()) for n in ps.names() if params[n].grad is not None)
+    for n in ps.names():
+        want_g = params[n].grad if params[n].grad is not None else torch.zeros_like(params[n])
+        w32 = p32[n].grad if p32[n].grad is not None else torch.zeros_like(p32[n])
+        got = ps.g(n).cpu().to(D)
+        scale = max(float(want_g.abs().max()), 1e-3 * gmax)
+        err = float((got - want_g).abs().max()) / scale
+        floor = float((w32.to(D) - want_g).abs().max()) / scale
+        assert _grad_ok(got, want_g, err, floor, 1e-3), (n, err, floor)
+
+
 def test_ragged_batch_padding_rows_are_ignored():
     """dataset/loader.py pads ragged batches with zero boxes / label -1 and train.py passes no counts.
     The chain must count the valid rows itself (#label >= 0, on the device); a zero box treated as a gt would make every
