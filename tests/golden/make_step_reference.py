@@ -48,7 +48,7 @@ WEIGHT_SEED, NP_SEED = 20260, 515
 
 
 def install():
-    cuda = g._mod('chainer.cuda', get_array_module=lambda *a: np, to_cpu=lambda x: np.asarray(x), to_gpu=lambda x: x)
+    cuda = g._mod('chainer.cuda', get_array_module=lambda *a: np, to_cpu=lambda x: np.asarray(x), to_gpu=lambda x: x, available=False)
     backends = g._mod('chainer.backends', cuda=cuda)
     g._mod('chainer.backends.cuda', get_array_module=lambda *a: np)
     links = g._mod('chainer.links', Convolution2D=mc.Convolution2D, Linear=mc.Linear, Deconvolution2D=mc.Deconvolution2D,
@@ -57,11 +57,12 @@ def install():
     g._mod('chainer.links.model.vision.resnet', ResNet50Layers=mc.ResNet50Layers, BuildingBlock=mc.BuildingBlock,
            _global_average_pooling_2d=None)
     functions = g._mod('chainer.functions', relu=mc.relu, max_pooling_2d=mc.max_pooling_2d, unpooling_2d=mc.unpooling_2d,
-                       concat=mc.concat, softmax_cross_entropy=mc.softmax_cross_entropy, sigmoid_cross_entropy=mc.sigmoid_cross_entropy)
+                       concat=mc.concat, softmax_cross_entropy=mc.softmax_cross_entropy, sigmoid_cross_entropy=mc.sigmoid_cross_entropy,
+                       softmax=mc.softmax, sigmoid=mc.sigmoid)
     reporter = g._mod('chainer.reporter', report=mc.report)
     initializers = g._mod('chainer.initializers', Normal=mc._Normal)
     g._mod('chainer', cuda=cuda, backends=backends, links=links, functions=functions, reporter=reporter, initializers=initializers,
-           Chain=mc.Chain, Variable=mc.Var, config=mc.config)
+           Chain=mc.Chain, Variable=mc.Var, config=mc.config, using_config=mc.using_config)
     base = 'chainercv.links.model.faster_rcnn'
     for n in ('chainercv', 'chainercv.links', 'chainercv.links.model', base, base + '.utils', 'chainercv.utils', 'chainercv.utils.bbox'):
         g._mod(n)

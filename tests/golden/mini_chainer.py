@@ -30,6 +30,9 @@ D = np.float64
 class Var(np.ndarray):
     """chainer.Variable: here an ndarray that also answers .array / .data."""
 
+    def __new__(cls, data):          # chainer.Variable(array)
+        return np.ascontiguousarray(np.asarray(data, D)).view(cls)
+
     @property
     def array(self):
         return np.asarray(self)
@@ -59,7 +62,18 @@ class Chain(object):
         yield
 
 
-config = types.SimpleNamespace(train=True)
+config = types.SimpleNamespace(train=True, enable_backprop=True)
+
+
+@contextlib.contextmanager
+def using_config(name, value):
+    old = getattr(config, name)
+    setattr(config, name, value)
+    try:
+        yield
+    finally:
+        setattr(config, name, old)
+
 REPORTED = {}
 
 
@@ -103,13 +117,19 @@ class Linear(Chain):
 
 class BatchNormalization(Chain):
     def __init__(self, size, **kw):
-        self.gamma = self.beta = None
+        self.gamma = self.beta = self.avg_mean = self.avg_var = None
         self.eps = 2e-5
+        self.last_mean = self.last_var = None
 
-    def __call__(self, x):          # chainer.config.train: batch statistics over (N, H, W), biased variance
+    def __call__(self, x):
         x = np.asarray(x, D)
-        m = x.mean(axis=(0, 2, 3), keepdims=True)
-        v = x.var(axis=(0, 2, 3), keepdims=True)
+        if config.train:            # batch statistics over (N, H, W), biased variance (kept: a generator may adopt them as the
+            m = x.mean(axis=(0, 2, 3), keepdims=True)          # running statistics of a later inference-mode call)
+            v = x.var(axis=(0, 2, 3), keepdims=True)
+            self.last_mean, self.last_var = m.reshape(-1), v.reshape(-1)
+        else:                       # inference: the running statistics
+            m = np.asarray(self.avg_mean, D)[None, :, None, None]
+            v = np.asarray(self.avg_var, D)[None, :, None, None]
         g, b = np.asarray(self.gamma, D)[None, :, None, None], np.asarray(self.beta, D)[None, :, None, None]
         return V(g * (x - m) / np.sqrt(v + self.eps) + b)
 
@@ -193,6 +213,16 @@ def unpooling_2d(x, ksize, stride=None, pad=0, outsize=None, cover_all=True):
 
 def concat(xs, axis=1):
     return V(np.concatenate([np.asarray(x, D) for x in xs], axis=axis))
+
+
+def softmax(x, axis=1):
+    x = np.asarray(x, D)
+    e = np.exp(x - x.max(axis=axis, keepdims=True))
+    return V(e / e.sum(axis=axis, keepdims=True))
+
+
+def sigmoid(x):
+    return V(1.0 / (1.0 + np.exp(-np.asarray(x, D))))
 
 
 def softmax_cross_entropy(x, t, normalize=True, ignore_label=-1):
