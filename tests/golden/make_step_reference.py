@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Golden vector of ONE WHOLE TRAINING-STEP FORWARD made by executing the reference's own model code (build container only).
 
-Run from the repo root:   python tests/golden/make_step_reference.py          (needs /root/reference; ~1 min)
+Run from the repo root:   python tests/golden/make_step_reference.py [mask|keypoint]      (needs /root/reference; ~1 min each;
+                          one kind per process - the reference's modules are imported once)
 
 Executed from /root/reference, unmodified, in this process:
     MaskRCNN.__init__                              chainer_maskrcnn/model/maskrcnn.py:26-135
@@ -58,11 +59,11 @@ def install():
            _global_average_pooling_2d=None)
     functions = g._mod('chainer.functions', relu=mc.relu, max_pooling_2d=mc.max_pooling_2d, unpooling_2d=mc.unpooling_2d,
                        concat=mc.concat, softmax_cross_entropy=mc.softmax_cross_entropy, sigmoid_cross_entropy=mc.sigmoid_cross_entropy,
-                       softmax=mc.softmax, sigmoid=mc.sigmoid)
+                       softmax=mc.softmax, sigmoid=mc.sigmoid, resize_images=mc.resize_images)
     reporter = g._mod('chainer.reporter', report=mc.report)
     initializers = g._mod('chainer.initializers', Normal=mc._Normal)
     g._mod('chainer', cuda=cuda, backends=backends, links=links, functions=functions, reporter=reporter, initializers=initializers,
-           Chain=mc.Chain, Variable=mc.Var, config=mc.config, using_config=mc.using_config)
+           Chain=mc.Chain, ChainList=mc.ChainList, Variable=mc.Var, config=mc.config, using_config=mc.using_config)
     base = 'chainercv.links.model.faster_rcnn'
     for n in ('chainercv', 'chainercv.links', 'chainercv.links.model', base, base + '.utils', 'chainercv.utils', 'chainercv.utils.bbox'):
         g._mod(n)
@@ -93,14 +94,21 @@ def assign(model, weights):
         setattr(obj, parts[-1], mc.V(arr))
 
 
-def main():
+def main(kind='mask'):
+    """kind 'mask': train.py's model (FPNRoIMaskHead, 80 classes, calc_mask_loss) -> step_reference.npz;
+    kind 'keypoint': train_keypoints.py's (FPNRoIKeypointHead, 1 class, 17 keypoints, 8 convolutions, its calc_mask_loss =
+    soft-max cross-entropy over the 56x56 positions, binary_mask=False) -> step_keypoint_reference.npz."""
     install()
     sys.path.insert(0, REF)
     from chainer_maskrcnn.model.maskrcnn import MaskRCNN
     from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain
     import chainer_maskrcnn.functions.roi_align_2d_yx as ref_yx
-    import train as ref_train
+    if kind == 'mask':
+        import train as ref_train
+    else:
+        import train_keypoints as ref_train
     assert os.path.dirname(os.path.abspath(ref_train.__file__)) == REF
+    K = 17
 
     def roi_align_2d(x, rois_xy, outh, outw, spatial_scale):       # the absent submodule's operator: this repo's oracle
         return mc.V(oroi.roi_align_fwd(np.asarray(x), np.asarray(rois_xy), outh, outw, spatial_scale, 2))
@@ -108,16 +116,28 @@ def main():
 
     H, W, G = 128, 160, 4
     _, bbox, label, mask = g.synth_case(81, 8, G, H, W)
+    if kind == 'keypoint':
+        _, _, _, kps = g.synth_case(81, 8, G, H, W, keypoints=True)         # same boxes (same seed), (y, x, v) keypoints inside them
+        kps[:, :, 2] = np.where(kps[:, :, 2] == 0, 2, kps[:, :, 2])           # mostly visible: enough labelled positions
+        label = np.zeros(G, np.int32)
     img = np.floor(np.random.RandomState(82).rand(1, 3, H, W) * 256).astype(np.float32)
     img -= np.array([122.7717, 115.9465, 102.9801], np.float32)[None, :, None, None]
     for gi in range(G):           # the objects are visible in the image, so that the features are not pure noise
         img[0][:, mask[gi] > 0] += np.float32(40.0 * (gi + 1) / G)
 
     t0 = time.time()
-    weights = chainer_weights(WEIGHT_SEED)
-    model = MaskRCNN(n_fg_class=80)
-    assign(model, weights)
-    chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=ref_train.calc_mask_loss)
+    if kind == 'mask':
+        weights = chainer_weights(WEIGHT_SEED)
+        model = MaskRCNN(n_fg_class=80)
+        assign(model, weights)
+        chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=ref_train.calc_mask_loss)
+        gt_in = mask
+    else:
+        weights = chainer_weights(WEIGHT_SEED + 1, n_fg_class=1, n_keypoints=K)
+        model = MaskRCNN(n_fg_class=1, n_keypoints=K, head_arch='fpn_keypoint')          # train_keypoints.py:119-120
+        assign(model, weights)
+        chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=ref_train.calc_mask_loss, binary_mask=False)
+        gt_in = kps.copy()               # the reference's ProposalTargetCreator writes into it
 
     cap = {}
 
@@ -138,7 +158,7 @@ def main():
     chain.anchor_target_creator = Tap(chain.anchor_target_creator, 'atc')
 
     np.random.seed(NP_SEED)
-    loss = chain(mc.V(img), bbox[None], label[None], mask[None], np.array(1.0, np.float32))
+    loss = chain(mc.V(img), bbox[None], label[None], gt_in[None], np.array(1.0, np.float32))
     print('reference step executed in %.1f s' % (time.time() - t0), dict(mc.REPORTED))
 
     feats = cap['extractor'][1]
@@ -152,8 +172,7 @@ def main():
     assert abs(float(loss) - sum(v for k, v in mc.REPORTED.items() if k != 'loss')) < 1e-9
     f32 = lambda a: np.asarray(a, np.float32)
     out = {
-        'in_img': img, 'in_bbox': bbox, 'in_label': label, 'in_mask': np.packbits(mask, axis=-1), 'in_mask_shape': np.array(mask.shape),
-        'in_weight_seed': np.int64(WEIGHT_SEED), 'in_np_seed': np.int64(NP_SEED),
+        'in_img': img, 'in_bbox': bbox, 'in_label': label, 'in_weight_seed': np.int64(WEIGHT_SEED + (kind == 'keypoint')), 'in_np_seed': np.int64(NP_SEED),
         'anchor': f32(anchor), 'rois': f32(rois), 'levels': np.asarray(levels, np.int32),
         'sample_roi': f32(sample_roi), 'sample_levels': np.asarray(sample_levels, np.int32), 'gt_roi_loc': f32(gt_roi_loc),
         'gt_roi_label': np.asarray(gt_roi_label, np.int32), 'gt_roi_mask': np.asarray(gt_roi_mask, np.int8),
@@ -163,16 +182,24 @@ def main():
         'p2_sub': f32(feats[0][:, ::8, ::4, ::4]),
         'rpn_locs': f32(rpn_locs), 'rpn_scores': f32(rpn_scores),
         'roi_cls_locs': f32(roi_cls_locs), 'roi_scores': f32(roi_scores),
-        'roi_mask_pos': f32(np.asarray(roi_cls_mask)[np.arange(n_pos), np.asarray(gt_roi_label)[:n_pos] - 1]),
-        'roi_mask_sub': f32(np.asarray(roi_cls_mask)[:, ::16, ::2, ::2]),
     }
+    if kind == 'mask':
+        out.update({'in_mask': np.packbits(mask, axis=-1), 'in_mask_shape': np.array(mask.shape),
+                    'roi_mask_pos': f32(np.asarray(roi_cls_mask)[np.arange(n_pos), np.asarray(gt_roi_label)[:n_pos] - 1]),
+                    'roi_mask_sub': f32(np.asarray(roi_cls_mask)[:, ::16, ::2, ::2])})
+    else:
+        assert roi_cls_mask.shape[1:] == (K, 56, 56) and gt_roi_mask.shape == (n_pos, K) and (np.asarray(gt_roi_mask) >= 0).sum() >= 20
+        out.update({'in_keypoints': kps, 'roi_mask_sub': f32(np.asarray(roi_cls_mask)[:n_pos, :, ::4, ::4]),
+                    'roi_mask_at_label': f32(np.asarray(roi_cls_mask)[:n_pos].reshape(n_pos, K, -1)[
+                        np.arange(n_pos)[:, None], np.arange(K)[None, :], np.maximum(np.asarray(gt_roi_mask), 0)])})
+        out['gt_roi_mask'] = np.asarray(gt_roi_mask, np.int32)
     for k, v in mc.REPORTED.items():
         out['loss_' + k] = np.float64(v)
-    path = os.path.join(HERE, 'step_reference.npz')
+    path = os.path.join(HERE, 'step_reference.npz' if kind == 'mask' else 'step_keypoint_reference.npz')
     np.savez_compressed(path, **out)
-    print('step_reference.npz %.2f MB' % (os.path.getsize(path) / 2 ** 20), 'rois', rois.shape, 'samples', sample_roi.shape, 'positives', n_pos,
+    print(os.path.basename(path) + ' %.2f MB' % (os.path.getsize(path) / 2 ** 20), 'rois', rois.shape, 'samples', sample_roi.shape, 'positives', n_pos,
           'rpn positives', int((gt_rpn_label == 1).sum()), 'levels', np.bincount(np.asarray(sample_levels, np.int64), minlength=5))
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else 'mask')

@@ -8,10 +8,11 @@ run on these primitives, in float64 NumPy (torch-CPU float64 for the convolution
 by tests/golden/make_reference_vectors.py alone; nothing here is product code and nothing here is taken from the reference -
 every function restates the public behaviour of the Chainer / ChainerCV API it is named after:
 
-    chainer.Chain / init_scope / Variable(.array, .data) / cuda / config / reporter
+    chainer.Chain / ChainList / init_scope / Variable(.array, .data) / cuda / config / using_config / reporter
     chainer.links: Convolution2D, Linear, Deconvolution2D, BatchNormalization (training mode: batch statistics, eps 2e-5)
     chainer.links.model.vision.resnet: ResNet50Layers, BuildingBlock (BottleneckA / BottleneckB, stride on the first 1x1)
-    chainer.functions: relu, max_pooling_2d (cover_all), unpooling_2d, concat, softmax_cross_entropy, sigmoid_cross_entropy
+    chainer.functions: relu, max_pooling_2d (cover_all), unpooling_2d, resize_images, concat, softmax, sigmoid,
+      softmax_cross_entropy, sigmoid_cross_entropy
     chainercv: FasterRCNN, FasterRCNNTrainChain, _fast_rcnn_loc_loss, AnchorTargetCreator, ProposalCreator, anchors
       (the last three are this repo's oracle restatements, as everywhere in this generator)
 
@@ -60,6 +61,28 @@ class Chain(object):
     @contextlib.contextmanager
     def init_scope(self):
         yield
+
+
+class ChainList(Chain):
+    """chainer.ChainList: children are registered under their index ('0', '1', ...: the snapshot keys)."""
+
+    def __init__(self, *links):
+        self._children = []
+        for l in links:
+            self.add_link(l)
+
+    def add_link(self, link):
+        setattr(self, str(len(self._children)), link)
+        self._children.append(link)
+
+    def children(self):
+        return iter(self._children)
+
+    def __iter__(self):
+        return iter(self._children)
+
+    def __len__(self):
+        return len(self._children)
 
 
 config = types.SimpleNamespace(train=True, enable_backprop=True)
@@ -209,6 +232,22 @@ def unpooling_2d(x, ksize, stride=None, pad=0, outsize=None, cover_all=True):
     x = np.asarray(x, D)
     y = np.repeat(np.repeat(x, ksize, axis=2), ksize, axis=3)
     return V(y[:, :, :outsize[0], :outsize[1]])
+
+
+def resize_images(x, output_shape):
+    """chainer.functions.resize_images: bilinear with the corner pixels aligned, u = linspace(0, H - 1, out_H)
+    (SURVEY.md Appendix A-8)."""
+    x = np.asarray(x, D)
+
+    def axis(n, m):
+        u = np.linspace(0, n - 1, m)
+        u0 = np.clip(np.floor(u).astype(np.int64), 0, max(n - 2, 0))
+        u1 = np.minimum(u0 + 1, n - 1)
+        return u0, u1, u0 + 1 - u, u - u0
+    y0, y1, wy0, wy1 = axis(x.shape[2], output_shape[0])
+    x0, x1, wx0, wx1 = axis(x.shape[3], output_shape[1])
+    rows = x[:, :, y0] * wy0[None, None, :, None] + x[:, :, y1] * wy1[None, None, :, None]
+    return V(rows[:, :, :, x0] * wx0 + rows[:, :, :, x1] * wx1)
 
 
 def concat(xs, axis=1):

@@ -6,7 +6,7 @@ the fixture does not have to carry 44 M numbers.  Test infrastructure."""
 import numpy as np
 
 
-def layer_list(n_fg_class=80):
+def layer_list(n_fg_class=80, n_keypoints=None, n_mask_convs=8):
     """[(key prefix, kind, shape of W, has bias)] in a fixed order."""
     out = []
     conv = lambda name, cout, cin, k, bias=True: out.append((name, 'conv', (cout, cin, k, k), bias))
@@ -35,17 +35,21 @@ def layer_list(n_fg_class=80):
     out.append(('head/fc2', 'linear', (1024, 1024), True))
     out.append(('head/cls_loc', 'linear', (4, 1024), True))
     out.append(('head/score', 'linear', (n_fg_class + 1, 1024), True))
-    for i in range(1, 5):
-        conv('head/mask%d' % i, 256, 256, 3)
+    if n_keypoints is None:         # FPNRoIMaskHead: mask1..mask4, one mask per foreground class
+        for i in range(1, 5):
+            conv('head/mask%d' % i, 256, 256, 3)
+    else:                           # FPNRoIKeypointHead: a ChainList of n_mask_convs convolutions, one heat map per keypoint
+        for i in range(n_mask_convs):
+            conv('head/mask_convs/%d' % i, 256, 256, 3)
     out.append(('head/deconv1', 'deconv', (256, 256, 2, 2), True))
-    conv('head/conv2', n_fg_class, 256, 1)
+    conv('head/conv2', n_fg_class if n_keypoints is None else n_keypoints, 256, 1)
     return out
 
 
-def chainer_weights(seed, n_fg_class=80):
+def chainer_weights(seed, n_fg_class=80, n_keypoints=None, n_mask_convs=8):
     rs = np.random.RandomState(seed)
     d = {}
-    for name, kind, shape, bias in layer_list(n_fg_class):
+    for name, kind, shape, bias in layer_list(n_fg_class, n_keypoints, n_mask_convs):
         if kind == 'bn':
             d[name + '/gamma'] = (1.0 + 0.2 * rs.standard_normal(shape)).astype(np.float32)
             d[name + '/beta'] = (0.1 * rs.standard_normal(shape)).astype(np.float32)

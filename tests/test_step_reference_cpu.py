@@ -27,10 +27,11 @@ def _rel(got, want):
     return float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-30)
 
 
-def load_step_golden(golden_dir):
-    d = dict(np.load(os.path.join(golden_dir, 'step_reference.npz')))
-    shape = tuple(d['in_mask_shape'])
-    d['in_mask'] = np.unpackbits(d['in_mask'], axis=-1)[..., :shape[-1]].reshape(shape)
+def load_step_golden(golden_dir, name='step_reference.npz'):
+    d = dict(np.load(os.path.join(golden_dir, name)))
+    if 'in_mask' in d:
+        shape = tuple(d['in_mask_shape'])
+        d['in_mask'] = np.unpackbits(d['in_mask'], axis=-1)[..., :shape[-1]].reshape(shape)
     return d
 
 
@@ -74,6 +75,38 @@ def test_oracle_step_equals_reference_executed_step(golden_dir):
     sel = mk[np.arange(n_pos), :, :, d['gt_roi_label'][:n_pos] - 1]
     assert _rel(sel, d['roi_mask_pos']) < 1e-5
     assert _rel(mk[..., :80:16][:, ::2, ::2].transpose(0, 3, 1, 2), d['roi_mask_sub'][:n_pos]) < 1e-5
+
+
+def test_oracle_keypoint_step_equals_reference_executed_step(golden_dir):
+    """train_keypoints.py's model: FPNRoIKeypointHead (8 convolutions in a ChainList, deconvolution, 17 heat maps, F.resize_images
+    to 56x56), one foreground class, its calc_mask_loss (soft-max cross-entropy over the positions of every labelled keypoint
+    of the positive rows), binary_mask=False targets from the reference's ProposalTargetCreator (incl. its in-place quirk)."""
+    d = load_step_golden(golden_dir, 'step_keypoint_reference.npz')
+    K, NMC = 17, 8
+    m = MaskRCNN(n_fg_class=1, n_keypoints=K, head_arch='fpn_keypoint', device='cpu', seed=1)
+    weights = chainer_weights(int(d['in_weight_seed']), n_fg_class=1, n_keypoints=K, n_mask_convs=NMC)
+    assert set(ChainerNpzMap(m).from_chainer(weights, strict=False)) == set(weights)
+    ps = m.ps
+    params = {n: ps.p(n).detach().to(D) for n in ps.names()}
+    step = OracleStep(params, (3, 4, 6, 3), m.head.n_class, m.head.LOC0, mask_conv_names=['mask_convs/%d' % i for i in range(NMC)], n_keypoints=K)
+    img = torch.from_numpy(d['in_img'])
+    img4 = torch.cat([img.permute(0, 2, 3, 1), torch.zeros((1,) + img.shape[2:] + (1,))], -1).to(D)
+    t = oracle_targets(d)
+    n_pos = d['gt_roi_mask'].shape[0]
+    assert d['gt_roi_mask'].shape == (n_pos, K) and int((d['gt_roi_label'][:n_pos] == 1).all())
+    with torch.no_grad():
+        out = step.losses(img4, t)
+    for k in ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss'):
+        want = float(d['loss_' + k])
+        assert abs(float(out[k]) - want) <= 1e-6 * max(abs(want), 1e-3), (k, float(out[k]), want)
+    assert _rel(out['locs'].numpy(), d['rpn_locs']) < 1e-6 and _rel(out['scores'].numpy(), d['rpn_scores']) < 1e-6
+    box = out['box'].numpy()
+    assert _rel(box[:, :2], d['roi_scores']) < 1e-5 and _rel(box[:, m.head.LOC0:m.head.LOC0 + 4], d['roi_cls_locs']) < 1e-5
+    mk = out['mask'].numpy()[..., :K].transpose(0, 3, 1, 2)                           # (n_pos, K, 56, 56)
+    assert mk.shape == (n_pos, K, 56, 56)
+    assert _rel(mk[:, :, ::4, ::4], d['roi_mask_sub']) < 1e-5
+    at = mk.reshape(n_pos, K, -1)[np.arange(n_pos)[:, None], np.arange(K)[None, :], np.maximum(d['gt_roi_mask'], 0)]
+    assert _rel(at, d['roi_mask_at_label']) < 1e-5
 
 
 def test_proposals_and_levels_of_the_reference_step(golden_dir):

@@ -122,3 +122,55 @@ def test_heads_and_losses_on_the_reference_sampled_targets(step):
         want = float(d['loss_' + k])
         assert abs(float(v) - want) <= TOL * max(abs(want), 1e-3), (k, float(v), want)
     assert abs(float(ops.loss_total(losses)[0]) - float(d['loss_loss'])) <= TOL * float(d['loss_loss'])
+
+
+def test_keypoint_model_on_the_reference_executed_keypoint_step():
+    """train_keypoints.py's model (FPNRoIKeypointHead: 8 convolutions, deconvolution, 17 heat maps resized to 56x56; one class)
+    with the reference-sampled targets of tests/golden/step_keypoint_reference.npz: RPN outputs, box head, keypoint logits of the
+    positive rows and the five losses - the keypoint loss through the same soft-max cross-entropy launch the chain makes."""
+    d = load_step_golden(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'), 'step_keypoint_reference.npz')
+    K = 17
+    m = MaskRCNN(n_fg_class=1, n_keypoints=K, head_arch='fpn_keypoint', device=DEV, seed=1)
+    weights = chainer_weights(int(d['in_weight_seed']), n_fg_class=1, n_keypoints=K, n_mask_convs=8)
+    assert set(ChainerNpzMap(m).from_chainer(weights, strict=False)) == set(weights)
+    core.TRAIN = True
+    m.rpn.train = True
+    dev = torch.device(DEV)
+    img = torch.from_numpy(d['in_img']).to(dev)
+    feats = m.extractor(m.to_nhwc4(img))
+    r = m.rpn.forward_padded(feats, tuple(img.shape[2:]), 1.0)
+    assert _rel(r['locs'], d['rpn_locs']) < TOL and _rel(r['scores'], d['rpn_scores']) < TOL
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt).contiguous()
+    head = m.head
+    xy5 = t(d['indices_and_rois'][:, [0, 2, 1, 4, 3]], torch.float32)
+    levels = t(d['sample_levels'], torch.int32)
+    label = t(d['gt_roi_label'], torch.int32)
+    R, n_pos = xy5.shape[0], d['gt_roi_mask'].shape[0]
+    scales = m.extractor.spatial_scales
+    losses = torch.zeros((5, 2), dtype=torch.float32, device=dev)
+    A = d['anchor'].shape[0]
+    rl = t(d['gt_rpn_label'], torch.int32)
+    ops.smooth_l1(r['locs'].view(A, 4), 4, t(d['gt_rpn_loc'], torch.float32), rl, A, 3.0, out=losses[0])
+    ops.softmax_ce(r['scores'].view(A, 2), rl, A, 2, (1, 2, 0, 1), out=losses[1])
+    box = head.box_branch(feats, xy5, levels, scales)
+    ld = head.out_p
+    g_box = torch.empty_like(box)
+    ops.softmax_ce(box, label, R, head.n_class, (1, ld, 0, 1), Kfill=head.LOC0, gx=g_box, out=losses[3])
+    ops.smooth_l1(box, ld, t(d['gt_roi_loc'], torch.float32), label, R, 1.0, gfill=ld - head.LOC0, col0=head.LOC0, gx=g_box, out=losses[2])
+    assert _rel(box[:, :head.n_class], d['roi_scores']) < TOL and _rel(box[:, head.LOC0:head.LOC0 + 4], d['roi_cls_locs']) < TOL
+    # keypoint branch on the positive rows (calc_mask_loss of train_keypoints.py:21-27 uses roi_cls_mask[:n_pos])
+    mk = head.mask_branch(feats, xy5[:n_pos].contiguous(), levels[:n_pos].contiguous(), scales)            # (n_pos, 56, 56, Cp)
+    Rm, Hm, Wm, Cm = mk.shape
+    assert (Rm, Hm, Wm) == (n_pos, 56, 56)
+    nchw = mk[..., :K].permute(0, 3, 1, 2)
+    assert _rel(nchw[:, :, ::4, ::4], d['roi_mask_sub']) < TOL
+    gt = t(d['gt_roi_mask'], torch.int32)
+    at = nchw.reshape(n_pos, K, -1).gather(2, gt.clamp(min=0).long()[..., None])[..., 0]
+    assert _rel(at, d['roi_mask_at_label']) < TOL
+    ops.softmax_ce(mk, gt.view(-1), Rm * K, Hm * Wm, (K, Hm * Wm * Cm, 1, Cm), gx=torch.zeros_like(mk), out=losses[4])
+    got = losses[:, 0].cpu().numpy()
+    names = ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
+    print('keypoint step reference losses: device', dict(zip(names, got.round(6))), 'reference', {k: round(float(d['loss_' + k]), 6) for k in names})
+    for k, v in zip(names, got):
+        want = float(d['loss_' + k])
+        assert abs(float(v) - want) <= TOL * max(abs(want), 1e-3), (k, float(v), want)
