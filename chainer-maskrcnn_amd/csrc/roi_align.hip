@@ -568,6 +568,7 @@ __global__ __launch_bounds__(BWD_THREADS, 3) void k_roi_align_bwd_nhwc(Levels lv
 // ------------------------------------------------------------------------------------------
 constexpr int W2_DEPTH = 2;       // 2 * W2_DEPTH gy rows in flight per wave during a drain
 constexpr int W2_SEG = 512;       // RoIs per segment: their boxes and bin geometry sit in the workgroup's LDS table
+constexpr int PRIO_CAND[3] = {10, 14, 18};      // candidate counts from which a wave runs at priority 1 / 2 / 3
 
 template <int QC>
 struct WaveQueue {
@@ -606,8 +607,14 @@ __device__ __forceinline__ void drain_wave_queue(const WaveQueue<QC> &q, int n, 
             return f;
         };
         float4 buf[2 * DEPTH];
+        // The first loads must ISSUE in slot order: slot d is consumed with 2*DEPTH-1 younger loads outstanding (vmcnt counts
+        // in issue order).  Left alone the scheduler issued them in reverse, the waitcnt pass then had to assume slot 0 is the
+        // youngest and put s_waitcnt vmcnt(0) in front of EVERY entry - no load of the wave ever overlapped its own FMAs.
 #pragma unroll
-        for (int d = 0; d < 2 * DEPTH; ++d) buf[d] = ldrow(d);
+        for (int d = 0; d < 2 * DEPTH; ++d) {
+            buf[d] = ldrow(d);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma nounroll
         for (int j = 0; j < m; j += 2 * DEPTH) {
 #pragma unroll
@@ -771,6 +778,15 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
             }
             __builtin_amdgcn_wave_barrier();
             if (STAMP) st_scan += stamp_now() - st_tmp;
+            // Every wave of the launch is resident at once and the kernel ends with its slowest wave; a wave's work grows with
+            // its candidate count (median 12, maximum 23 on configs[1]).  VALU issue is arbitrated by priority, then age: the
+            // heavy waves are raised so that they run at their own pace from the start and the light waves of the SIMD fill
+            // the slots they leave, instead of everybody sharing evenly and the heavy ones running on alone at the end.
+            if (seg == 0 && cb == 0) {
+                if (nlist >= PRIO_CAND[2]) __builtin_amdgcn_s_setprio(3);
+                else if (nlist >= PRIO_CAND[1]) __builtin_amdgcn_s_setprio(2);
+                else if (nlist >= PRIO_CAND[0]) __builtin_amdgcn_s_setprio(1);
+            }
             // ---- list units (RoI, 64-bin chunk): table pass at the start of every batch of SPP RoIs, then queue entries;
             //      the queue is drained whenever it cannot take another unit (accumulators stay in registers)
             const int units = nlist * CH;
