@@ -767,14 +767,22 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
             // ---- scan the table: 4 compares per (lane, RoI); candidates compacted in ascending RoI order
             int nlist = 0;
             const int seg_n = min(W2_SEG, R - seg);
+            // four 64-RoI groups per round: their box reads are issued together (one LDS round trip per round, not the two
+            // dependent ones per group a short-circuit `&&` chain compiles to), the tests are bitwise ANDs of four compares
 #pragma unroll
-            for (int g2 = 0; g2 < W2_SEG / 64; ++g2) {
-                if (g2 * 64 >= seg_n) break;
-                const float4 bx = sBox[g2 * 64 + lane];
-                const bool f = bx.x < fy1 && bx.y >= fy0 && bx.z < fx1 && bx.w >= fx0;
-                const unsigned long long bal = __ballot(f);
-                if (f) lds.idx[nlist + __popcll(bal & lt_mask)] = (unsigned short)(g2 * 64 + lane);
-                nlist += __popcll(bal);
+            for (int g4 = 0; g4 < W2_SEG / 64; g4 += 4) {
+                if (g4 * 64 >= seg_n) break;
+                float4 bx[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bx[u] = sBox[(g4 + u) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g2 = g4 + u;
+                    const bool f = (g2 * 64 < seg_n) & (bx[u].x < fy1) & (bx[u].y >= fy0) & (bx[u].z < fx1) & (bx[u].w >= fx0);
+                    const unsigned long long bal = __ballot(f);
+                    if (f) lds.idx[nlist + __popcll(bal & lt_mask)] = (unsigned short)(g2 * 64 + lane);
+                    nlist += __popcll(bal);
+                }
             }
             __builtin_amdgcn_wave_barrier();
             if (STAMP) st_scan += stamp_now() - st_tmp;
@@ -789,55 +797,100 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
             }
             // ---- list units (RoI, 64-bin chunk): table pass at the start of every batch of SPP RoIs, then queue entries;
             //      the queue is drained whenever it cannot take another unit (accumulators stay in registers)
-            const int units = nlist * CH;
             unsigned long long nzb = 0;
+            // table pass for the batch of SPP RoIs starting at list item li: lane = (slot, axis, bin) -> the summed sample weights
+            // of that bin on the patch's 4 rows / 4 columns; nzb = ballot of the bins with a non-zero weight
+            auto table_pass = [&](int li) {
+                unsigned long long st_t0 = 0;
+                if (STAMP) { st_t0 = stamp_now(); st_cnt += 1 << 16; }
+                const int slot = lane / (2 * PBT), axis = (lane / PBT) & 1, bin = lane % PBT;
+                const bool tv = li + slot < nlist && bin < (axis ? PW : PH);
+                const float4 ge = sGeo[lds.idx[min(li + slot, nlist - 1)]];
+                float w[PT] = {0.f, 0.f, 0.f, 0.f};
+                const int size = axis ? W : H, t0 = axis ? px0 : py0;
+                const float start = axis ? ge.x : ge.y, bsz = axis ? ge.z : ge.w;
+                for (int i2 = 0; i2 < sr; ++i2) {
+                    const Samp sp = axis_sample(start, bsz, bin, i2, sr, size);
+                    const int dl = sp.lo - t0, dh = sp.hi - t0;
+#pragma unroll
+                    for (int j = 0; j < PT; ++j) {
+                        w[j] += (tv && sp.lo >= 0 && dl == j) ? sp.wl : 0.0f;
+                        w[j] += (tv && sp.hi >= 0 && dh == j) ? sp.wh : 0.0f;
+                    }
+                }
+                const float sc = axis == 0 ? inv_cnt : 1.0f;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) w[j] *= sc;
+                lds.tab[slot][axis][bin] = make_float4(w[0], w[1], w[2], w[3]);
+                nzb = __ballot(w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f);
+                __builtin_amdgcn_wave_barrier();
+                if (STAMP) st_tab += stamp_now() - st_t0;
+            };
+            auto drain_now = [&]() {
+                __builtin_amdgcn_wave_barrier();
+                if (STAMP) st_tmp = stamp_now();
+                drain_wave_queue<QC, DEPTH>(lds.q, qn, rs_gy, vlane, row_bytes, acc, lane);
+                if (STAMP) st_drain += stamp_now() - st_tmp;
+                __builtin_amdgcn_wave_barrier();
+                qn = 0;
+            };
+            if constexpr (PBT == 8) {
+                // 7x7 pooling: a batch of SPP = 4 candidates per table pass; their queue entries are appended TOGETHER - the
+                // entry counts follow from the ballots (scalar), so all LDS reads of the batch (bin weights, RoI indices) are
+                // issued at once and the appends cost one LDS round trip per batch instead of three dependent ones per candidate
+                const int ph = lane >> 3, pw = lane & 7;
+#pragma nounroll
+                for (int li = 0; li < nlist; li += SPP) {
+                    if (STAMP) st_cnt += min(SPP, nlist - li);
+                    table_pass(li);
+                    if (nzb == 0ull) continue;
+                    // two candidates per round (their 4 weight vectors = 16 VGPRs; all four would spill next to the 64
+                    // accumulators); a pair adds at most 98 entries, so it always fits an empty queue
+#pragma nounroll
+                    for (int h = 0; h < SPP; h += 2) {
+                        const unsigned pairbits = (unsigned)(nzb >> (h * 2 * PBT));
+                        const unsigned ym0 = pairbits & 0xFFu, xm0 = (pairbits >> 8) & 0xFFu, ym1 = (pairbits >> 16) & 0xFFu, xm1 = pairbits >> 24;
+                        const int c0 = __popc(ym0) * __popc(xm0), c1 = __popc(ym1) * __popc(xm1);
+                        if (c0 + c1 == 0) continue;
+                        touched = true;
+                        if (qn + c0 + c1 > QC) drain_now();
+                        const float4 wy0 = lds.tab[h][0][ph], wx0 = lds.tab[h][1][pw], wy1 = lds.tab[h + 1][0][ph], wx1 = lds.tab[h + 1][1][pw];
+                        const int r0 = seg + (int)lds.idx[min(li + h, nlist - 1)], r1 = seg + (int)lds.idx[min(li + h + 1, nlist - 1)];
+                        const bool in0 = ((ym0 >> ph) & 1u) & ((xm0 >> pw) & 1u), in1 = ((ym1 >> ph) & 1u) & ((xm1 >> pw) & 1u);
+                        const unsigned long long b0 = __ballot(in0), b1 = __ballot(in1);
+                        if (in0) {
+                            const int pos = qn + __popcll(b0 & lt_mask);
+                            lds.q.wy[pos] = wy0;
+                            lds.q.wx[pos] = wx0;
+                            lds.q.row[pos] = (r0 * PH + ph) * PW + pw;
+                        }
+                        if (in1) {
+                            const int pos = qn + c0 + __popcll(b1 & lt_mask);
+                            lds.q.wy[pos] = wy1;
+                            lds.q.wx[pos] = wx1;
+                            lds.q.row[pos] = (r1 * PH + ph) * PW + pw;
+                        }
+                        qn += c0 + c1;
+                    }
+                }
+            } else {
+            // 14x14 pooling: list units (RoI, 64-bin chunk): table pass at the start of every batch of SPP RoIs, then queue
+            // entries; the queue is drained whenever it cannot take another unit (accumulators stay in registers)
+            const int units = nlist * CH;
 #pragma nounroll
             for (int u = 0; u < units; ++u) {
-                if (qn + 64 > QC) {
-                    __builtin_amdgcn_wave_barrier();
-                    if (STAMP) st_tmp = stamp_now();
-                    drain_wave_queue<QC, DEPTH>(lds.q, qn, rs_gy, vlane, row_bytes, acc, lane);
-                    if (STAMP) st_drain += stamp_now() - st_tmp;
-                    __builtin_amdgcn_wave_barrier();
-                    qn = 0;
-                }
+                if (qn + 64 > QC) drain_now();
                 const int li = u / CH, ch = u - li * CH;
                 const int sl = li % SPP;
                 if (STAMP) st_cnt += 1;
-                if (ch == 0 && sl == 0) {
-                    unsigned long long st_t0 = 0;
-                    if (STAMP) { st_t0 = stamp_now(); st_cnt += 1 << 16; }
-                    // table pass for the batch of SPP RoIs starting at list item li: lane = (slot, axis, bin)
-                    const int slot = lane / (2 * PBT), axis = (lane / PBT) & 1, bin = lane % PBT;
-                    const bool tv = li + slot < nlist && bin < (axis ? PW : PH);
-                    const float4 ge = sGeo[lds.idx[min(li + slot, nlist - 1)]];
-                    float w[PT] = {0.f, 0.f, 0.f, 0.f};
-                    const int size = axis ? W : H, t0 = axis ? px0 : py0;
-                    const float start = axis ? ge.x : ge.y, bsz = axis ? ge.z : ge.w;
-                    for (int i2 = 0; i2 < sr; ++i2) {
-                        const Samp sp = axis_sample(start, bsz, bin, i2, sr, size);
-                        const int dl = sp.lo - t0, dh = sp.hi - t0;
-#pragma unroll
-                        for (int j = 0; j < PT; ++j) {
-                            w[j] += (tv && sp.lo >= 0 && dl == j) ? sp.wl : 0.0f;
-                            w[j] += (tv && sp.hi >= 0 && dh == j) ? sp.wh : 0.0f;
-                        }
-                    }
-                    const float sc = axis == 0 ? inv_cnt : 1.0f;
-#pragma unroll
-                    for (int j = 0; j < PT; ++j) w[j] *= sc;
-                    lds.tab[slot][axis][bin] = make_float4(w[0], w[1], w[2], w[3]);
-                    nzb = __ballot(w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f);
-                    __builtin_amdgcn_wave_barrier();
-                    if (STAMP) st_tab += stamp_now() - st_t0;
-                }
+                if (ch == 0 && sl == 0) table_pass(li);
                 // queue pass of unit (list item li, chunk ch): lane = (ph, pw)
                 const unsigned ym = (unsigned)(nzb >> (sl * 2 * PBT)) & ((1u << PBT) - 1u);
                 const unsigned xm = (unsigned)(nzb >> (sl * 2 * PBT + PBT)) & ((1u << PBT) - 1u);
                 if (ym && xm) {
                     const int r = seg + __builtin_amdgcn_readfirstlane((int)lds.idx[li]);
-                    const int ph = (PBT == 8) ? (lane >> 3) : (ch * 4 + (lane >> 4));
-                    const int pw = (PBT == 8) ? (lane & 7) : (lane & 15);
+                    const int ph = ch * 4 + (lane >> 4);
+                    const int pw = lane & 15;
                     const bool in = ((ym >> ph) & 1u) && ((xm >> pw) & 1u);
                     const unsigned long long bal = __ballot(in);
                     if (in) {
@@ -849,6 +902,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
                     qn += __popcll(bal);
                     touched = touched || bal != 0ull;
                 }
+            }
             }
         }
         if (!live) continue;
