@@ -1060,46 +1060,74 @@ __global__ __launch_bounds__(256) void k_wino_filter(const float *__restrict__ w
 }
 
 // V[k][t][c] = (B^T d B)[k], d = the a x a input patch of tile t (rows m*ty-1 .., zero outside).  Thread = (t, 4 channels).
+// All global traffic goes through buffer descriptors with 32-bit byte offsets (wino_ok() bounds x and V below 4 GiB): a tap
+// outside the image is an out-of-range offset (the load returns 0), so the a*a loads are unconditional and issue back to back
+// - with plain pointers every tap sat in its own exec-masked branch and the waitcnt pass serialised them into ~16 dependent
+// rounds of memory latency per thread.
+// HARDWARE NOTE (measured on gfx950, ROCm 7.2): the plane offset k * Tp * C * 4 of a STORE must NOT ride in the SGPR soffset.
+// A buffer_store_dwordx4 needs one wait state before a VALU instruction overwrites its data registers; hipcc inserts that
+// s_nop only when soffset is an immediate (the rule of the older ISA manuals: "stores with an SGPR offset need no wait
+// state") - with an SGPR soffset the second data register of lanes 12-15 of every row of 16 lanes was stored AFTER the
+// following v_pk_add_f32 had overwritten it: 7 of the 16 planes wrong in element y of those lanes, different from run to
+// run.  Loads with an SGPR soffset are fine (k_wino_output), and so are stores whose data registers are not rewritten at once
+// (roi_align.hip).  The plane offset is therefore added to the VGPR offset (one v_add per store).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ V4 v4buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ void v4bufst(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, V4 v) {
+    const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, soff, 0);
+}
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
                                                     int th, int tw, long long T, long long Tp) {
     constexpr int A_ = M_ + 2;
-    const int C4 = C / 4;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Tp * C4) return;
-    const int c = (int)(i % C4) * 4;
-    const long long t = i / C4;
-    if (t >= T) {           // rows that pad T to a multiple of the GEMM tile: zero (the filter-gradient GEMM sums them)
+    // 32-bit index arithmetic (wino_ok(): 16 * Tp * C < 2^30): the 64-bit divisions this replaces were ~600 instructions of
+    // branchy software division per thread
+    const unsigned C4 = (unsigned)C / 4u;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)Tp * C4) return;
+    const unsigned t = i / C4;
+    const int c = (int)(i - t * C4) * 4;
+    const unsigned ks = (unsigned)((size_t)Tp * C * 4);                 // bytes per k plane
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void *)V, 0, (unsigned)((size_t)A_ * A_ * Tp * C * 4), 0x00020000);
+    const unsigned vo = (unsigned)(((size_t)t * C + c) * 4);
+    if (t >= (unsigned)T) {           // rows that pad T to a multiple of the GEMM tile: zero (the filter-gradient GEMM sums them)
 #pragma unroll
-        for (int k = 0; k < A_ * A_; ++k) v4st(V + ((size_t)k * Tp + t) * C + c, v4zero());
+        for (int k = 0; k < A_ * A_; ++k) v4bufst(rsV, vo + (unsigned)k * ks, 0, v4zero());
         return;
     }
-    const int tx = (int)(t % tw);
-    const int ty = (int)((t / tw) % th);
-    const int n = (int)(t / ((long long)tw * th));
+    const unsigned trow = t / (unsigned)tw;
+    const int tx = (int)(t - trow * (unsigned)tw);
+    const int n = (int)(trow / (unsigned)th);
+    const int ty = (int)(trow - (unsigned)n * (unsigned)th);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (unsigned)((size_t)N * H * W * C * 4), 0x00020000);
+    const unsigned OOB = 0xFFFFFFFFu;
+    unsigned rowo[A_], colo[A_];
+#pragma unroll
+    for (int r = 0; r < A_; ++r) {
+        const int h = M_ * ty - 1 + r, ww = M_ * tx - 1 + r;
+        rowo[r] = (unsigned)h < (unsigned)H ? (unsigned)(((size_t)n * H + h) * W * C * 4) : OOB;
+        colo[r] = (unsigned)ww < (unsigned)W ? (unsigned)(((size_t)ww * C + c) * 4) : OOB;
+    }
     V4 b[A_][A_];           // B^T d, built column by column
 #pragma unroll
     for (int q = 0; q < A_; ++q) {
-        const int ww = M_ * tx - 1 + q;
         V4 d[A_], r[A_];
 #pragma unroll
-        for (int rr = 0; rr < A_; ++rr) {
-            const int h = M_ * ty - 1 + rr;
-            const bool ok = (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W;
-            d[rr] = ok ? v4ld(x + (((size_t)n * H + h) * W + ww) * C + c) : v4zero();
-        }
+        for (int rr = 0; rr < A_; ++rr) d[rr] = v4buf(rsX, (rowo[rr] == OOB || colo[q] == OOB) ? OOB : rowo[rr] + colo[q], 0);
         wino_bt<M_, V4>(d, r);
 #pragma unroll
         for (int rr = 0; rr < A_; ++rr) b[rr][q] = r[rr];
     }
-    const size_t ks = (size_t)Tp * C;
-    float *o = V + (size_t)t * C + c;
 #pragma unroll
     for (int rr = 0; rr < A_; ++rr) {
         V4 row[A_];
         wino_bt<M_, V4>(b[rr], row);
 #pragma unroll
-        for (int q = 0; q < A_; ++q) v4st(o + (size_t)(rr * A_ + q) * ks, row[q]);
+        for (int q = 0; q < A_; ++q) v4bufst(rsV, vo + (unsigned)(rr * A_ + q) * ks, 0, row[q]);
     }
 }
 
@@ -1114,48 +1142,69 @@ __global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ M
                                                      float *__restrict__ bn_part) {
     constexpr int A_ = M_ + 2;
     __shared__ float4 sred[2][256];
-    const int C4 = C / 4;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned C4 = (unsigned)C / 4u;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
     V4 bs = v4zero(), bq = v4zero();
-    if (i < T * C4) {
-        const int c = (int)(i % C4) * 4;
-        const long long t = i / C4;
-        const int tx = (int)(t % tw);
-        const int ty = (int)((t / tw) % th);
-        const int n = (int)(t / ((long long)tw * th));
-        const size_t ks = (size_t)Tp * C;
-        const float *src = Mb + (size_t)t * C + c;
+    if (i < (unsigned)T * C4) {
+        const unsigned t = i / C4;                      // 32-bit index arithmetic, as in k_wino_input
+        const int c = (int)(i - t * C4) * 4;
+        const unsigned trow = t / (unsigned)tw;
+        const int tx = (int)(t - trow * (unsigned)tw);
+        const int n = (int)(trow / (unsigned)th);
+        const int ty = (int)(trow - (unsigned)n * (unsigned)th);
+        // buffer descriptors (see k_wino_input): the a*a plane reads share one VGPR offset, pixels outside the image are
+        // out-of-range offsets - their stores are dropped, their optional reads return 0 - so nothing here is divergent
+        const unsigned ks = (unsigned)((size_t)Tp * C * 4);
+        const auto rsM = __builtin_amdgcn_make_buffer_rsrc((void *)Mb, 0, (unsigned)((size_t)A_ * A_ * Tp * C * 4), 0x00020000);
+        const unsigned ybytes = (unsigned)((size_t)N * H * W * C * 4);
+        const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, ybytes, 0x00020000);
+        const auto rsR = __builtin_amdgcn_make_buffer_rsrc((void *)relu_x, 0, relu_x ? ybytes : 0u, 0x00020000);
+        const unsigned mo = (unsigned)(((size_t)t * C + c) * 4);
         V4 s[M_][A_];           // A^T m, column by column
 #pragma unroll
         for (int q = 0; q < A_; ++q) {
             V4 m[A_], r[M_];
 #pragma unroll
-            for (int rr = 0; rr < A_; ++rr) m[rr] = v4ld(src + (size_t)(rr * A_ + q) * ks);
+            for (int rr = 0; rr < A_; ++rr) m[rr] = v4buf(rsM, mo, (unsigned)(rr * A_ + q) * ks);
             wino_at<M_, V4>(m, r);
 #pragma unroll
             for (int a = 0; a < M_; ++a) s[a][q] = r[a];
         }
         const V4 bv = bias ? v4ld(bias + c) : v4zero();
+        const unsigned OOB = 0xFFFFFFFFu;
 #pragma unroll
         for (int a = 0; a < M_; ++a) {
-            V4 row[M_];
+            V4 row[M_], old[M_], xm[M_];
             wino_at<M_, V4>(s[a], row);
             const int h = M_ * ty + a;
+            unsigned off[M_];
 #pragma unroll
             for (int b = 0; b < M_; ++b) {
                 const int ww = M_ * tx + b;
-                if (h >= H || ww >= W) continue;
+                off[b] = (h < H && ww < W) ? (unsigned)((((size_t)n * H + h) * W + ww) * C + c) * 4u : OOB;
+            }
+            // the optional reads of a row of pixels go out together (one block-uniform branch per row, not per pixel)
+            if (accumulate) {
+#pragma unroll
+                for (int b = 0; b < M_; ++b) old[b] = v4buf(rsY, off[b], 0);
+            }
+            if (relu_x) {
+#pragma unroll
+                for (int b = 0; b < M_; ++b) xm[b] = v4buf(rsR, off[b], 0);
+            }
+#pragma unroll
+            for (int b = 0; b < M_; ++b) {
                 V4 v = row[b] + bv;
-                const size_t off = (((size_t)n * H + h) * W + ww) * C + c;
                 if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (accumulate) v = v + v4ld(y + off);
+                if (accumulate) v = v + old[b];
                 if (relu_x) {
-                    const V4 xm = v4ld(relu_x + off);
-                    v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f; v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
+                    v.x = xm[b].x > 0.f ? v.x : 0.f; v.y = xm[b].y > 0.f ? v.y : 0.f; v.z = xm[b].z > 0.f ? v.z : 0.f; v.w = xm[b].w > 0.f ? v.w : 0.f;
                 }
-                v4st(y + off, v);
-                bs = bs + v;
-                bq.x = fmaf(v.x, v.x, bq.x); bq.y = fmaf(v.y, v.y, bq.y); bq.z = fmaf(v.z, v.z, bq.z); bq.w = fmaf(v.w, v.w, bq.w);
+                v4bufst(rsY, off[b], 0, v);
+                if (off[b] != OOB) {       // (statistics: only pixels of the image)
+                    bs = bs + v;
+                    bq.x = fmaf(v.x, v.x, bq.x); bq.y = fmaf(v.y, v.y, bq.y); bq.z = fmaf(v.z, v.z, bq.z); bq.w = fmaf(v.w, v.w, bq.w);
+                }
             }
         }
     }
@@ -1163,9 +1212,9 @@ __global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ M
         sred[0][threadIdx.x] = make_float4(bs.x, bs.y, bs.z, bs.w);
         sred[1][threadIdx.x] = make_float4(bq.x, bq.y, bq.z, bq.w);
         __syncthreads();
-        if ((int)threadIdx.x < C4) {        // the block's tiles in tile order (fixed => bit-reproducible)
+        if (threadIdx.x < C4) {        // the block's tiles in tile order (fixed => bit-reproducible)
             float4 a = sred[0][threadIdx.x], b2 = sred[1][threadIdx.x];
-            for (int k = threadIdx.x + C4; k < 256; k += C4) {
+            for (unsigned k = threadIdx.x + C4; k < 256; k += C4) {
                 const float4 q = sred[0][k], r = sred[1][k];
                 a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
                 b2.x += r.x; b2.y += r.y; b2.z += r.z; b2.w += r.w;
@@ -1185,19 +1234,26 @@ __global__ __launch_bounds__(256) void k_wino_gy(const float *__restrict__ gy, f
                                                  int th, int tw, long long T, long long Tp, float *__restrict__ bias_part) {
     constexpr int A_ = M_ + 2;
     __shared__ float4 sred[256];
-    const int C4 = C / 4;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool in_range = i < Tp * C4;
-    const int c = in_range ? (int)(i % C4) * 4 : 0;
-    const long long t = in_range ? i / C4 : Tp;
+    const unsigned C4 = (unsigned)C / 4u;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    const bool in_range = i < (unsigned)Tp * C4;
+    const unsigned t = in_range ? i / C4 : (unsigned)Tp;         // 32-bit index arithmetic, as in k_wino_input
+    const int c = in_range ? (int)(i - t * C4) * 4 : 0;
     V4 bsum = v4zero();
-    if (in_range && t >= T) {           // padded rows: zero
+    // buffer descriptors as in k_wino_input: unconditional loads (pixels outside the image = out-of-range offset = 0), plane
+    // offsets of the stores in the VGPR offset (see the hardware note there)
+    const unsigned ks = (unsigned)((size_t)Tp * C * 4);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void *)Wt, 0, (unsigned)((size_t)A_ * A_ * Tp * C * 4), 0x00020000);
+    const unsigned vo = (unsigned)(((size_t)t * C + c) * 4);
+    if (in_range && t >= (unsigned)T) {           // padded rows: zero
 #pragma unroll
-        for (int k = 0; k < A_ * A_; ++k) v4st(Wt + ((size_t)k * Tp + t) * C + c, v4zero());
+        for (int k = 0; k < A_ * A_; ++k) v4bufst(rsW, vo + (unsigned)k * ks, 0, v4zero());
     } else if (in_range) {
-        const int tx = (int)(t % tw);
-        const int ty = (int)((t / tw) % th);
-        const int n = (int)(t / ((long long)tw * th));
+        const unsigned trow = t / (unsigned)tw;
+        const int tx = (int)(t - trow * (unsigned)tw);
+        const int n = (int)(trow / (unsigned)th);
+        const int ty = (int)(trow - (unsigned)n * (unsigned)th);
+        const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void *)gy, 0, (unsigned)((size_t)N * H * W * C * 4), 0x00020000);
         V4 r[A_][M_];           // A y, column by column
 #pragma unroll
         for (int b = 0; b < M_; ++b) {
@@ -1206,29 +1262,27 @@ __global__ __launch_bounds__(256) void k_wino_gy(const float *__restrict__ gy, f
 #pragma unroll
             for (int a = 0; a < M_; ++a) {
                 const int h = M_ * ty + a;
-                y[a] = (h < H && ww < W) ? v4ld(gy + (((size_t)n * H + h) * W + ww) * C + c) : v4zero();
+                y[a] = v4buf(rsG, (h < H && ww < W) ? (unsigned)((((size_t)n * H + h) * W + ww) * C + c) * 4u : 0xFFFFFFFFu, 0);
                 bsum = bsum + y[a];
             }
             wino_a<M_, V4>(y, col, v4zero());
 #pragma unroll
             for (int q = 0; q < A_; ++q) r[q][b] = col[q];
         }
-        const size_t ks = (size_t)Tp * C;
-        float *o = Wt + (size_t)t * C + c;
 #pragma unroll
         for (int q = 0; q < A_; ++q) {
             V4 row[A_];
             wino_a<M_, V4>(r[q], row, v4zero());
 #pragma unroll
-            for (int j = 0; j < A_; ++j) v4st(o + (size_t)(q * A_ + j) * ks, row[j]);
+            for (int j = 0; j < A_; ++j) v4bufst(rsW, vo + (unsigned)(q * A_ + j) * ks, 0, row[j]);
         }
     }
     if (bias_part) {            // block-uniform
         sred[threadIdx.x] = make_float4(bsum.x, bsum.y, bsum.z, bsum.w);
         __syncthreads();
-        if ((int)threadIdx.x < C4) {        // the block's tiles in tile order (fixed => bit-reproducible)
+        if (threadIdx.x < C4) {        // the block's tiles in tile order (fixed => bit-reproducible)
             float4 a = sred[threadIdx.x];
-            for (int k = threadIdx.x + C4; k < 256; k += C4) {
+            for (unsigned k = threadIdx.x + C4; k < 256; k += C4) {
                 const float4 q = sred[k];
                 a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
             }
