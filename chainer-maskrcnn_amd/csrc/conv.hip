@@ -1028,10 +1028,10 @@ template <int M_> __device__ __forceinline__ void wino_gt(const float (&D)[M_ + 
 // U[k][co][ci] from w (Cout,3,3,Cin).  transposed: the backward-data filter w'[ci][u][v][co] = w[co][2-u][2-v][ci],
 // written as U[k][ci][co] (the GEMM's "Cout" axis is then Cin).
 template <int M_>
-__global__ __launch_bounds__(256) void k_wino_filter(const float *__restrict__ w, float *__restrict__ U, int Cout, int Cin,
-                                                     int transposed) {
+__device__ __forceinline__ void wino_filter_body(const float *__restrict__ w, float *__restrict__ U, int Cout, int Cin,
+                                                 int transposed, unsigned blk) {
     constexpr int A_ = M_ + 2;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(blk * 256u + threadIdx.x);
     if (i >= Cout * Cin) return;
     // the 36 (16) writes per thread dominate: threads run along the output's contiguous axis (ci, or co when transposed)
     const int ci = transposed ? i / Cout : i % Cin, co = transposed ? i % Cout : i / Cin;
@@ -1058,6 +1058,11 @@ __global__ __launch_bounds__(256) void k_wino_filter(const float *__restrict__ w
         for (int q = 0; q < A_; ++q) U[(size_t)(r * A_ + q) * stride + o] = row[q];
     }
 }
+template <int M_>
+__global__ __launch_bounds__(256) void k_wino_filter(const float *__restrict__ w, float *__restrict__ U, int Cout, int Cin,
+                                                     int transposed) {
+    wino_filter_body<M_>(w, U, Cout, Cin, transposed, blockIdx.x);
+}
 
 // V[k][t][c] = (B^T d B)[k], d = the a x a input patch of tile t (rows m*ty-1 .., zero outside).  Thread = (t, 4 channels).
 // All global traffic goes through buffer descriptors with 32-bit byte offsets (wino_ok() bounds x and V below 4 GiB): a tap
@@ -1081,13 +1086,13 @@ __device__ __forceinline__ void v4bufst(__amdgpu_buffer_rsrc_t rs, unsigned voff
     __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, soff, 0);
 }
 template <int M_>
-__global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
-                                                    int th, int tw, long long T, long long Tp) {
+__device__ __forceinline__ void wino_input_body(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
+                                                int th, int tw, long long T, long long Tp, unsigned blk) {
     constexpr int A_ = M_ + 2;
     // 32-bit index arithmetic (wino_ok(): 16 * Tp * C < 2^30): the 64-bit divisions this replaces were ~600 instructions of
     // branchy software division per thread
     const unsigned C4 = (unsigned)C / 4u;
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    const unsigned i = blk * 256u + threadIdx.x;
     if (i >= (unsigned)Tp * C4) return;
     const unsigned t = i / C4;
     const int c = (int)(i - t * C4) * 4;
@@ -1129,6 +1134,21 @@ __global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x,
 #pragma unroll
         for (int q = 0; q < A_; ++q) v4bufst(rsV, vo + (unsigned)(rr * A_ + q) * ks, 0, row[q]);
     }
+}
+template <int M_>
+__global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
+                                                    int th, int tw, long long T, long long Tp) {
+    wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, blockIdx.x);
+}
+// Filter and input transform of one convolution call in ONE launch (the first `fblocks` workgroups transform the filter):
+// the two are independent, and a separate 5-8 us filter launch in front of every Winograd GEMM is pure launch latency on the
+// critical stream of the deep layers.
+template <int M_>
+__global__ __launch_bounds__(256) void k_wino_input_filter(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
+                                                           int th, int tw, long long T, long long Tp, const float *__restrict__ w,
+                                                           float *__restrict__ U, int Cout_w, int Cin_w, int transposed, unsigned fblocks) {
+    if (blockIdx.x < fblocks) wino_filter_body<M_>(w, U, Cout_w, Cin_w, transposed, blockIdx.x);
+    else wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, blockIdx.x - fblocks);
 }
 
 // y (m x m pixels of tile t) = A^T M A + bias, then ReLU | + old y (accumulate) | zeroed where relu_x <= 0.
@@ -1485,9 +1505,9 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
     char *base = (char *)ws;
     float *U = (float *)(base + L.u), *V = v_keep ? v_keep : (float *)(base + L.v), *Mb = (float *)(base + L.m);
     // the layer's weight tensor is (Cout_layer, 3, 3, Cin_layer): forward Cout_layer = Cout; transposed Cout_layer = Cin
-    WINO_LAUNCH(k_wino_filter, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), w, U, transposed ? Cin : Cout, transposed ? Cout : Cin,
-                transposed ? 1 : 0);
     const long long nin = g.Tp * (Cin / 4), nout = g.T * (Cout / 4);       // k_wino_input zeroes the padded rows of V
+    const unsigned fblocks = (unsigned)mrcnn::cdiv(Cout * Cin, 256);
+    if (w_keep) WINO_LAUNCH(k_wino_filter, g, dim3(fblocks), w, U, transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0);
     if (w_keep) {           // backward pass: one read of gy feeds this GEMM, the filter-gradient GEMM and the bias gradient
         const bool wb = gbias && (256 % (Cin / 4)) == 0;
         const int nblk = (int)std::min<long long>((nin + 255) / 256, 512);
@@ -1506,7 +1526,8 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
             MRCNN_LAUNCH_CHECK();
         }
     } else
-        WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), in, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
+        WINO_LAUNCH(k_wino_input_filter, g, dim3(fblocks + (unsigned)((nin + 255) / 256)), in, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp, w, U,
+                    transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, fblocks);
     // batched GEMM: 1x1 "convolution" over nk*Tp pixels, weight matrix selected by the row block
     ConvP p = make_p(1, 1, (int)(g.nk * g.Tp), Cin, Cout, 1, 1, 1, 0);
     p.a = V; p.b = U; p.c = Mb;

@@ -28,7 +28,8 @@ else:
     agg = collections.OrderedDict()
     for r in rows:
         n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name']).split('(')[0].replace('void ', '')
-        if not (n.startswith('k_wino') or n.startswith('k_sum_slabs') or n.startswith('k_conv_igemm') or n.startswith('k_tail') or n.startswith('k_colsum')):
+        pre = sys.argv[3].split(',') if len(sys.argv) > 3 else ['k_wino', 'k_sum_slabs', 'k_conv_igemm', 'k_tail', 'k_colsum']
+        if not any(n.startswith(q) for q in pre):
             continue
         key = (n[:44], int(r['Grid_Size_X']) if 'Grid_Size_X' in r else int(r['Grid_Size']))
         agg.setdefault(key, []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
