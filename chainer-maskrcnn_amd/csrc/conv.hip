@@ -479,6 +479,26 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             const bool nv = n < p.Ng;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == MODE_FWD && plain && p.bias) bv = ldg4(p.bias + (nv ? n : 0));
+            // BWD_DATA: the old value (accumulate) and the ReLU mask operand of the tile's four rows are read up front under
+            // ONE block-uniform branch each, from clamped (always valid) addresses - inside the per-row `if` the two loads of
+            // every row were followed by s_waitcnt vmcnt(0): 32 serialised memory latencies per 64 x 64 wave tile
+            float4 old4[4], xm4[4];
+            if (MODE == MODE_BWD_DATA && plain && (p.accumulate || p.relu_x)) {
+                size_t off4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + wm * (BM_ / 2) + tm * 32 + er + 8 * j;
+                    off4[j] = (size_t)min(m, p.M - 1) * ldc + (nv ? n : 0);
+                }
+                if (p.accumulate) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) old4[j] = ldg4(cbase + off4[j]);
+                }
+                if (p.relu_x) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xm4[j] = ldg4(p.relu_x + off4[j]);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = er + 8 * j;
@@ -494,11 +514,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
                 }
                 if (MODE == MODE_FWD && p.relu && plain) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (MODE == MODE_BWD_DATA && p.accumulate && plain) {
-                    const float4 o = ldg4(dst);
+                    const float4 o = old4[j];
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
                 if (MODE == MODE_BWD_DATA && p.relu_x && plain) {
-                    const float4 xm = ldg4(p.relu_x + (size_t)m * ldc + n);
+                    const float4 xm = xm4[j];
                     v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f;
                     v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
                 }
