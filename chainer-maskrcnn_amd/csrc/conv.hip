@@ -1429,17 +1429,33 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restric
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Cout * Cin) return;
     const int ci = i % Cin, co = i / Cin;
+    // all a*a reads first (they were interleaved with the slab loop's branches: one memory latency per element)
+    float Dall[A_][A_];
+    const size_t o0 = (size_t)co * (A_ * A_) * Cin + ci;
+#pragma unroll
+    for (int q = 0; q < A_; ++q)
+#pragma unroll
+        for (int j = 0; j < A_; ++j) Dall[q][j] = dU[o0 + (size_t)(q * A_ + j) * Cin];
+    for (int sl = 1; sl < nslab; ++sl) {            // the split-K slabs of dU are added here, in slab order
+        const float *ds = dU + (size_t)sl * Cout * (A_ * A_) * Cin + o0;
+#pragma unroll
+        for (int q = 0; q < A_; ++q)
+#pragma unroll
+            for (int j = 0; j < A_; ++j) Dall[q][j] += ds[(size_t)(q * A_ + j) * Cin];
+    }
+    float old[3][3];
+    if (accumulate) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) old[u][v] = gw[(((size_t)co * 3 + u) * 3 + v) * Cin + ci];
+    }
     float r[3][A_];         // G^T D, column by column
 #pragma unroll
     for (int j = 0; j < A_; ++j) {
         float D[A_], c3[3];
 #pragma unroll
-        for (int q = 0; q < A_; ++q) {          // the split-K slabs of dU are added here, in slab order
-            const size_t o = ((size_t)co * (A_ * A_) + q * A_ + j) * Cin + ci;
-            float a = dU[o];
-            for (int sl = 1; sl < nslab; ++sl) a += dU[(size_t)sl * Cout * (A_ * A_) * Cin + o];
-            D[q] = a;
-        }
+        for (int q = 0; q < A_; ++q) D[q] = Dall[q][j];
         wino_gt<M_>(D, c3);
 #pragma unroll
         for (int u = 0; u < 3; ++u) r[u][j] = c3[u];
@@ -1449,10 +1465,7 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restric
         float o[3];
         wino_gt<M_>(r[u], o);
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            float *dst = gw + (((size_t)co * 3 + u) * 3 + v) * Cin + ci;
-            *dst = accumulate ? *dst + o[v] : o[v];
-        }
+        for (int v = 0; v < 3; ++v) gw[(((size_t)co * 3 + u) * 3 + v) * Cin + ci] = accumulate ? old[u][v] + o[v] : o[v];
     }
 }
 
