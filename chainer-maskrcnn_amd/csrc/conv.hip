@@ -469,6 +469,17 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     float4 bsum[TN], bsq[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) { bsum[tn] = make_float4(0.f, 0.f, 0.f, 0.f); bsq[tn] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    // The bias of the wave's TN column groups is read ONCE here and waited for explicitly.  Read per tile inside the loops
+    // below, the waitcnt pass could not prove across the rows' exec-masked blocks that the load had completed and put
+    // s_waitcnt vmcnt(0) in front of EVERY row - and on gfx9 stores count in vmcnt too, so every row's store waited for the
+    // previous row's store to be acknowledged: 16 serialised store round trips per wave and tile.
+    float4 bvs[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn * (BN_ / 2) + tn * 32 + ec;
+        bvs[tn] = (MODE == MODE_FWD && plain && p.bias) ? ldg4(p.bias + (n < p.Ng ? n : 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (MODE == MODE_FWD) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) only (expcnt / lgkmcnt fields = no wait)
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -477,8 +488,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             for (int e = 0; e < 16; ++e) et[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_LD + r] = acc[tm][tn][e];
             const int n = n0 + wn * (BN_ / 2) + tn * 32 + ec;
             const bool nv = n < p.Ng;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (MODE == MODE_FWD && plain && p.bias) bv = ldg4(p.bias + (nv ? n : 0));
+            const float4 bv = bvs[tn];
             // BWD_DATA: the old value (accumulate) and the ReLU mask operand of the tile's four rows are read up front under
             // ONE block-uniform branch each, from clamped (always valid) addresses - inside the per-row `if` the two loads of
             // every row were followed by s_waitcnt vmcnt(0): 32 serialised memory latencies per 64 x 64 wave tile
