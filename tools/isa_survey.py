@@ -31,7 +31,7 @@ with tempfile.TemporaryDirectory() as tmp:
 
 def demangle(n):
     try:
-        return subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', n], capture_output=True, text=True).stdout.strip().replace('(anonymous namespace)::', '').split('(')[0]
+        return subprocess.run(['c++filt', n], capture_output=True, text=True).stdout.strip().replace('(anonymous namespace)::', '').split('(')[0]
     except Exception:
         return n
 
