@@ -1,3 +1,7 @@
+"""Winograd input transform check: V = B^T d B of a forward call (F(2x2), kept with keep_v) against a float64 NumPy/torch
+reference, plus run-to-run reproducibility of V and of the output.  This is the script that localised the gfx950 store-data hazard
+of DESIGN.md section 3.1b (buffer_store_dwordx4 with an SGPR soffset followed by a VALU overwrite of the data registers): wrong
+elements showed up as channel % 64 in {49, 53, 57, 61} of 7 of the 16 planes."""
 import os, sys
 sys.path.insert(0, '/root/repo/chainer-maskrcnn_amd'); sys.path.insert(0, '/root/repo')
 import torch
