@@ -629,11 +629,11 @@ __device__ __forceinline__ void drain_wave_queue(const WaveQueue<QC> &q, int n, 
                     for (int i = 0; i < PT; ++i) {
                         if (wyb[i] != 0) {               // wave-uniform: scalar compare + branch
                             const float wyi = __int_as_float(wyb[i]);
+                            // (gy * wy) * wx: the row weight is applied once to the gy row (2 packed multiplies), each of the
+                            // 4 cells then takes 2 packed FMAs with its scalar column weight - 10 VALU per row, not 4 x (1 + 2) + 1
+                            const float4 t = make_float4(buf[d].x * wyi, buf[d].y * wyi, buf[d].z * wyi, buf[d].w * wyi);
 #pragma unroll
-                            for (int k = 0; k < PT; ++k) {
-                                const float c = wyi * wx[k];
-                                MRCNN_FMA4(acc[i][k], c, buf[d])
-                            }
+                            for (int k = 0; k < PT; ++k) { MRCNN_FMA4(acc[i][k], wx[k], t) }
                         }
                     }
                 }
