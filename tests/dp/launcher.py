@@ -35,6 +35,22 @@ def main(out):
             break
     rc |= rcd
     open(os.path.join(out, 'done'), 'w').write(str(rc))
+    # ---- bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per "GPU"): both ranks on the one
+    #      device of the test box, gloo in place of RCCL (MRCNN_BENCH_SINGLE_DEVICE / MRCNN_BENCH_BACKEND)
+    root = os.path.dirname(os.path.dirname(HERE))
+    env = dict(os.environ, MRCNN_BENCH_SINGLE_DEVICE='1', MRCNN_BENCH_BACKEND='gloo')
+    blog = open(os.path.join(out, 'bench_log.txt'), 'w')
+    brc = 1
+    for attempt in range(3):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
+        try:
+            brc = subprocess.call(cmd, stdout=blog, stderr=subprocess.STDOUT, env=env, cwd=root, timeout=600)
+        except subprocess.TimeoutExpired:
+            brc = 1
+        if brc == 0:
+            break
+    open(os.path.join(out, 'bench_done'), 'w').write(str(brc))
 
 
 if __name__ == '__main__':

@@ -39,3 +39,26 @@ def test_two_rank_data_parallel_equals_sum_of_single_image_steps():
     assert float(emu['grads'].abs().max()) > 0
     assert torch.equal(r0['params'], r1['params'])
     assert torch.equal(r0['params'], emu['params'])
+
+
+def test_bench_two_ranks_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2
+    --steps K --warmup W` (the driver's command for N > 1): rank 0 prints ONE JSON line for the whole job - n_gpus 2, weak
+    scaling, the data-parallel all-reduce report - with both ranks on the one GPU of the test box (gloo in place of RCCL)."""
+    import json
+    out = os.environ.get('MRCNN_DP_TEST_DIR')
+    if not out:
+        pytest.skip('started by tests/conftest.py when pytest runs with -m gpu')
+    t0 = time.time()
+    while not os.path.exists(os.path.join(out, 'bench_done')):
+        assert time.time() - t0 < 1500, 'bench.py --gpus 2 did not finish'
+        time.sleep(1.0)
+    log = open(os.path.join(out, 'bench_log.txt')).read()
+    assert open(os.path.join(out, 'bench_done')).read() == '0', log[-4000:]
+    lines = [l for l in log.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, log[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['config']['global_batch'] == 4 and 'allreduce_rank0' in d['config']
+    assert abs(d['value'] - 4 * 1e3 / d['ms_per_step']) <= 1e-2 * d['value']          # whole-job images/s = global batch / step time
+    assert d['roofline']['frac'] <= 1.0 and 'roi_align_microbench' in d
