@@ -28,7 +28,6 @@ Only data (inputs, sampled targets, activations, losses) is stored: step_referen
 import os
 import sys
 import time
-import types
 
 import numpy as np
 
