@@ -1,6 +1,7 @@
-"""ROIAlign forward on BASELINE configs[1]: time + bit-exact check against the NumPy oracle on a RoI subset."""
+"""(test infrastructure: imports oracle/ - hence under tests/, not tools/)
+ROIAlign forward on BASELINE configs[1]: time + bit-exact check against the NumPy oracle on a RoI subset."""
 import os, sys
-R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R_, 'chainer-maskrcnn_amd')); sys.path.insert(0, R_)
 import numpy as np
 import torch

@@ -1,7 +1,8 @@
-"""Which pass of F(4x4,3x3) costs gradient accuracy?  The full-width parity run of tests/test_full_width_gpu.py (one
+"""(test infrastructure: uses the oracle through tests/test_full_width_gpu.py - hence under tests/, not tools/)
+Which pass of F(4x4,3x3) costs gradient accuracy?  The full-width parity run of tests/test_full_width_gpu.py (one
 512x512 image, float64 + float32 oracles) under per-pass tile choices (mrcnn_conv2d_set_winograd_pass_tiles)."""
 import os, sys
-R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R_, 'chainer-maskrcnn_amd')); sys.path.insert(0, R_)
 import numpy as np
 from chainer_maskrcnn import _hip
