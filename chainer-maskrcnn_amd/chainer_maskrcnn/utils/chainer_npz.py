@@ -180,3 +180,13 @@ def save_npz(path, model):
 def load_npz(path, model, strict=False):
     z = np.load(path)
     return ChainerNpzMap(model).from_chainer({k: z[k] for k in z.files}, strict=strict)
+
+
+def load_resnet50_npz(path, model, strict=False):
+    """ImageNet initialisation of the bottom-up pathway: a snapshot of ``chainer.links.ResNet50Layers`` (the file Chainer's
+    ``ResNet50Layers('auto')`` loads for the reference's extractor, feature_pyramid_network.py:22 - keys ``conv1/W``,
+    ``bn1/gamma``, ``res2/a/conv1/W`` ... ``res5/b2/bn3/avg_var``, ``fc6/W``) goes under ``extractor/resnet/``; ``fc6`` is
+    dropped like the reference does (:23).  Returns the list of keys loaded (with the prefix)."""
+    z = np.load(path)
+    arrays = {'extractor/resnet/' + k: z[k] for k in z.files if not k.startswith('fc6/')}
+    return ChainerNpzMap(model).from_chainer(arrays, strict=strict)

@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from chainer_maskrcnn.model.maskrcnn import MaskRCNN
-from chainer_maskrcnn.utils.chainer_npz import ChainerNpzMap, save_npz, load_npz
+from chainer_maskrcnn.utils.chainer_npz import ChainerNpzMap, save_npz, load_npz, load_resnet50_npz
 
 
 def _model(seed):
@@ -55,3 +55,22 @@ def test_fc1_and_deconv_layout_equivalence():
     t = F.conv2d(y, m.ps.p(h.deconv1.name + '/W')[:, 0, 0, :c][:, :, None, None])         # (2, 4C, 5, 5), channel = (a*2+b)*C+o
     ours = t.reshape(2, 2, 2, c, 5, 5).permute(0, 3, 4, 1, 5, 2).reshape(2, c, 10, 10) + m.ps.p(h.deconv_b)[None, :, None, None]
     assert torch.allclose(ref, ours, atol=1e-5)
+
+
+def test_resnet50_snapshot_initialises_the_bottom_up_pathway(tmp_path):
+    """A ``ResNet50Layers`` snapshot (keys without the ``extractor/resnet/`` prefix, with an ``fc6`` the FPN deletes,
+    feature_pyramid_network.py:22-23) fills exactly the bottom-up parameters and leaves everything else alone."""
+    src, dst = _model(4), _model(5)
+    d = ChainerNpzMap(src).to_chainer()
+    pre = 'extractor/resnet/'
+    snap = {k[len(pre):]: v for k, v in d.items() if k.startswith(pre)}
+    snap['fc6/W'], snap['fc6/b'] = np.zeros((1000, 16), np.float32), np.zeros((1000,), np.float32)
+    path = str(tmp_path / 'ResNet-50-model.npz')
+    np.savez(path, **snap)
+    before = ChainerNpzMap(dst).to_chainer()
+    loaded = load_resnet50_npz(path, dst)
+    assert set(loaded) == {pre + k for k in snap if not k.startswith('fc6/') and not k.endswith('/N')}        # (N: Chainer's step counter)
+    after = ChainerNpzMap(dst).to_chainer()
+    for k in after:
+        want = d[k] if k.startswith(pre) else before[k]
+        assert np.array_equal(after[k], want), k

@@ -30,6 +30,7 @@ def build_parser(keypoints=False):
     parser.add_argument('--out', '-o', default='result', help='Output directory')
     parser.add_argument('--iteration', '-i', type=int, default=200000)
     parser.add_argument('--weight', '-w', type=str, default='')
+    parser.add_argument('--resnet50-npz', type=str, default='', help="a chainer.links.ResNet50Layers snapshot for the bottom-up pathway (what ResNet50Layers('auto') loads in the reference, feature_pyramid_network.py:22)")
     if keypoints:   # train_keypoints.py spells its flags with underscores (train_keypoints.py:73-89)
         parser.add_argument('--backbone', type=str, default='fpn')
         parser.add_argument('--head_arch', '-a', type=str, default='fpn_keypoint')
@@ -90,6 +91,11 @@ def run(args, keypoints=False):
         with open(args.label_file) as f:
             labels = f.read().strip().split('\n')
     faster_rcnn.use_preset('evaluate')
+    if args.resnet50_npz:           # ImageNet initialisation of the bottom-up pathway (before --weight, which may override it)
+        from chainer_maskrcnn.utils import chainer_npz
+        n = len(chainer_npz.load_resnet50_npz(args.resnet50_npz, faster_rcnn))
+        if rank == 0:
+            print('ResNet-50 snapshot: %d arrays loaded from %s' % (n, args.resnet50_npz))
     if args.weight and os.path.exists(args.weight):
         load_npz(args.weight, faster_rcnn)
     optimizer = MomentumSGD(lr=args.lr, momentum=0.9)
