@@ -237,7 +237,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(_local_device())
         # RCCL over xGMI; MRCNN_BENCH_BACKEND=gloo only for the 1-GPU functional check of the multi-process path
-        torch.distributed.init_process_group(os.environ.get('MRCNN_BENCH_BACKEND', 'nccl'))
+        from chainer_maskrcnn.optimizers import init_process_group
+        init_process_group(os.environ.get('MRCNN_BENCH_BACKEND', 'nccl'))
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
     workload = args.workload

@@ -13,6 +13,23 @@ import torch
 from chainer_maskrcnn._hip import ops
 
 
+def init_process_group(backend='nccl', **kw):
+    """torch.distributed.init_process_group for the one-process-per-GPU layout.  With RCCL (backend 'nccl') the collectives'
+    internal streams are created at HIGH priority: the training step runs on a high-priority compute stream
+    (MomentumSGD.update), and the bucket all-reduces - a few small, latency-critical kernels per step - must not queue
+    behind the normal-priority weight-gradient GEMMs.  Falls back to the default options where the installed torch lacks
+    the switch."""
+    opts = None
+    if backend == 'nccl':
+        try:
+            opts = torch.distributed.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except Exception:
+            opts = None
+    if opts is not None:
+        kw['pg_options'] = opts
+    return torch.distributed.init_process_group(backend, **kw)
+
+
 class WeightDecay(object):
     def __init__(self, rate):
         self.rate = rate

@@ -74,7 +74,8 @@ def run(args, keypoints=False):
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl')
+        from chainer_maskrcnn.optimizers import init_process_group
+        init_process_group('nccl')
     if keypoints:
         n_fg, K = 1, 17
         faster_rcnn = MaskRCNN(n_fg_class=n_fg, n_keypoints=K, backbone=args.backbone, head_arch=args.head_arch, device=dev)
