@@ -36,7 +36,7 @@ METRIC = 'images/sec (1024^2 COCO, bs=2/GPU) at 1/2/4/8 MI355X; ROIAlign bwd HBM
 
 
 def roialign_inputs(seed_shift=0):
-    from tests.util import config2_inputs
+    from chainer_maskrcnn.utils.synthetic import config2_inputs
     x, yx, gy = config2_inputs()
     if seed_shift:          # distinct batches per rank
         rs = np.random.RandomState(100 + seed_shift)
@@ -45,12 +45,16 @@ def roialign_inputs(seed_shift=0):
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    """(HBM bytes per launch, source) from the newest committed rocprofv3 --pmc summary (profiles/), or (None, None).  The
+    counters need rocprofv3, so this is a constant from the repository, not something this run measured - the line says so."""
+    from chainer_maskrcnn.bench_step import latest_profile
+    f, d = latest_profile('roialign_pmc_traffic.json')
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_roialign_pmc_traffic.json')))
-        return d[kernel]['hbm_bytes']
+        key = [k for k in d if k.startswith(kernel)][0]
+        return d[key]['hbm_bytes'], {'file': f, 'collected_at_commit': d.get('_commit'),
+                                     'kind': 'constant read from the committed rocprofv3 --pmc summary, not collected by this run'}
     except Exception:
-        return None
+        return None, None
 
 
 def bench_roialign(args, rank, world):
@@ -133,7 +137,8 @@ def bench_roialign(args, rank, world):
                    'parallelism': 'independent batch per rank, no collective'},
         'roofline': {'bound': 'hbm', 'kernel': 'k_roi_align_bwd_waves', 'achieved': round(bwd_gbps, 2),
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(bwd_gbps / HBM_PEAK_GBPS, 4),
-                     'traffic': _pmc_traffic('k_roi_align_bwd_waves'), 'algorithmic_bytes_per_launch': algo_bytes,
+                     'traffic': _pmc_traffic('k_roi_align_bwd')[0], 'traffic_source': _pmc_traffic('k_roi_align_bwd')[1],
+                     'algorithmic_bytes_per_launch': algo_bytes,
                      'avg_launch_us': round(bwd_avg_s * 1e6, 3), 'median_launch_us': round(float(np.median(bwd_b2b)) * 1e3, 3),
                      'event_pair_per_launch_us': round(float(bwd_ms.mean()) * 1e3, 3),
                      'note': 'avg_launch_us: %d groups of %d back-to-back launches per HIP event pair; event_pair_per_launch_us: one '
@@ -141,7 +146,7 @@ def bench_roialign(args, rank, world):
         'roi_align_fwd': {'avg_launch_us': round(fwd_avg_s * 1e6, 3), 'event_pair_per_launch_us': round(float(fwd_ms.mean()) * 1e3, 3),
                           'achieved_GBps': round(algo_bytes / fwd_avg_s / 1e9, 2),
                           'frac': round(algo_bytes / fwd_avg_s / 1e9 / HBM_PEAK_GBPS, 4), 'kernel': 'k_roi_align_fwd_rows',
-                          'traffic': _pmc_traffic('k_roi_align_fwd_rows')},
+                          'traffic': _pmc_traffic('k_roi_align_fwd')[0]},
         'roi_align_adaptive_sampling': adaptive,
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -233,6 +238,10 @@ def main():
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
+    # one process per GPU: this rank's host threads stay on cores of its GPU's NUMA node (ranks sharing a node split it)
+    from chainer_maskrcnn.utils.affinity import pin_rank
+    cpus = pin_rank(int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('LOCAL_WORLD_SIZE', world))) if world > 1 else None
+    args.cpu_affinity = None if cpus is None else '%d cores: %d..%d' % (len(cpus), cpus[0], cpus[-1])
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(_local_device())

@@ -63,6 +63,7 @@ def bench_step(args, rank, world):
         step()
     _sync(world)
     dt = time.perf_counter() - t0
+    per_rank_ms = _gather_over_ranks(dt / args.steps * 1e3, world, dev)
     dt = _max_over_ranks(dt, world, dev)
     loss = float(chain.observation['loss'])
     ips = N * world * args.steps / dt
@@ -130,7 +131,7 @@ def bench_step(args, rank, world):
     secs = sum(a[2] for a in agg.values()) / n_prof
     launches = sum(a[0] for a in agg.values()) // n_prof
     split = _replay_split(recs, n_prof, dev)
-    traffic = _pmc_conv_traffic()
+    pmc = _pmc_step_counters()
     out = {
         'metric': 'images/sec (1024^2 COCO, bs=2/GPU) at 1/2/4/8 MI355X; ROIAlign bwd HBM GB/s',
         'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -148,7 +149,12 @@ def bench_step(args, rank, world):
         # whole convolution bracket (GEMM launches + Winograd transforms + slab / column sums) / fp32 MFMA peak: <= 1.
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm<fwd|bwd_data|bwd_filter> (all %d convolution calls of a step)' % launches,
                      'achieved': round(exe_flops / secs / 1e12, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(exe_flops / secs / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+                     'frac': round(exe_flops / secs / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': pmc['traffic'],
+                     'traffic_source': pmc['traffic_source'],
+                     'hbm_bytes_per_step_by_family': pmc.get('hbm_bytes_per_step_by_family'),
+                     'hbm_bytes_per_step_whole_step': pmc.get('hbm_bytes_per_step_whole_step'),
+                     'pmc_mfma_busy_fraction_all_k_conv_igemm': pmc.get('pmc_mfma_busy_fraction_all_k_conv_igemm'),
+                     'pmc_mfma_source': pmc.get('pmc_mfma_source'),
                      'executed_flops_per_step': exe_flops, 'conv_ms_per_step': round(secs * 1e3, 3),
                      'effective_TFLOPs': round(flops / secs / 1e12, 3), 'algorithmic_flops_per_step': flops,
                      'gemm_kernels_only': split['gemm'],
@@ -170,6 +176,11 @@ def bench_step(args, rank, world):
                                                                       'RPN / head convolutions run their forward pass with 0')
     if dp_report is not None:
         out['config']['allreduce_rank0'] = dp_report
+    if world > 1:       # a straggler shows here: `ms_per_step` is the MAX over ranks (the contract), this is every rank's own clock
+        out['config']['ms_per_step_per_rank'] = {'min': round(min(per_rank_ms), 3), 'max': round(max(per_rank_ms), 3),
+                                                 'all': [round(v, 3) for v in per_rank_ms]}
+    if getattr(args, 'cpu_affinity', None) is not None:
+        out['config']['cpu_affinity_rank0'] = args.cpu_affinity
     return out, model, dev
 
 
@@ -188,14 +199,49 @@ def _max_over_ranks(v, world, dev):
     return float(t.item())
 
 
-def _pmc_conv_traffic():
-    """HBM bytes per step of the convolution kernels from the committed rocprofv3 --pmc passes (profiles/), or None."""
+def latest_profile(suffix):
+    """(path relative to the repo root, parsed JSON) of the newest profiles/rNN_<suffix> (highest round), or (None, None)."""
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    try:
-        d = json.load(open(os.path.join(root, 'profiles', 'r02_step_pmc_traffic.json')))
-        return d['conv_bracket']['hbm_bytes_per_step']
-    except Exception:
-        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r[0-9][0-9]_' + suffix)))
+    for f in reversed(files):
+        try:
+            return os.path.relpath(f, root), json.load(open(f))
+        except Exception:
+            continue
+    return None, None
+
+
+def _gather_over_ranks(v, world, dev):
+    if world == 1:
+        return [v]
+    t = torch.tensor([v], dtype=torch.float64, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
+    out = [torch.zeros_like(t) for _ in range(world)]
+    torch.distributed.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def _pmc_step_counters():
+    """What the hardware counters said about this step - NOT measured by this run: counters need rocprofv3 (separate --pmc
+    passes, tools/round_end.sh), so the numbers are read from the summaries committed under profiles/ and the line says
+    which file and which commit of the kernels they were collected at (`traffic_source`)."""
+    f, d = latest_profile('step_pmc_traffic.json')
+    g, m = latest_profile('conv_pmc_mfma.json')
+    out = {'traffic': None, 'traffic_source': None}
+    if d is not None:
+        out['traffic'] = d['conv_bracket']['hbm_bytes_per_step']
+        fam = {k: v['hbm_bytes_per_step'] for k, v in d.items() if isinstance(v, dict) and 'hbm_bytes_per_step' in v and k != 'conv_bracket'}
+        out['traffic_source'] = {'file': f, 'collected_at_commit': d.get('_commit'), 'kind': 'constant read from the committed rocprofv3 --pmc summary, '
+                                 'not collected by this run', 'method': d.get('_method')}
+        out['hbm_bytes_per_step_by_family'] = fam
+        out['hbm_bytes_per_step_whole_step'] = sum(fam.values())
+    if m is not None:
+        ks = m.get('kernels', {})
+        cyc = sum(v['gpu_cycles_per_step'] for k, v in ks.items() if k.startswith('k_conv_igemm'))
+        busy = sum(v['gpu_cycles_per_step'] * v['mfma_busy_fraction'] for k, v in ks.items() if k.startswith('k_conv_igemm'))
+        out['pmc_mfma_busy_fraction_all_k_conv_igemm'] = round(busy / cyc, 4) if cyc else None
+        out['pmc_mfma_source'] = {'file': g, 'collected_at_commit': m.get('_commit')}
+    return out
 
 
 def _replay_split(recs, n_prof, dev):

@@ -26,7 +26,10 @@ def init_process_group(backend='nccl', **kw):
         except Exception:
             opts = None
     if opts is not None:
-        kw['pg_options'] = opts
+        try:
+            return torch.distributed.init_process_group(backend, pg_options=opts, **kw)
+        except TypeError:           # a torch build whose init_process_group does not take pg_options: default options
+            pass
     return torch.distributed.init_process_group(backend, **kw)
 
 
@@ -45,7 +48,9 @@ class GradientSynchronizer(object):
     transfer in the bandwidth regime while leaving >= 7 buckets to overlap with backward.
     """
 
-    def __init__(self, grads, bucket_bytes=25 << 20, group=None, average=False):
+    def __init__(self, grads, bucket_bytes=25 << 20, group=None, average=False, sync_single_rank=False):
+        """sync_single_rank: run the collectives even in a one-rank group (a SUM over one rank is the identity) - the
+        RCCL code path of an N-GPU job, exercised on a one-GPU box (tests/test_dp_gpu.py)."""
         self.grads = grads
         self.group = group
         self.average = average
@@ -62,6 +67,7 @@ class GradientSynchronizer(object):
         self._events, self._bwd_end = [], None
         self.stream = torch.cuda.Stream() if grads.is_cuda else None
         self.world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
+        self.active = self.world > 1 or (sync_single_rank and torch.distributed.is_initialized())
 
     def begin(self):
         self.next = 0
@@ -96,7 +102,7 @@ class GradientSynchronizer(object):
             self._all_reduce(sl)
 
     def mark_ready(self, offset):
-        if self.world == 1:
+        if not self.active:
             return
         while self.next < len(self.buckets) and self.buckets[self.next][0] >= offset:
             self._reduce(*self.buckets[self.next])
@@ -104,7 +110,7 @@ class GradientSynchronizer(object):
 
     def finish(self):
         """All buckets reduced and visible to the compute stream."""
-        if self.world == 1:
+        if not self.active:
             return
         self.mark_ready(0)
         if self.stream is not None:
@@ -166,15 +172,15 @@ class MomentumSGD(object):
         else:
             raise TypeError('only WeightDecay hooks exist on this path (train.py:109)')
 
-    def enable_data_parallel(self, bucket_bytes=25 << 20, average=False, broadcast=True):
+    def enable_data_parallel(self, bucket_bytes=25 << 20, average=False, broadcast=True, sync_single_rank=False):
         """One process per GPU; every rank keeps a replica and applies the same update to the summed gradients.  The
         replicas must START equal: rank 0's parameters, momentum and BatchNorm running statistics are broadcast once
         here (the reference's MultiprocessParallelUpdater broadcasts the master's parameters every step,
         SURVEY.md section 3.5; with identical updates once is enough) - so per-rank ``--weight`` files or seeds cannot
         silently diverge."""
-        self.sync = GradientSynchronizer(self.ps.grads, bucket_bytes, average=average)
+        self.sync = GradientSynchronizer(self.ps.grads, bucket_bytes, average=average, sync_single_rank=sync_single_rank)
         self.target.grad_ready_hook = self.sync.mark_ready
-        if broadcast and self.sync.world > 1:
+        if broadcast and self.sync.active:
             bufs = [self.ps.params, self.ps.momentum] + [self.ps.buffers[k] for k in sorted(self.ps.buffers)]
             gloo = torch.distributed.get_backend() == 'gloo'
             for b in bufs:

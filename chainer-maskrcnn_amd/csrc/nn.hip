@@ -139,18 +139,47 @@ __global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_stats_final(const fl
                                                          float *__restrict__ mean, float *__restrict__ invstd,
                                                          float *__restrict__ run_mean, float *__restrict__ run_var) {
     __shared__ double sa[FIN_SLICES][FIN_CH], sb[FIN_SLICES][FIN_CH];
-    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, slice = threadIdx.x / FIN_CH;
+    __shared__ double smean[FIN_CH];
+    __shared__ int sredo;
+    const int cl = threadIdx.x % FIN_CH;
+    const int c = blockIdx.x * FIN_CH + cl, slice = threadIdx.x / FIN_CH;
     double a, b;
-    reduce_partials(part, nblk, C, c, slice, sa, sb, a, b);
-    if (slice != 0 || c >= C) return;
-    const double ms = a / P;
-    double var = b / P - ms * ms;
-    if (var < 0.0) var = 0.0;
+    if (threadIdx.x == 0) sredo = 0;
+    reduce_partials(part, nblk, C, c, slice, sa, sb, a, b);        // (contains a barrier: sredo is visible below)
     // shifted: the partials are sums of (x - K), K = x[0][c] (k_bn_stats_partial); else plain sums (the convolution epilogue)
-    const float m = (float)((shifted ? (double)x[c] : 0.0) + ms), v = (float)var;
-    mean[c] = m;
+    double ms = a / P, var = b / P - ms * ms;
+    double m = (shifted ? (double)x[c < C ? c : 0] : 0.0) + ms;
+    // Un-shifted float32 partials lose var's digits to cancellation once mean^2 >> var (relative error ~1e-7 mean^2 / var:
+    // 9e-6 at |mean|/std = 34, measured) - e.g. a pretrained backbone's first BatchNorms.  Past |mean|/std = 32 the block
+    // recomputes its FIN_CH channels exactly: sums of (x - mean) and (x - mean)^2 over all P rows in double (a second pass
+    // over x for these channels only; never taken on the step's own activations).
+    if (slice == 0 && c < C && !shifted && var < ms * ms * (1.0 / 1024.0)) atomicOr(&sredo, 1);
+    if (slice == 0) smean[cl] = m;
+    __syncthreads();
+    if (sredo) {            // block-uniform
+        const double mc = smean[cl];
+        double d1 = 0.0, d2 = 0.0;
+        if (c < C)
+            for (int r = slice; r < P; r += FIN_SLICES) {
+                const double d = (double)x[(size_t)r * C + c] - mc;
+                d1 += d; d2 += d * d;
+            }
+        __syncthreads();
+        sa[slice][cl] = d1; sb[slice][cl] = d2;
+        __syncthreads();
+        if (slice == 0) {
+            for (int k = 1; k < FIN_SLICES; ++k) { d1 += sa[k][cl]; d2 += sb[k][cl]; }
+            const double dm = d1 / P;
+            m = mc + dm;
+            var = d2 / P - dm * dm;
+        }
+    }
+    if (slice != 0 || c >= C) return;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, v = (float)var;
+    mean[c] = mf;
     invstd[c] = 1.0f / sqrtf(v + eps);
-    if (run_mean) run_mean[c] = decay * run_mean[c] + (1.0f - decay) * m;
+    if (run_mean) run_mean[c] = decay * run_mean[c] + (1.0f - decay) * mf;
     if (run_var) {
         const float adj = (float)P / (float)max(P - 1, 1);
         run_var[c] = decay * run_var[c] + (1.0f - decay) * v * adj;

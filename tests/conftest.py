@@ -12,29 +12,67 @@ for p in (ROOT, PKG):
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+_DP = {'proc': None, 'dir': None}
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     _start_dp_workers(config)
 
 
-def _start_dp_workers(config):
-    """tests/test_dp_gpu.py compares child processes (2 data-parallel ranks + a single-process emulation).  They are
-    started HERE - before any test module is imported, i.e. before this process has initialised the GPU - by a launcher
-    that itself never touches the GPU; the test only waits for their result files."""
+def _selects_dp_tests(config):
+    """True when this session can run tests/test_dp_gpu.py: -m gpu, and the file is among (or below) the given paths."""
     expr = config.getoption('markexpr', '') or ''
-    if 'gpu' not in expr or 'not gpu' in expr or os.environ.get('MRCNN_DP_TEST_DIR'):
-        return
-    try:
-        import torch
-        if torch.cuda.device_count() < 1:       # does not initialise the device
-            return
-    except Exception:
+    if 'gpu' not in expr or 'not gpu' in expr:
+        return False
+    target = os.path.join(ROOT, 'tests', 'test_dp_gpu.py')
+    args = [a for a in (config.args or []) if not a.startswith('-')] or [os.path.join(ROOT, 'tests')]
+    for a in args:
+        path = os.path.abspath(os.path.join(str(config.invocation_params.dir), a.split('::')[0]))
+        if path == target or (os.path.isdir(path) and target.startswith(path.rstrip(os.sep) + os.sep)):
+            return True
+    return False
+
+
+def _start_dp_workers(config):
+    """tests/test_dp_gpu.py compares child processes (2 data-parallel ranks, a single-process emulation, a one-rank RCCL
+    run, bench.py under torch.distributed.run).  They are started HERE - before any test module is imported, i.e. before
+    this process has initialised the GPU (a process that has must not fork + exec on the GPU pool) - by a launcher that
+    itself never touches the GPU; the tests only wait for the result files.  Only when that file is part of the session
+    and the box has a GPU device node (checked without loading any GPU runtime); the launcher and its directory are
+    cleaned up in pytest_unconfigure."""
+    if os.environ.get('MRCNN_DP_TEST_DIR') or not _selects_dp_tests(config) or not os.path.exists('/dev/kfd'):
         return
     import subprocess
     import tempfile
     out = tempfile.mkdtemp(prefix='mrcnn_dp_')
     os.environ['MRCNN_DP_TEST_DIR'] = out
-    subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp', 'launcher.py'), out])
+    _DP['dir'] = out
+    _DP['proc'] = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp', 'launcher.py'), out], start_new_session=True)
+
+
+def pytest_unconfigure(config):
+    proc, out = _DP['proc'], _DP['dir']
+    if proc is not None:
+        if proc.poll() is None:             # an aborted session: end the launcher and its children (its own process group)
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+            except OSError:
+                pass
+            try:
+                proc.wait(timeout=20)
+            except Exception:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+        _DP['proc'] = None
+    if out is not None:
+        import shutil
+        shutil.rmtree(out, ignore_errors=True)
+        os.environ.pop('MRCNN_DP_TEST_DIR', None)
+        _DP['dir'] = None
 
 
 @pytest.fixture(scope='session')

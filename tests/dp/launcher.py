@@ -35,6 +35,13 @@ def main(out):
             break
     rc |= rcd
     open(os.path.join(out, 'done'), 'w').write(str(rc))
+    # ---- one rank on RCCL: the collective code path of an N-GPU job (tests/test_dp_gpu.py::test_rccl_path_single_rank)
+    try:
+        rr = subprocess.call([sys.executable, w, 'rccl1', str(_free_port()), out], stdout=log, stderr=subprocess.STDOUT, timeout=600)
+    except subprocess.TimeoutExpired:
+        rr = 1
+    log.flush()
+    open(os.path.join(out, 'rccl1_done'), 'w').write(str(rr))
     # ---- bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per "GPU"): both ranks on the one
     #      device of the test box, gloo in place of RCCL (MRCNN_BENCH_SINGLE_DEVICE / MRCNN_BENCH_BACKEND)
     root = os.path.dirname(os.path.dirname(HERE))

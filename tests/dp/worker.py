@@ -3,6 +3,11 @@
     worker.py dp  <rank> <world> <port> <outdir>    one data-parallel rank: batch of ONE image, gloo all-reduce of the
                                                     flat gradient buffer (RCCL refuses two ranks on one GPU), 3 steps
     worker.py emu <outdir>                          single process: the same 3 steps computed as g(img0) + g(img1)
+    worker.py rccl1 <port> <outdir>                 ONE rank on RCCL (backend 'nccl'): the code path an N-GPU job executes -
+                                                    optimizers.init_process_group (high-priority collective streams),
+                                                    the rank-0 broadcast, device-buffer bucket all-reduces on the side
+                                                    stream, timing_report(), finish() - against the same steps without
+                                                    any synchroniser (a SUM over one rank is the identity)
 Both save the gradient buffer after step 1 and the parameters after step 3."""
 import os
 import sys
@@ -90,8 +95,45 @@ def run_emu(out):
     torch.save(res, os.path.join(out, 'emu.pt'))
 
 
+def run_rccl1(port, out):
+    from chainer_maskrcnn import optimizers
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+
+    def steps(sync):
+        model = MaskRCNN(n_fg_class=80, device=DEV, seed=7, _test_shrink=SHRINK)
+        chain = make_chain(model, 0)
+        opt = make_opt(chain)
+        rep = None
+        if sync:
+            opt.enable_data_parallel(bucket_bytes=1 << 20, sync_single_rank=True)
+            assert opt.sync.active and opt.sync.world == 1 and len(opt.sync.buckets) > 3
+            opt.sync.timing = True
+        batch = image(0)
+        for s in range(STEPS):
+            opt.update(chain, *batch, 1.0)
+            if s == 0:
+                g = model.ps.grads.cpu().clone()
+        torch.cuda.synchronize()
+        if sync:
+            rep = opt.sync.timing_report()
+            assert opt.sync.next == len(opt.sync.buckets)            # every bucket went through the collective
+        return g, model.ps.params.cpu().clone(), float(chain.observation['loss']), rep
+
+    g0, p0, l0, _ = steps(False)
+    optimizers.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        assert torch.distributed.get_backend() == 'nccl'
+        g1, p1, l1, rep = steps(True)
+    finally:
+        torch.distributed.destroy_process_group()
+    torch.save(dict(g0=g0, p0=p0, l0=l0, g1=g1, p1=p1, l1=l1, report=rep), os.path.join(out, 'rccl1.pt'))
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'dp':
+    if sys.argv[1] == 'rccl1':
+        run_rccl1(int(sys.argv[2]), sys.argv[3])
+    elif sys.argv[1] == 'dp':
         run_dp(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
     else:
         run_emu(sys.argv[2])

@@ -41,6 +41,29 @@ def test_two_rank_data_parallel_equals_sum_of_single_image_steps():
     assert torch.equal(r0['params'], emu['params'])
 
 
+def test_rccl_path_single_rank():
+    """The RCCL branch of the data-parallel code, before an 8-GPU node meets it: a child process creates
+    a ONE-rank process group on backend 'nccl' through optimizers.init_process_group (high-priority collective streams) and
+    drives GradientSynchronizer on the DEVICE gradient buffer - rank-0 broadcast, > 3 buckets each all-reduced by RCCL on
+    the side stream as backward passes their offsets, timing_report(), finish() - for 3 steps; a SUM over one rank is the
+    identity, so gradients, parameters and loss must equal the un-synchronised run bit for bit."""
+    out = os.environ.get('MRCNN_DP_TEST_DIR')
+    if not out:
+        pytest.skip('started by tests/conftest.py when pytest runs with -m gpu')
+    t0 = time.time()
+    while not os.path.exists(os.path.join(out, 'rccl1_done')):
+        assert time.time() - t0 < 1200, 'the RCCL worker did not finish'
+        time.sleep(1.0)
+    log = open(os.path.join(out, 'log.txt')).read()
+    assert open(os.path.join(out, 'rccl1_done')).read() == '0', log[-4000:]
+    r = torch.load(os.path.join(out, 'rccl1.pt'))
+    assert torch.equal(r['g0'], r['g1']) and float(r['g1'].abs().max()) > 0
+    assert torch.equal(r['p0'], r['p1']) and r['l0'] == r['l1']
+    rep = r['report']
+    assert rep is not None and len(rep['bucket_ms']) > 3 and all(v >= 0 for v in rep['bucket_ms'])
+    assert rep['allreduce_ms_total'] > 0 and 0.0 <= rep['overlap_fraction'] <= 1.0
+
+
 def test_bench_two_ranks_as_the_driver_launches_it():
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2
     --steps K --warmup W` (the driver's command for N > 1): rank 0 prints ONE JSON line for the whole job - n_gpus 2, weak
@@ -60,5 +83,8 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['value'] > 0
     assert d['config']['global_batch'] == 4 and 'allreduce_rank0' in d['config']
+    pr = d['config']['ms_per_step_per_rank']            # every rank's own clock beside the job number (a straggler is visible)
+    assert len(pr['all']) == 2 and pr['min'] <= pr['max'] and abs(pr['max'] - d['ms_per_step']) <= 1e-2 * d['ms_per_step']
+    assert d['roofline']['traffic_source']['file'].startswith('profiles/')
     assert abs(d['value'] - 4 * 1e3 / d['ms_per_step']) <= 1e-2 * d['value']          # whole-job images/s = global batch / step time
     assert d['roofline']['frac'] <= 1.0 and 'roi_align_microbench' in d

@@ -93,10 +93,10 @@ def _rel(got, want):
     return float((got.detach().double().cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-30)
 
 
-def _run(S, mode, keypoints=False):
+def _run(S, mode, keypoints=False, N=1, seed=11, G=6):
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     m, chain = _model(keypoints)
-    b = make_batch(11, 1, S, S, G=6, n_fg_class=1 if keypoints else 80, n_keypoints=17 if keypoints else None)
+    b = make_batch(seed, N, S, S, G=G, n_fg_class=1 if keypoints else 80, n_keypoints=17 if keypoints else None)
     b['bboxes'][:, :, 2:] = np.minimum(b['bboxes'][:, :, 2:], [S, S])
     bt = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(*MODES[mode][0]))
@@ -110,8 +110,8 @@ def _run(S, mode, keypoints=False):
         loss.backward()
         obs = {k: float(v) for k, v in chain.observation.items()}
         t = _targets(chain)
-        img4 = torch.cat([bt['imgs'].cpu().permute(0, 2, 3, 1), torch.zeros((1, S, S, 1))], -1)
-        key = ('oracle', S, keypoints)
+        img4 = torch.cat([bt['imgs'].cpu().permute(0, 2, 3, 1), torch.zeros((N, S, S, 1))], -1)
+        key = ('oracle', S, keypoints, N, seed, G)
         if not (key in _cache and _same_targets(_cache[key]['t'], t)):      # proposals can differ between conv paths
             t0 = time.time()
             o64, out64, g64 = _oracle(m, t, img4, torch.float64, tap=TAP, keypoints=keypoints)
@@ -162,9 +162,9 @@ def _run(S, mode, keypoints=False):
     errs = sorted(r[1] for r in rows)
     flo = sorted(r[2] for r in rows)
     q = lambda v, f: v[int(f * (len(v) - 1))]
-    with open(os.path.join(out_dir, 'full_width_parity_%d_%s%s.txt' % (S, mode, '_keypoint' if keypoints else '')), 'w') as f:
-        f.write('# full ResNet-50-FPN %s R-CNN, one' % ('Keypoint' if keypoints else 'Mask'))
-        f.write(' %dx%d image, conv path %s; oracle float64 + float32 took %.0f s\n' % (S, S, mode, c['secs']))
+    with open(os.path.join(out_dir, 'full_width_parity_%d_%s%s%s.txt' % (S, mode, '_keypoint' if keypoints else '', '_n%d' % N if N > 1 else '')), 'w') as f:
+        f.write('# full ResNet-50-FPN %s R-CNN, %d' % ('Keypoint' if keypoints else 'Mask', N))
+        f.write(' %dx%d image(s), conv path %s; oracle float64 + float32 took %.0f s\n' % (S, S, mode, c['secs']))
         f.write('# activations, max |device - fp64 oracle| / max |oracle|: %s\n' % ', '.join('%s %.2e' % kv for kv in acts.items()))
         f.write('# losses, relative: %s\n' % ', '.join('%s %.2e' % kv for kv in losses.items()))
         f.write('# isolated %s filter gradient (oracle x, gy -> mrcnn_conv2d_bwd_filter_f32): %.2e\n' % (wname, iso))
@@ -176,8 +176,8 @@ def _run(S, mode, keypoints=False):
     return acts, losses, rows, iso
 
 
-def _check(S, mode, keypoints=False):
-    acts, losses, rows, iso = _run(S, mode, keypoints)
+def _check(S, mode, keypoints=False, **kw):
+    acts, losses, rows, iso = _run(S, mode, keypoints, **kw)
     for k, v in acts.items():
         assert v <= 1e-3, ('activation', k, v)          # BASELINE.json north_star: conv activations within 1e-3 relative
     for k, v in losses.items():
@@ -211,6 +211,15 @@ def test_full_width_512(mode):
 def test_full_width_1024_shipped():
     """BASELINE.json configs[2]'s image size with the shipped (benchmarked) kernel selection."""
     _check(1024, 'shipped')
+
+
+def test_full_width_1024_batch2_shipped():
+    """The benchmarked configuration itself: BASELINE.json configs[2] = TWO 1024x1024 images (bench.py's
+    batch: make_batch(100, 2, 1024, 1024, G=8)), full width, shipped kernel selection, mask branch on all 256 rows - per-image
+    target blocks, roi_indices, BatchNorm statistics over two images and the concatenated-batch loss normalisers at full
+    size, against the float64 oracle with the same bars as the one-image tests."""
+    _check(1024, 'shipped', N=2, seed=100, G=8)
+    _cache.pop(('oracle', 1024, False, 2, 100, 8), None)       # ~10 GB of float64 gradients and activations
 
 
 def test_full_width_keypoint_512_shipped():

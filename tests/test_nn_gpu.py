@@ -229,3 +229,34 @@ def test_bn_statistics_fusion_declines_split_launches():
     assert lib().mrcnn_conv2d_bnstats_rows(2, 64, 64, 256, 256, 3, 3, 1, 1) > 0         # Winograd layer: output transform
     assert lib().mrcnn_conv2d_bnstats_rows(2, 8, 8, 2048, 512, 1, 1, 1, 0) == 0         # few tiles, long K: split-K
     assert lib().mrcnn_conv2d_bnstats_rows(2, 64, 64, 256, 1024, 1, 1, 1, 0) > 0
+
+
+@pytest.mark.parametrize('ratio', [20.0, 80.0, 400.0])
+def test_bn_statistics_from_the_epilogue_with_a_large_mean(ratio):
+    """the epilogue's partials are UN-shifted float32 sums, so var = E[x^2] - E[x]^2 cancels once |mean| >> std
+    (a pretrained backbone's first BatchNorms).  A convolution output with |mean| / std of 20 / 80 / 400 per channel
+    (an input with a large constant component): past |mean| / std = 32 k_bn_stats_final recomputes the channel's statistics
+    exactly from x, so 1 / sigma stays within 2e-5 of float64 and the normalised output within 1e-4 of its scale - where the
+    plain formula would be off by ~1e-7 * ratio^2 (6e-4 at 80, 1.6e-2 at 400)."""
+    from chainer_maskrcnn._hip import nn as hnn
+    N, H, W, Ci, Co = 2, 64, 64, 64, 128
+    rs = np.random.RandomState(11)
+    w = (rs.standard_normal((Co, 1, 1, Ci)) / np.sqrt(Ci)).astype(np.float32)
+    x = rs.standard_normal((N, H, W, Ci)).astype(np.float32)
+    # y = x w^T has unit std per channel; add a per-channel constant of `ratio` stds through a constant input component
+    shift = np.linalg.lstsq(w.reshape(Co, Ci).astype(np.float64), np.full(Co, ratio), rcond=None)[0].astype(np.float32)
+    x = x + shift
+    xt, wt = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
+    y, _, part = hnn.conv2d_fwd_bnstats_raw(xt, wt, 1, 0)
+    P = y.numel() // Co
+    yd = y.double().cpu().reshape(P, Co)
+    m64, v64 = yd.mean(0), yd.var(0, unbiased=False)
+    big = (m64.abs() / v64.sqrt()) > 0.5 * ratio
+    assert int(big.sum()) >= Co // 2             # the construction worked: most channels have the intended |mean| / std
+    gamma, beta = torch.ones(Co, device=DEV), torch.zeros(Co, device=DEV)
+    o, mean, invstd = ops.bn_train_fwd_stats(y, part, gamma, beta, None, False, None, None)
+    want_is = 1.0 / torch.sqrt(v64 + 2e-5)
+    assert float(((invstd.double().cpu() - want_is).abs() / want_is).max()) <= 2e-5
+    assert float((mean.double().cpu() - m64).abs().max()) <= 2e-6 * float(m64.abs().max())
+    want = (yd - m64) * want_is
+    assert float((o.double().cpu().reshape(P, Co) - want).abs().max()) <= 1e-4 * float(want.abs().max())

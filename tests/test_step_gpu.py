@@ -463,3 +463,27 @@ def test_padded_batch_uses_each_images_own_size_and_scale():
     assert torch.equal(chain.rpn_out['rois'].reshape(2, -1, 4)[0], rois0)
     assert not torch.equal(chain.rpn_targets[1][1], lab_batch[1])
     chain.sampler_keys = None
+
+
+def test_overfits_one_fixed_batch():
+    """Does it learn: 150 MomentumSGD steps (lr 0.01, momentum 0.9, weight decay 5e-4 - train.py's
+    optimiser at a learning rate that fits the reduced network) on ONE fixed batch with fixed sampler seeds: the total
+    loss falls by at least half, every one of the five losses stays finite at every step, and the box-classification and
+    mask losses - the two that depend on the whole chain of proposals -> targets -> heads - both fall."""
+    m, chain = _build('all', seed=11)
+    opt = MomentumSGD(lr=0.01, momentum=0.9).setup(chain)
+    opt.add_hook(WeightDecay(0.0005))
+    b = _batch()
+    names = ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss', 'loss')
+    hist = []
+    for it in range(150):
+        chain.proposal_target_creator.set_seed(100 + it)
+        chain.anchor_target_creator.set_seed(200 + it)
+        opt.update(chain, b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+        hist.append(torch.stack([chain.observation[k].detach() for k in names]))
+    h = torch.stack(hist).cpu().numpy()                  # one device->host copy at the end
+    assert np.isfinite(h).all(), np.argwhere(~np.isfinite(h))[:5]
+    first, last = h[:5].mean(0), h[-5:].mean(0)
+    assert last[5] <= 0.5 * first[5], (first, last)
+    assert last[3] < first[3] and last[4] < first[4], (first, last)
+    assert torch.isfinite(m.ps.params).all()

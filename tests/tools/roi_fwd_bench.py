@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(R_, 'chainer-maskrcnn_amd')); sys.path.insert(0,
 import numpy as np
 import torch
 from chainer_maskrcnn import _hip
-from tests.util import config2_inputs
+from chainer_maskrcnn.utils.synthetic import config2_inputs
 from oracle import roi_align as ora
 dev = torch.device('cuda:0')
 lib = _hip.lib()

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 from chainer_maskrcnn import _hip
 from chainer_maskrcnn.model.head import fpn_roi_mask_head as hd
-from tests.util import config2_inputs
+from chainer_maskrcnn.utils.synthetic import config2_inputs
 dev = torch.device('cuda:0')
 lib = _hip.lib()
 

@@ -3,7 +3,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, 'chainer-maskrcnn_amd')); sys.path.insert(0, R)
 import numpy as np, torch, ctypes
 from chainer_maskrcnn import _hip
-from tests.util import config2_inputs
+from chainer_maskrcnn.utils.synthetic import config2_inputs
 x, yx, gy = config2_inputs()
 dev = torch.device('cuda:0')
 N, C, H, W = x.shape; R_, _, PH, PW = gy.shape

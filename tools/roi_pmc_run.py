@@ -4,7 +4,7 @@ R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R_, 'chainer-maskrcnn_amd')); sys.path.insert(0, R_)
 import torch
 from chainer_maskrcnn import _hip
-from tests.util import config2_inputs
+from chainer_maskrcnn.utils.synthetic import config2_inputs
 dev = torch.device('cuda:0')
 lib = _hip.lib()
 x, yx, gy = config2_inputs()

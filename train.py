@@ -71,6 +71,11 @@ def run(args, keypoints=False):
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', args.gpu))
     dev = torch.device('cuda', local)
+    if world > 1:       # one process per GPU: host threads (enqueue loop, loader workers, RCCL proxy) on the GPU's NUMA node
+        from chainer_maskrcnn.utils.affinity import pin_rank
+        cpus = pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+        if cpus:
+            print('rank %d: pinned to %d cores (%d..%d)' % (rank, len(cpus), cpus[0], cpus[-1]))
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -124,7 +129,7 @@ def run(args, keypoints=False):
             tf = RawTransform(faster_rcnn)
         loader = BatchLoader(data, tf, batch_size=bs, shuffle=True, seed=1234, rank=rank, world=world,
                              num_workers=args.num_workers, max_gt=args.max_gt or None, keypoints=keypoints, device=dev,
-                             start_ticket=resume['loader_ticket'] if resume else 0)
+                             start_ticket=_rank_ticket(resume['loader_ticket'], rank) if resume else 0)
     pool = []
     if loader is None:
         for j in range(8):
@@ -174,12 +179,33 @@ def run(args, keypoints=False):
                 print(entry)
         if args.lr_shift_interval and it % args.lr_shift_interval == 0:
             optimizer.lr *= 0.1                                       # ExponentialShift('lr', 0.1), train.py:139-140
-        if rank == 0 and it % args.snapshot_interval == 0:
-            save_npz(os.path.join(args.out, 'model_%d.npz' % it), faster_rcnn)      # snapshot_object, train.py:134-137
-            torch.save({'iteration': it, 'optimizer': optimizer.state_dict(), 'loader_ticket': loader.ticket if loader is not None else 0},
-                       os.path.join(args.out, 'trainer_%d.pt' % it))
+        if it % args.snapshot_interval == 0:
+            # every rank's data position goes into the trainer state: tickets count popped examples (skipped empty ones
+            # included), so ranks can stand at different positions of their shards - a resumed rank continues from ITS own
+            tickets = _all_rank_tickets(loader.ticket if loader is not None else 0, world, dev)
+            if rank == 0:
+                save_npz(os.path.join(args.out, 'model_%d.npz' % it), faster_rcnn)      # snapshot_object, train.py:134-137
+                torch.save({'iteration': it, 'optimizer': optimizer.state_dict(), 'loader_ticket': tickets},
+                           os.path.join(args.out, 'trainer_%d.pt' % it))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def _all_rank_tickets(ticket, world, dev):
+    """Every rank's loader ticket, in rank order (a collective when world > 1: called by all ranks)."""
+    if world == 1:
+        return [int(ticket)]
+    t = torch.tensor([int(ticket)], dtype=torch.int64, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
+    out = [torch.zeros_like(t) for _ in range(world)]
+    torch.distributed.all_gather(out, t)
+    return [int(o.item()) for o in out]
+
+
+def _rank_ticket(saved, rank):
+    """A trainer state holds one ticket per rank (older files: a single number = rank 0's)."""
+    if isinstance(saved, (list, tuple)):
+        return int(saved[rank]) if rank < len(saved) else int(saved[0])
+    return int(saved)
 
 
 class _Roctx(object):
