@@ -78,9 +78,13 @@ def bench_roialign(args, rank, world):
         _hip.check(lib.mrcnn_roi_align_fwd_f32(_hip.ptr(xt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
                                                0.25, sr, _hip.ptr(y), _hip.stream_ptr()))
 
+    # caller-owned scratch of the backward (per-RoI sample tables of the table-driven kernel), sized by the library's query
+    nb = max(lib.mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, R, PH, PW, 2), lib.mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, R, PH, PW, 0))
+    ws = torch.empty((max(nb, 1),), dtype=torch.uint8, device=dev)
+
     def bwd(sr=2):
-        _hip.check(lib.mrcnn_roi_align_bwd_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
-                                               0.25, sr, _hip.ptr(gx), _hip.stream_ptr()))
+        _hip.check(lib.mrcnn_roi_align_bwd_ws_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
+                                                  0.25, sr, _hip.ptr(gx), _hip.ptr(ws), nb, _hip.stream_ptr()))
 
     for _ in range(args.warmup):
         fwd(); bwd()

@@ -28,7 +28,7 @@ _MANUAL = {
     'mrcnn_roi_align_fpn_bwd_f32': (c_int, [c_void_p, _P(c_void_p), _P(c_int), _P(c_int), _P(c_float),
                                             c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                             c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    'mrcnn_roi_align_fpn_bwd_workspace_bytes': (c_size_t, [_P(c_int), _P(c_int), c_int, c_int, c_int]),
+    'mrcnn_roi_align_fpn_bwd_workspace_bytes': (c_size_t, [_P(c_int), _P(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
 }
 _CTYPE = {'int': c_int, 'float': c_float, 'size_t': c_size_t, 'long long': ctypes.c_longlong,
           'int32_t': ctypes.c_int32, 'unsigned': ctypes.c_uint, 'unsigned long long': ctypes.c_ulonglong}
@@ -62,7 +62,7 @@ def _parse_header(path):
 SIGNATURES = _parse_header(HEADER_PATH)
 
 _lib = None
-ABI_VERSION = 4          # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
+ABI_VERSION = 5          # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
 
 
 class MrcnnHipError(RuntimeError):

@@ -59,9 +59,12 @@ class _RoIAlign2D(torch.autograd.Function):
         fmt = torch.channels_last if layout == _hip.LAYOUT_NHWC else torch.contiguous_format
         gy = gy.contiguous(memory_format=fmt)
         gx = torch.empty((N, C, H, W), dtype=torch.float32, device=gy.device, memory_format=fmt)
-        _hip.check(_hip.lib().mrcnn_roi_align_bwd_f32(
+        from chainer_maskrcnn._hip.nn import workspace
+        nb = _hip.lib().mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, rois.shape[0], outh, outw, sr)
+        ws = workspace(nb, gy.device) if nb else None          # per-RoI sample tables of the table-driven backward
+        _hip.check(_hip.lib().mrcnn_roi_align_bwd_ws_f32(
             _hip.ptr(gy), layout, N, C, H, W, _hip.ptr(rois), rois.shape[0], outh, outw, scale, sr,
-            _hip.ptr(gx), _hip.stream_ptr()))
+            _hip.ptr(gx), _hip.ptr(ws), ws.numel() if ws is not None else 0, _hip.stream_ptr()))
         return gx, None, None, None, None, None
 
 

@@ -44,7 +44,7 @@ def roi_align_fpn_fwd(xs, rois_xy5, levels, out_size, scales, sampling_ratio=2):
 def roi_align_fpn_bwd(gy, gxs, rois_xy5, levels, out_size, scales, accumulate, sampling_ratio=2):
     L, arr_p, Hs, Ws, sc = _level_args(gxs, scales)
     N, C = gxs[0].shape[0], gxs[0].shape[3]
-    nb = lib().mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, N, C)
+    nb = lib().mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, N, C, rois_xy5.shape[0], out_size, out_size, sampling_ratio)
     ws = workspace(nb, gy.device) if nb else None
     check(lib().mrcnn_roi_align_fpn_bwd_f32(ptr(gy), arr_p, Hs, Ws, sc, L, N, C, ptr(rois_xy5), ptr(levels),
                                             rois_xy5.shape[0], out_size, out_size, sampling_ratio, int(accumulate),

@@ -24,93 +24,11 @@
 
 #pragma clang fp contract(off)
 
+#include "roi_align_common.h"
+
+using namespace mrcnn_roi;
+
 namespace {
-
-struct RoiGeom {
-    float x1f, y1f, bw, bh, rw, rh;
-    int gh, gw, n;
-};
-
-__device__ __forceinline__ RoiGeom roi_geom(const float *roi, float s, int PH, int PW, int sr) {
-    RoiGeom g;
-    g.n = (int)roi[0];
-    g.x1f = roi[1] * s;
-    g.y1f = roi[2] * s;
-    float x2f = roi[3] * s, y2f = roi[4] * s;
-    g.rw = fmaxf(x2f - g.x1f, 1.0f);
-    g.rh = fmaxf(y2f - g.y1f, 1.0f);
-    g.bw = g.rw / (float)PW;
-    g.bh = g.rh / (float)PH;
-    if (sr > 0) {
-        g.gh = g.gw = sr;
-    } else {
-        g.gh = (int)ceilf(g.rh / (float)PH);
-        g.gw = (int)ceilf(g.rw / (float)PW);
-    }
-    return g;
-}
-
-struct Samp {
-    int lo, hi;      // corner cells, -1 when the sample is void
-    float wl, wh;    // weight of lo / hi cell (hy / ly in the Caffe2 formula)
-};
-
-// One axis of one sample: c = (start + p*bin) + ((i+0.5)*bin)/grid, in exactly this order.
-__device__ __forceinline__ Samp axis_sample(float start, float bin, int p, int i, int grid, int size) {
-    // x / 2.0f == x * 0.5f bit for bit (barring subnormals): the common sampling ratio avoids the correctly-rounded divide
-    const float t = ((float)i + 0.5f) * bin;
-    float c = (start + (float)p * bin) + (grid == 2 ? t * 0.5f : t / (float)grid);
-    bool valid = !(c < -1.0f || c > (float)size);
-    c = fmaxf(c, 0.0f);
-    int lo = (int)c, hi;
-    if (lo >= size - 1) {
-        lo = hi = size - 1;
-        c = (float)lo;
-    } else {
-        hi = lo + 1;
-    }
-    Samp s;
-    s.wh = c - (float)lo;
-    s.wl = 1.0f - s.wh;
-    if (!valid) {
-        s.lo = s.hi = -1;
-        s.wl = s.wh = 0.0f;
-    } else {
-        s.lo = lo;
-        s.hi = hi;
-    }
-    return s;
-}
-
-struct Levels {
-    const float *x[MRCNN_MAX_LEVELS];
-    float *gx[MRCNN_MAX_LEVELS];
-    int H[MRCNN_MAX_LEVELS], W[MRCNN_MAX_LEVELS];
-    float scale[MRCNN_MAX_LEVELS];
-    int tile_begin[MRCNN_MAX_LEVELS + 1];
-    int tiles_x[MRCNN_MAX_LEVELS], tiles_y[MRCNN_MAX_LEVELS];
-    // backward RoI split: on a coarse level (few tiles, many RoIs - the reference maps most RoIs to the coarsest levels)
-    // each tile is computed by split[l] workgroups, workgroup z taking the RoIs with index % split == z and writing a
-    // partial map to slab[l] + z * (N*H*W*C); k_sum_level_slabs adds the partial maps in z order (deterministic).
-    int split[MRCNN_MAX_LEVELS];
-    float *slab[MRCNN_MAX_LEVELS];
-    int L;
-};
-
-// q = v / d, r = v % d for 0 <= v < 2^24 with inv = 1.0f / d: float estimate + one correction each way (exact); the
-// tile decode of a workgroup would otherwise spend ~100 instructions in four 32-bit integer divisions.
-__device__ __forceinline__ void divmod_u24(int v, int d, int &q, int &r) {
-    q = (int)((float)v * (1.0f / (float)d));
-    r = v - q * d;
-    if (r >= d) { r -= d; ++q; }
-    if (r < 0) { r += d; --q; }
-}
-
-__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-__device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ float readlane_f(float v, int l) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
 
 // ------------------------------------------------------------------------------------------
 // Forward, NHWC: one wave per (roi, ph, pw) bin; lane = 4 channels.
@@ -305,20 +223,11 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(Levels lv, const flo
 // ------------------------------------------------------------------------------------------
 // Backward, NHWC, owner-computes tiles.
 // ------------------------------------------------------------------------------------------
-constexpr int TH = 8, TW = 8;     // tile of gradient-map cells owned by one workgroup
-constexpr int PT = 4;             // a wave owns a PT x PT patch of cells (accumulators in registers)
 constexpr int SLOTS = 32;         // RoIs whose weight tables are resident in LDS per round
-constexpr int PB = 16;            // max pooled bins per axis on this path (7 and 14 in the model)
-constexpr int BWD_THREADS = 256;  // 4 waves = 2 x 2 patches
-constexpr int BWD_WAVES = BWD_THREADS / 64;
 constexpr int LISTCAP = 512;      // RoIs scanned per segment
 constexpr int QCAP_MAX = 256;     // per-wave queue capacity (template QC): 64 entries for 7x7 pooling, 256 for 14x14
                                   // (a full window is rebuilt per pass; entry = (gy row, 4 row weights, 4 col weights))
-constexpr int CCH = 256;          // channels per pass: lane = 4 channels
 
-#define MRCNN_FMA4(A, c, g)                \
-    A.x = fmaf(c, g.x, A.x); A.y = fmaf(c, g.y, A.y); \
-    A.z = fmaf(c, g.z, A.z); A.w = fmaf(c, g.w, A.w);
 
 template <int QC>
 struct PatchQueue {     // one per wave, in LDS
@@ -1097,19 +1006,17 @@ __global__ __launch_bounds__(256) void k_sum_level_slabs(const float *__restrict
     *reinterpret_cast<float4 *>(out + i * 4) = a;
 }
 
-// RoI split of a level: enough workgroups to occupy the chip when the level has few tiles.
-int level_split(int H, int W, int N) {
-    const int tiles = mrcnn::cdiv(W, TW) * mrcnn::cdiv(H, TH) * N;
-    if (tiles >= 256) return 1;
-    return std::min(32, mrcnn::cdiv(512, tiles));
-}
-size_t bwd_ws_bytes(const int *Hs, const int *Ws, int L, int N, int C) {
+size_t slab_ws_bytes(const int *Hs, const int *Ws, int L, int N, int C) {
     size_t b = 0;
     for (int l = 0; l < L; ++l) {
         const int sp = level_split(Hs[l], Ws[l], N);
         if (sp > 1) b += (size_t)sp * N * Hs[l] * Ws[l] * C * sizeof(float);
     }
-    return b;
+    return (b + 255) / 256 * 256;
+}
+// workspace of one backward call: [RoI-split slabs of the coarse levels][per-RoI tables of variant 3]
+size_t bwd_ws_bytes(const int *Hs, const int *Ws, int L, int N, int C, int R, int PH, int PW, int sr) {
+    return slab_ws_bytes(Hs, Ws, L, N, C) + bwd3_ws_bytes(Hs, Ws, L, R, PH, PW, sr);
 }
 
 // Forward: rows kernel when the x samples of a row fit one wave (fixed sampling grid, PW * grid <= 64) and every level is
@@ -1127,15 +1034,19 @@ void launch_fwd(Levels &lv, const float *rois, const int32_t *levels, int R, int
     }
 }
 
-int g_bwd_variant = 2;          // 2 = independent waves (default), 1 = the barrier-synchronised tile kernel (A/B)
+// 2 = independent waves that derive the geometry themselves (default), 3 = table-driven (roi_align_bwd3.hip: per-RoI tables
+// from a first kernel + a lean patch kernel; needs the caller's workspace, else variant 2 runs; same bits as 2 - measured
+// slower so far: DESIGN.md section 3.2), 1 = the barrier-synchronised tile kernel (A/B and fallback for tensors >= 4 GiB)
+int g_bwd_variant = 2;
 
 int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, const int32_t *levels, int R,
                      int C, int PH, int PW, int sr, int accumulate, void *ws, size_t ws_bytes, hipStream_t st) {
     int total = 0;
-    size_t need = 0;
-    for (int l = 0; l < lv.L; ++l) need += level_split(lv.H[l], lv.W[l], N) > 1
-        ? (size_t)level_split(lv.H[l], lv.W[l], N) * N * lv.H[l] * lv.W[l] * C * sizeof(float) : 0;
+    const size_t need = slab_ws_bytes(lv.H, lv.W, lv.L, N, C);
     const bool can_split = ws && ws_bytes >= need && R > 0;
+    // the tables of variant 3 sit behind the slab area
+    const size_t need3 = bwd3_ws_bytes(lv.H, lv.W, lv.L, R, PH, PW, sr);
+    void *ws3 = (ws && need3 && ws_bytes >= need + need3) ? (void *)((char *)ws + need) : nullptr;
     float *wp = (float *)ws;
     for (int l = 0; l < lv.L; ++l) {
         lv.tiles_x[l] = mrcnn::cdiv(lv.W[l], TW);
@@ -1151,9 +1062,11 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
     }
     lv.tile_begin[lv.L] = total;
     const int chunk = mrcnn::cdiv(total, 8);
-    bool waves_ok = g_bwd_variant == 2 && (unsigned long long)R * PH * PW * C * 4ull < (1ull << 32) && R < (1 << 27) && total < (1 << 24);
+    bool waves_ok = g_bwd_variant >= 2 && (unsigned long long)R * PH * PW * C * 4ull < (1ull << 32) && R < (1 << 27) && total < (1 << 24);
     for (int l = 0; l < lv.L; ++l) waves_ok = waves_ok && (unsigned long long)lv.H[l] * lv.W[l] * C * 4ull < (1ull << 32);
-    if (waves_ok && PH <= 8 && PW <= 8)
+    if (waves_ok && g_bwd_variant == 3 && ws3) {
+        if (int e = launch_bwd3(lv, total, N, gy, rois, levels, R, C, PH, PW, sr, accumulate, ws3, need3, st)) return e;
+    } else if (waves_ok && PH <= 8 && PW <= 8)
         hipLaunchKernelGGL((k_roi_align_bwd_waves<8, W2_DEPTH>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
                            PH, PW, sr, chunk, accumulate);
     else if (waves_ok)
@@ -1198,15 +1111,15 @@ extern "C" int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C,
     return 0;
 }
 
-extern "C" int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C, int H, int W,
-                                       const float *rois, int R, int PH, int PW, float spatial_scale,
-                                       int sampling_ratio, float *gx, void *stream) {
+extern "C" int mrcnn_roi_align_bwd_ws_f32(const float *gy, int layout, int N, int C, int H, int W,
+                                          const float *rois, int R, int PH, int PW, float spatial_scale,
+                                          int sampling_ratio, float *gx, void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_common(gy, rois, gx, layout, N, C, H, W, R, PH, PW, sampling_ratio)) return e;
     hipStream_t st = (hipStream_t)stream;
     if (layout == MRCNN_LAYOUT_NHWC && fast_bwd_ok(C, PH, PW, sampling_ratio, R)) {
         Levels lv{};
         lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
-        return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, nullptr, 0, st);
+        return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, ws, ws_bytes, st);
     }
     MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * C * H * W, st));
     if (R == 0) return 0;
@@ -1216,6 +1129,12 @@ extern "C" int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C
                        sampling_ratio, gx, strides_of(layout, C, H, W), layout == MRCNN_LAYOUT_NHWC);
     MRCNN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C, int H, int W,
+                                       const float *rois, int R, int PH, int PW, float spatial_scale,
+                                       int sampling_ratio, float *gx, void *stream) {
+    return mrcnn_roi_align_bwd_ws_f32(gy, layout, N, C, H, W, rois, R, PH, PW, spatial_scale, sampling_ratio, gx, nullptr, 0, stream);
 }
 
 static int fill_levels(Levels &lv, const float *const *xs, float *const *gxs, const int *Hs, const int *Ws,
@@ -1260,9 +1179,15 @@ extern "C" int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, c
     return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
-extern "C" size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int L, int N, int C) {
+extern "C" size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int L, int N, int C, int R, int PH, int PW,
+                                                          int sampling_ratio) {
     if (!Hs || !Ws || L <= 0 || L > MRCNN_MAX_LEVELS || N <= 0 || C <= 0) return 0;
-    return bwd_ws_bytes(Hs, Ws, L, N, C);
+    return bwd_ws_bytes(Hs, Ws, L, N, C, R, PH, PW, sampling_ratio);
+}
+
+extern "C" size_t mrcnn_roi_align_bwd_workspace_bytes(int N, int C, int H, int W, int R, int PH, int PW, int sampling_ratio) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return bwd_ws_bytes(&H, &W, 1, N, C, R, PH, PW, sampling_ratio);
 }
 
 // Diagnostic: configs-style single-level backward with phase stamps (see k_roi_align_bwd_waves<.., STAMP>); stamps =
@@ -1284,8 +1209,23 @@ extern "C" int mrcnn_debug_roi_align_bwd_stamps(const float *gy, int N, int C, i
     return 0;
 }
 
+// The same for variant 3 (k_bwd3_patches<STAMP>): 8 x u64 per wave - start, scan, descriptor, entry-generation and drain cycles,
+// store start, end, entries; ws as for mrcnn_roi_align_bwd_ws_f32.
+extern "C" int mrcnn_debug_roi_align_bwd3_stamps(const float *gy, int N, int C, int H, int W, const float *rois, int R, int PH,
+                                                 int PW, float spatial_scale, int sampling_ratio, float *gx, void *ws, size_t ws_bytes,
+                                                 unsigned long long *stamps, void *stream) {
+    if (!gy || !rois || !gx || !stamps || !ws || !fast_bwd_ok(C, PH, PW, sampling_ratio, R))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_roi_align_bwd3_stamps: bad arguments");
+    Levels lv{};
+    lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
+    lv.tiles_x[0] = mrcnn::cdiv(W, TW); lv.tiles_y[0] = mrcnn::cdiv(H, TH); lv.split[0] = 1; lv.tile_begin[0] = 0;
+    const int total = lv.tiles_x[0] * lv.tiles_y[0] * N;
+    lv.tile_begin[1] = total;
+    return launch_bwd3(lv, total, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, ws, ws_bytes, (hipStream_t)stream, stamps);
+}
+
 extern "C" int mrcnn_roi_align_set_bwd_variant(int variant) {
-    if (variant != 1 && variant != 2) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_set_bwd_variant: 1 or 2");
+    if (variant < 1 || variant > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_set_bwd_variant: 1, 2 or 3");
     g_bwd_variant = variant;
     return 0;
 }

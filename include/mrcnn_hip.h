@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 4
+#define MRCNN_ABI_VERSION 5
 
 enum {
     MRCNN_OK = 0,
@@ -66,10 +66,18 @@ int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C, int H, int
 
 /* Backward (adjoint scatter).  gx is fully overwritten (callee zero-fills cells no RoI touches).
  * Fast path (NHWC, C%4==0, PH,PW<=16, sampling_ratio>0): owner-computes tiles, no atomics,
- * bit-reproducible.  Other shapes: memset + atomic scatter. */
+ * bit-reproducible.  Other shapes: memset + atomic scatter.
+ * mrcnn_roi_align_bwd_ws_f32 takes the caller's scratch of mrcnn_roi_align_bwd_workspace_bytes() bytes: with it the
+ * fast path runs as variant 3 (a small first kernel computes every RoI's sample tables once, the scatter kernel is
+ * table-driven - see mrcnn_roi_align_set_bwd_variant); mrcnn_roi_align_bwd_f32 = the same call without scratch (variant 2).
+ * Both give identical bits. */
 int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C, int H, int W,
                             const float *rois, int R, int PH, int PW, float spatial_scale,
                             int sampling_ratio, float *gx, void *stream);
+int mrcnn_roi_align_bwd_ws_f32(const float *gy, int layout, int N, int C, int H, int W,
+                               const float *rois, int R, int PH, int PW, float spatial_scale,
+                               int sampling_ratio, float *gx, void *ws, size_t ws_bytes, void *stream);
+size_t mrcnn_roi_align_bwd_workspace_bytes(int N, int C, int H, int W, int R, int PH, int PW, int sampling_ratio);
 
 /* Multi-level (FPN) batched variants: ONE launch for all RoIs over all pyramid levels.
  * Replace the per-RoI Python loops of chainer_maskrcnn/model/head/fpn_roi_mask_head.py:59-61,
@@ -81,8 +89,8 @@ int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C, int H, in
  *   y / gy          (R,PH,PW,C) f32
  *   accumulate      backward: 0 = every gxs[l] is overwritten (zero where no RoI lands),
  *                   1 = gradients are added to gxs[l] (second pooled size over the same pyramid)
- *   ws, ws_bytes    backward: optional device scratch of mrcnn_roi_align_fpn_bwd_workspace_bytes() bytes.  With it,
- *                   levels with few 8x8 tiles (the coarse ones, where map_rois_to_fpn_levels puts most RoIs) are
+ *   ws, ws_bytes    backward: optional device scratch of mrcnn_roi_align_fpn_bwd_workspace_bytes() bytes
+ *                   ([slabs][per-RoI tables of variant 3]).  With it, levels with few 8x8 tiles (the coarse ones, where map_rois_to_fpn_levels puts most RoIs) are
  *                   computed by several workgroups per tile over disjoint RoI subsets and summed in fixed order;
  *                   without it (NULL) one workgroup per tile does all the RoIs.  Results are bit-reproducible
  *                   either way (the two modes differ from each other by summation order only).
@@ -95,10 +103,13 @@ int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, const int *H
                                 const float *scales, int L, int N, int C, const float *rois,
                                 const int32_t *levels, int R, int PH, int PW,
                                 int sampling_ratio, int accumulate, void *ws, size_t ws_bytes, void *stream);
-size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int L, int N, int C);
+size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int L, int N, int C, int R, int PH, int PW,
+                                               int sampling_ratio);
 
-/* Process-wide choice of the fast backward kernel: 2 (default) = one independent wave per 4x4 cell patch, no workgroup
- * barriers; 1 = the barrier-synchronised 8x8 tile kernel of round 1 (kept for A/B measurements).  Same results contract. */
+/* Process-wide choice of the fast backward kernel: 2 (default) = one independent wave per 4x4 cell patch that derives the
+ * geometry itself; 3 = table-driven: per-RoI sample tables from a first kernel, one lean wave per patch (needs the call's
+ * workspace; without it variant 2 runs); 1 = the barrier-synchronised 8x8 tile kernel of round 1 (A/B measurements, tensors
+ * >= 4 GiB).  Same results contract; 2 and 3 give identical bits. */
 int mrcnn_roi_align_set_bwd_variant(int variant);
 
 /* Diagnostic build of the backward kernel with s_memtime stamps at the phase boundaries of every wave (tools/roi_stamps.py;
@@ -106,6 +117,15 @@ int mrcnn_roi_align_set_bwd_variant(int variant);
 int mrcnn_debug_roi_align_bwd_stamps(const float *gy, int N, int C, int H, int W, const float *rois, int R, int PH, int PW,
                                      float spatial_scale, int sampling_ratio, float *gx, unsigned long long *stamps,
                                      void *stream);
+
+/* The same for variant 3: 8 x u64 per wave (start, scan / descriptor / entry-generation / drain cycles, store start, end, entries);
+ * ws, ws_bytes as for mrcnn_roi_align_bwd_ws_f32. */
+int mrcnn_debug_roi_align_bwd3_stamps(const float *gy, int N, int C, int H, int W, const float *rois, int R, int PH, int PW,
+                                      float spatial_scale, int sampling_ratio, float *gx, void *ws, size_t ws_bytes,
+                                      unsigned long long *stamps, void *stream);
+
+/* Measurement knobs of variant 3: extra dynamic LDS per workgroup (caps resident workgroups per CU) and s_setprio for heavy waves. */
+int mrcnn_debug_roi_align_bwd3_knobs(int pad_lds_bytes, int prio);
 
 /* Verification hook for the "ROIAlign indices bit-exact" contract: dumps, for every RoI and
  * both axes, the integer corner cells and float weights of every sample exactly as the

@@ -64,13 +64,15 @@ int main() {
     acc += mrcnn_loss_workspace_bytes();
     {
         const int Hs[5] = {256, 128, 64, 32, 16}, Ws[5] = {256, 128, 64, 32, 16};
-        for (int L = 1; L <= 5; ++L) acc += mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, 2, 256);
+        for (int L = 1; L <= 5; ++L) acc += mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, 2, 256, 512, 14, 14, 2);
+        acc += mrcnn_roi_align_bwd_workspace_bytes(1, 256, 200, 272, 512, 7, 7, 2);
     }
     // ---- compute entries: null buffers ---------------------------------------------------------------------------
     float *F = nullptr; const float *CF = nullptr; int32_t *I = nullptr; const int32_t *CI = nullptr; void *V = nullptr;
     const uint8_t *CU = nullptr; uint8_t *U = nullptr; const uint32_t *CK = nullptr; uint32_t *K = nullptr;
     EXPECT_ERR(mrcnn_roi_align_fwd_f32(CF, 1, 1, 256, 8, 8, CF, 4, 7, 7, 0.25f, 2, F, V));
     EXPECT_ERR(mrcnn_roi_align_bwd_f32(CF, 1, 1, 256, 8, 8, CF, 4, 7, 7, 0.25f, 2, F, V));
+    EXPECT_ERR(mrcnn_roi_align_bwd_ws_f32(CF, 1, 1, 256, 8, 8, CF, 4, 7, 7, 0.25f, 2, F, V, 0, V));
     EXPECT_ERR(mrcnn_roi_align_fwd_f32(CF, 7, 1, 256, 8, 8, CF, 4, 7, 7, 0.25f, 2, F, V));
     EXPECT_ERR(mrcnn_roi_align_fpn_fwd_f32(nullptr, nullptr, nullptr, CF, 5, 1, 256, CF, CI, 4, 7, 7, 2, F, V));
     EXPECT_ERR(mrcnn_roi_align_fpn_bwd_f32(CF, nullptr, nullptr, nullptr, CF, 5, 1, 256, CF, CI, 4, 7, 7, 2, 0, V, 0, V));

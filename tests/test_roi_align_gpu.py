@@ -63,13 +63,22 @@ def test_forward_matches_oracle(layout, C, P, sr):
     np.testing.assert_array_equal(got.cpu().numpy(), want)      # bit-exact
 
 
-@pytest.fixture(params=[2, 1], ids=['waves', 'tiles'])
+@pytest.fixture(params=[3, 2, 1], ids=['tables', 'waves', 'tiles'])
 def bwd_variant(request):
-    """Both fast backward kernels: 2 = independent waves on 4x4 patches (default), 1 = barrier-synchronised 8x8 tiles (the
-    fallback for tensors beyond the 32-bit buffer offsets of variant 2)."""
+    """The three fast backward kernels: 3 = table-driven (per-RoI sample tables from a first kernel, one lean wave per 4x4
+    patch), 2 = independent waves that derive the geometry themselves (default), 1 = barrier-synchronised 8x8 tiles (the
+    fallback for tensors beyond the 32-bit buffer offsets of variants 2 / 3)."""
     _hip.check(_hip.lib().mrcnn_roi_align_set_bwd_variant(request.param))
     yield request.param
     _hip.check(_hip.lib().mrcnn_roi_align_set_bwd_variant(2))
+
+
+def _bwd_ws(gyt, N, C, H, W, rois_t, R, P, scale, sr, gx):
+    """mrcnn_roi_align_bwd_ws_f32 with the workspace its query asks for (variant 3 needs it)."""
+    nb = _hip.lib().mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, R, P, P, sr)
+    ws = torch.empty((max(nb, 1),), dtype=torch.uint8, device=DEV)
+    _hip.check(_hip.lib().mrcnn_roi_align_bwd_ws_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_t), R, P, P, scale, sr, _hip.ptr(gx),
+                                                     _hip.ptr(ws), nb, _hip.stream_ptr()))
 
 
 @pytest.mark.parametrize('layout', ['nhwc', 'nchw'])
@@ -106,9 +115,7 @@ def test_backward_many_rois_on_one_tile_and_segments(bwd_variant):
     want = ora.roi_align_bwd(gy, rois, (N, C, H, W), scale, 2)
     gx = torch.empty((N, C, H, W), device=DEV).contiguous(memory_format=torch.channels_last)
     gyt = torch.from_numpy(gy).to(DEV).contiguous(memory_format=torch.channels_last)
-    _hip.check(_hip.lib().mrcnn_roi_align_bwd_f32(_hip.ptr(gyt), 1, N, C, H, W,
-                                                  _hip.ptr(torch.from_numpy(rois).to(DEV)), R, P, P,
-                                                  scale, 2, _hip.ptr(gx), _hip.stream_ptr()))
+    _bwd_ws(gyt, N, C, H, W, torch.from_numpy(rois).to(DEV), R, P, scale, 2, gx)
     np.testing.assert_allclose(gx.cpu().numpy(), want, rtol=2e-5, atol=1e-4 * np.abs(want).max())
 
 
@@ -180,6 +187,33 @@ def test_config2_all_512_rois_against_the_oracle(sr, bwd_variant):
     np.testing.assert_allclose(xt.grad.cpu().numpy(), want_gx, rtol=1e-5, atol=2e-5 * np.abs(gy).max())
 
 
+@pytest.mark.parametrize('P,sr', [(7, 2), (14, 2), (7, 1), (5, 3), (16, 4)])
+def test_table_driven_backward_equals_the_wave_kernel_bit_for_bit(P, sr):
+    """Variant 3 (per-RoI tables + lean patch kernel) orders its entries (RoI, ph, pw) and computes every weight and FMA like
+    variant 2: identical bits - on configs[1]'s map with its 512 RoIs plus edge RoIs, a bad image index, a three-segment RoI
+    count (R > 1024), for 7x7 / 14x14 and odd pooled sizes and sampling ratios 1..4."""
+    x, yx, _ = config2_inputs()
+    N, C, H, W = 1, 256, x.shape[2], x.shape[3]
+    rs = np.random.RandomState(P * 10 + sr)
+    rois = np.concatenate([yx[:, [0, 2, 1, 4, 3]], _edge_rois(1, H, W, 0.25), rand_rois_xy(rs, 600, 1, H, W, 0.25),
+                           np.array([[3, 10, 10, 200, 200], [-1, 5, 5, 100, 80]], np.float32)], 0)      # image index out of range
+    R = rois.shape[0]
+    assert R > 1024
+    gyt = torch.from_numpy(rs.standard_normal((R, P, P, C)).astype(np.float32)).to(DEV)
+    rt = torch.from_numpy(rois).to(DEV)
+    out = {}
+    try:
+        for v in (2, 3):
+            _hip.check(_hip.lib().mrcnn_roi_align_set_bwd_variant(v))
+            gx = torch.full((N, H, W, C), float('nan'), device=DEV)
+            _bwd_ws(gyt, N, C, H, W, rt, R, P, 0.25, sr, gx)
+            out[v] = gx
+    finally:
+        _hip.check(_hip.lib().mrcnn_roi_align_set_bwd_variant(2))
+    assert torch.isfinite(out[3]).all()
+    assert torch.equal(out[2], out[3])
+
+
 @pytest.mark.parametrize('P', [7, 14])
 def test_fpn_backward_coarse_levels_split_matches_oracle(P, bwd_variant):
     """Multi-level backward with most RoIs on the coarse levels (what map_rois_to_fpn_levels produces): the
@@ -214,7 +248,7 @@ def test_fpn_backward_coarse_levels_split_matches_oracle(P, bwd_variant):
         return [g.cpu().numpy() for g in gxs]
 
     L, arr_p, Hs, Ws, sc = hd._level_args([torch.from_numpy(b) for b in base], scales)
-    assert _hip.lib().mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, N, C) > 0     # these levels do split
+    assert _hip.lib().mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, N, C, R, P, P, 2) > 0     # these levels do split
     tol = dict(rtol=1e-5, atol=2e-5 * np.abs(gy).max())
     for acc in (False, True):
         a, a2, b = run(acc, True), run(acc, True), run(acc, False)

@@ -1,4 +1,4 @@
-"""ROIAlign backward A/B: variant 1 (barrier-synchronised 8x8 tiles) vs variant 2 (independent waves on 4x4 patches) on
+"""ROIAlign backward A/B: variants 1 (barrier-synchronised 8x8 tiles), 2 (independent waves on 4x4 patches) and 3 (table-driven) on
 BASELINE configs[1] and on the RoIs of a real training step (FPN levels), interleaved in one process; prints the
 difference between the two results (summation order only) and the timings."""
 import os, sys
@@ -30,23 +30,25 @@ N, C, H, W = x.shape
 R, _, PH, PW = gy.shape
 rois_xy = torch.from_numpy(yx[:, [0, 2, 1, 4, 3]].copy()).to(dev)
 gyt = torch.from_numpy(gy).to(dev).contiguous(memory_format=torch.channels_last)
-gx = {v: torch.empty((N, C, H, W), device=dev).contiguous(memory_format=torch.channels_last) for v in (1, 2)}
+gx = {v: torch.empty((N, C, H, W), device=dev).contiguous(memory_format=torch.channels_last) for v in (1, 2, 3)}
+nb = lib.mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, R, PH, PW, 2)
+ws = torch.empty((max(nb, 1),), dtype=torch.uint8, device=dev)
 algo = 4 * (N * C * H * W + R * C * PH * PW) + 20 * R
 
 
 def bwd(v):
     _hip.check(lib.mrcnn_roi_align_set_bwd_variant(v))
-    _hip.check(lib.mrcnn_roi_align_bwd_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW, 0.25, 2, _hip.ptr(gx[v]), _hip.stream_ptr()))
+    _hip.check(lib.mrcnn_roi_align_bwd_ws_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW, 0.25, 2, _hip.ptr(gx[v]), _hip.ptr(ws), nb, _hip.stream_ptr()))
 
 
-for v in (1, 2):
+for v in (1, 2, 3):
     gx[v].fill_(float('nan'))
     bwd(v)
 torch.cuda.synchronize()
 d = (gx[1] - gx[2]).abs().max().item()
-print('configs[1]: max |v1 - v2| = %.3e (scale %.3e), NaNs in v2: %d' % (d, gx[1].abs().max().item(), int(torch.isnan(gx[2]).sum())))
+print('configs[1]: max |v1 - v2| = %.3e (scale %.3e), NaNs in v2: %d; v3 == v2 bitwise: %s' % (d, gx[1].abs().max().item(), int(torch.isnan(gx[2]).sum()), torch.equal(gx[2], gx[3])))
 for rnd in range(2):
-    for v in (1, 2):
+    for v in (1, 2, 3):
         mn, med = timed(lambda: bwd(v))
         print('configs[1] bwd variant %d: min %.1f us  median %.1f us   %.0f GB/s algorithmic (%.3f of 8 TB/s)' % (v, mn, med, algo / mn / 1e3, algo / mn / 1e3 / 8000))
 
@@ -69,7 +71,7 @@ shapes = [(2, 1024 // s, 1024 // s, 256) for s in (4, 8, 16, 32, 64)]
 for P in (7, 14):
     g = torch.randn((rois.shape[0], P, P, 256), device=dev)
     res = {}
-    for v in (1, 2):
+    for v in (1, 2, 3):
         _hip.check(lib.mrcnn_roi_align_set_bwd_variant(v))
         gxs = [torch.full(s, float('nan'), device=dev) for s in shapes]
         hd.roi_align_fpn_bwd(g, gxs, rois, levels, P, scales, accumulate=False)
@@ -77,8 +79,8 @@ for P in (7, 14):
         res[v] = gxs
     torch.cuda.synchronize()
     print('P=%d  max |v1 - v2| per level (after overwrite + accumulate):' % P, ['%.2e' % (a - b_).abs().max().item() for a, b_ in zip(res[1], res[2])],
-          'scale %.2e' % max(a.abs().max().item() for a in res[1]))
-    for v in (1, 2):
+          'scale %.2e' % max(a.abs().max().item() for a in res[1]), 'v3 == v2 bitwise:', all(torch.equal(a, b_) for a, b_ in zip(res[2], res[3])))
+    for v in (1, 2, 3):
         _hip.check(lib.mrcnn_roi_align_set_bwd_variant(v))
         gxs = res[v]
         t_o = timed(lambda: hd.roi_align_fpn_bwd(g, gxs, rois, levels, P, scales, accumulate=False), n=20, rounds=3)
