@@ -55,7 +55,7 @@ def install():
                    BatchNormalization=mc.BatchNormalization)
     g._mod('chainer.links.model'); g._mod('chainer.links.model.vision')
     g._mod('chainer.links.model.vision.resnet', ResNet50Layers=mc.ResNet50Layers, BuildingBlock=mc.BuildingBlock,
-           _global_average_pooling_2d=None)
+           _global_average_pooling_2d=mc._global_average_pooling_2d)
     functions = g._mod('chainer.functions', relu=mc.relu, max_pooling_2d=mc.max_pooling_2d, unpooling_2d=mc.unpooling_2d,
                        concat=mc.concat, softmax_cross_entropy=mc.softmax_cross_entropy, sigmoid_cross_entropy=mc.sigmoid_cross_entropy,
                        softmax=mc.softmax, sigmoid=mc.sigmoid, resize_images=mc.resize_images)

@@ -143,6 +143,10 @@ class BatchNormalization(Chain):
         self.gamma = self.beta = self.avg_mean = self.avg_var = None
         self.eps = 2e-5
         self.last_mean = self.last_var = None
+        self.update_enabled = True
+
+    def disable_update(self):           # chainer.Link.disable_update: the optimizer skips this link's parameters (forward unchanged)
+        self.update_enabled = False
 
     def __call__(self, x):
         x = np.asarray(x, D)
@@ -219,6 +223,39 @@ class ResNet50Layers(Chain):
         self.res4 = BuildingBlock(6, 512, 256, 1024, 2)
         self.res5 = BuildingBlock(3, 1024, 512, 2048, 2)
         self.fc6 = Linear(2048, 1000)
+
+    def links(self):
+        """chainer.Chain.links(): this link and every descendant (used by C4Backbone to find its BatchNormalization links)."""
+        seen, stack = set(), [self]
+        while stack:
+            l = stack.pop()
+            if id(l) in seen:
+                continue
+            seen.add(id(l))
+            yield l
+            for v in vars(l).values():
+                if isinstance(v, Chain):
+                    stack.append(v)
+
+    def __call__(self, x, layers=['prob'], **kwargs):
+        """chainer ResNet50Layers.__call__: the entries of the ``functions`` OrderedDict are applied in order; the outputs
+        named in ``layers`` are collected, and evaluation stops once all of them have been produced."""
+        h, out, todo = x, {}, set(layers)
+        for key, funcs in self.functions.items():
+            if not todo:
+                break
+            for f in funcs:
+                h = f(h)
+            if key in todo:
+                out[key] = h
+                todo.discard(key)
+        return out
+
+
+def _global_average_pooling_2d(x):
+    """chainer.links.model.vision.resnet._global_average_pooling_2d: average_pooling_2d over the whole map, reshaped (n, c)."""
+    x = np.asarray(x, D)
+    return V(x.mean(axis=(2, 3)))
 
 
 # ---- functions ----------------------------------------------------------------------------------------------------------
