@@ -557,278 +557,6 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     }
 }
 
-// ---- the same GEMM as a persistent, cross-tile software pipeline ------------------------------------------------------
-// For the plain launches (forward / backward-data, no split-K, no tail split) whose grid is several rounds of workgroup
-// slots.  k_conv_igemm starts a workgroup per tile: kernel arguments, row decomposition (8 divisions per thread), the
-// first operand loads (a full memory latency with nothing to overlap inside the workgroup) and the epilogue's stores sit
-// outside the MFMA loop - 23 % of the time of a K = 256 tile (the Winograd batched GEMMs), half of a K = 64 one (the
-// ResNet 64 -> 256 1x1 layers).  Here a workgroup walks tiles v, v + grid, v + 2 grid, ...: during the LAST K step of a
-// tile it decodes the next tile and issues that tile's first operand loads, so they fly under the step's MFMAs and under
-// the epilogue; bias vectors are fetched one tile ahead.  Per-tile arithmetic (K order, accumulators, epilogue) is that
-// of k_conv_igemm: identical bits.
-// BNS: the epilogue also produces the BatchNorm statistics partials (p.bn_part); launches whose epilogue READS memory
-// (backward-data with accumulate / ReLU mask) stay on k_conv_igemm - those reads would have to wait for the prefetch anyway.
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-// Tiles are handed out dynamically: a workgroup's first tile is its id, every further one comes from an atomic counter
-// (fetched at the start of the current tile, so the round trip is hidden) - workgroups that find no tile left exit and
-// their CU's remaining workgroups speed up, which is the balance the hardware dispatcher gives the per-tile kernel.  The
-// counter pair (next, done) of a launch is reset by the workgroup that finishes last.
-template <int MODE, int BM_, int BN_, bool BNS>
-__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_pipe(ConvP p, int total_tiles, int *__restrict__ sched) {
-    __shared__ int s_next;
-    static_assert(MODE == MODE_FWD || MODE == MODE_BWD_DATA, "persistent pipeline: forward-kind GEMMs only");
-    constexpr bool B_KC = (MODE == MODE_FWD);
-    constexpr int TM = BM_ / 64, TN = BN_ / 64;
-    constexpr int LDB = BN_ + 4;
-    constexpr int A_ELEMS = BM_ * LDK;
-    constexpr int B_ELEMS = B_KC ? BN_ * LDK : BK * LDB;
-    constexpr int NA = BM_ / 32, NB = BN_ / 32;
-    constexpr int B_TPR = BN_ / 4, B_KPP = CONV_THREADS / B_TPR;
-    constexpr int EPI_LD = 36, EPI_ELEMS = 4 * 32 * EPI_LD;
-    constexpr int SMEM_ELEMS = (A_ELEMS + B_ELEMS) > EPI_ELEMS ? (A_ELEMS + B_ELEMS) : EPI_ELEMS;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_ELEMS];
-    float *const sA = smem, *const sB = smem + A_ELEMS;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int kc = tid & 7, r0 = tid >> 3;
-    const int rcB = tid % B_TPR, k0B = tid / B_TPR;
-    const int taps = p.KH * p.KW;
-    const int cin_steps = p.Cin / BK, cout_steps = p.Cout / BK;
-    const int nsteps = (MODE == MODE_FWD) ? taps * cin_steps : taps * cout_steps;
-    const int PW_ = (MODE == MODE_FWD) ? p.Wo : p.W, PH_ = (MODE == MODE_FWD) ? p.Ho : p.H;
-    const float invW = 1.0f / (float)PW_, invH = 1.0f / (float)PH_;
-    const int srcH = (MODE == MODE_FWD) ? p.H : p.Ho, srcW = (MODE == MODE_FWD) ? p.W : p.Wo;
-    const int srcC = (MODE == MODE_FWD) ? p.Cin : p.Cout;
-    const int krowF = taps * p.Cin;
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.a, 0, p.bytes_a, 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void *)p.b, 0, p.bytes_b, 0x00020000);
-    const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.c, 0, (unsigned)((size_t)p.M * ((MODE == MODE_FWD) ? p.Cout : p.Cin) * 4), 0x00020000);
-
-    // ---- per-tile state (re-written by setup() one tile ahead of the MFMAs that use it)
-    int m0 = 0, n0 = 0;
-    int a_off[NA], a_h0[NA], a_w0[NA], b_off[NB];
-    unsigned rowmask = 0, colmask = 0;
-    int w_cs = 0, w_kh = 0, w_kw = 0, w_toff = 0, w_boff = 0, w_step = 0;
-    auto setup = [&](int vid) {
-        {       // bijective XCD remap (cdna_hip_programming.md T1): ids equal mod 8 share an XCD and walk one contiguous tile range
-            const int q = total_tiles >> 3, r = total_tiles & 7, xcd = vid & 7;
-            vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vid >> 3);
-        }
-        const int bx = vid / p.tiles_n, by = vid - bx * p.tiles_n;
-        m0 = bx * BM_; n0 = by * BN_;
-        rowmask = 0; colmask = 0;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int m = m0 + r0 + 32 * i;
-            const bool v = m < p.M;
-            rowmask |= v ? (1u << i) : 0u;
-            int q, w_, n_, h_;
-            divmod_small(v ? m : 0, PW_, invW, q, w_);
-            divmod_small(q, PH_, invH, n_, h_);
-            a_h0[i] = (MODE == MODE_FWD) ? h_ * p.stride - p.pad : h_ + p.pad;
-            a_w0[i] = (MODE == MODE_FWD) ? w_ * p.stride - p.pad_w : w_ + p.pad;
-            a_off[i] = ((n_ * srcH + a_h0[i]) * srcW + a_w0[i]) * srcC;
-        }
-        if (MODE == MODE_FWD) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int n = n0 + r0 + 32 * i;
-                colmask |= (n < p.Ng) ? (1u << i) : 0u;
-                b_off[i] = ((p.wbatch_rows ? (m0 / p.wbatch_rows) * p.Ng : 0) + (n < p.Ng ? n : 0)) * krowF;
-            }
-        }
-        w_cs = w_kh = w_kw = 0; w_toff = 0; w_boff = 0; w_step = 0;
-    };
-    float4 ra[NA], rb[NB];
-    auto ldA = [&](bool ok, int off) -> float4 {
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (unsigned)off * 4u : 0xFFFFFFFFu, 0, 0);
-        float4 f;
-        __builtin_memcpy(&f, &v, 16);
-        return f;
-    };
-    auto ldB = [&](bool ok, int off) -> float4 {
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? (unsigned)off * 4u : 0xFFFFFFFFu, 0, 0);
-        float4 f;
-        __builtin_memcpy(&f, &v, 16);
-        return f;
-    };
-    // loads of the walker's current K step, then the walker advances (as in k_conv_igemm)
-    auto load_step = [&]() {
-        if (MODE == MODE_FWD) {
-            const int toff = w_toff + kc * 4;
-            const int woff = w_step * BK + kc * 4;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int hi = a_h0[i] + w_kh, wi = a_w0[i] + w_kw;
-                const bool ok = (bool)((rowmask >> i) & 1u) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-                ra[i] = ldA(ok, a_off[i] + toff);
-            }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = ldB((colmask >> i) & 1u, b_off[i] + woff);
-            const bool tapdone = ++w_cs == cin_steps;
-            w_toff += BK;
-            w_cs = tapdone ? 0 : w_cs;
-            w_kw += tapdone ? 1 : 0;
-            const bool rowdone = w_kw == p.KW;
-            w_kw = rowdone ? 0 : w_kw;
-            w_kh += rowdone ? 1 : 0;
-            w_toff += rowdone ? (p.W - p.KW) * p.Cin : 0;
-        } else {
-            const int toff = w_toff + kc * 4;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int ho = a_h0[i] - w_kh, wo = a_w0[i] - w_kw;
-                const bool ok = (bool)((rowmask >> i) & 1u) & ((unsigned)ho < (unsigned)p.Ho) & ((unsigned)wo < (unsigned)p.Wo);
-                ra[i] = ldA(ok, a_off[i] + toff);
-            }
-            const int ci = n0 + rcB * 4;
-            const int krow = taps * p.Cin;
-            const int wbase = w_boff + ci + k0B * krow;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = ldB(ci < p.Ng, wbase + B_KPP * i * krow);
-            const bool tapdone = ++w_cs == cout_steps;
-            w_toff += BK; w_boff += BK * krow;
-            w_cs = tapdone ? 0 : w_cs;
-            w_kw += tapdone ? 1 : 0;
-            w_toff -= tapdone ? 2 * p.Cout : 0;
-            w_boff += tapdone ? p.Cin - p.Cout * krow : 0;
-            const bool rowdone = w_kw == p.KW;
-            w_kw = rowdone ? 0 : w_kw;
-            w_kh += rowdone ? 1 : 0;
-            w_toff -= rowdone ? (p.Wo - p.KW) * p.Cout : 0;
-        }
-        ++w_step;
-    };
-    auto store_step = [&]() {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<float4 *>(&sA[(r0 + 32 * i) * LDK + kc * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            if (B_KC) *reinterpret_cast<float4 *>(&sB[(r0 + 32 * i) * LDK + kc * 4]) = rb[i];
-            else *reinterpret_cast<float4 *>(&sB[(k0B + B_KPP * i) * LDB + rcB * 4]) = rb[i];
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    int v = blockIdx.x;
-    setup(v);
-    load_step();
-    int fetched = 0;
-    if (tid == 0) fetched = (int)gridDim.x + atomicAdd(&sched[0], 1);
-    const size_t ldc = (MODE == MODE_FWD) ? p.Cout : p.Cin;
-    float *const et = smem + wave * (32 * EPI_LD);
-    const int r = lane & 31, h = lane >> 5;
-    const int er = lane >> 3, ec = (lane & 7) * 4;
-    constexpr bool bn = MODE == MODE_FWD && BNS;
-    store_step();
-    __syncthreads();
-    for (;;) {
-#pragma nounroll
-        for (int s = 0; s + 1 < nsteps; ++s) {
-            load_step();
-            mma_step<true, B_KC, BM_, BN_>(sA, sB, acc, wm, wn, lane);
-            __builtin_amdgcn_sched_group_barrier(0x8, (TM * TN * 16) / 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x20, NA + NB, 0);
-            __builtin_amdgcn_sched_group_barrier(0x8, (TM * TN * 16) * 3 / 4, 0);
-            __syncthreads();
-            store_step();
-            __syncthreads();
-        }
-        // ---- last K step of this tile: the "next step" is the first step of the workgroup's next tile
-        const int m0e = m0, n0e = n0;
-        if (tid == 0) s_next = fetched;
-        __syncthreads();
-        const int vn = s_next;
-        const bool more = vn < total_tiles;
-        if (tid == 0 && more) fetched = (int)gridDim.x + atomicAdd(&sched[0], 1);       // the tile after the next: a whole tile ahead
-        setup(more ? vn : v);               // (no next tile: this tile's first step again - harmless, keeps ONE basic block)
-        load_step();
-        mma_step<true, B_KC, BM_, BN_>(sA, sB, acc, wm, wn, lane);
-        // the decode's VALU work and the prefetch loads go out under the first MFMAs of the step
-        __builtin_amdgcn_sched_group_barrier(0x8, (TM * TN * 16) / 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x20, NA + NB, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, (TM * TN * 16) * 3 / 4, 0);
-        __syncthreads();                    // every wave has read its last fragments: the staging area becomes the epilogue's
-        // ---- epilogue of tile (m0e, n0e): acc[tm][tn][reg] -> C[m][n] through the wave's private LDS tile, float4 stores.
-        // Straight-line code: no load (launches with a bias, an accumulate or a ReLU-mask operand stay on k_conv_igemm) and no
-        // branch - rows / columns outside the tensor are out-of-range buffer offsets, the store is dropped - so the waitcnt pass
-        // can COUNT the stores issued behind the prefetch and the next tile's store_step waits for its loads only
-        float4 bsum[bn ? TN : 1], bsq[bn ? TN : 1];
-        if (bn) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) { bsum[tn] = make_float4(0.f, 0.f, 0.f, 0.f); bsq[tn] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) et[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_LD + r] = acc[tm][tn][e];
-                const int n = n0e + wn * (BN_ / 2) + tn * 32 + ec;
-                const bool nv = n < p.Ng;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = er + 8 * j;
-                    const int m = m0e + wm * (BM_ / 2) + tm * 32 + row;
-                    float4 o = *reinterpret_cast<const float4 *>(&et[row * EPI_LD + ec]);
-                    const bool ok = nv & (m < p.M);
-                    if (bn) {
-                        const float4 z = ok ? o : make_float4(0.f, 0.f, 0.f, 0.f);
-                        bsum[tn].x += z.x; bsum[tn].y += z.y; bsum[tn].z += z.z; bsum[tn].w += z.w;
-                        bsq[tn].x = fmaf(z.x, z.x, bsq[tn].x); bsq[tn].y = fmaf(z.y, z.y, bsq[tn].y);
-                        bsq[tn].z = fmaf(z.z, z.z, bsq[tn].z); bsq[tn].w = fmaf(z.w, z.w, bsq[tn].w);
-                    }
-                    if (MODE == MODE_FWD && p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                    const unsigned off = ok ? (unsigned)(m * (int)ldc + n) * 4u : 0xFFFFFFFFu;
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t *>(&o), rsC, off, 0, 0);
-                }
-            }
-        if (MODE == MODE_FWD && bn) {
-            const int prow = (m0e / BM_) * 2 + wm;
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-#pragma unroll
-                for (int o = 8; o <= 32; o <<= 1) {
-                    bsum[tn].x += __shfl_xor(bsum[tn].x, o, 64); bsum[tn].y += __shfl_xor(bsum[tn].y, o, 64);
-                    bsum[tn].z += __shfl_xor(bsum[tn].z, o, 64); bsum[tn].w += __shfl_xor(bsum[tn].w, o, 64);
-                    bsq[tn].x += __shfl_xor(bsq[tn].x, o, 64); bsq[tn].y += __shfl_xor(bsq[tn].y, o, 64);
-                    bsq[tn].z += __shfl_xor(bsq[tn].z, o, 64); bsq[tn].w += __shfl_xor(bsq[tn].w, o, 64);
-                }
-                const int n = n0e + wn * (BN_ / 2) + tn * 32 + ec;
-                if (er == 0 && n < p.Ng) {
-                    *reinterpret_cast<float4 *>(p.bn_part + ((size_t)prow * 2) * p.Ng + n) = bsum[tn];
-                    *reinterpret_cast<float4 *>(p.bn_part + ((size_t)prow * 2 + 1) * p.Ng + n) = bsq[tn];
-                }
-            }
-        }
-        if (!more) {
-            // the last workgroup to finish re-arms the counters for the launch that uses this slot next
-            if (tid == 0 && atomicAdd(&sched[1], 1) == (int)gridDim.x - 1) { sched[0] = 0; sched[1] = 0; }
-            break;
-        }
-        v = vn;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-        __syncthreads();                    // the epilogue's LDS tiles have been read: the next tile's first step may be staged
-        // (staged HERE, not at the loop top: on this path the waitcnt pass knows exactly how many stores sit behind the
-        // prefetch loads and waits for the loads only; merged with the kernel entry it assumed none and waited for the stores)
-        store_step();
-        __syncthreads();
-    }
-}
-
 // ---- launch planning -------------------------------------------------------------------------------------
 // Workgroup slots of the chip for one kernel instantiation = resident workgroups per CU (runtime occupancy query,
 // cached) x CUs.  Tiles and split-K factors are chosen so that the grid is a whole number of slot "rounds": a grid of
@@ -886,52 +614,6 @@ TileChoice choose_tile(long long M, long long Ng, long long z) {
 // Results are garbage while a bit is set; kernel durations do not depend on the data.
 int g_debug_skip = 0;
 
-// Persistent pipeline (k_conv_pipe) for the plain forward-kind launches: 0 = off, 1 = on when the grid is at least
-// g_conv_persist_min_rounds rounds of workgroup slots (mrcnn_conv2d_set_persistent).
-int g_conv_persist = 0;
-float g_conv_persist_min_rounds = 1.5f;
-template <int MODE, int BM_, int BN_, bool BNS>
-int pipe_slots_of() {
-    static int slots = 0;
-    if (!slots) {
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(&k_conv_pipe<MODE, BM_, BN_, BNS>), CONV_THREADS, 0) != hipSuccess || occ <= 0)
-            occ = 2;
-        (void)hipGetLastError();
-        slots = occ * g_cus();
-    }
-    return slots;
-}
-// Scheduler counters: a ring of (next, done) pairs in device memory, one pair per launch in flight (launches on different
-// streams overlap); zeroed once, re-armed by each launch's last workgroup.
-constexpr int PIPE_SLOTS = 512;
-int *pipe_sched_slot() {
-    static int *base = nullptr;
-    static unsigned cursor = 0;
-    if (!base) {
-        if (hipMalloc((void **)&base, PIPE_SLOTS * 2 * sizeof(int)) != hipSuccess || hipMemset(base, 0, PIPE_SLOTS * 2 * sizeof(int)) != hipSuccess) {
-            (void)hipGetLastError();
-            base = nullptr;
-            return nullptr;
-        }
-    }
-    return base + 2 * (cursor++ % PIPE_SLOTS);
-}
-template <int MODE, int BM_, int BN_, bool BNS>
-bool launch_pipe_(const ConvP &p, int tiles, hipStream_t st) {
-    const int slots = pipe_slots_of<MODE, BM_, BN_, BNS>();
-    if ((float)tiles < g_conv_persist_min_rounds * (float)slots) return false;
-    int *sched = pipe_sched_slot();
-    if (!sched) return false;
-    hipLaunchKernelGGL((k_conv_pipe<MODE, BM_, BN_, BNS>), dim3(slots), dim3(CONV_THREADS), 0, st, p, tiles, sched);
-    return true;
-}
-template <int MODE, int BM_, int BN_>
-bool launch_pipe(const ConvP &p, int tiles, hipStream_t st) {
-    if (MODE == MODE_FWD && p.bn_part) return launch_pipe_<MODE, BM_, BN_, MODE == MODE_FWD>(p, tiles, st);
-    return launch_pipe_<MODE, BM_, BN_, false>(p, tiles, st);
-}
-
 template <int MODE>
 void launch_conv(ConvP &p, int zdim, TileChoice t, hipStream_t st) {
     // zdim: BWD_FILTER taps * ksplit; FWD / BWD_DATA ksplit
@@ -947,18 +629,6 @@ void launch_conv(ConvP &p, int zdim, TileChoice t, hipStream_t st) {
     }
     const dim3 grid(total), blk(CONV_THREADS);
     if (g_debug_skip & 1) return;
-    if constexpr (MODE != MODE_BWD_FILTER) {
-        // plain launches with a load-free epilogue; the output within 32-bit buffer offsets
-        if (g_conv_persist && !p.smallc && zdim == 1 && p.ksplit == 1 && !p.tail_ks && !p.bias && !(MODE == MODE_BWD_DATA && (p.accumulate || p.relu_x)) &&
-            (unsigned long long)p.M * (unsigned long long)(MODE == MODE_FWD ? p.Cout : p.Cin) * 4ull < (1ull << 32)) {
-            bool done = false;
-            if (t.bm == 128 && t.bn == 128) done = launch_pipe<MODE, 128, 128>(p, tiles, st);
-            else if (t.bm == 128 && t.bn == 64) done = launch_pipe<MODE, 128, 64>(p, tiles, st);
-            else if (t.bm == 64 && t.bn == 128) done = launch_pipe<MODE, 64, 128>(p, tiles, st);
-            else done = launch_pipe<MODE, 64, 64>(p, tiles, st);
-            if (done) return;
-        }
-    }
     if (p.smallc) {
         if (MODE == MODE_FWD) hipLaunchKernelGGL((k_conv_igemm<MODE_FWD, 128, 64, true>), grid, blk, 0, st, p);
         else hipLaunchKernelGGL((k_conv_igemm<MODE_BWD_FILTER, 64, 128, true>), grid, blk, 0, st, p);
@@ -1957,13 +1627,6 @@ extern "C" int mrcnn_conv2d_set_winograd_pass_tiles(int fwd, int bwd_data, int b
 extern "C" int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3) {
     if (!tiles3) return mrcnn::fail_arg(MRCNN_E_INVALID, "get_winograd_pass_tiles: null output");
     for (int i = 0; i < 3; ++i) tiles3[i] = g_wino_pass_tile[i];
-    return 0;
-}
-
-extern "C" int mrcnn_conv2d_set_persistent(int on, float min_rounds) {
-    if (on < 0 || on > 1 || !(min_rounds >= 1.0f)) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_persistent: on in {0,1}, min_rounds >= 1");
-    g_conv_persist = on;
-    g_conv_persist_min_rounds = min_rounds;
     return 0;
 }
 

@@ -175,10 +175,6 @@ int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels, int t
  * The setting is read on the host when a convolution entry point is called.  The getter writes the three current values. */
 int mrcnn_conv2d_set_winograd_pass_tiles(int fwd, int bwd_data, int bwd_filter);
 int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3);
-/* Persistent, cross-tile software-pipelined form of the plain forward / backward-data GEMM launches (no split-K, no tail split):
- * on = 1 uses it for grids of at least min_rounds rounds of resident workgroups.  Identical bits to the per-tile kernel. */
-int mrcnn_conv2d_set_persistent(int on, float min_rounds);
-
 /* Measurement knob for bench.py's roofline split (never set on a product path): bit 0 skips the MFMA GEMM launches of
  * the convolution calls, bit 1 skips every other kernel they launch (Winograd transforms, slab / tail / column sums).
  * Outputs are garbage while a bit is set; 0 restores normal operation. */
