@@ -101,36 +101,48 @@ __global__ __launch_bounds__(NT) void k_bn_stats_partial(const float *__restrict
     }
 }
 
-// Sum of the per-block partials of FIN_CH channels by a 256-thread block: thread (slice s, channel c) adds partials
-// s, s+16, ... in double, the 16 slice sums are then added in slice order (fixed order => bit-reproducible).  256 threads,
-// not 1024: a workgroup of 16 waves cannot start until a whole CU has drained, and these kernels run beside the
-// weight-gradient GEMMs of the other stream.
-constexpr int FIN_SLICES = 16, FIN_CH = 16;
-__device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int nblk, int C, int c, int slice,
-                                                double (*sa)[FIN_CH], double (*sb)[FIN_CH], double &a, double &b) {
-    a = 0.0; b = 0.0;
-    if (c < C) {
+// Sum of the per-block partials (nblk rows of (2, C) floats: sums, sums of squares) of the block's FIN_CH = 16 channels by
+// a 256-thread block, in double.  These kernels are pure latency on the step's critical chain (a convolution's statistics
+// must be final before its BatchNorm can be applied), so the rows are spread over as many loads in flight as the block has:
+// thread = (row slice of 64, channel quad): slice s adds rows s, s + 64, ... (float4 loads, eight in flight, row order), the
+// 64 slice sums of a channel are then added in slice order by the channel's thread (fixed order => bit-reproducible).
+// 2048 partial rows (the res2 layers): 14.5 -> ~5 us per launch against 16 slices of scalar loads.  Still 256 threads, not
+// 1024: a workgroup of 16 waves cannot start until a whole CU has drained when these run beside GEMMs of another stream.
+// Returns the sums in (a, b) of the threads with threadIdx.x < FIN_CH (channel blockIdx.x * FIN_CH + threadIdx.x).
+constexpr int FIN_SLICES = 16, FIN_CH = 16;         // (the thread layout of the callers' own passes: 16 slices x 16 channels)
+constexpr int RED_SLICES = 64, RED_QUADS = FIN_CH / 4;
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int nblk, int C, double &a, double &b) {
+    __shared__ double ra[RED_SLICES][FIN_CH], rb[RED_SLICES][FIN_CH];
+    const int quad = threadIdx.x % RED_QUADS, slice = threadIdx.x / RED_QUADS;
+    const int c0 = blockIdx.x * FIN_CH + quad * 4;
+    double sa4[4] = {0.0, 0.0, 0.0, 0.0}, sb4[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c0 < C) {           // C is a multiple of 4: a quad is inside or outside as a whole
         int k = slice;
-        for (; k + 3 * FIN_SLICES < nblk; k += 4 * FIN_SLICES) {      // 8 independent loads in flight, added in order
-            float va[4], vb[4];
+        for (; k + 3 * RED_SLICES < nblk; k += 4 * RED_SLICES) {
+            float4 va[4], vb[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                va[j] = part[(size_t)(k + j * FIN_SLICES) * 2 * C + c];
-                vb[j] = part[(size_t)(k + j * FIN_SLICES) * 2 * C + C + c];
+                va[j] = ld4(part + (size_t)(k + j * RED_SLICES) * 2 * C + c0);
+                vb[j] = ld4(part + (size_t)(k + j * RED_SLICES) * 2 * C + C + c0);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { a += (double)va[j]; b += (double)vb[j]; }
+            for (int j = 0; j < 4; ++j) {
+                sa4[0] += (double)va[j].x; sa4[1] += (double)va[j].y; sa4[2] += (double)va[j].z; sa4[3] += (double)va[j].w;
+                sb4[0] += (double)vb[j].x; sb4[1] += (double)vb[j].y; sb4[2] += (double)vb[j].z; sb4[3] += (double)vb[j].w;
+            }
         }
-        for (; k < nblk; k += FIN_SLICES) {
-            a += (double)part[(size_t)k * 2 * C + c];
-            b += (double)part[(size_t)k * 2 * C + C + c];
+        for (; k < nblk; k += RED_SLICES) {
+            const float4 va = ld4(part + (size_t)k * 2 * C + c0), vb = ld4(part + (size_t)k * 2 * C + C + c0);
+            sa4[0] += (double)va.x; sa4[1] += (double)va.y; sa4[2] += (double)va.z; sa4[3] += (double)va.w;
+            sb4[0] += (double)vb.x; sb4[1] += (double)vb.y; sb4[2] += (double)vb.z; sb4[3] += (double)vb.w;
         }
     }
-    sa[slice][threadIdx.x % FIN_CH] = a;
-    sb[slice][threadIdx.x % FIN_CH] = b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ra[slice][quad * 4 + e] = sa4[e]; rb[slice][quad * 4 + e] = sb4[e]; }
     __syncthreads();
-    if (slice == 0) {
-        for (int k = 1; k < FIN_SLICES; ++k) { a += sa[k][threadIdx.x % FIN_CH]; b += sb[k][threadIdx.x % FIN_CH]; }
+    a = 0.0; b = 0.0;
+    if (threadIdx.x < FIN_CH) {
+        for (int k = 0; k < RED_SLICES; ++k) { a += ra[k][threadIdx.x]; b += rb[k][threadIdx.x]; }
     }
 }
 
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_stats_final(const fl
     const int c = blockIdx.x * FIN_CH + cl, slice = threadIdx.x / FIN_CH;
     double a, b;
     if (threadIdx.x == 0) sredo = 0;
-    reduce_partials(part, nblk, C, c, slice, sa, sb, a, b);        // (contains a barrier: sredo is visible below)
+    reduce_partials(part, nblk, C, a, b);        // (contains a barrier: sredo is visible below)
     // shifted: the partials are sums of (x - K), K = x[0][c] (k_bn_stats_partial); else plain sums (the convolution epilogue)
     double ms = a / P, var = b / P - ms * ms;
     double m = (shifted ? (double)x[c < C ? c : 0] : 0.0) + ms;
@@ -291,10 +303,9 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__
 
 __global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_bwd_final(const float *__restrict__ part, int nblk, int C,
                                                        float *__restrict__ gbeta, float *__restrict__ ggamma) {
-    __shared__ double sa[FIN_SLICES][FIN_CH], sb[FIN_SLICES][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, slice = threadIdx.x / FIN_CH;
     double a, b;
-    reduce_partials(part, nblk, C, c, slice, sa, sb, a, b);
+    reduce_partials(part, nblk, C, a, b);
     if (slice != 0 || c >= C) return;
     gbeta[c] = (float)a;
     ggamma[c] = (float)b;
