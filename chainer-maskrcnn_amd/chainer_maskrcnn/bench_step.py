@@ -109,6 +109,29 @@ def bench_step(args, rank, world):
         check(lib().mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))
         opt.update(chain, imgs, bb, lab, masks, 1.0)
 
+    # EXPLORATORY opt-in modes (reported, never `value`): the GEMMs with three-term split operands on the 16-bit
+    # MFMA (hi + lo planes per float32 operand, float32 accumulation) - gfx950 has no xf32, this is what the 157.3 TF/s ceiling
+    # costs.  (0,1,1): float32 forward, bf16 planes in both backward passes - passes the full-width parity bars of the float32
+    # configuration unchanged; (2,1,1): half planes in the forward pass too - activations at the float32 kernels' level, a few
+    # gradient tensors up to 7.6 x the float32 noise floor (tests/test_full_width_gpu.py)
+    split = {}
+    if world == 1 and not tiles:
+        from chainer_maskrcnn._hip import lib, check
+        for name, mode in (('split_bf16_backward', (0, 1, 1)), ('split_half_forward_bf16_backward', (2, 1, 1))):
+            check(lib().mrcnn_conv2d_set_split_operands(*mode))
+            try:
+                for _ in range(2):
+                    opt.update(chain, imgs, bb, lab, masks, 1.0)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    opt.update(chain, imgs, bb, lab, masks, 1.0)
+                torch.cuda.synchronize()
+                split[name] = N * 5 / (time.perf_counter() - t1)
+            finally:
+                check(lib().mrcnn_conv2d_set_split_operands(0, 0, 0))
+        opt.update(chain, imgs, bb, lab, masks, 1.0)
+
     # roofline of the dominant kernel family (k_conv_igemm): instrumented steps, HIP events around every launch
     hnn.PROFILE = []
     chain.use_aux_stream = False      # instrumented steps: one stream, every conv launch bracketed by events
@@ -172,6 +195,16 @@ def bench_step(args, rank, world):
         out['config']['images_per_sec_mask_branch_on_positive_rows_only'] = round(alt, 3)
     if fast is not None:
         out['config']['images_per_sec_opt_in_winograd_f4_forward'] = round(fast, 3)
+    if split:
+        out['config']['exploratory_opt_in_split_operands'] = {
+            'images_per_sec_f32_forward_bf16x3_backward': round(split['split_bf16_backward'], 3),
+            'images_per_sec_f16x3_forward_bf16x3_backward': round(split['split_half_forward_bf16_backward'], 3),
+            'dtype': 'float32 tensors; GEMM operands staged as hi + lo 16-bit planes (bf16: 16 significant bits, half: 22), products '
+                     'al*bh + ah*bl + ah*bh on the bf16 / f16 MFMA, float32 accumulation',
+            'note': 'mrcnn_conv2d_set_split_operands; NOT the headline (`value` is the float32-MFMA step).  f32 forward + bf16x3 backward '
+                    'passes the same full-width parity bars as the float32 configuration (test_full_width_*_split_bf16_backward_opt_in); '
+                    'with f16x3 forward activations stay at the float32 level and 2 of 180 gradient tensors reach 7.6x the float32 noise '
+                    'floor (bar 6x)'}
     out['config']['winograd_tiles_fwd_bwddata_bwdfilter'] = tiles or ('2,0,0 (0 = F(4x4) where the layer is large enough, else F(2x2)); the FPN / '
                                                                       'RPN / head convolutions run their forward pass with 0')
     if dp_report is not None:

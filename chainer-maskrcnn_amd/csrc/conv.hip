@@ -119,6 +119,90 @@ __device__ __forceinline__ void mma_step(const float *__restrict__ sA, const flo
     }
 }
 
+// ---- EXPLORATORY (opt-in, mrcnn_conv2d_set_split_bf16; never the default): the same K step with three-term split-bf16 operands.
+// gfx950 has no xf32, so an fp32-input MFMA runs at 1/16 of the bf16 rate.  Every operand x is staged as hi = bf16(x) and
+// lo = bf16(x - hi) (16 significant bits between them) and a product a*b is accumulated in float32 as al*bh + ah*bl + ah*bh (the
+// al*bl term, <= 2^-18 |ab|, is dropped): three v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32
+// (64 cycles each) per 16 of K - 5.3x fewer MFMA cycles, products accurate to ~1e-5 relative instead of 6e-8.  LDS holds the two
+// bf16 planes of each operand ([row][32 k], row stride 80 B): the same bytes as the float32 tiles.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int LDKH = BK + 8;           // bf16 elements per LDS row of a split plane (80 B: 16-B aligned fragments)
+__device__ __forceinline__ void split_bf16x4(const float4 v, uint2 &hi, uint2 &lo) {
+    const f32x2_t v01 = {v.x, v.y}, v23 = {v.z, v.w};
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, bf16x2_t));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, bf16x2_t));
+    const f32x2_t r01 = {v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u)};
+    const f32x2_t r23 = {v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u)};
+    hi = make_uint2(h01, h23);
+    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2_t)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2_t)));
+}
+// The same split with IEEE half planes (11 significant bits each: 22 between them, products accurate to ~5e-7 - within 10x of
+// float32 - at the bf16 MFMA rate), for operands that live in half's range: hi = rtz(x), lo = rtz(x - hi).  Values beyond
+// +-65504 would overflow (forward activations, weights and Winograd-domain inputs of this model stay below 1e4); values below
+// 6e-5 keep an absolute precision of 6e-8, which is why the BACKWARD passes (gradients of 1e-6 .. 1e-3) use the bf16 planes.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __fp16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_f16x4(const float4 v, uint2 &hi, uint2 &lo) {
+    const f16x2_t h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+    const f16x2_t l01 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h01[0], v.y - (float)h01[1]);
+    const f16x2_t l23 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h23[0], v.w - (float)h23[1]);
+    hi = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+// Fragment of a 32-row MFMA tile from a split plane.  KC plane ([row][32 k], stride LDKH): one ds_read_b128.  RC plane ([k][rows],
+// the layout the operand has in HBM when K is the pixel or the output-channel axis): two ds_read_b64_tr_b16 - per 16-lane group the
+// hardware reads a 4 (k) x 16 (rows) block and hands lane i the 4 k values of row i (cdna_hip_programming.md T10); EXEC is full here.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+template <bool KC>
+__device__ __forceinline__ uint4 split_frag(const unsigned short *__restrict__ plane, int row0, int ld, int kk, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    if (KC) return *reinterpret_cast<const uint4 *>(plane + (row0 + r) * LDKH + kk * 16 + 8 * h);
+    const int li = lane & 15, q = li >> 2, pp = li & 3, g16 = (lane >> 4) & 1;
+    const unsigned short *a0 = plane + (kk * 16 + 8 * h + q) * ld + row0 + 16 * g16 + 4 * pp;
+    const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3))) *)a0);
+    const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3))) *)(a0 + 4 * ld));
+    const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
+    return make_uint4(u0.x, u0.y, u1.x, u1.y);
+}
+template <bool A_KC, bool B_KC, int BM_, int BN_, int SPLIT>
+__device__ __forceinline__ void mma_step_split(const unsigned short *__restrict__ aH, const unsigned short *__restrict__ aL,
+                                               const unsigned short *__restrict__ bH, const unsigned short *__restrict__ bL,
+                                               f32x16 (&acc)[BM_ / 64][BN_ / 64], int wm, int wn, int lane) {
+    constexpr int TM = BM_ / 64, TN = BN_ / 64;
+    constexpr int LDAH = BM_ + 32, LDBH = BN_ + 32;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+        uint4 ah[TM], al[TM], bh[TN], bl[TN];           // 8 16-bit elements each
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            ah[t] = split_frag<A_KC>(aH, wm * (BM_ / 2) + t * 32, LDAH, kk, lane);
+            al[t] = split_frag<A_KC>(aL, wm * (BM_ / 2) + t * 32, LDAH, kk, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            bh[t] = split_frag<B_KC>(bH, wn * (BN_ / 2) + t * 32, LDBH, kk, lane);
+            bl[t] = split_frag<B_KC>(bL, wn * (BN_ / 2) + t * 32, LDBH, kk, lane);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                if constexpr (SPLIT == 1) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al[tm]), __builtin_bit_cast(bf16x8_t, bh[tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah[tm]), __builtin_bit_cast(bf16x8_t, bl[tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah[tm]), __builtin_bit_cast(bf16x8_t, bh[tn]), acc[tm][tn], 0, 0, 0);
+                } else {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, al[tm]), __builtin_bit_cast(f16x8_t, bh[tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah[tm]), __builtin_bit_cast(f16x8_t, bl[tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah[tm]), __builtin_bit_cast(f16x8_t, bh[tn]), acc[tm][tn], 0, 0, 0);
+                }
+            }
+    }
+}
+
 // ---- the kernel ----------------------------------------------------------------------------
 // All tensor offsets are 32-bit element indices (the host checks every tensor has < 2^31 elements); the per-row
 // part of every gather address is computed once, a K step only adds a wave-uniform tap/channel offset.
@@ -130,14 +214,19 @@ __device__ __forceinline__ void divmod_small(int v, int d, float inv, int &q, in
     if (r < 0) { r += d; --q; }
 }
 
-template <int MODE, int BM_, int BN_, bool SMALLC>
+template <int MODE, int BM_, int BN_, bool SMALLC, int SPLIT = 0>         // SPLIT: 0 float32 MFMA, 1 bf16 hi/lo planes, 2 half hi/lo planes
 __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
+    constexpr bool BF3 = SPLIT != 0;
+    static_assert(!BF3 || !SMALLC, "split operands: not for the 4-channel image layer");
     constexpr bool A_KC = (MODE != MODE_BWD_FILTER);
     constexpr bool B_KC = (MODE == MODE_FWD);
     constexpr int TM = BM_ / 64, TN = BN_ / 64;
     constexpr int LDA = BM_ + 4, LDB = BN_ + 4;
-    constexpr int A_ELEMS = A_KC ? BM_ * LDK : BK * LDA;
-    constexpr int B_ELEMS = B_KC ? BN_ * LDK : BK * LDB;
+    // (split operands: two 16-bit planes per operand - KC: rows x LDKH, RC: BK x (rows + 32) elements each; in floats: half of it x 2)
+    constexpr int LDAH = BM_ + 32, LDBH = BN_ + 32;
+    constexpr int A_PLANE = A_KC ? BM_ * LDKH : BK * LDAH, B_PLANE = B_KC ? BN_ * LDKH : BK * LDBH;       // 16-bit elements
+    constexpr int A_ELEMS = BF3 ? A_PLANE : (A_KC ? BM_ * LDK : BK * LDA);
+    constexpr int B_ELEMS = BF3 ? B_PLANE : (B_KC ? BN_ * LDK : BK * LDB);
     constexpr int NA = BM_ / 32, NB = BN_ / 32;          // float4 loads per thread per K step
     // RC loader geometry: a k-row of width Wd floats is covered by Wd/4 threads; 256/(Wd/4) k-rows per pass
     constexpr int B_TPR = BN_ / 4, B_KPP = CONV_THREADS / B_TPR;
@@ -408,7 +497,33 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             f_h0 -= c2 ? f_hback : 0; f_off0 += c2 ? f_c2off : 0;
         }
     };
+    unsigned short *const aH = reinterpret_cast<unsigned short *>(sA), *const aL = aH + A_PLANE;
+    unsigned short *const bH = reinterpret_cast<unsigned short *>(sB), *const bL = bH + B_PLANE;
     auto store_step = [&]() {
+        if constexpr (BF3) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                uint2 hi, lo;
+                if constexpr (SPLIT == 1) split_bf16x4(ra[i], hi, lo); else split_f16x4(ra[i], hi, lo);
+                const int o = A_KC ? (r0 + 32 * i) * LDKH + kc * 4 : fp * LDAH + (fc + 8 * i) * 4;
+                *reinterpret_cast<uint2 *>(&aH[o]) = hi;
+                *reinterpret_cast<uint2 *>(&aL[o]) = lo;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                uint2 hi, lo;
+                // half planes: the weight operand is scaled by 2^12 (exact; undone in the epilogue) - Winograd-domain filters
+                // G g G^T of 1e-2 weights are 1e-6 .. 1e-3, below half's normal range
+                if constexpr (SPLIT == 1) split_bf16x4(rb[i], hi, lo);
+                else if constexpr (MODE == MODE_FWD) split_f16x4(make_float4(rb[i].x * 4096.0f, rb[i].y * 4096.0f, rb[i].z * 4096.0f, rb[i].w * 4096.0f), hi, lo);
+                else split_f16x4(rb[i], hi, lo);
+                const int o = B_KC ? (r0 + 32 * i) * LDKH + kc * 4
+                                   : (MODE == MODE_BWD_FILTER ? fp * LDBH + (fc + 8 * i) * 4 : (k0B + B_KPP * i) * LDBH + rcB * 4);
+                *reinterpret_cast<uint2 *>(&bH[o]) = hi;
+                *reinterpret_cast<uint2 *>(&bL[o]) = lo;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const float4 v = ra[i];
@@ -432,12 +547,16 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             // Always load (the last iteration re-reads its own step: harmless) so that the gather address arithmetic and
             // the global loads share ONE basic block with the MFMAs and the scheduler can interleave them.
             load_step(sbeg + min(s + 1, nsteps - 1));
+            if constexpr (BF3) {
+                mma_step_split<A_KC, B_KC, BM_, BN_, SPLIT>(aH, aL, bH, bL, acc, wm, wn, lane);
+            } else {
             mma_step<A_KC, B_KC, BM_, BN_>(sA, sB, acc, wm, wn, lane);
             // schedule: the gather loads go out after the first quarter of the step's MFMAs (their address arithmetic is
             // hidden under those), so the data is back long before the LDS stores at the end of the step
             __builtin_amdgcn_sched_group_barrier(0x8, (TM * TN * 16) / 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x20, NA + NB, 0);
             __builtin_amdgcn_sched_group_barrier(0x8, (TM * TN * 16) * 3 / 4, 0);
+            }
             __syncthreads();
             store_step();
             __syncthreads();
@@ -445,6 +564,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     }
 
     // ---- epilogue: acc[tm][tn][reg] -> C[m][n], row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
+    if constexpr (SPLIT == 2 && MODE == MODE_FWD) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= (1.0f / 4096.0f);
+    }
     const int r = lane & 31, h = lane >> 5;
     size_t ldc;
     float *cbase;
@@ -613,6 +740,10 @@ TileChoice choose_tile(long long M, long long Ng, long long z) {
 // bit 1 = every other kernel of the convolution calls (Winograd transforms, slab / tail / column sums) is skipped.
 // Results are garbage while a bit is set; kernel durations do not depend on the data.
 int g_debug_skip = 0;
+// EXPLORATORY: forward-kind GEMM launches with three-term split-bf16 operands (mrcnn_conv2d_set_split_bf16).  Off by default;
+// results then differ from the float32 kernels by ~1e-5 relative per product.
+int g_split_mode[3] = {0, 0, 0};        // per pass (forward, backward-data, backward-filter): 0 float32, 1 bf16 planes, 2 half planes
+thread_local int g_cur_pass = 0;        // set by the entry points around their launches (PASS_*)
 
 template <int MODE>
 void launch_conv(ConvP &p, int zdim, TileChoice t, hipStream_t st) {
@@ -633,6 +764,23 @@ void launch_conv(ConvP &p, int zdim, TileChoice t, hipStream_t st) {
         if (MODE == MODE_FWD) hipLaunchKernelGGL((k_conv_igemm<MODE_FWD, 128, 64, true>), grid, blk, 0, st, p);
         else hipLaunchKernelGGL((k_conv_igemm<MODE_BWD_FILTER, 64, 128, true>), grid, blk, 0, st, p);
         return;
+    }
+    {   // exploratory opt-in: three-term split operands; the planes' type per PASS of the calling entry point
+        const int split = g_split_mode[g_cur_pass];
+        if (split == 1) {
+            if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 128, false, 1>), grid, blk, 0, st, p);
+            else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64, false, 1>), grid, blk, 0, st, p);
+            else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 128, false, 1>), grid, blk, 0, st, p);
+            else hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 64, false, 1>), grid, blk, 0, st, p);
+            return;
+        }
+        if (split == 2) {
+            if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 128, false, 2>), grid, blk, 0, st, p);
+            else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64, false, 2>), grid, blk, 0, st, p);
+            else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 128, false, 2>), grid, blk, 0, st, p);
+            else hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 64, false, 2>), grid, blk, 0, st, p);
+            return;
+        }
     }
     if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 128, false>), grid, blk, 0, st, p);
     else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64, false>), grid, blk, 0, st, p);
@@ -1630,6 +1778,14 @@ extern "C" int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3) {
     return 0;
 }
 
+extern "C" int mrcnn_conv2d_set_split_operands(int fwd, int bwd_data, int bwd_filter) {
+    const int m[3] = {fwd, bwd_data, bwd_filter};
+    for (int i = 0; i < 3; ++i)
+        if (m[i] < 0 || m[i] > 2) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_split_operands: each of 0 (float32), 1 (bf16 hi/lo), 2 (half hi/lo)");
+    for (int i = 0; i < 3; ++i) g_split_mode[i] = m[i];
+    return 0;
+}
+
 extern "C" int mrcnn_conv2d_set_debug_skip(int mask) {
     if (mask < 0 || mask > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_debug_skip: mask in [0,3]");
     g_debug_skip = mask;
@@ -1658,6 +1814,7 @@ extern "C" size_t mrcnn_conv2d_winograd_v_bytes(int N, int H, int W, int Cin, in
 extern "C" int mrcnn_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                                     int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                                     float *wino_v, void *ws, size_t ws_bytes, void *stream) {
+    g_cur_pass = 0;
     if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cin, Cout, PASS_FWD))
         return wino_conv(x, w, y, N, H, W, Cin, Cout, false, bias, relu, 0, nullptr, ws, ws_bytes, (hipStream_t)stream, wino_v);
@@ -1701,6 +1858,7 @@ extern "C" size_t mrcnn_conv2d_bnstats_rows(int N, int H, int W, int Cin, int Co
 extern "C" int mrcnn_conv2d_fwd_bnstats_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH,
                                             int KW, int stride, int pad, float *bn_part, float *wino_v, void *ws, size_t ws_bytes,
                                             void *stream) {
+    g_cur_pass = 0;
     if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     ConvP p;
     TileChoice t;
@@ -1724,6 +1882,7 @@ extern "C" int mrcnn_conv2d_fwd_bnstats_f32(const float *x, const float *w, floa
 extern "C" int mrcnn_conv2d_fwd_rect_f32(const float *x, const float *w, const float *bias, float *y, int N, int H, int W,
                                          int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int relu, void *ws,
                                          size_t ws_bytes, void *stream) {
+    g_cur_pass = 0;
     if (pad_h < 0 || pad_w < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "conv2d_fwd_rect: negative padding");
     // sizes and limits are validated for the larger of the two paddings (a superset of the real output)
     if (int e = check_conv(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, std::max(pad_h, pad_w))) return e;
@@ -1751,6 +1910,7 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
                                          int Cin, int Cout, int KH, int KW, int stride, int pad,
                                          int accumulate, float *wino_w, float *gbias, int gbias_accumulate, void *ws,
                                          size_t ws_bytes, void *stream) {
+    g_cur_pass = 1;
     if (int e = check_conv(gy, w, gx, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     if (stride != 1)
         return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: stride %d (only 1; strided 1x1 convs are "
@@ -1791,6 +1951,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
                                            int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                            int accumulate, const float *wino_v, const float *wino_w, void *ws, size_t ws_bytes,
                                            void *stream) {
+    g_cur_pass = 2;
     if (int e = check_conv(x, gy, gw, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     const size_t need = mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (!ws || ws_bytes < need) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "conv2d_bwd_filter: workspace %zu < %zu", ws_bytes, need);

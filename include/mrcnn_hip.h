@@ -175,6 +175,14 @@ int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels, int t
  * The setting is read on the host when a convolution entry point is called.  The getter writes the three current values. */
 int mrcnn_conv2d_set_winograd_pass_tiles(int fwd, int bwd_data, int bwd_filter);
 int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3);
+/* EXPLORATORY, opt-in, never the default (and never bench.py's `value`): the forward-kind GEMM launches (forward convolutions and
+ * both Winograd batched GEMMs) of a pass (forward, backward-data, backward-filter) with three-term split operands on the 16-bit
+ * MFMA - every float32 operand staged as hi + lo planes, float32 accumulation of al*bh + ah*bl + ah*bh: 0 = float32 MFMA,
+ * 1 = bf16 planes (16 significant bits, float32 range; ~4e-6 per product), 2 = IEEE-half planes (22 bits, ~5e-7 per product;
+ * operands must stay below 65504 and lose relative precision below 6e-5).  gfx950 has no xf32: this is what challenging the
+ * 157.3 TF/s fp32-MFMA ceiling costs in accuracy and buys in time. */
+int mrcnn_conv2d_set_split_operands(int fwd, int bwd_data, int bwd_filter);
+
 /* Measurement knob for bench.py's roofline split (never set on a product path): bit 0 skips the MFMA GEMM launches of
  * the convolution calls, bit 1 skips every other kernel they launch (Winograd transforms, slab / tail / column sums).
  * Outputs are garbage while a bit is set; 0 restores normal operation. */

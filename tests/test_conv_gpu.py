@@ -206,3 +206,59 @@ def _winograd_case(case, tol, shared_gy=True):
     acc_w, acc_b = (torch.ones_like(gw), torch.ones_like(gb))
     hnn.conv2d_bwd_filter_raw(x.to(DEV), gy.to(DEV), tuple(w.shape), 1, 1, True, gw=acc_w, gb=acc_b, accumulate=True)
     assert (acc_w.cpu().double() - (wref + 1)).abs().max().item() / wref.abs().max().item() < tol
+
+
+# ---- EXPLORATORY opt-in: three-term split operands on the 16-bit MFMA (mrcnn_conv2d_set_split_operands) -----------------------
+SPLIT_CASES = [  # N, H, W, Cin, Cout, K, pad
+    (2, 9, 11, 32, 32, 1, 0), (1, 16, 20, 64, 160, 3, 1), (2, 13, 9, 96, 64, 3, 1), (3, 1, 1, 256, 96, 1, 0),
+    (1, 40, 36, 32, 288, 3, 1),       # several M and N tiles, ragged M
+    (2, 8, 8, 2048, 512, 1, 0),       # few tiles, long K: the forward / backward-data split-K launches
+    (16, 14, 14, 256, 256, 3, 1),     # Winograd in all three passes
+    (1, 67, 63, 256, 288, 3, 1),      # Winograd, ragged tiles, Cout not a tile multiple
+]
+
+
+@pytest.mark.parametrize('planes', [1, 2], ids=['bf16', 'half'])
+@pytest.mark.parametrize('case', SPLIT_CASES)
+def test_conv_split_operands_all_three_passes(case, planes):
+    """Every GEMM of the three passes with hi + lo 16-bit planes per float32 operand and float32 accumulation of
+    al*bh + ah*bl + ah*bh: against float64, bf16 planes within 3e-5 of the tensor scale (float32 MFMA: 5e-7), half planes within
+    3e-6 - times 30 on the F(4x4) Winograd layers, whose transforms amplify every GEMM's error alike.  K- and row-contiguous
+    operand layouts (the latter through ds_read_b64_tr_b16), split-K / tail-split launches, accumulate and ReLU-mask epilogues."""
+    from chainer_maskrcnn import _hip
+    N, H, W, Cin, Cout, K, p = case
+    g = torch.Generator().manual_seed(900 + sum(case))
+    x = torch.randn((N, H, W, Cin), generator=g)
+    w = torch.randn((Cout, K, K, Cin), generator=g) / (K * K * Cin) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    gy = torch.randn((N, H, W, Cout), generator=g)
+    base = torch.randn((N, H, W, Cin), generator=g)
+    ref_y = _ref_conv(x, w, b, 1, p)
+    ref_gx = F.conv_transpose2d(gy.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), None, stride=1, padding=p).permute(0, 2, 3, 1)
+    ref_gw = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (Cout, Cin, K, K), gy.double().permute(0, 3, 1, 2), 1, p).permute(0, 2, 3, 1)
+    wino = K == 3 and Cin >= 256
+    tol = (3e-5 if planes == 1 else 3e-6) * (30 if wino else 1)
+    rel = lambda got, ref: (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    xd, wd, bd, gyd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
+    _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(0, 0, 0))
+    _hip.check(_hip.lib().mrcnn_conv2d_set_split_operands(planes, planes, planes))
+    try:
+        y = hnn.conv2d_fwd_raw(xd, wd, bd, 1, p, False)
+        assert torch.equal(y, hnn.conv2d_fwd_raw(xd, wd, bd, 1, p, False))                 # reproducible
+        assert rel(y, ref_y) < tol, ('fwd', rel(y, ref_y))
+        assert rel(hnn.conv2d_fwd_raw(xd, wd, bd, 1, p, True), ref_y.clamp_min(0)) < tol
+        gx = hnn.conv2d_bwd_data_raw(gyd, wd, tuple(x.shape), 1, p)
+        assert rel(gx, ref_gx) < tol, ('bwd_data', rel(gx, ref_gx))
+        out = base.to(DEV).clone()
+        hnn.conv2d_bwd_data_raw(gyd, wd, tuple(x.shape), 1, p, out=out)
+        assert (out.cpu().double() - (ref_gx + base.double())).abs().max().item() / ref_gx.abs().max().item() < tol
+        xr = torch.randn((N, H, W, Cin), generator=g).clamp_min(0).to(DEV)
+        assert torch.equal(hnn.conv2d_bwd_data_raw(gyd, wd, tuple(x.shape), 1, p, relu_x=xr), torch.where(xr > 0, gx, torch.zeros_like(gx)))
+        gw, gb = hnn.conv2d_bwd_filter_raw(xd, gyd, tuple(w.shape), 1, p, True)
+        assert rel(gw, ref_gw) < tol, ('bwd_filter', rel(gw, ref_gw))
+        assert rel(gb, gy.double().sum((0, 1, 2))) < 2e-5
+    finally:
+        _hip.check(_hip.lib().mrcnn_conv2d_set_split_operands(0, 0, 0))
+        _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))
+    # and the default is untouched: float32 MFMA again
+    assert rel(hnn.conv2d_fwd_raw(xd, wd, bd, 1, p, False), ref_y) < (3e-4 if wino else 2e-6)
