@@ -114,7 +114,7 @@ def bench_step(args, rank, world):
     # costs.  (0,1,1): float32 forward, bf16 planes in both backward passes - passes the full-width parity bars of the float32
     # configuration unchanged; (2,1,1): half planes in the forward pass too - activations at the float32 kernels' level, a few
     # gradient tensors up to 7.6 x the float32 noise floor (tests/test_full_width_gpu.py)
-    split = {}
+    split_ips = {}
     if world == 1 and not tiles:
         from chainer_maskrcnn._hip import lib, check
         for name, mode in (('split_bf16_backward', (0, 1, 1)), ('split_half_forward_bf16_backward', (2, 1, 1))):
@@ -127,7 +127,7 @@ def bench_step(args, rank, world):
                 for _ in range(5):
                     opt.update(chain, imgs, bb, lab, masks, 1.0)
                 torch.cuda.synchronize()
-                split[name] = N * 5 / (time.perf_counter() - t1)
+                split_ips[name] = N * 5 / (time.perf_counter() - t1)
             finally:
                 check(lib().mrcnn_conv2d_set_split_operands(0, 0, 0))
         opt.update(chain, imgs, bb, lab, masks, 1.0)
@@ -195,10 +195,10 @@ def bench_step(args, rank, world):
         out['config']['images_per_sec_mask_branch_on_positive_rows_only'] = round(alt, 3)
     if fast is not None:
         out['config']['images_per_sec_opt_in_winograd_f4_forward'] = round(fast, 3)
-    if split:
+    if split_ips:
         out['config']['exploratory_opt_in_split_operands'] = {
-            'images_per_sec_f32_forward_bf16x3_backward': round(split['split_bf16_backward'], 3),
-            'images_per_sec_f16x3_forward_bf16x3_backward': round(split['split_half_forward_bf16_backward'], 3),
+            'images_per_sec_f32_forward_bf16x3_backward': round(split_ips['split_bf16_backward'], 3),
+            'images_per_sec_f16x3_forward_bf16x3_backward': round(split_ips['split_half_forward_bf16_backward'], 3),
             'dtype': 'float32 tensors; GEMM operands staged as hi + lo 16-bit planes (bf16: 16 significant bits, half: 22), products '
                      'al*bh + ah*bl + ah*bh on the bf16 / f16 MFMA, float32 accumulation',
             'note': 'mrcnn_conv2d_set_split_operands; NOT the headline (`value` is the float32-MFMA step).  f32 forward + bf16x3 backward '
