@@ -113,11 +113,12 @@ def bench_step(args, rank, world):
     # MFMA (hi + lo planes per float32 operand, float32 accumulation) - gfx950 has no xf32, this is what the 157.3 TF/s ceiling
     # costs.  (0,1,1): float32 forward, bf16 planes in both backward passes - passes the full-width parity bars of the float32
     # configuration unchanged; (2,1,1): half planes in the forward pass too - activations at the float32 kernels' level, a few
-    # gradient tensors up to 7.6 x the float32 noise floor (tests/test_full_width_gpu.py)
+    # gradient tensors up to 7.6 x the float32 noise floor (tests/test_full_width_gpu.py); (3,3,3): THREE bf16 planes (= the float32
+    # operand exactly) and six products in every pass - a float32-ACCURATE emulation (error against float64 <= the float32 MFMA's own)
     split_ips = {}
     if world == 1 and not tiles:
         from chainer_maskrcnn._hip import lib, check
-        for name, mode in (('split_bf16_backward', (0, 1, 1)), ('split_half_forward_bf16_backward', (2, 1, 1))):
+        for name, mode in (('bf16x6', (3, 3, 3)), ('split_bf16_backward', (0, 1, 1)), ('split_half_forward_bf16_backward', (2, 1, 1))):
             check(lib().mrcnn_conv2d_set_split_operands(*mode))
             try:
                 for _ in range(2):
@@ -197,11 +198,15 @@ def bench_step(args, rank, world):
         out['config']['images_per_sec_opt_in_winograd_f4_forward'] = round(fast, 3)
     if split_ips:
         out['config']['exploratory_opt_in_split_operands'] = {
+            'images_per_sec_float32_accurate_bf16x6_all_passes': round(split_ips['bf16x6'], 3),
             'images_per_sec_f32_forward_bf16x3_backward': round(split_ips['split_bf16_backward'], 3),
             'images_per_sec_f16x3_forward_bf16x3_backward': round(split_ips['split_half_forward_bf16_backward'], 3),
             'dtype': 'float32 tensors; GEMM operands staged as hi + lo 16-bit planes (bf16: 16 significant bits, half: 22), products '
                      'al*bh + ah*bl + ah*bh on the bf16 / f16 MFMA, float32 accumulation',
-            'note': 'mrcnn_conv2d_set_split_operands; NOT the headline (`value` is the float32-MFMA step).  f32 forward + bf16x3 backward '
+            'note': 'mrcnn_conv2d_set_split_operands; NOT the headline (`value` is the float32-MFMA step).  bf16x6 = three bf16 planes per '
+                    'operand (hi + mid + lo = the float32 value exactly), six products: per-layer error against float64 <= the float32 '
+                    "MFMA kernels' (tools/ab_bf16.py), all float32 parity bars pass (test_full_width_512_float32_accurate_emulation_opt_in).  "
+                    'f32 forward + bf16x3 backward '
                     'passes the same full-width parity bars as the float32 configuration (test_full_width_*_split_bf16_backward_opt_in); '
                     'with f16x3 forward activations stay at the float32 level and 2 of 180 gradient tensors reach 7.6x the float32 noise '
                     'floor (bar 6x)'}

@@ -156,6 +156,25 @@ __device__ __forceinline__ void split_f16x4(const float4 v, uint2 &hi, uint2 &lo
 // the layout the operand has in HBM when K is the pixel or the output-channel axis): two ds_read_b64_tr_b16 - per 16-lane group the
 // hardware reads a 4 (k) x 16 (rows) block and hands lane i the 4 k values of row i (cdna_hip_programming.md T10); EXEC is full here.
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
+// SPLIT = 3: THREE bf16 planes hi + mid + lo = the float32 operand EXACTLY (3 x 8 significant bits = float32's 24; bf16 has float32's
+// exponent range), and the six products of weight >= 2^-16: lh + hl + mm + mh + hm + hh.  The dropped ml, lm, ll are <= 3 x 2^-24
+// of |ab| - the size of the rounding the float32 MFMA itself makes when it adds a product to its accumulator - so this GEMM is a
+// float32-ACCURATE emulation (the "BF16x6 / BF16x9" float32 modes of vendor BLAS libraries) at 3/8 of the float32 MFMA cycles.
+__device__ __forceinline__ void split3_bf16x4(const float4 v, uint2 &hi, uint2 &mid, uint2 &lo) {
+    const f32x2_t v01 = {v.x, v.y}, v23 = {v.z, v.w};
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, bf16x2_t));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, bf16x2_t));
+    const f32x2_t r01 = {v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u)};
+    const f32x2_t r23 = {v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u)};
+    const unsigned m01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2_t));
+    const unsigned m23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2_t));
+    const f32x2_t q01 = {r01[0] - __uint_as_float(m01 << 16), r01[1] - __uint_as_float(m01 & 0xffff0000u)};
+    const f32x2_t q23 = {r23[0] - __uint_as_float(m23 << 16), r23[1] - __uint_as_float(m23 & 0xffff0000u)};
+    hi = make_uint2(h01, h23);
+    mid = make_uint2(m01, m23);
+    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(q01, bf16x2_t)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(q23, bf16x2_t)));
+}
 template <bool KC>
 __device__ __forceinline__ uint4 split_frag(const unsigned short *__restrict__ plane, int row0, int ld, int kk, int lane) {
     const int r = lane & 31, h = lane >> 5;
@@ -170,9 +189,42 @@ __device__ __forceinline__ uint4 split_frag(const unsigned short *__restrict__ p
 template <bool A_KC, bool B_KC, int BM_, int BN_, int SPLIT>
 __device__ __forceinline__ void mma_step_split(const unsigned short *__restrict__ aH, const unsigned short *__restrict__ aL,
                                                const unsigned short *__restrict__ bH, const unsigned short *__restrict__ bL,
-                                               f32x16 (&acc)[BM_ / 64][BN_ / 64], int wm, int wn, int lane) {
+                                               f32x16 (&acc)[BM_ / 64][BN_ / 64], int wm, int wn, int lane,
+                                               const unsigned short *__restrict__ aM = nullptr, const unsigned short *__restrict__ bM = nullptr) {
     constexpr int TM = BM_ / 64, TN = BN_ / 64;
     constexpr int LDAH = BM_ + 32, LDBH = BN_ + 32;
+    if constexpr (SPLIT == 3) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                ah[t] = split_frag<A_KC>(aH, wm * (BM_ / 2) + t * 32, LDAH, kk, lane);
+                am[t] = split_frag<A_KC>(aM, wm * (BM_ / 2) + t * 32, LDAH, kk, lane);
+                al[t] = split_frag<A_KC>(aL, wm * (BM_ / 2) + t * 32, LDAH, kk, lane);
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                bh[t] = split_frag<B_KC>(bH, wn * (BN_ / 2) + t * 32, LDBH, kk, lane);
+                bm[t] = split_frag<B_KC>(bM, wn * (BN_ / 2) + t * 32, LDBH, kk, lane);
+                bl[t] = split_frag<B_KC>(bL, wn * (BN_ / 2) + t * 32, LDBH, kk, lane);
+            }
+#define MRCNN_BF(x) __builtin_bit_cast(bf16x8_t, x)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {       // smallest products first
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MRCNN_BF(al[tm]), MRCNN_BF(bh[tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MRCNN_BF(ah[tm]), MRCNN_BF(bl[tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MRCNN_BF(am[tm]), MRCNN_BF(bm[tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MRCNN_BF(am[tm]), MRCNN_BF(bh[tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MRCNN_BF(ah[tm]), MRCNN_BF(bm[tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MRCNN_BF(ah[tm]), MRCNN_BF(bh[tn]), acc[tm][tn], 0, 0, 0);
+                }
+#undef MRCNN_BF
+        }
+        return;
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
         uint4 ah[TM], al[TM], bh[TN], bl[TN];           // 8 16-bit elements each
@@ -225,8 +277,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     // (split operands: two 16-bit planes per operand - KC: rows x LDKH, RC: BK x (rows + 32) elements each; in floats: half of it x 2)
     constexpr int LDAH = BM_ + 32, LDBH = BN_ + 32;
     constexpr int A_PLANE = A_KC ? BM_ * LDKH : BK * LDAH, B_PLANE = B_KC ? BN_ * LDKH : BK * LDBH;       // 16-bit elements
-    constexpr int A_ELEMS = BF3 ? A_PLANE : (A_KC ? BM_ * LDK : BK * LDA);
-    constexpr int B_ELEMS = BF3 ? B_PLANE : (B_KC ? BN_ * LDK : BK * LDB);
+    constexpr int NPL = SPLIT == 3 ? 3 : 2;            // planes per operand (16-bit elements: NPL * PLANE / 2 floats)
+    constexpr int A_ELEMS = BF3 ? A_PLANE * NPL / 2 : (A_KC ? BM_ * LDK : BK * LDA);
+    constexpr int B_ELEMS = BF3 ? B_PLANE * NPL / 2 : (B_KC ? BN_ * LDK : BK * LDB);
     constexpr int NA = BM_ / 32, NB = BN_ / 32;          // float4 loads per thread per K step
     // RC loader geometry: a k-row of width Wd floats is covered by Wd/4 threads; 256/(Wd/4) k-rows per pass
     constexpr int B_TPR = BN_ / 4, B_KPP = CONV_THREADS / B_TPR;
@@ -497,30 +550,35 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             f_h0 -= c2 ? f_hback : 0; f_off0 += c2 ? f_c2off : 0;
         }
     };
-    unsigned short *const aH = reinterpret_cast<unsigned short *>(sA), *const aL = aH + A_PLANE;
-    unsigned short *const bH = reinterpret_cast<unsigned short *>(sB), *const bL = bH + B_PLANE;
+    unsigned short *const aH = reinterpret_cast<unsigned short *>(sA), *const aL = aH + A_PLANE, *const aM = aL + A_PLANE;
+    unsigned short *const bH = reinterpret_cast<unsigned short *>(sB), *const bL = bH + B_PLANE, *const bM = bL + B_PLANE;
     auto store_step = [&]() {
         if constexpr (BF3) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                uint2 hi, lo;
-                if constexpr (SPLIT == 1) split_bf16x4(ra[i], hi, lo); else split_f16x4(ra[i], hi, lo);
+                uint2 hi, lo, mid;
+                if constexpr (SPLIT == 1) split_bf16x4(ra[i], hi, lo);
+                else if constexpr (SPLIT == 3) split3_bf16x4(ra[i], hi, mid, lo);
+                else split_f16x4(ra[i], hi, lo);
                 const int o = A_KC ? (r0 + 32 * i) * LDKH + kc * 4 : fp * LDAH + (fc + 8 * i) * 4;
                 *reinterpret_cast<uint2 *>(&aH[o]) = hi;
                 *reinterpret_cast<uint2 *>(&aL[o]) = lo;
+                if constexpr (SPLIT == 3) *reinterpret_cast<uint2 *>(&aM[o]) = mid;
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                uint2 hi, lo;
+                uint2 hi, lo, mid;
                 // half planes: the weight operand is scaled by 2^12 (exact; undone in the epilogue) - Winograd-domain filters
                 // G g G^T of 1e-2 weights are 1e-6 .. 1e-3, below half's normal range
                 if constexpr (SPLIT == 1) split_bf16x4(rb[i], hi, lo);
+                else if constexpr (SPLIT == 3) split3_bf16x4(rb[i], hi, mid, lo);
                 else if constexpr (MODE == MODE_FWD) split_f16x4(make_float4(rb[i].x * 4096.0f, rb[i].y * 4096.0f, rb[i].z * 4096.0f, rb[i].w * 4096.0f), hi, lo);
                 else split_f16x4(rb[i], hi, lo);
                 const int o = B_KC ? (r0 + 32 * i) * LDKH + kc * 4
                                    : (MODE == MODE_BWD_FILTER ? fp * LDBH + (fc + 8 * i) * 4 : (k0B + B_KPP * i) * LDBH + rcB * 4);
                 *reinterpret_cast<uint2 *>(&bH[o]) = hi;
                 *reinterpret_cast<uint2 *>(&bL[o]) = lo;
+                if constexpr (SPLIT == 3) *reinterpret_cast<uint2 *>(&bM[o]) = mid;
             }
             return;
         }
@@ -548,7 +606,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
             // the global loads share ONE basic block with the MFMAs and the scheduler can interleave them.
             load_step(sbeg + min(s + 1, nsteps - 1));
             if constexpr (BF3) {
-                mma_step_split<A_KC, B_KC, BM_, BN_, SPLIT>(aH, aL, bH, bL, acc, wm, wn, lane);
+                mma_step_split<A_KC, B_KC, BM_, BN_, SPLIT>(aH, aL, bH, bL, acc, wm, wn, lane, aM, bM);
             } else {
             mma_step<A_KC, B_KC, BM_, BN_>(sA, sB, acc, wm, wn, lane);
             // schedule: the gather loads go out after the first quarter of the step's MFMAs (their address arithmetic is
@@ -772,6 +830,13 @@ void launch_conv(ConvP &p, int zdim, TileChoice t, hipStream_t st) {
             else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64, false, 1>), grid, blk, 0, st, p);
             else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 128, false, 1>), grid, blk, 0, st, p);
             else hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 64, false, 1>), grid, blk, 0, st, p);
+            return;
+        }
+        if (split == 3) {
+            if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 128, false, 3>), grid, blk, 0, st, p);
+            else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64, false, 3>), grid, blk, 0, st, p);
+            else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 128, false, 3>), grid, blk, 0, st, p);
+            else hipLaunchKernelGGL((k_conv_igemm<MODE, 64, 64, false, 3>), grid, blk, 0, st, p);
             return;
         }
         if (split == 2) {
@@ -1781,7 +1846,7 @@ extern "C" int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3) {
 extern "C" int mrcnn_conv2d_set_split_operands(int fwd, int bwd_data, int bwd_filter) {
     const int m[3] = {fwd, bwd_data, bwd_filter};
     for (int i = 0; i < 3; ++i)
-        if (m[i] < 0 || m[i] > 2) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_split_operands: each of 0 (float32), 1 (bf16 hi/lo), 2 (half hi/lo)");
+        if (m[i] < 0 || m[i] > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_split_operands: each of 0 (float32), 1 (bf16 hi/lo), 2 (half hi/lo), 3 (bf16 hi/mid/lo, float32-accurate)");
     for (int i = 0; i < 3; ++i) g_split_mode[i] = m[i];
     return 0;
 }

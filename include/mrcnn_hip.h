@@ -179,8 +179,10 @@ int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3);
  * both Winograd batched GEMMs) of a pass (forward, backward-data, backward-filter) with three-term split operands on the 16-bit
  * MFMA - every float32 operand staged as hi + lo planes, float32 accumulation of al*bh + ah*bl + ah*bh: 0 = float32 MFMA,
  * 1 = bf16 planes (16 significant bits, float32 range; ~4e-6 per product), 2 = IEEE-half planes (22 bits, ~5e-7 per product;
- * operands must stay below 65504 and lose relative precision below 6e-5).  gfx950 has no xf32: this is what challenging the
- * 157.3 TF/s fp32-MFMA ceiling costs in accuracy and buys in time. */
+ * operands must stay below 65504 and lose relative precision below 6e-5), 3 = THREE bf16 planes hi + mid + lo (= the float32
+ * operand exactly) and the six products of weight >= 2^-16 - a float32-ACCURATE emulation (the dropped terms are <= 3 x 2^-24 of
+ * |ab|, the size of the float32 MFMA's own accumulation rounding) at 3/8 of the float32 MFMA cycles.  gfx950 has no xf32: this is
+ * what challenging the 157.3 TF/s fp32-MFMA ceiling costs in accuracy and buys in time.  Values outside 0..3: MRCNN_E_ARG. */
 int mrcnn_conv2d_set_split_operands(int fwd, int bwd_data, int bwd_filter);
 
 /* Measurement knob for bench.py's roofline split (never set on a product path): bit 0 skips the MFMA GEMM launches of

@@ -218,13 +218,14 @@ SPLIT_CASES = [  # N, H, W, Cin, Cout, K, pad
 ]
 
 
-@pytest.mark.parametrize('planes', [1, 2], ids=['bf16', 'half'])
+@pytest.mark.parametrize('planes', [1, 2, 3], ids=['bf16', 'half', 'bf16x6'])
 @pytest.mark.parametrize('case', SPLIT_CASES)
 def test_conv_split_operands_all_three_passes(case, planes):
     """Every GEMM of the three passes with hi + lo 16-bit planes per float32 operand and float32 accumulation of
     al*bh + ah*bl + ah*bh: against float64, bf16 planes within 3e-5 of the tensor scale (float32 MFMA: 5e-7), half planes within
     3e-6 - times 30 on the F(4x4) Winograd layers, whose transforms amplify every GEMM's error alike.  K- and row-contiguous
-    operand layouts (the latter through ds_read_b64_tr_b16), split-K / tail-split launches, accumulate and ReLU-mask epilogues."""
+    operand layouts (the latter through ds_read_b64_tr_b16), split-K / tail-split launches, accumulate and ReLU-mask epilogues.
+    planes = 3: hi + mid + lo bf16 planes (= the float32 operand exactly) and six products - held to the FLOAT32 kernels' own bar."""
     from chainer_maskrcnn import _hip
     N, H, W, Cin, Cout, K, p = case
     g = torch.Generator().manual_seed(900 + sum(case))
@@ -238,6 +239,8 @@ def test_conv_split_operands_all_three_passes(case, planes):
     ref_gw = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (Cout, Cin, K, K), gy.double().permute(0, 3, 1, 2), 1, p).permute(0, 2, 3, 1)
     wino = K == 3 and Cin >= 256
     tol = (3e-5 if planes == 1 else 3e-6) * (30 if wino else 1)
+    if planes == 3:
+        tol = 3e-4 if wino else 2e-6              # the bar of the float32-MFMA default (last line of this test)
     rel = lambda got, ref: (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     xd, wd, bd, gyd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(0, 0, 0))

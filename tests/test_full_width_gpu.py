@@ -44,9 +44,11 @@ MODES = {'direct': ((100000, 1 << 30, 0), (0, 0, 0)),
          # EXPLORATORY opt-in: the shipped selection with the forward-kind GEMMs (forward convolutions and both Winograd batched
          # GEMMs) on three-term split-bf16 operands (mrcnn_conv2d_set_split_bf16): the same bars as 'shipped'
          'split_bf16': ((256, 2048, 0), (2, 0, 0)), 'split_f16_fwd': ((256, 2048, 0), (2, 0, 0)), 'split_f16': ((256, 2048, 0), (2, 0, 0)),
-         'split_f16_fwd_only': ((256, 2048, 0), (2, 0, 0)), 'split_bf16_bwd_only': ((256, 2048, 0), (2, 0, 0))}
+         'split_f16_fwd_only': ((256, 2048, 0), (2, 0, 0)), 'split_bf16_bwd_only': ((256, 2048, 0), (2, 0, 0)),
+         'bf16x6': ((256, 2048, 0), (2, 0, 0)), 'bf16x6_fwd': ((256, 2048, 0), (2, 0, 0))}
 # split operands per pass (forward, backward-data, backward-filter) of the exploratory modes: 1 = bf16 hi / lo planes, 2 = half planes
-SPLIT = {'split_bf16': (1, 1, 1), 'split_f16_fwd': (2, 1, 1), 'split_f16': (2, 2, 2), 'split_f16_fwd_only': (2, 0, 0), 'split_bf16_bwd_only': (0, 1, 1)}
+SPLIT = {'split_bf16': (1, 1, 1), 'split_f16_fwd': (2, 1, 1), 'split_f16': (2, 2, 2), 'split_f16_fwd_only': (2, 0, 0), 'split_bf16_bwd_only': (0, 1, 1),
+         'bf16x6': (3, 3, 3), 'bf16x6_fwd': (3, 1, 1)}
 DEFAULT = MODES['shipped']
 NAMES = ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
 TAP = 'extractor/resnet/res5/b2'
@@ -243,6 +245,15 @@ def test_full_width_1024_batch2_split_bf16_backward_opt_in():
     # of the tensor scale (float32 MFMA: 8e-6) - two orders below the float32 noise floor of the gradients it is part of
     _check(1024, 'split_bf16_bwd_only', N=2, seed=100, G=8, iso_tol=1e-3)
     _cache.pop(('oracle', 1024, False, 2, 100, 8), None)       # ~10 GB of float64 gradients and activations
+
+
+@pytest.mark.parametrize('mode', ['bf16x6', 'bf16x6_fwd'])
+def test_full_width_512_float32_accurate_emulation_opt_in(mode):
+    """EXPLORATORY opt-in: three bf16 planes per operand (hi + mid + lo = the float32 value exactly) and the six products of weight
+    >= 2^-16 - a float32-ACCURATE GEMM on the bf16 MFMA (the dropped terms are of the size of the float32 MFMA's own accumulation
+    rounding) - in every pass ('bf16x6'), or in the forward pass with the two-plane bf16 split in the backward passes
+    ('bf16x6_fwd').  Held to ALL the bars of the float32 configuration."""
+    _check(512, mode)
 
 
 def test_full_width_512_split_half_forward_opt_in():
