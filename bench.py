@@ -74,9 +74,13 @@ def bench_roialign(args, rank, world):
     lib = _hip.lib()
     algo_bytes = 4 * (N * C * H * W + R * C * PH * PW) + 20 * R
 
+    # caller-owned scratch of the forward: the map-order permutation of the RoIs (ranking kernel + forward kernel per call)
+    nbf = lib.mrcnn_roi_align_fwd_workspace_bytes(R)
+    wsf = torch.empty((max(nbf, 1),), dtype=torch.uint8, device=dev)
+
     def fwd(sr=2):
-        _hip.check(lib.mrcnn_roi_align_fwd_f32(_hip.ptr(xt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
-                                               0.25, sr, _hip.ptr(y), _hip.stream_ptr()))
+        _hip.check(lib.mrcnn_roi_align_fwd_ws_f32(_hip.ptr(xt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
+                                                  0.25, sr, _hip.ptr(y), _hip.ptr(wsf), nbf, _hip.stream_ptr()))
 
     # caller-owned scratch of the backward (per-RoI sample tables of the table-driven kernel), sized by the library's query
     nb = max(lib.mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, R, PH, PW, 2), lib.mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, R, PH, PW, 0))
@@ -149,7 +153,7 @@ def bench_roialign(args, rank, world):
                              'event pair per launch inside the timed fwd+bwd loop (includes ~3.5 us of dispatch latency)' % (NG, GROUP)},
         'roi_align_fwd': {'avg_launch_us': round(fwd_avg_s * 1e6, 3), 'event_pair_per_launch_us': round(float(fwd_ms.mean()) * 1e3, 3),
                           'achieved_GBps': round(algo_bytes / fwd_avg_s / 1e9, 2),
-                          'frac': round(algo_bytes / fwd_avg_s / 1e9 / HBM_PEAK_GBPS, 4), 'kernel': 'k_roi_align_fwd_rows',
+                          'frac': round(algo_bytes / fwd_avg_s / 1e9 / HBM_PEAK_GBPS, 4), 'kernel': 'k_roi_map_order + k_roi_align_fwd_rows (RoIs walked in map order)',
                           'traffic': _pmc_traffic('k_roi_align_fwd')[0]},
         'roi_align_adaptive_sampling': adaptive,
     }

@@ -25,6 +25,9 @@ _MANUAL = {
     'mrcnn_roi_align_fpn_fwd_f32': (c_int, [_P(c_void_p), _P(c_int), _P(c_int), _P(c_float), c_int,
                                             c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                             c_int, c_void_p, c_void_p]),
+    'mrcnn_roi_align_fpn_fwd_ws_f32': (c_int, [_P(c_void_p), _P(c_int), _P(c_int), _P(c_float), c_int,
+                                               c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                               c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mrcnn_roi_align_fpn_bwd_f32': (c_int, [c_void_p, _P(c_void_p), _P(c_int), _P(c_int), _P(c_float),
                                             c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                             c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
@@ -62,7 +65,7 @@ def _parse_header(path):
 SIGNATURES = _parse_header(HEADER_PATH)
 
 _lib = None
-ABI_VERSION = 5          # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
+ABI_VERSION = 6          # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
 
 
 class MrcnnHipError(RuntimeError):

@@ -45,9 +45,13 @@ class _RoIAlign2D(torch.autograd.Function):
         R = rois.shape[0]
         fmt = torch.channels_last if layout == _hip.LAYOUT_NHWC else torch.contiguous_format
         y = torch.empty((R, C, outh, outw), dtype=torch.float32, device=x.device, memory_format=fmt)
-        _hip.check(_hip.lib().mrcnn_roi_align_fwd_f32(
+        from chainer_maskrcnn._hip.nn import workspace
+        nb = _hip.lib().mrcnn_roi_align_fwd_workspace_bytes(R)
+        ws = workspace(nb, x.device) if nb else None           # the map-order permutation of the RoIs
+        _hip.check(_hip.lib().mrcnn_roi_align_fwd_ws_f32(
             _hip.ptr(x), layout, N, C, H, W, _hip.ptr(rois), R, outh, outw,
-            float(spatial_scale), int(sampling_ratio), _hip.ptr(y), _hip.stream_ptr()))
+            float(spatial_scale), int(sampling_ratio), _hip.ptr(y), _hip.ptr(ws), ws.numel() if ws is not None else 0,
+            _hip.stream_ptr()))
         ctx.save_for_backward(rois)
         ctx.meta = (layout, N, C, H, W, outh, outw, float(spatial_scale), int(sampling_ratio))
         return y

@@ -36,8 +36,11 @@ def roi_align_fpn_fwd(xs, rois_xy5, levels, out_size, scales, sampling_ratio=2):
     N, C = xs[0].shape[0], xs[0].shape[3]
     R = rois_xy5.shape[0]
     y = torch.empty((R, out_size, out_size, C), dtype=torch.float32, device=rois_xy5.device)
-    check(lib().mrcnn_roi_align_fpn_fwd_f32(arr_p, Hs, Ws, sc, L, N, C, ptr(rois_xy5), ptr(levels), R, out_size,
-                                            out_size, sampling_ratio, ptr(y), stream_ptr()))
+    nb = lib().mrcnn_roi_align_fwd_workspace_bytes(R)
+    ws = workspace(nb, y.device) if nb else None          # the map-order permutation of the RoIs
+    check(lib().mrcnn_roi_align_fpn_fwd_ws_f32(arr_p, Hs, Ws, sc, L, N, C, ptr(rois_xy5), ptr(levels), R, out_size,
+                                               out_size, sampling_ratio, ptr(y), ptr(ws), ws.numel() if ws is not None else 0,
+                                               stream_ptr()))
     return y
 
 

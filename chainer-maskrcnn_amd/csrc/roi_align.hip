@@ -82,6 +82,46 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_nhwc(Levels lv, const flo
 }
 
 // ------------------------------------------------------------------------------------------
+// Forward: MAP ORDER.  The caller's RoIs arrive in sampling order (random in space), so the taps of co-resident waves are
+// spread over the whole map and a line is fetched again by other XCDs' L2s (3.4x the map on configs[1]).  This kernel
+// computes a permutation that walks the RoIs by (level, image, 64-row band of the box centre, centre column):
+// perm[rank] = RoI index (measured on configs[1], ranking + forward: caller order 33.3 us; 8 / 16 / 32 / 64 / 128-row bands
+// 32.5 / 31.6 / 29.5 / 28.5 / 28.6 us; Z order of 4..32-cell blocks 29.1-29.7; columns only 29.8; rows only 32.5).  The forward kernel processes RoI perm[i] at position i and writes output row perm[i], so the
+// result is the same bits in the same place.  Rank by counting (every thread compares its key with all R keys in LDS,
+// ties by index): R <= MAP_ORDER_MAX_R, sixteen lanes per RoI, any number of workgroups.
+// ------------------------------------------------------------------------------------------
+constexpr int MAP_ORDER_MAX_R = 8192;
+int g_fwd_map_order = 1;
+__global__ __launch_bounds__(256) void k_roi_map_order(Levels lv, const float *__restrict__ rois, const int32_t *__restrict__ levels,
+                                                       int R, int32_t *__restrict__ perm) {
+    extern __shared__ unsigned mo_keys[];
+    for (int r = threadIdx.x; r < R; r += 256) {
+        int l = levels ? levels[r] : 0;
+        l = min(max(l, 0), lv.L - 1);
+        const float *roi = rois + (size_t)r * 5;
+        const float s = lv.scale[l];
+        const int n = min(max((int)roi[0], 0), 63);
+        const float cy = 0.5f * (roi[2] + roi[4]) * s, cx = 0.5f * (roi[1] + roi[3]) * s;
+        const int iy = min(max((int)cy, 0), min(lv.H[l], 4096) - 1), ix = min(max((int)cx, 0), min(lv.W[l], 4096) - 1);
+        const unsigned pos = ((unsigned)min(iy >> 6, 255) << 12) | (unsigned)ix;
+        mo_keys[r] = ((unsigned)l << 26) | ((unsigned)n << 20) | pos;
+    }
+    __syncthreads();
+    // 16 lanes per RoI: lane q counts the keys j = q, q + 16, ... that sort before the RoI's (ties: lower index first)
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15;
+    const int rc = min(r, R - 1);
+    const unsigned k = mo_keys[rc];
+    int cnt = 0;
+#pragma unroll 8
+    for (int j = q; j < R; j += 16) {
+        const unsigned kj = mo_keys[j];
+        cnt += (kj < k || (kj == k && j < rc)) ? 1 : 0;
+    }
+    cnt += __shfl_xor(cnt, 1); cnt += __shfl_xor(cnt, 2); cnt += __shfl_xor(cnt, 4); cnt += __shfl_xor(cnt, 8);
+    if (r < R && q == 0) perm[cnt] = r;
+}
+
+// ------------------------------------------------------------------------------------------
 // Forward, NHWC, one wave per (roi, ph) ROW of bins (the default for sampling grids with PW * grid <= 64).
 // The per-bin kernel above spends ~550 VALU instructions per bin, most of them the coordinate arithmetic that all 64
 // lanes repeat; it is VALU-bound at a quarter of the HBM rate.  Here the geometry is done once per row: lane t computes
@@ -92,15 +132,18 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_nhwc(Levels lv, const flo
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(Levels lv, const float *__restrict__ rois,
                                                             const int32_t *__restrict__ levels, int R, int N, int C, int PH, int PW,
-                                                            int sr, float *__restrict__ y, int chunk) {
+                                                            int sr, float *__restrict__ y, int chunk,
+                                                            const int32_t *__restrict__ perm) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= chunk) return;
-    const int row_id = wg * 4 + wave;                  // (r, ph)
-    if (row_id >= R * PH) return;
+    const int pos_id = wg * 4 + wave;                  // (position in processing order, ph)
+    if (pos_id >= R * PH) return;
     int r, ph;
-    divmod_u24(row_id, PH, r, ph);
+    divmod_u24(pos_id, PH, r, ph);
+    if (perm) r = __builtin_amdgcn_readfirstlane(perm[r]);      // map order: process RoI perm[i], write ITS rows
+    const int row_id = r * PH + ph;
     int l = levels ? levels[r] : 0;
     l = __builtin_amdgcn_readfirstlane(min(max(l, 0), lv.L - 1));
     const int H = lv.H[l], W = lv.W[l];
@@ -1019,15 +1062,23 @@ size_t bwd_ws_bytes(const int *Hs, const int *Ws, int L, int N, int C, int R, in
     return slab_ws_bytes(Hs, Ws, L, N, C) + bwd3_ws_bytes(Hs, Ws, L, R, PH, PW, sr);
 }
 
+size_t fwd_ws_bytes(int R) { return R > 0 ? ((size_t)R * sizeof(int32_t) + 255) / 256 * 256 : 0; }
+
 // Forward: rows kernel when the x samples of a row fit one wave (fixed sampling grid, PW * grid <= 64) and every level is
 // within 32-bit buffer offsets; else the one-wave-per-bin kernel.
 void launch_fwd(Levels &lv, const float *rois, const int32_t *levels, int R, int N, int C, int PH, int PW, int sr, float *y,
-                hipStream_t st) {
+                hipStream_t st, void *ws = nullptr, size_t ws_bytes = 0) {
     bool rows_ok = sr > 0 && PW * sr <= 64 && (long long)R * PH < (1 << 24);
     for (int l = 0; l < lv.L; ++l) rows_ok = rows_ok && (unsigned long long)lv.H[l] * lv.W[l] * C * 4ull < (1ull << 32);
     if (rows_ok) {
         const int wgs = mrcnn::cdiv((long long)R * PH, 4), chunk = mrcnn::cdiv(wgs, 8);
-        hipLaunchKernelGGL(k_roi_align_fwd_rows, dim3(chunk * 8), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW, sr, y, chunk);
+        // map order (needs R ints of workspace; worth a second launch from a few waves per CU on)
+        int32_t *perm = nullptr;
+        if (g_fwd_map_order && ws && ws_bytes >= fwd_ws_bytes(R) && R >= 128 && R <= MAP_ORDER_MAX_R) {
+            perm = reinterpret_cast<int32_t *>(ws);
+            hipLaunchKernelGGL(k_roi_map_order, dim3(mrcnn::cdiv(R, 16)), dim3(256), (size_t)R * sizeof(unsigned), st, lv, rois, levels, R, perm);
+        }
+        hipLaunchKernelGGL(k_roi_align_fwd_rows, dim3(chunk * 8), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW, sr, y, chunk, perm);
     } else {
         const long long waves = (long long)R * PH * PW;
         hipLaunchKernelGGL(k_roi_align_fwd_nhwc, dim3(mrcnn::cdiv(waves, 4)), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW, sr, y);
@@ -1091,16 +1142,16 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
 
 }  // namespace
 
-extern "C" int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C, int H, int W,
-                                       const float *rois, int R, int PH, int PW, float spatial_scale,
-                                       int sampling_ratio, float *y, void *stream) {
+extern "C" int mrcnn_roi_align_fwd_ws_f32(const float *x, int layout, int N, int C, int H, int W,
+                                          const float *rois, int R, int PH, int PW, float spatial_scale,
+                                          int sampling_ratio, float *y, void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_common(y, rois, x, layout, N, C, H, W, R, PH, PW, sampling_ratio)) return e;
     if (R == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (layout == MRCNN_LAYOUT_NHWC && (C % 4) == 0) {
         Levels lv{};
         lv.L = 1; lv.x[0] = x; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
-        launch_fwd(lv, rois, nullptr, R, N, C, PH, PW, sampling_ratio, y, st);
+        launch_fwd(lv, rois, nullptr, R, N, C, PH, PW, sampling_ratio, y, st, ws, ws_bytes);
     } else {
         const long long total = (long long)R * C * PH * PW;
         hipLaunchKernelGGL(k_roi_align_fwd_generic, dim3(mrcnn::cdiv(total, 256)), dim3(256), 0, st, x,
@@ -1108,6 +1159,19 @@ extern "C" int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C,
                            sampling_ratio, y, strides_of(layout, C, PH, PW), layout == MRCNN_LAYOUT_NHWC);
     }
     MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C, int H, int W,
+                                       const float *rois, int R, int PH, int PW, float spatial_scale,
+                                       int sampling_ratio, float *y, void *stream) {
+    return mrcnn_roi_align_fwd_ws_f32(x, layout, N, C, H, W, rois, R, PH, PW, spatial_scale, sampling_ratio, y, nullptr, 0, stream);
+}
+
+extern "C" size_t mrcnn_roi_align_fwd_workspace_bytes(int R) { return fwd_ws_bytes(R); }
+
+extern "C" int mrcnn_roi_align_set_fwd_map_order(int on) {
+    g_fwd_map_order = on ? 1 : 0;
     return 0;
 }
 
@@ -1151,19 +1215,26 @@ static int fill_levels(Levels &lv, const float *const *xs, float *const *gxs, co
     return 0;
 }
 
-extern "C" int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs, const int *Ws,
-                                           const float *scales, int L, int N, int C, const float *rois,
-                                           const int32_t *levels, int R, int PH, int PW,
-                                           int sampling_ratio, float *y, void *stream) {
+extern "C" int mrcnn_roi_align_fpn_fwd_ws_f32(const float *const *xs, const int *Hs, const int *Ws,
+                                              const float *scales, int L, int N, int C, const float *rois,
+                                              const int32_t *levels, int R, int PH, int PW,
+                                              int sampling_ratio, float *y, void *ws, size_t ws_bytes, void *stream) {
     if (!xs || !y || (R > 0 && (!rois || !levels))) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_fwd: null pointer");
     if (N <= 0 || C <= 0 || (C % 4) || PH <= 0 || PW <= 0 || R < 0 || sampling_ratio < 0)
         return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_fwd: bad sizes (C must be a multiple of 4)");
     Levels lv{};
     if (int e = fill_levels(lv, xs, nullptr, Hs, Ws, scales, L)) return e;
     if (R == 0) return 0;
-    launch_fwd(lv, rois, levels, R, N, C, PH, PW, sampling_ratio, y, (hipStream_t)stream);
+    launch_fwd(lv, rois, levels, R, N, C, PH, PW, sampling_ratio, y, (hipStream_t)stream, ws, ws_bytes);
     MRCNN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs, const int *Ws,
+                                           const float *scales, int L, int N, int C, const float *rois,
+                                           const int32_t *levels, int R, int PH, int PW,
+                                           int sampling_ratio, float *y, void *stream) {
+    return mrcnn_roi_align_fpn_fwd_ws_f32(xs, Hs, Ws, scales, L, N, C, rois, levels, R, PH, PW, sampling_ratio, y, nullptr, 0, stream);
 }
 
 extern "C" int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 5
+#define MRCNN_ABI_VERSION 6
 
 enum {
     MRCNN_OK = 0,
@@ -63,6 +63,17 @@ const char *mrcnn_last_error(void);
 int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C, int H, int W,
                             const float *rois, int R, int PH, int PW, float spatial_scale,
                             int sampling_ratio, float *y, void *stream);
+/* The same call with the caller's scratch of mrcnn_roi_align_fwd_workspace_bytes(R) bytes (ABI v6).  With it the NHWC fast path
+ * walks the RoIs in MAP ORDER: a first small kernel ranks them by (level, image, 64-row band of the box centre, centre column)
+ * and the forward kernel processes RoI perm[i] at position i, writing ITS output rows - the reference's per-RoI loop
+ * (fpn_roi_mask_head.py:59-61) has no order dependence, the results are the same bits in the same rows, and co-resident waves
+ * read neighbouring map lines instead of random ones.  Without scratch (or R < 128, or R > 8192): caller order. */
+int mrcnn_roi_align_fwd_ws_f32(const float *x, int layout, int N, int C, int H, int W,
+                               const float *rois, int R, int PH, int PW, float spatial_scale,
+                               int sampling_ratio, float *y, void *ws, size_t ws_bytes, void *stream);
+size_t mrcnn_roi_align_fwd_workspace_bytes(int R);
+/* A/B switch of the map-order walk (process-wide; default 1 = on when scratch is given). */
+int mrcnn_roi_align_set_fwd_map_order(int on);
 
 /* Backward (adjoint scatter).  gx is fully overwritten (callee zero-fills cells no RoI touches).
  * Fast path (NHWC, C%4==0, PH,PW<=16, sampling_ratio>0): owner-computes tiles, no atomics,
@@ -99,6 +110,11 @@ int mrcnn_roi_align_fpn_fwd_f32(const float *const *xs, const int *Hs, const int
                                 const float *scales, int L, int N, int C, const float *rois,
                                 const int32_t *levels, int R, int PH, int PW,
                                 int sampling_ratio, float *y, void *stream);
+/* forward with scratch of mrcnn_roi_align_fwd_workspace_bytes(R) bytes: map-order walk, see mrcnn_roi_align_fwd_ws_f32 */
+int mrcnn_roi_align_fpn_fwd_ws_f32(const float *const *xs, const int *Hs, const int *Ws,
+                                   const float *scales, int L, int N, int C, const float *rois,
+                                   const int32_t *levels, int R, int PH, int PW,
+                                   int sampling_ratio, float *y, void *ws, size_t ws_bytes, void *stream);
 int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws,
                                 const float *scales, int L, int N, int C, const float *rois,
                                 const int32_t *levels, int R, int PH, int PW,

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'libmrcnn_hip.so lacks %s' % n
         assert n in _hip.SIGNATURES, 'ctypes binding lacks %s' % n
     assert set(_hip.SIGNATURES) == set(names)
-    assert lib.mrcnn_abi_version() == 5
+    assert lib.mrcnn_abi_version() == 6
 
 
 def test_argument_errors_do_not_need_a_device():

@@ -257,3 +257,39 @@ def test_fpn_backward_coarse_levels_split_matches_oracle(P, bwd_variant):
             np.testing.assert_allclose(a[l], ref, **tol)
             np.testing.assert_allclose(b[l], ref, **tol)
             np.testing.assert_array_equal(a[l], a2[l])
+
+
+@pytest.mark.parametrize('R', [127, 128, 513, 3000])
+def test_forward_map_order_walk_gives_the_same_rows(R):
+    """ABI v6: with scratch the forward ranks the RoIs by (level, image, band of the box centre, centre column) and walks them in that
+    order, writing every RoI's OWN output rows: identical bits to the caller-order walk (single level and FPN; RoIs with equal keys,
+    bad image indices, edge RoIs; R below the threshold, not a multiple of 64, several ranking workgroups)."""
+    from chainer_maskrcnn.model.head import fpn_roi_mask_head as hd
+    rs = np.random.RandomState(R)
+    N, C, P = 2, 64, 7
+    shapes = [(100, 136), (50, 68), (25, 34), (13, 17)]
+    scales = [1 / 4., 1 / 8., 1 / 16., 1 / 32.]
+    xy = rand_rois_xy(rs, R, N, 100, 136, 0.25)
+    xy[:6] = _edge_rois(N, 100, 136, 0.25)
+    xy[10:20] = xy[10]                                         # ten RoIs with one key: ties are broken by index
+    xy[20, 0], xy[21, 0] = 7, -3                               # image index out of range: rows of zeros either way
+    lev = rs.choice(4, size=R, p=[0.1, 0.2, 0.3, 0.4]).astype(np.int32)
+    xs = [torch.from_numpy(rs.standard_normal((N, h, w, C)).astype(np.float32)).to(DEV) for h, w in shapes]
+    rt, lt = torch.from_numpy(xy).to(DEV), torch.from_numpy(lev).to(DEV)
+    lib = _hip.lib()
+    assert lib.mrcnn_roi_align_fwd_workspace_bytes(R) >= 4 * R
+    out = {}
+    try:
+        for on in (1, 0):
+            _hip.check(lib.mrcnn_roi_align_set_fwd_map_order(on))
+            out[on] = (hd.roi_align_fpn_fwd(xs, rt, lt, P, scales),
+                       roi_align_2d(xs[0].permute(0, 3, 1, 2), rt, P, P, 0.25))
+    finally:
+        _hip.check(lib.mrcnn_roi_align_set_fwd_map_order(1))
+    for a, b in zip(out[1], out[0]):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
+    # and the ABI's scratch-less entry point is the caller-order walk
+    y = torch.full((R, P, P, C), float('nan'), device=DEV)
+    _hip.check(lib.mrcnn_roi_align_fwd_f32(_hip.ptr(xs[0]), 1, N, C, 100, 136, _hip.ptr(rt), R, P, P, 0.25, 2, _hip.ptr(y), _hip.stream_ptr()))
+    assert torch.equal(y.permute(0, 3, 1, 2), out[0][1])

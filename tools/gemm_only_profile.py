@@ -10,6 +10,7 @@ from chainer_maskrcnn.optimizers import MomentumSGD, WeightDecay
 from chainer_maskrcnn.utils.synthetic import make_batch
 from chainer_maskrcnn._hip import nn as hnn, lib, check
 dev = torch.device('cuda:0')
+SPLIT = tuple(int(v) for v in sys.argv[1].split(',')) if len(sys.argv) > 1 else (0, 0, 0)      # mrcnn_conv2d_set_split_operands
 model = MaskRCNN(n_fg_class=80, device=dev)
 chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows='all')
 opt = MomentumSGD(lr=1e-3).setup(chain); opt.add_hook(WeightDecay(5e-4))
@@ -26,6 +27,7 @@ geoms = {}
 for rec in recs:
     geoms[(rec[0], rec[6], rec[7])] = geoms.get((rec[0], rec[6], rec[7]), 0) + 1
 rows = []
+check(lib().mrcnn_conv2d_set_split_operands(*SPLIT))
 base = hnn.winograd_pass_tiles()
 for (kind, g, tiles), cnt in geoms.items():
     hnn.set_winograd_pass_tiles(*tiles)
@@ -49,7 +51,9 @@ for (kind, g, tiles), cnt in geoms.items():
     rows.append((t * cnt, kind, g, tiles, cnt, t, exe))
 hnn.set_winograd_pass_tiles(*base)
 tot = sum(r[0] for r in rows); totf = sum(r[6] * r[4] for r in rows)
-print('GEMM-only total %.2f ms, %.1f TF/s executed' % (tot * 1e3, totf / tot / 1e12))
+print('split operands %s: GEMM-only total %.2f ms, %.1f TF/s executed (float32-equivalent flops)' % (SPLIT, tot * 1e3, totf / tot / 1e12))
+for kd in ('fwd', 'bwd_data', 'bwd_filter'):
+    print('  %-10s %.2f ms' % (kd, 1e3 * sum(r[0] for r in rows if r[1] == kd)))
 print('%-10s %-38s %5s %3s %8s %7s %9s' % ('kind', 'N,H,W,Cin,Cout,KH,KW,s,p', 'tiles', 'n', 'ms', 'TF/s', 'lost@135'))
 for r in sorted(rows, key=lambda r: -(r[0] - r[6] * r[4] / 135e12)):
     print('%-10s %-38s %5s %3d %8.3f %7.1f %9.3f' % (r[1], ','.join(map(str, r[2])), ''.join(str(t) if t >= 0 else 'd' for t in r[3]), r[4], r[0] * 1e3,
