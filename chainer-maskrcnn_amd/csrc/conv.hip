@@ -68,6 +68,7 @@ struct ConvP {
     // FWD, un-split launches only (nullable): BatchNorm statistics of the output from the epilogue.  Row (M tile * 2 + wave
     // row) of bn_part (rows, 2, Ng) receives the sums and the sums of squares of that wave's BM_/2 output rows, per channel.
     float *bn_part;
+    int dbg;              // split-operand kernels, measurement only (mrcnn_debug_conv_parts): 1 = no MFMA, 2 = no in-loop global loads, 4 = no epilogue
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -604,10 +605,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         for (int s = 0; s < nsteps; ++s) {
             // Always load (the last iteration re-reads its own step: harmless) so that the gather address arithmetic and
             // the global loads share ONE basic block with the MFMAs and the scheduler can interleave them.
-            load_step(sbeg + min(s + 1, nsteps - 1));
             if constexpr (BF3) {
-                mma_step_split<A_KC, B_KC, BM_, BN_, SPLIT>(aH, aL, bH, bL, acc, wm, wn, lane, aM, bM);
+                if (!(p.dbg & 2)) load_step(sbeg + min(s + 1, nsteps - 1));
+                if (!(p.dbg & 1)) mma_step_split<A_KC, B_KC, BM_, BN_, SPLIT>(aH, aL, bH, bL, acc, wm, wn, lane, aM, bM);
             } else {
+            load_step(sbeg + min(s + 1, nsteps - 1));
             mma_step<A_KC, B_KC, BM_, BN_>(sA, sB, acc, wm, wn, lane);
             // schedule: the gather loads go out after the first quarter of the step's MFMAs (their address arithmetic is
             // hidden under those), so the data is back long before the LDS stores at the end of the step
@@ -622,6 +624,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     }
 
     // ---- epilogue: acc[tm][tn][reg] -> C[m][n], row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
+    if constexpr (BF3) { if (p.dbg & 4) return; }
     if constexpr (SPLIT == 2 && MODE == MODE_FWD) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -778,14 +781,20 @@ int slots_for(int bm, int bn) {
 }
 
 struct TileChoice { int bm, bn; };
+int g_plan_fill = 2;          // workgroups per CU a tile choice / split-K plan aims for (measurement knob: mrcnn_debug_conv_plan)
+int g_plan_filter_rounds = 1;
+int g_dbg_parts = 0;
+int g_plan_force_tile = 0;    // measurement: the forward / backward-data tile choice is 1 = 128x64, 2 = 64x64 (applied BEFORE the split plans)
 // The largest tile that still gives every CU at least two workgroups (measured on gfx950: 128x128 ~118 TF, 128x64 ~103,
 // 64x64 ~80 on large layers, so a smaller tile only pays when the big one cannot fill the chip); narrow GEMM sides
 // (<= 64) take the 64-wide tile.
 template <int MODE>
 TileChoice choose_tile(long long M, long long Ng, long long z) {
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Ng + bn - 1) / bn) * z; };
-    const long long fill = 2ll * g_cus();
+    const long long fill = (long long)g_plan_fill * g_cus();
     const bool narrow_n = Ng <= 64, narrow_m = M <= 64;
+    if (g_plan_force_tile == 2) return {64, 64};
+    if (g_plan_force_tile == 1 && !narrow_m) return {128, 64};
     if (!narrow_n && !narrow_m && tiles(128, 128) >= fill) return {128, 128};
     if (!narrow_m && tiles(128, 64) >= fill) return {128, 64};
     if (!narrow_n && !narrow_m && tiles(128, 128) >= fill * 3 / 4) return {128, 128};
@@ -817,6 +826,7 @@ void launch_conv(ConvP &p, int zdim, TileChoice t, hipStream_t st) {
         total = p.tail_full + (tiles - p.tail_full) * p.tail_ks;
     }
     const dim3 grid(total), blk(CONV_THREADS);
+    p.dbg = g_dbg_parts;
     if (g_debug_skip & 1) return;
     if (p.smallc) {
         if (MODE == MODE_FWD) hipLaunchKernelGGL((k_conv_igemm<MODE_FWD, 128, 64, true>), grid, blk, 0, st, p);
@@ -1052,7 +1062,7 @@ void filter_plan(const ConvP &p, int &ksplit, int &kchunk) {
                                      : (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.Cin, t.bn) * (p.wbatch_rows ? p.wbatch_n : p.KH * p.KW);
     const long long slots = p.smallc ? slots_of<MODE_BWD_FILTER, 64, 128, true>() : slots_for<MODE_BWD_FILTER>(t.bm, t.bn);
     const long long maxsplit = std::max(1ll, P / (8 * BK));
-    long long want = slots / tiles;                               // one full round
+    long long want = slots * g_plan_filter_rounds / tiles;        // one full round
     if (want < 1) want = 1;
     ksplit = (int)std::max(1ll, std::min(std::min(want, maxsplit), 256ll));
     kchunk = (int)(((P + ksplit - 1) / ksplit + BK - 1) / BK * BK);
@@ -1065,7 +1075,7 @@ template <int MODE>
 void data_plan(ConvP &p, TileChoice &t, int nsteps) {
     t = choose_tile<MODE>(p.M, p.Ng, 1);
     const long long tiles = (long long)mrcnn::cdiv(p.M, t.bm) * mrcnn::cdiv(p.Ng, t.bn);
-    const long long fill = 2ll * g_cus();
+    const long long fill = (long long)g_plan_fill * g_cus();
     p.ksplit = 1;
     p.kchunk = nsteps;
     p.tail_ks = 0;
@@ -1804,7 +1814,7 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
     const long long Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
     if (Ho <= 0 || Wo <= 0) return 0;
     const long long a = (long long)N * Ho * Wo * Cout, b = (long long)N * H * W * Cin;
-    const long long fill = 2ll * g_cus();
+    const long long fill = (long long)g_plan_fill * g_cus();
     // split-K only engages when the 64x64 tiling has fewer than `fill` tiles: M*Ng < fill*4096
     const long long cap = fill * 8192;
     long long need = 0;
@@ -1817,6 +1827,17 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
     if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD)) bytes = std::max(bytes, wino_ws_bytes(N, H, W, Cin, Cout, PASS_FWD));
     if (wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad, PASS_BWD_DATA)) bytes = std::max(bytes, wino_ws_bytes(N, H, W, Cout, Cin, PASS_BWD_DATA));
     return bytes;
+}
+
+extern "C" int mrcnn_debug_conv_parts(int mask) {
+    g_dbg_parts = mask & 7;
+    return 0;
+}
+
+extern "C" int mrcnn_debug_conv_plan(int fill, int filter_rounds, int force_tile) {
+    if (fill < 1 || fill > 16 || filter_rounds < 1 || filter_rounds > 8) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_conv_plan: fill 1..16, filter_rounds 1..8");
+    g_plan_fill = fill; g_plan_filter_rounds = filter_rounds; g_plan_force_tile = force_tile;
+    return 0;
 }
 
 extern "C" int mrcnn_conv2d_set_winograd_thresholds(int min_channels, int min_pixels, int tile) {

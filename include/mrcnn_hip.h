@@ -200,6 +200,12 @@ int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3);
  * |ab|, the size of the float32 MFMA's own accumulation rounding) at 3/8 of the float32 MFMA cycles.  gfx950 has no xf32: this is
  * what challenging the 157.3 TF/s fp32-MFMA ceiling costs in accuracy and buys in time.  Values outside 0..3: MRCNN_E_ARG. */
 int mrcnn_conv2d_set_split_operands(int fwd, int bwd_data, int bwd_filter);
+/* Measurement knob (tools/gemm_only_profile.py): workgroups per CU the tile choice and the forward / backward-data split-K plan aim
+ * for (default 2) and the rounds of workgroup slots the filter-gradient split-K fills (default 1). */
+int mrcnn_debug_conv_plan(int fill, int filter_rounds, int force_tile);
+/* Measurement knob, split-operand GEMM kernels only: 1 = the MFMAs are skipped, 2 = the global loads inside the K loop are skipped,
+ * 4 = the epilogue is skipped (results are garbage while a bit is set; where does such a kernel's time go?). */
+int mrcnn_debug_conv_parts(int mask);
 
 /* Measurement knob for bench.py's roofline split (never set on a product path): bit 0 skips the MFMA GEMM launches of
  * the convolution calls, bit 1 skips every other kernel they launch (Winograd transforms, slab / tail / column sums).

@@ -28,6 +28,9 @@ for rec in recs:
     geoms[(rec[0], rec[6], rec[7])] = geoms.get((rec[0], rec[6], rec[7]), 0) + 1
 rows = []
 check(lib().mrcnn_conv2d_set_split_operands(*SPLIT))
+if len(sys.argv) > 2:
+    check(lib().mrcnn_debug_conv_plan(*[int(v) for v in sys.argv[2].split(',')]))
+PARTS = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0]
 base = hnn.winograd_pass_tiles()
 for (kind, g, tiles), cnt in geoms.items():
     hnn.set_winograd_pass_tiles(*tiles)
@@ -41,20 +44,28 @@ for (kind, g, tiles), cnt in geoms.items():
           'bwd_filter': lambda: hnn.conv2d_bwd_filter_raw(x, gy, tuple(w.shape), stride, pad, False, wino_v=v)}[kind]
     check(lib().mrcnn_conv2d_set_debug_skip(2))
     fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5): fn()
-    e1.record(); torch.cuda.synchronize()
+    ts = []
+    for parts in PARTS:
+        check(lib().mrcnn_debug_conv_parts(parts))
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 5 * 1e-3)
+    check(lib().mrcnn_debug_conv_parts(0))
     check(lib().mrcnn_conv2d_set_debug_skip(0))
-    t = e0.elapsed_time(e1) / 5 * 1e-3
+    t = ts[0]
     exe = 2.0 * lib().mrcnn_conv2d_executed_macs(*g, {'fwd': 0, 'bwd_data': 1, 'bwd_filter': 2}[kind])
-    rows.append((t * cnt, kind, g, tiles, cnt, t, exe))
+    rows.append((t * cnt, kind, g, tiles, cnt, t, exe, ts))
 hnn.set_winograd_pass_tiles(*base)
 tot = sum(r[0] for r in rows); totf = sum(r[6] * r[4] for r in rows)
 print('split operands %s: GEMM-only total %.2f ms, %.1f TF/s executed (float32-equivalent flops)' % (SPLIT, tot * 1e3, totf / tot / 1e12))
 for kd in ('fwd', 'bwd_data', 'bwd_filter'):
     print('  %-10s %.2f ms' % (kd, 1e3 * sum(r[0] for r in rows if r[1] == kd)))
 print('%-10s %-38s %5s %3s %8s %7s %9s' % ('kind', 'N,H,W,Cin,Cout,KH,KW,s,p', 'tiles', 'n', 'ms', 'TF/s', 'lost@135'))
+if len(PARTS) > 1:
+    print('totals per debug_conv_parts mask %s: %s ms' % (PARTS, ' '.join('%.2f' % (1e3 * sum(r[7][i] * r[4] for r in rows)) for i in range(len(PARTS)))))
 for r in sorted(rows, key=lambda r: -(r[0] - r[6] * r[4] / 135e12)):
-    print('%-10s %-38s %5s %3d %8.3f %7.1f %9.3f' % (r[1], ','.join(map(str, r[2])), ''.join(str(t) if t >= 0 else 'd' for t in r[3]), r[4], r[0] * 1e3,
-                                                  r[6] / r[5] / 1e12, (r[0] - r[6] * r[4] / 135e12) * 1e3))
+    print('%-10s %-38s %5s %3d %8.3f %7.1f %9.3f  %s' % (r[1], ','.join(map(str, r[2])), ''.join(str(t) if t >= 0 else 'd' for t in r[3]), r[4], r[0] * 1e3,
+                                                  r[6] / r[5] / 1e12, (r[0] - r[6] * r[4] / 135e12) * 1e3, ' '.join('%.0f' % (v * 1e6) for v in r[7])))
