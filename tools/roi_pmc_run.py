@@ -15,7 +15,9 @@ rois_xy = torch.from_numpy(yx[:, [0, 2, 1, 4, 3]].copy()).to(dev)
 gyt = torch.from_numpy(gy).to(dev).contiguous(memory_format=torch.channels_last)
 y = torch.empty((R, C, PH, PW), device=dev).contiguous(memory_format=torch.channels_last)
 gx = torch.empty_like(xt)
+nbf = lib.mrcnn_roi_align_fwd_workspace_bytes(R)
+wsf = torch.empty((max(nbf, 1),), dtype=torch.uint8, device=dev)       # the forward's map-order permutation
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
-    _hip.check(lib.mrcnn_roi_align_fwd_f32(_hip.ptr(xt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW, 0.25, 2, _hip.ptr(y), _hip.stream_ptr()))
+    _hip.check(lib.mrcnn_roi_align_fwd_ws_f32(_hip.ptr(xt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW, 0.25, 2, _hip.ptr(y), _hip.ptr(wsf), nbf, _hip.stream_ptr()))
     _hip.check(lib.mrcnn_roi_align_bwd_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW, 0.25, 2, _hip.ptr(gx), _hip.stream_ptr()))
 torch.cuda.synchronize()

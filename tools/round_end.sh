@@ -18,7 +18,11 @@ rocprofv3 --kernel-trace --stats -d $O/prof_roi --output-format csv -- python3 $
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python3 $R/tools/step_pmc_run.py 2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python3 $R/tools/step_pmc_run.py 2 > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_m -- python3 $R/tools/step_pmc_run.py 2 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_rf -- python3 $R/tools/roi_pmc_run.py 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_rw -- python3 $R/tools/roi_pmc_run.py 5 > /dev/null 2>&1
 cd $R
+python tools/pmc_roi_traffic.py $O/pmc_rf $O/pmc_rw > $O/roialign_pmc_traffic.json 2> $O/pmc_roi.err
+rm -rf $O/pmc_rf $O/pmc_rw
 python tools/pmc_step_traffic.py $O/pmc_f $O/pmc_w 2 > $O/step_pmc_traffic.json 2> $O/pmc_traffic.err
 python tools/pmc_mfma_summary.py $O/pmc_m 2 > $O/conv_pmc_mfma.json 2> $O/pmc_mfma.err
 rm -rf $O/pmc_f $O/pmc_w $O/pmc_m
