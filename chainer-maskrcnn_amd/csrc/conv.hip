@@ -782,7 +782,7 @@ int slots_for(int bm, int bn) {
 
 struct TileChoice { int bm, bn; };
 int g_plan_fill = 2;          // workgroups per CU a tile choice / split-K plan aims for (measurement knob: mrcnn_debug_conv_plan)
-int g_plan_filter_rounds = 1;
+int g_plan_filter_rounds = 2;     // in HALF rounds of workgroup slots
 int g_dbg_parts = 0;
 int g_plan_force_tile = 0;    // measurement: the forward / backward-data tile choice is 1 = 128x64, 2 = 64x64 (applied BEFORE the split plans)
 // The largest tile that still gives every CU at least two workgroups (measured on gfx950: 128x128 ~118 TF, 128x64 ~103,
@@ -1062,7 +1062,7 @@ void filter_plan(const ConvP &p, int &ksplit, int &kchunk) {
                                      : (long long)mrcnn::cdiv(p.Cout, t.bm) * mrcnn::cdiv(p.Cin, t.bn) * (p.wbatch_rows ? p.wbatch_n : p.KH * p.KW);
     const long long slots = p.smallc ? slots_of<MODE_BWD_FILTER, 64, 128, true>() : slots_for<MODE_BWD_FILTER>(t.bm, t.bn);
     const long long maxsplit = std::max(1ll, P / (8 * BK));
-    long long want = slots * g_plan_filter_rounds / tiles;        // one full round
+    long long want = slots * g_plan_filter_rounds / 2 / tiles;    // one full round
     if (want < 1) want = 1;
     ksplit = (int)std::max(1ll, std::min(std::min(want, maxsplit), 256ll));
     kchunk = (int)(((P + ksplit - 1) / ksplit + BK - 1) / BK * BK);
@@ -1835,7 +1835,7 @@ extern "C" int mrcnn_debug_conv_parts(int mask) {
 }
 
 extern "C" int mrcnn_debug_conv_plan(int fill, int filter_rounds, int force_tile) {
-    if (fill < 1 || fill > 16 || filter_rounds < 1 || filter_rounds > 8) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_conv_plan: fill 1..16, filter_rounds 1..8");
+    if (fill < 1 || fill > 16 || filter_rounds < 1 || filter_rounds > 8) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_conv_plan: fill 1..16, filter_rounds (in half rounds) 1..8");
     g_plan_fill = fill; g_plan_filter_rounds = filter_rounds; g_plan_force_tile = force_tile;
     return 0;
 }

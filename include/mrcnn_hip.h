@@ -201,7 +201,8 @@ int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3);
  * what challenging the 157.3 TF/s fp32-MFMA ceiling costs in accuracy and buys in time.  Values outside 0..3: MRCNN_E_ARG. */
 int mrcnn_conv2d_set_split_operands(int fwd, int bwd_data, int bwd_filter);
 /* Measurement knob (tools/gemm_only_profile.py): workgroups per CU the tile choice and the forward / backward-data split-K plan aim
- * for (default 2) and the rounds of workgroup slots the filter-gradient split-K fills (default 1). */
+ * for (default 2), the HALF rounds of workgroup slots the filter-gradient split-K fills (default 2 = one round), and a forced forward /
+ * backward-data tile (0 = the planner's choice, 1 = 128x64, 2 = 64x64). */
 int mrcnn_debug_conv_plan(int fill, int filter_rounds, int force_tile);
 /* Measurement knob, split-operand GEMM kernels only: 1 = the MFMAs are skipped, 2 = the global loads inside the K loop are skipped,
  * 4 = the epilogue is skipped (results are garbage while a bit is set; where does such a kernel's time go?). */
