@@ -17,9 +17,8 @@ def _declared_symbols():
 
 
 def test_library_exports_every_declared_symbol():
-    if not os.path.exists(_hip.LIB_PATH):
-        import __graft_entry__
-        __graft_entry__.build()
+    import __graft_entry__
+    __graft_entry__.build()            # the driver's "does it build" entry (make is a no-op when the library is current)
     lib = _hip.lib()
     names = _declared_symbols()
     assert len(names) >= 7
@@ -27,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'libmrcnn_hip.so lacks %s' % n
         assert n in _hip.SIGNATURES, 'ctypes binding lacks %s' % n
     assert set(_hip.SIGNATURES) == set(names)
-    assert lib.mrcnn_abi_version() == 6
+    assert lib.mrcnn_abi_version() == _hip.ABI_VERSION == 6
 
 
 def test_argument_errors_do_not_need_a_device():
