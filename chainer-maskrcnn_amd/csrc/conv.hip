@@ -68,7 +68,7 @@ struct ConvP {
     // FWD, un-split launches only (nullable): BatchNorm statistics of the output from the epilogue.  Row (M tile * 2 + wave
     // row) of bn_part (rows, 2, Ng) receives the sums and the sums of squares of that wave's BM_/2 output rows, per channel.
     float *bn_part;
-    int dbg;              // split-operand kernels, measurement only (mrcnn_debug_conv_parts): 1 = no MFMA, 2 = no in-loop global loads, 4 = no epilogue
+    int dbg;              // split-operand kernels, measurement only (mrcnn_debug_conv_parts): 1 = no MFMA, 2 = no in-loop global loads, 4 = no epilogue (1, 2: plain loop only), 8 = plain K loop
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -598,6 +598,79 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
         }
     };
 
+    // Split operands, pipelined K loop: the raw operands of step s+1 are split into their planes in REGISTERS while the MFMAs
+    // of step s run (the ~700 VALU cycles of the split in the MFMAs' shadow instead of between the two barriers), and the loads of
+    // step s+2 go out as soon as the split has consumed the registers - a whole step of latency cover instead of one MFMA phase.
+    uint2 pa[BF3 ? NA : 1][3], pb[BF3 ? NB : 1][3];              // [hi, lo, mid]
+    auto split_regs = [&]() {
+        if constexpr (BF3) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if constexpr (SPLIT == 1) split_bf16x4(ra[i], pa[i][0], pa[i][1]);
+                else if constexpr (SPLIT == 3) split3_bf16x4(ra[i], pa[i][0], pa[i][2], pa[i][1]);
+                else split_f16x4(ra[i], pa[i][0], pa[i][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if constexpr (SPLIT == 1) split_bf16x4(rb[i], pb[i][0], pb[i][1]);
+                else if constexpr (SPLIT == 3) split3_bf16x4(rb[i], pb[i][0], pb[i][2], pb[i][1]);
+                else if constexpr (MODE == MODE_FWD) split_f16x4(make_float4(rb[i].x * 4096.0f, rb[i].y * 4096.0f, rb[i].z * 4096.0f, rb[i].w * 4096.0f), pb[i][0], pb[i][1]);
+                else split_f16x4(rb[i], pb[i][0], pb[i][1]);
+            }
+        }
+    };
+    auto store_planes = [&]() {
+        if constexpr (BF3) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int o = A_KC ? (r0 + 32 * i) * LDKH + kc * 4 : fp * LDAH + (fc + 8 * i) * 4;
+                *reinterpret_cast<uint2 *>(&aH[o]) = pa[i][0];
+                *reinterpret_cast<uint2 *>(&aL[o]) = pa[i][1];
+                if constexpr (SPLIT == 3) *reinterpret_cast<uint2 *>(&aM[o]) = pa[i][2];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int o = B_KC ? (r0 + 32 * i) * LDKH + kc * 4
+                                   : (MODE == MODE_BWD_FILTER ? fp * LDBH + (fc + 8 * i) * 4 : (k0B + B_KPP * i) * LDBH + rcB * 4);
+                *reinterpret_cast<uint2 *>(&bH[o]) = pb[i][0];
+                *reinterpret_cast<uint2 *>(&bL[o]) = pb[i][1];
+                if constexpr (SPLIT == 3) *reinterpret_cast<uint2 *>(&bM[o]) = pb[i][2];
+            }
+        }
+    };
+    bool piped = false;
+    if constexpr (BF3) piped = (p.dbg & 8) == 0;               // default; mrcnn_debug_conv_parts(8) = the plain loop (A/B)
+    if (piped && nsteps > 0) {
+        load_step(sbeg);
+        split_regs();
+        store_planes();
+        load_step(sbeg + min(1, nsteps - 1));
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            mma_step_split<A_KC, B_KC, BM_, BN_, SPLIT>(aH, aL, bH, bL, acc, wm, wn, lane, aM, bM);
+            split_regs();                                        // step s+1's planes (garbage after the last step: not stored)
+            // the planes are only read after the barrier: without this pin hipcc sinks the whole split behind it
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) asm volatile("" : "+v"(pa[i][j].x), "+v"(pa[i][j].y));
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) asm volatile("" : "+v"(pb[i][j].x), "+v"(pb[i][j].y));
+            load_step(sbeg + min(s + 2, nsteps - 1));
+            // one MFMA, then a handful of the split's VALU instructions in its shadow
+#pragma unroll
+            for (int i = 0; i < TM * TN * (SPLIT == 3 ? 6 : 3) * (BK / 16); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, SPLIT == 3 ? 6 : 8, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (s + 1 < nsteps) store_planes();
+            __syncthreads();
+        }
+    } else
     if (nsteps > 0) {
         load_step(sbeg);
         store_step();
@@ -1830,7 +1903,7 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
 }
 
 extern "C" int mrcnn_debug_conv_parts(int mask) {
-    g_dbg_parts = mask & 7;
+    g_dbg_parts = mask & 15;          // 8: the three-plane kernels run the plain K loop instead of the pipelined one
     return 0;
 }
 

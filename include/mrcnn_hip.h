@@ -205,7 +205,9 @@ int mrcnn_conv2d_set_split_operands(int fwd, int bwd_data, int bwd_filter);
  * backward-data tile (0 = the planner's choice, 1 = 128x64, 2 = 64x64). */
 int mrcnn_debug_conv_plan(int fill, int filter_rounds, int force_tile);
 /* Measurement knob, split-operand GEMM kernels only: 1 = the MFMAs are skipped, 2 = the global loads inside the K loop are skipped,
- * 4 = the epilogue is skipped (results are garbage while a bit is set; where does such a kernel's time go?). */
+ * 4 = the epilogue is skipped (results are garbage while one of these bits is set; where does such a kernel's time go?);
+ * 8 = the three-plane (bf16x6) kernels run the plain K loop (split + LDS stores between the barriers) instead of the pipelined one
+ * (split in registers in the MFMAs' shadow, loads two steps ahead) - same results, for A/B.  Bits 1 and 2 act on the plain loop. */
 int mrcnn_debug_conv_parts(int mask);
 
 /* Measurement knob for bench.py's roofline split (never set on a product path): bit 0 skips the MFMA GEMM launches of

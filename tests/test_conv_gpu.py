@@ -218,7 +218,7 @@ SPLIT_CASES = [  # N, H, W, Cin, Cout, K, pad
 ]
 
 
-@pytest.mark.parametrize('planes', [1, 2, 3], ids=['bf16', 'half', 'bf16x6'])
+@pytest.mark.parametrize('planes', [1, 2, 3, 11], ids=['bf16', 'half', 'bf16x6', 'bf16x6_plain_loop'])
 @pytest.mark.parametrize('case', SPLIT_CASES)
 def test_conv_split_operands_all_three_passes(case, planes):
     """Every GEMM of the three passes with hi + lo 16-bit planes per float32 operand and float32 accumulation of
@@ -227,6 +227,7 @@ def test_conv_split_operands_all_three_passes(case, planes):
     operand layouts (the latter through ds_read_b64_tr_b16), split-K / tail-split launches, accumulate and ReLU-mask epilogues.
     planes = 3: hi + mid + lo bf16 planes (= the float32 operand exactly) and six products - held to the FLOAT32 kernels' own bar."""
     from chainer_maskrcnn import _hip
+    piped, planes = planes == 11, (3 if planes == 11 else planes)      # 11: bf16x6 with the plain K loop (mrcnn_debug_conv_parts(8)) instead of the pipelined default
     N, H, W, Cin, Cout, K, p = case
     g = torch.Generator().manual_seed(900 + sum(case))
     x = torch.randn((N, H, W, Cin), generator=g)
@@ -245,6 +246,7 @@ def test_conv_split_operands_all_three_passes(case, planes):
     xd, wd, bd, gyd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(0, 0, 0))
     _hip.check(_hip.lib().mrcnn_conv2d_set_split_operands(planes, planes, planes))
+    _hip.check(_hip.lib().mrcnn_debug_conv_parts(8 if piped else 0))
     try:
         y = hnn.conv2d_fwd_raw(xd, wd, bd, 1, p, False)
         assert torch.equal(y, hnn.conv2d_fwd_raw(xd, wd, bd, 1, p, False))                 # reproducible
@@ -262,6 +264,7 @@ def test_conv_split_operands_all_three_passes(case, planes):
         assert rel(gb, gy.double().sum((0, 1, 2))) < 2e-5
     finally:
         _hip.check(_hip.lib().mrcnn_conv2d_set_split_operands(0, 0, 0))
+        _hip.check(_hip.lib().mrcnn_debug_conv_parts(0))
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))
     # and the default is untouched: float32 MFMA again
     assert rel(hnn.conv2d_fwd_raw(xd, wd, bd, 1, p, False), ref_y) < (3e-4 if wino else 2e-6)
