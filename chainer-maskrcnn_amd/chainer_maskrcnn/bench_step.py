@@ -118,7 +118,7 @@ def bench_step(args, rank, world):
     split_ips = {}
     if world == 1 and not tiles:
         from chainer_maskrcnn._hip import lib, check
-        for name, mode in (('bf16x6', (3, 3, 3)), ('split_bf16_backward', (0, 1, 1)), ('split_half_forward_bf16_backward', (2, 1, 1))):
+        for name, mode in (('bf16x6', (3, 3, 3)), ('bf16x6_backward', (0, 3, 3)), ('split_bf16_backward', (0, 1, 1)), ('split_half_forward_bf16_backward', (2, 1, 1))):
             check(lib().mrcnn_conv2d_set_split_operands(*mode))
             try:
                 for _ in range(2):
@@ -199,6 +199,7 @@ def bench_step(args, rank, world):
     if split_ips:
         out['config']['exploratory_opt_in_split_operands'] = {
             'images_per_sec_float32_accurate_bf16x6_all_passes': round(split_ips['bf16x6'], 3),
+            'images_per_sec_f32_forward_bf16x6_backward': round(split_ips['bf16x6_backward'], 3),
             'images_per_sec_f32_forward_bf16x3_backward': round(split_ips['split_bf16_backward'], 3),
             'images_per_sec_f16x3_forward_bf16x3_backward': round(split_ips['split_half_forward_bf16_backward'], 3),
             'dtype': 'float32 tensors; GEMM operands staged as hi + lo 16-bit planes (bf16: 16 significant bits, half: 22), products '
