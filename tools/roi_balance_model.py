@@ -1,0 +1,109 @@
+"""CPU model of the ROIAlign backward's load balance on BASELINE configs[1] (no GPU): entries and candidates per 4x4 patch from the RoIs, VALU
+work per wave = 900 + 55 x candidates + 48 x entries instructions (the measured phase medians), workgroup -> (XCD, CU) as the hardware deals
+them (id % 8, then round robin over the 32 CUs), wave s -> SIMD s.  Prints the most loaded SIMD against the mean for (i) the shipped order,
+(ii) heavy patches split into parts, (iii) tiles sorted by work and dealt serpentine over the CUs with the patches of a workgroup permuted over the
+SIMDs - what a planned launch could reach IF the per-tile work were known before the launch."""
+import sys, numpy as np
+import os
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, 'chainer-maskrcnn_amd'))
+from chainer_maskrcnn.utils.synthetic import config2_inputs
+x, yx, gy = config2_inputs()
+N,C,H,W = x.shape; R=yx.shape[0]; P=7; sr=2; scale=0.25
+rois = yx[:,[0,2,1,4,3]]
+def axis(start, binsz, p, i, size):
+    c = (start + p*binsz) + ((i+0.5)*binsz)/sr
+    if c < -1.0 or c > size: return []
+    c = max(c,0.0); lo=int(c)
+    if lo >= size-1: return [size-1]
+    return [lo, lo+1]
+TY, TX = (H+3)//4, (W+3)//4
+E = np.zeros((TY,TX),int); Cn = np.zeros((TY,TX),int)
+for r in range(R):
+    _,x1,y1,x2,y2 = rois[r]; x1*=scale;y1*=scale;x2*=scale;y2*=scale
+    rw=max(x2-x1,1.0); rh=max(y2-y1,1.0); bw=rw/P; bh=rh/P
+    seen=set()
+    rowsets=[sorted(set(sum([axis(y1,bh,p,i,H) for i in range(sr)],[]))) for p in range(P)]
+    colsets=[sorted(set(sum([axis(x1,bw,p,i,W) for i in range(sr)],[]))) for p in range(P)]
+    for ph in range(P):
+        py=set(y//4 for y in rowsets[ph])
+        for pw in range(P):
+            px=set(xx//4 for xx in colsets[pw])
+            for a in py:
+                for b in px:
+                    E[a,b]+=1; seen.add((a,b))
+    for (a,b) in seen: Cn[a,b]+=1
+print('patches',TY*TX,'entries total',E.sum(),'mean',E.mean(),'max',E.max(),'cand mean',Cn.mean(),'max',Cn.max())
+# work per wave (VALU instr): overhead + per-candidate + per-entry
+def work(E,Cn): return 900 + 55*Cn + 48*E
+tiles_y,tiles_x=(H+7)//8,(W+7)//8
+ntiles=tiles_y*tiles_x
+def simulate(units):   # units: list of WGs, each = list of 4 wave works ; in dispatch order
+    nwg=len(units); chunk=(nwg+7)//8
+    load=np.zeros((8,32,4))
+    cnt=np.zeros((8,32),int)
+    # hardware: blockIdx b -> XCD b%8, sequential within XCD round robin over CUs
+    for b in range(chunk*8):
+        wg=(b&7)*chunk+(b>>3)
+        if (b>>3)>=chunk or wg>=nwg: continue
+        xcd=b%8; j=b//8; cu=j%32
+        load[xcd,cu]+=units[wg]
+    return load
+units=[]
+for ty in range(tiles_y):
+    for tx in range(tiles_x):
+        w=[]
+        for s in range(4):
+            a,b=2*ty+(s>>1),2*tx+(s&1)
+            w.append(work(E[a,b],Cn[a,b]) if a<TY and b<TX else 0)
+        units.append(np.array(w,float))
+L=simulate(units)
+print('baseline: max SIMD load %.0f mean %.0f ratio %.2f ; slowest wave %.0f'%(L.max(),L.mean(),L.max()/L.mean(),max(u.max() for u in units)))
+for T in (60,45,35,25):
+    units2=[]; extra=[]
+    for ty in range(tiles_y):
+        for tx in range(tiles_x):
+            w=[]; parts=[]
+            for s in range(4):
+                a,b=2*ty+(s>>1),2*tx+(s&1)
+                if a<TY and b<TX:
+                    k=max(1,int(np.ceil(E[a,b]/T)))
+                    w.append(work(E[a,b]/k,Cn[a,b]/k+ (0 if k==1 else 2)))
+                    for z in range(1,k): parts.append(work(E[a,b]/k,Cn[a,b]/k+2))
+                else: w.append(0)
+            units2.append(np.array(w,float))
+            extra+=parts
+    # pack extra parts into WGs of 4 waves
+    extra.sort(reverse=True)
+    for i in range(0,len(extra),4):
+        w=extra[i:i+4]+[0]*(4-len(extra[i:i+4])); units2.append(np.array(w,float))
+    L2=simulate(units2)
+    print('split T=%d: WGs %d (+%d part waves) max %.0f mean %.0f -> kernel x%.2f ; slowest wave %.0f'%(T,len(units2),len(extra),L2.max(),L2.mean(),L2.max()/L.max(),max(u.max() for u in units2)))
+
+# --- balanced assignment: tiles sorted by work, serpentine over 256 CUs; patches of a WG permuted over the SIMDs
+tw=[(u.sum(),i) for i,u in enumerate(units)]
+tw.sort(reverse=True)
+load=np.zeros((256,4))
+for k,(w,i) in enumerate(tw):
+    rnd,pos=divmod(k,256)
+    cu=pos if rnd%2==0 else 255-pos
+    ws=sorted(units[i],reverse=True)
+    order=np.argsort(load[cu])          # lightest SIMD gets the heaviest patch
+    for a,s in zip(ws,order): load[cu,s]+=a
+print('serpentine + SIMD permutation: max %.0f mean %.0f -> kernel x%.2f'%(load.max(),load.mean(),load.max()/L.max()))
+# greedy LPT over SIMD granularity (upper bound on what any static assignment can do with waves as units, 4 waves of a WG on ONE CU)
+load=np.zeros((256,4)); cnt=np.zeros(256,int)
+for w,i in tw:
+    cands=np.where(cnt<4)[0]
+    cu=cands[np.argmin(load[cands].sum(1))]
+    ws=sorted(units[i],reverse=True); order=np.argsort(load[cu])
+    for a,s in zip(ws,order): load[cu,s]+=a
+    cnt[cu]+=1
+print('greedy LPT by CU + SIMD permutation: max %.0f mean %.0f -> kernel x%.2f'%(load.max(),load.mean(),load.max()/L.max()))
+# without SIMD permutation
+load=np.zeros((256,4))
+for k,(w,i) in enumerate(tw):
+    rnd,pos=divmod(k,256)
+    cu=pos if rnd%2==0 else 255-pos
+    load[cu]+=units[i]
+print('serpentine only: max %.0f -> kernel x%.2f'%(load.max(),load.max()/L.max()))
