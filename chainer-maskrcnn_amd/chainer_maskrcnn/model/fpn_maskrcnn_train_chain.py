@@ -223,9 +223,9 @@ class FPNMaskRCNNTrainChain(object):
         else:
             Rm, Hm, Wm, Cm = mask_out.shape
             K = head.n_keypoints
-            g_mask = torch.zeros_like(mask_out)
-            ops.softmax_ce(mask_out, t['gt_roi_mask'].view(-1), Rm * K, Hm * Wm, (K, Hm * Wm * Cm, 1, Cm), gx=g_mask,
-                           out=losses[4])
+            xmap = (K, Hm * Wm * Cm, 1, Cm)
+            g_mask = torch.empty_like(mask_out) if ops.softmax_ce_fills_gradient(Rm * K, Hm * Wm, xmap) else torch.zeros_like(mask_out)
+            ops.softmax_ce(mask_out, t['gt_roi_mask'].view(-1), Rm * K, Hm * Wm, xmap, gx=g_mask, out=losses[4])
 
         main.wait_stream(aux)
         if aux is not main:             # allocated on the aux stream, consumed by the RPN backward on the main stream

@@ -352,6 +352,11 @@ int mrcnn_sgd_momentum_wd_f32(float *p, const float *g, float *v, size_t n, floa
  * gx (nullable) receives d loss / d logits.
  * ---------------------------------------------------------------------------------------- */
 size_t mrcnn_loss_workspace_bytes(void);
+/* softmax_ce: element (r, j) of the logical (M, K) logits lives at (r / A) * gs + (r % A) * rs + j * es floats (gx: ggs, grs, ges).
+ * Rows that are CHANNELS of an NHWC (G, K, C) tensor (rs = 1, es = C, gs = K * C, A <= C, C a multiple of 4 that divides 1024, K >= 64:
+ * the keypoint loss of train_keypoints.py:21-27, 17 heat maps in 32 padded channels) take a coalesced kernel - one workgroup per group,
+ * float4 loads over the (position, channel) plane, loss and gradient from one launch - which writes EVERY element of gx (zeros in the
+ * channels >= A and in the ignored rows); on the other paths gx receives the K (Kfill) columns of its M rows only. */
 int mrcnn_softmax_ce_f32(const float *x, int A, long long gs, long long rs, long long es, const int32_t *t,
                          int M, int K, int ignore_label, float *loss_out, float *gx, long long ggs,
                          long long grs, long long ges, int Kfill, void *ws, size_t ws_bytes, void *stream);

@@ -43,20 +43,34 @@ def test_softmax_cross_entropy_all_ignored():
     assert out[0].item() == 0 and torch.all(gx == 0)
 
 
-def test_softmax_cross_entropy_keypoint_layout():
-    """rows = (roi, keypoint), elements strided over NHWC positions (train_keypoints.py:21-27)."""
-    rs = np.random.RandomState(0)
-    R, HW, K, Cm = 3, 49, 17, 32
-    x = rs.standard_normal((R, HW, Cm)).astype(np.float32)
+@pytest.mark.parametrize('R,HW,K,Cm', [(3, 49, 17, 32), (5, 3136, 17, 32), (1300, 64, 17, 32), (4, 200, 3, 4), (2, 777, 40, 64), (2, 100, 17, 20)])
+def test_softmax_cross_entropy_keypoint_layout(R, HW, K, Cm):
+    """rows = (roi, keypoint), elements strided over NHWC positions (train_keypoints.py:21-27): the one-wave-per-row kernel (HW < 64
+    or a channel count the coalesced kernel does not take) and the channel-interleaved kernel (one workgroup per RoI, float4 loads
+    over the (position, channel) plane, loss partials and gradient from one launch, more RoIs than partial slots); with the
+    coalesced kernel the callee writes the WHOLE gradient tensor - zeros in the padded channels and the ignored rows - so a
+    NaN-filled buffer must come back finite."""
+    rs = np.random.RandomState(HW + K)
+    x = (3.0 * rs.standard_normal((R, HW, Cm))).astype(np.float32)
+    x[0, HW // 2, 0] = 60.0                                    # a dominant logit: the running maximum moves late
     t = rs.randint(-1, HW, (R, K)).astype(np.int32)
+    t[-1] = -1                                                 # a RoI whose rows are all ignored
     logical = x[:, :, :K].transpose(0, 2, 1).reshape(R * K, HW)
     loss, g = ol.softmax_cross_entropy(logical, t.reshape(-1))
     xd = torch.from_numpy(x).to(DEV)
-    gx = torch.zeros_like(xd)
-    out, gx = ops.softmax_ce(xd, torch.from_numpy(t.reshape(-1)).to(DEV), R * K, HW, (K, HW * Cm, 1, Cm), gx=gx)
+    xmap = (K, HW * Cm, 1, Cm)
+    fills = ops.softmax_ce_fills_gradient(R * K, HW, xmap)
+    assert fills == (HW >= 64 and Cm in (4, 32, 64))
+    gx = torch.full_like(xd, float('nan')) if fills else torch.zeros_like(xd)
+    out, gx = ops.softmax_ce(xd, torch.from_numpy(t.reshape(-1)).to(DEV), R * K, HW, xmap, gx=gx)
     _close(out[0].item(), loss)
-    got = gx.cpu().numpy()[:, :, :K].transpose(0, 2, 1).reshape(R * K, HW)
-    _close(got, g)
+    assert out[1].item() == max(1, int((t != -1).sum()))
+    got = gx.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert (got[:, :, K:] == 0).all() and (got[-1] == 0).all()
+    _close(got[:, :, :K].transpose(0, 2, 1).reshape(R * K, HW), g)
+    out2, _ = ops.softmax_ce(xd, torch.from_numpy(t.reshape(-1)).to(DEV), R * K, HW, xmap, want_grad=False)      # loss only
+    assert out2[0].item() == out[0].item()
 
 
 @pytest.mark.parametrize('sigma', [1.0, 3.0])
