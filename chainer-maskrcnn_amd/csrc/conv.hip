@@ -1229,6 +1229,7 @@ int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes
 constexpr int WINO_ROWS = 128;          // Tp = T rounded up to this: a GEMM tile never straddles two k
 
 int g_wino_min_channels = 256, g_wino_min_pixels = 2048, g_wino_tile = 0;      // tile 0 = automatic, 2 or 4 = forced
+int g_wino_banded = 1;        // input transforms: XCD-banded workgroup order (mrcnn_debug_wino_banded(0) = launch order, for A/B)
 // Per pass (PASS_FWD / PASS_BWD_DATA / PASS_BWD_FILTER) override of the tile: 0 = follow g_wino_tile, 2 / 4 = forced,
 // -1 = the pass never takes the Winograd path.  F(4x4,3x3) amplifies float32 rounding by ~|A|^2 |B|^2 |G|^2: harmless on
 // activations (measured 1.5e-4 of the tensor scale on the full network) but visible in gradients of layers whose own
@@ -1461,10 +1462,23 @@ __device__ __forceinline__ void wino_input_body(const float *__restrict__ x, flo
         for (int q = 0; q < A_; ++q) v4bufst(rsV, vo + (unsigned)(rr * A_ + q) * ks, 0, row[q]);
     }
 }
+// Workgroup -> tile-range order of the input transforms.  Neighbouring tile rows share two of their six input rows; dealt in launch
+// order, workgroups b and b + 1 sit on DIFFERENT XCDs (the hardware deals workgroup ids round robin over the 8 XCDs) and the shared rows
+// are fetched from HBM once per XCD: 173 MB for the 103-MB input of a mask-head layer (rocprofv3 FETCH_SIZE).  Banded, every XCD works
+// on a contiguous range of virtual blocks and the overlap is an L2 hit.  `g` = hardware workgroup id, `first` = id of the first
+// workgroup of this family in the launch (the filter blocks of k_wino_input_filter come before), `nb` = blocks of the family.
+__device__ __forceinline__ unsigned xcd_banded(unsigned g, unsigned first, unsigned nb, int on) {
+    const unsigned b = g - first;
+    if (!on) return b;
+    const unsigned f0 = first & 7u, n2 = nb + f0, b2 = b + f0;         // pretend f0 phantom blocks in front: id % 8 is then the XCD
+    const unsigned q = n2 >> 3, r = n2 & 7u, xcd = b2 & 7u;
+    const unsigned v2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b2 >> 3);
+    return v2 - min(xcd + 1u, f0);                                       // the phantoms are the first block of bands 0 .. f0-1
+}
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
-                                                    int th, int tw, long long T, long long Tp) {
-    wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, blockIdx.x);
+                                                    int th, int tw, long long T, long long Tp, int banded) {
+    wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, 0, gridDim.x, banded));
 }
 // Filter and input transform of one convolution call in ONE launch (the first `fblocks` workgroups transform the filter):
 // the two are independent, and a separate 5-8 us filter launch in front of every Winograd GEMM is pure launch latency on the
@@ -1472,9 +1486,10 @@ __global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x,
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_input_filter(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
                                                            int th, int tw, long long T, long long Tp, const float *__restrict__ w,
-                                                           float *__restrict__ U, int Cout_w, int Cin_w, int transposed, unsigned fblocks) {
+                                                           float *__restrict__ U, int Cout_w, int Cin_w, int transposed, unsigned fblocks,
+                                                           int banded) {
     if (blockIdx.x < fblocks) wino_filter_body<M_>(w, U, Cout_w, Cin_w, transposed, blockIdx.x);
-    else wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, blockIdx.x - fblocks);
+    else wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, fblocks, gridDim.x - fblocks, banded));
 }
 
 // y (m x m pixels of tile t) = A^T M A + bias, then ReLU | + old y (accumulate) | zeroed where relu_x <= 0.
@@ -1810,7 +1825,7 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     float *Vw = (float *)(base + L.v), *Wt = (float *)(base + L.w), *slabs = (float *)(base + L.slabs), *dU = (float *)(base + L.du);
     const float *V = v_cached ? v_cached : Vw;       // the forward pass's transformed input, kept by the caller
     const long long nin = g.Tp * (Cin / 4), nout = g.Tp * (Cout / 4);      // the transform kernels zero the padded rows
-    if (!v_cached) WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), x, Vw, N, H, W, Cin, g.th, g.tw, g.T, g.Tp);
+    if (!v_cached) WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), x, Vw, N, H, W, Cin, g.th, g.tw, g.T, g.Tp, g_wino_banded);
     const int C4o = Cout / 4;
     const bool fuse_bias = bias_part && bias_rows && !w_cached && C4o <= 256 && 256 % C4o == 0 && !(g_debug_skip & 2);
     if (bias_rows) *bias_rows = fuse_bias ? (int)((nout + 255) / 256) : 0;
@@ -1866,7 +1881,7 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
         }
     } else
         WINO_LAUNCH(k_wino_input_filter, g, dim3(fblocks + (unsigned)((nin + 255) / 256)), in, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp, w, U,
-                    transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, fblocks);
+                    transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, fblocks, g_wino_banded);
     // batched GEMM: 1x1 "convolution" over nk*Tp pixels, weight matrix selected by the row block
     ConvP p = make_p(1, 1, (int)(g.nk * g.Tp), Cin, Cout, 1, 1, 1, 0);
     p.a = V; p.b = U; p.c = Mb;
@@ -1904,6 +1919,11 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
 
 extern "C" int mrcnn_debug_conv_parts(int mask) {
     g_dbg_parts = mask & 15;          // 8: the three-plane kernels run the plain K loop instead of the pipelined one
+    return 0;
+}
+
+extern "C" int mrcnn_debug_wino_banded(int on) {
+    g_wino_banded = on ? 1 : 0;
     return 0;
 }
 
