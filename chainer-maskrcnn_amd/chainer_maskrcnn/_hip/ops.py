@@ -157,13 +157,15 @@ def upsample2x_bwd(gout, gtop=None, top_shape=None):
     return gtop
 
 
-def subsample_bwd(gsub, x_shape, stride, gx=None):
-    _ck(gsub, gx)
+def subsample_bwd(gsub, x_shape, stride, gx=None, relu_x=None):
+    """relu_x (x_shape, nullable): the scattered positions are zeroed where relu_x <= 0 (after the accumulation); positions off
+    the lattice keep what gx held - pass a gx that is already masked."""
+    _ck(gsub, gx, relu_x)
     N, H, W, C = x_shape
     acc = gx is not None
     if gx is None:
         gx = _empty(x_shape, gsub.device)
-    check(lib().mrcnn_subsample_bwd_f32(ptr(gsub), ptr(gx), N, H, W, C, stride, int(acc), stream_ptr()))
+    check(lib().mrcnn_subsample_bwd_f32(ptr(gsub), ptr(gx), N, H, W, C, stride, int(acc), ptr(relu_x), stream_ptr()))
     return gx
 
 

@@ -9,6 +9,11 @@ Tensors are NHWC; the image enters as (N,H,W,4) with a zero 4th channel.
 from chainer_maskrcnn.nn.core import Conv, BatchNorm, Bottleneck, ParamStore
 from chainer_maskrcnn._hip import ops
 
+# The ReLU backward of a bottleneck's output is applied by the kernels that WRITE that output's gradient (data-gradient epilogues,
+# lattice scatter) instead of by the block's own bn3 backward: bn3's two backward kernels read two streams instead of three and the
+# separate shortcut gradient is not written (same numbers bit for bit; False = the round-2 data flow, kept for A/B).
+MASK_IN_PRODUCER = True
+
 
 class FeaturePyramidNetwork(object):
     feat_strides = [4, 8, 16, 32, 64]
@@ -85,22 +90,27 @@ class FeaturePyramidNetwork(object):
         self.conv_p6.bwd(t['p6'], g_p6, gx_acc=g_p5)
         g_m2 = self.conv_p2.bwd(t['p2'], g_p2)
         ops.upsample2x_bwd(g_m2, gtop=g_p3)
-        g_c2 = self.lat_p2.bwd(t['lat2'], g_m2)
+        # c2..c5 are ReLU outputs (the last block of a stage): every contribution to their gradient is masked where it is written
+        # (mask_gx: data-gradient epilogue / lattice scatter), so the blocks' bn3 backward gets its gy with the mask applied
+        g_c2 = self.lat_p2.bwd(t['lat2'], g_m2, mask_gx=MASK_IN_PRODUCER)
         g_m3 = self.conv_p3.bwd(t['p3'], g_p3)
         ops.upsample2x_bwd(g_m3, gtop=g_p4)
-        g_c3 = self.lat_p3.bwd(t['lat3'], g_m3)
+        g_c3 = self.lat_p3.bwd(t['lat3'], g_m3, mask_gx=MASK_IN_PRODUCER)
         g_m4 = self.conv_p4.bwd(t['p4'], g_p4)
         ops.upsample2x_bwd(g_m4, gtop=g_p5)
-        g_c4 = self.lat_p4.bwd(t['lat4'], g_m4)
-        g_c5 = self.toplayer.bwd(t['top'], g_p5)
+        g_c4 = self.lat_p4.bwd(t['lat4'], g_m4, mask_gx=MASK_IN_PRODUCER)
+        g_c5 = self.toplayer.bwd(t['top'], g_p5, mask_gx=MASK_IN_PRODUCER)
         if progress:
             progress(self.toplayer.name)        # the FPN layers are registered after the ResNet
         # The gradient of c2..c4 is (lateral gradient) + (input gradient of the next stage): the next
         # stage's first block accumulates its input gradient into the lateral one (gx_acc).
         acc_for = {id(self.stages[k][0]): g for k, g in ((1, g_c2), (2, g_c3), (3, g_c4))}
         g = g_c5
+        first = t['blocks'][0][0]
         for b, ctx in reversed(t['blocks']):
-            g = b.bwd(ctx, g, gx_acc=acc_for.get(id(b)))
+            # every block's output gradient arrives masked (from the block after it, or from toplayer / the laterals above); its own
+            # input gradient is masked for the block before it - except the first block, whose input is the max-pool output
+            g = b.bwd(ctx, g, gx_acc=acc_for.get(id(b)), gy_masked=MASK_IN_PRODUCER, mask_gx=MASK_IN_PRODUCER and b is not first)
             if progress:
                 progress(b.conv1.name)
         g = ops.maxpool2x2_bwd(t['pool_in'], g)

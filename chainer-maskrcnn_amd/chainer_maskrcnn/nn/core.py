@@ -240,15 +240,15 @@ class Conv(object):
             if not need_gx:
                 return None
             if self.stride == 1:
-                assert not (mask_gx and gx_acc is not None)
+                # (the epilogue masks the TOTAL: (old + product) where relu_x > 0 - direct, split-K and tail-split launches alike)
+                assert not (mask_gx and gx_acc is not None) or self.k == 1
                 return hnn.conv2d_bwd_data_raw(gy, self.W, tuple(x.shape), 1, self.pad, out=gx_acc,
                                                relu_x=x if mask_gx else None)
-            assert not mask_gx
             assert self.k == 1 and self.pad == 0, 'strided backward-data only for 1x1 convolutions'
             g_sub = self.bwd_data_sub(gy)
         finally:
             hnn.LOGICAL = None
-        return ops.subsample_bwd(g_sub, tuple(x.shape), self.stride, gx=gx_acc)
+        return ops.subsample_bwd(g_sub, tuple(x.shape), self.stride, gx=gx_acc, relu_x=x if mask_gx else None)
 
     def bwd_data_sub(self, gy, out=None):
         """Data gradient of a strided 1x1 convolution on the subsampled lattice (N,Ho,Wo,Cin)."""
@@ -286,8 +286,13 @@ class BatchNorm(object):
         # kept for (or read by) the backward pass
         return y, (x, y if (residual is not None or not relu) else None, mean, invstd, relu)
 
-    def bwd(self, ctx, gy, want_gres=False):
+    def bwd(self, ctx, gy, want_gres=False, gy_masked=False):
+        """gy_masked: the producer of gy already zeroed it where this layer's ReLU output is <= 0 (its data-gradient epilogue
+        ran with mask_gx on the tensor this layer produced): no mask stream is read here and gres would be gy itself."""
         x, y, mean, invstd, relu = ctx
+        if gy_masked:
+            assert relu and not want_gres
+            relu, y = False, None
         from chainer_maskrcnn._hip import lib, check, ptr, stream_ptr
         C = self.c
         P = x.numel() // C
@@ -334,9 +339,17 @@ class Bottleneck(object):
         y, b3 = self.bn3.fwd(h3, relu=True, residual=r, partials=p3)
         return y, (c1, b1, c2, b2, c3, b3, c4, b4)
 
-    def bwd(self, ctx, gy, gx_acc=None):
+    def bwd(self, ctx, gy, gx_acc=None, gy_masked=False, mask_gx=False):
+        """gy_masked: gy already carries this block's output ReLU mask (its producer ran with mask_gx on this block's output);
+        bn3's backward then reads two streams instead of three and writes no separate shortcut gradient (it IS gy).
+        mask_gx: the block's input is itself a ReLU output (the previous block's): the returned gradient - the sum of all its
+        contributions - is zeroed where that input is <= 0, in the epilogue of the kernel that writes it last."""
         c1, b1, c2, b2, c3, b3, c4, b4 = ctx
-        g_h3, g_r = self.bn3.bwd(b3, gy, want_gres=True)
+        if gy_masked:
+            g_h3, _ = self.bn3.bwd(b3, gy, gy_masked=True)
+            g_r = gy
+        else:
+            g_h3, g_r = self.bn3.bwd(b3, gy, want_gres=True)
         g_a2 = self.conv3.bwd(c3, g_h3)
         g_h2, _ = self.bn2.bwd(b2, g_a2)
         g_a1 = self.conv2.bwd(c2, g_h2)
@@ -344,14 +357,14 @@ class Bottleneck(object):
         if not self.project:
             if gx_acc is not None:
                 g_r = ops.add(g_r, gx_acc, out=gx_acc)
-            return self.conv1.bwd(c1, g_h1, gx_acc=g_r)
+            return self.conv1.bwd(c1, g_h1, gx_acc=g_r, mask_gx=mask_gx)
         g_h4, _ = self.bn4.bwd(b4, g_r)
         if self.stride == 1:
             gx = self.conv1.bwd(c1, g_h1, gx_acc=gx_acc)
-            return self.conv4.bwd(c4, g_h4, gx_acc=gx)
+            return self.conv4.bwd(c4, g_h4, gx_acc=gx, mask_gx=mask_gx)
         # both strided 1x1 convolutions read the same lattice: sum on the lattice, scatter once
         self.conv1.bwd(c1, g_h1, need_gx=False)
         self.conv4.bwd(c4, g_h4, need_gx=False)
         g_sub = self.conv1.bwd_data_sub(g_h1)
         self.conv4.bwd_data_sub(g_h4, out=g_sub)
-        return ops.subsample_bwd(g_sub, tuple(c1[0].shape), self.stride, gx=gx_acc)
+        return ops.subsample_bwd(g_sub, tuple(c1[0].shape), self.stride, gx=gx_acc, relu_x=c1[0] if mask_gx else None)

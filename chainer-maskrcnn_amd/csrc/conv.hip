@@ -2096,7 +2096,8 @@ extern "C" int mrcnn_conv2d_bwd_data_f32(const float *gy, const float *w, float 
                                                     "handled by the host as a subsample + stride-1 conv)", stride);
     ConvP p = make_p(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (Cin == 4) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: Cin == 4 (image layer) has no data gradient");
-    if (relu_x && accumulate) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "conv2d_bwd_data: relu_x with accumulate");
+    // relu_x with accumulate: every path (direct epilogue, split-K / tail-split sums, Winograd output transform) adds the old value
+    // first and masks the TOTAL - the ReLU backward of the tensor gx is the gradient of, applied where its last contribution lands
     if (wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad, PASS_BWD_DATA) && ws && ws_bytes >= wino_ws_bytes(N, H, W, Cout, Cin, PASS_BWD_DATA))
         return wino_conv(gy, w, gx, N, H, W, Cout, Cin, true, nullptr, 0, accumulate, relu_x, ws, ws_bytes, (hipStream_t)stream, nullptr,
                          wino_w, wino_w ? gbias : nullptr, gbias_accumulate);

@@ -509,7 +509,8 @@ __global__ __launch_bounds__(NT) void k_upsample_bwd(const float *__restrict__ g
 
 // Backward of y[n,ho,wo] = x[n,ho*s,wo*s]: gx fully written (zeros off the lattice) or accumulated.
 __global__ __launch_bounds__(NT) void k_subsample_bwd(const float *__restrict__ gsub, float *__restrict__ gx, int N,
-                                                      int H, int W, int Ho, int Wo, int C4, int s, int accumulate) {
+                                                      int H, int W, int Ho, int Wo, int C4, int s, int accumulate,
+                                                      const float *__restrict__ relu_x) {
     const size_t n4 = (size_t)N * H * W * C4;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
         const Nhwc4 ix = split_nhwc4(i, C4, W, H, n4 > 0xFFFFFFFFull);
@@ -519,10 +520,21 @@ __global__ __launch_bounds__(NT) void k_subsample_bwd(const float *__restrict__ 
             if (!on) continue;
             const float4 g = ld4(gsub + ((((size_t)n * Ho + h / s) * Wo + w / s) * C4 + c) * 4);
             const float4 o = ld4(gx + i * 4);
-            st4(gx + i * 4, make_float4(o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w));
+            float4 v = make_float4(o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w);
+            if (relu_x) {
+                const float4 xm = ld4(relu_x + i * 4);
+                v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f; v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
+            }
+            st4(gx + i * 4, v);
         } else {
             float4 g = f4(0.f);
-            if (on) g = ld4(gsub + ((((size_t)n * Ho + h / s) * Wo + w / s) * C4 + c) * 4);
+            if (on) {
+                g = ld4(gsub + ((((size_t)n * Ho + h / s) * Wo + w / s) * C4 + c) * 4);
+                if (relu_x) {
+                    const float4 xm = ld4(relu_x + i * 4);
+                    g.x = xm.x > 0.f ? g.x : 0.f; g.y = xm.y > 0.f ? g.y : 0.f; g.z = xm.z > 0.f ? g.z : 0.f; g.w = xm.w > 0.f ? g.w : 0.f;
+                }
+            }
             st4(gx + i * 4, g);
         }
     }
@@ -971,11 +983,11 @@ extern "C" int mrcnn_upsample2x_bwd_f32(const float *gout, float *gtop, int N, i
 }
 
 extern "C" int mrcnn_subsample_bwd_f32(const float *gsub, float *gx, int N, int H, int W, int C, int stride,
-                                       int accumulate, void *stream) {
+                                       int accumulate, const float *relu_x, void *stream) {
     if (int e = chk(gsub && gx && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0 && stride > 0, "subsample_bwd: bad args")) return e;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     hipLaunchKernelGGL(k_subsample_bwd, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(NT), 0, (hipStream_t)stream, gsub, gx,
-                       N, H, W, Ho, Wo, C / 4, stride, accumulate);
+                       N, H, W, Ho, Wo, C / 4, stride, accumulate, relu_x);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

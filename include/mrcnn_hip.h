@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 6
+#define MRCNN_ABI_VERSION 7
 
 enum {
     MRCNN_OK = 0,
@@ -239,7 +239,8 @@ int mrcnn_conv2d_fwd_rect_f32(const float *x, const float *w, const float *bias,
                               int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int relu, void *ws,
                               size_t ws_bytes, void *stream);
 /* relu_x (nullable, same shape as gx): the layer's input when it is the output of a ReLU; gx is then zeroed where
- * relu_x <= 0, i.e. the ReLU backward of the layer below is fused into this epilogue (not with accumulate). */
+ * relu_x <= 0, i.e. the ReLU backward of the layer below is fused into this epilogue; with accumulate (ABI v7) the old value is
+ * added first and the TOTAL is masked (the last contribution to a fan-out point applies the mask to all of them). */
 /* wino_w (nullable, mrcnn_conv2d_winograd_w_bytes() bytes; only where that is > 0): the Winograd path reads gy ONCE
  * and leaves the filter-gradient GEMM's operand (A dy A^T) there for the mrcnn_conv2d_bwd_filter_f32 call of the same
  * layer; with wino_w, gbias (nullable, Cout) receives the bias gradient (column sums of gy; added to when
@@ -301,9 +302,11 @@ int mrcnn_upsample2x_add_fwd_f32(const float *top, const float *lat, float *out,
                                  int Wt, int C, void *stream);
 int mrcnn_upsample2x_bwd_f32(const float *gout, float *gtop, int N, int H, int W, int Ht, int Wt, int C,
                              int accumulate, void *stream);
-/* Backward of the lattice subsampling x[:, ::s, ::s] (strided 1x1 convolutions): gx (N,H,W,C). */
+/* Backward of the lattice subsampling x[:, ::s, ::s] (strided 1x1 convolutions): gx (N,H,W,C).  relu_x (nullable, ABI v7; shape of
+ * gx): the lattice positions are zeroed where relu_x <= 0 after the accumulation - the ReLU backward of the layer that produced the
+ * subsampled tensor, applied where its gradient is written last (positions off the lattice keep gx's contents). */
 int mrcnn_subsample_bwd_f32(const float *gsub, float *gx, int N, int H, int W, int C, int stride, int accumulate,
-                            void *stream);
+                            const float *relu_x, void *stream);
 /* 2x2/2 deconvolution data movement: (N,H,W,[2][2][C]) <-> (N,2H,2W,C); inverse != 0 is the backward. */
 int mrcnn_pixel_shuffle2x_f32(const float *src, const float *bias, float *dst, int N, int H, int W, int C, int inverse,
                               void *stream);      /* bias (C, nullable) is added in the forward direction */

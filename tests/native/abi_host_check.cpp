@@ -108,7 +108,7 @@ int main() {
     EXPECT_ERR(mrcnn_global_avg_pool_fwd_f32(CF, F, 2, 49, 32, V));
     EXPECT_ERR(mrcnn_upsample2x_add_fwd_f32(CF, CF, F, 1, 8, 8, 4, 4, 32, V));
     EXPECT_ERR(mrcnn_upsample2x_bwd_f32(CF, F, 1, 8, 8, 4, 4, 32, 0, V));
-    EXPECT_ERR(mrcnn_subsample_bwd_f32(CF, F, 1, 8, 8, 32, 2, 0, V));
+    EXPECT_ERR(mrcnn_subsample_bwd_f32(CF, F, 1, 8, 8, 32, 2, 0, CF, V));
     EXPECT_ERR(mrcnn_pixel_shuffle2x_f32(CF, CF, F, 1, 8, 8, 32, 0, V));
     EXPECT_ERR(mrcnn_deconv_merge_fwd_f32(CF, CF, CF, CF, F, F, 32, 32, 32, 32, V));
     EXPECT_ERR(mrcnn_deconv_merge_bwd_f32(CF, CF, CF, CF, CF, F, F, F, F, 32, 32, 32, 32, V));

@@ -487,3 +487,24 @@ def test_overfits_one_fixed_batch():
     assert last[5] <= 0.5 * first[5], (first, last)
     assert last[3] < first[3] and last[4] < first[4], (first, last)
     assert torch.isfinite(m.ps.params).all()
+
+
+def test_relu_mask_in_the_producer_gives_the_same_bits():
+    """(r3) The ReLU backward of a bottleneck's output is applied by the kernels that write that output's gradient (data-gradient
+    epilogues of the next block's conv1 / conv4, of toplayer and the laterals, the lattice scatter of the strided blocks) instead of by
+    the block's bn3 backward (one stream less in each of its two kernels, no separate shortcut gradient): the same masks on the same
+    sums, so every parameter gradient is bit-identical to the round-2 data flow (MASK_IN_PRODUCER = False)."""
+    import chainer_maskrcnn.model.extractor.feature_pyramid_network as F
+    grads = {}
+    try:
+        for flag in (True, False):
+            F.MASK_IN_PRODUCER = flag
+            m, chain = _build('all')
+            b = _batch()
+            chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0).backward()
+            grads[flag] = {n: m.ps.g(n).clone() for n in m.ps.names() if m.ps.g(n) is not None}
+    finally:
+        F.MASK_IN_PRODUCER = True
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 50
+    for n in grads[True]:
+        assert torch.equal(grads[True][n], grads[False][n]), n
