@@ -65,7 +65,7 @@ def _parse_header(path):
 SIGNATURES = _parse_header(HEADER_PATH)
 
 _lib = None
-ABI_VERSION = 7          # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
+ABI_VERSION = 8          # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
 
 
 class MrcnnHipError(RuntimeError):

@@ -33,7 +33,10 @@ def bench_step(args, rank, world):
         chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows=mask_rows)
     opt = MomentumSGD(lr=1e-3, momentum=0.9).setup(chain)
     opt.add_hook(WeightDecay(0.0005))
+    rccl = None
     if world > 1:
+        from chainer_maskrcnn.optimizers import rccl_evidence
+        rccl = rccl_evidence(dev, world)      # raises on every rank when two ranks share a device (and the functional-check switch is off)
         opt.enable_data_parallel()
     b = make_batch(100 + rank, N, H, W, G=8, n_fg_class=1 if keypoints else 80, n_keypoints=17 if keypoints else None)
     imgs, bb, lab, masks = (torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'keypoints' if keypoints else 'masks'))
@@ -118,8 +121,8 @@ def bench_step(args, rank, world):
     split_ips = {}
     if world == 1 and not tiles:
         from chainer_maskrcnn._hip import lib, check
-        for name, mode in (('bf16x6', (3, 3, 3)), ('bf16x6_backward', (0, 3, 3)), ('split_bf16_backward', (0, 1, 1)), ('split_half_forward_bf16_backward', (2, 1, 1))):
-            check(lib().mrcnn_conv2d_set_split_operands(*mode))
+        for name, smode in (('bf16x6', (3, 3, 3)), ('bf16x6_backward', (0, 3, 3)), ('split_bf16_backward', (0, 1, 1)), ('split_half_forward_bf16_backward', (2, 1, 1))):
+            check(lib().mrcnn_conv2d_set_split_operands(*smode))
             try:
                 for _ in range(2):
                     opt.update(chain, imgs, bb, lab, masks, 1.0)
@@ -215,6 +218,8 @@ def bench_step(args, rank, world):
                                                                       'RPN / head convolutions run their forward pass with 0')
     if dp_report is not None:
         out['config']['allreduce_rank0'] = dp_report
+    if rccl is not None:
+        out['config']['rccl'] = rccl
     if world > 1:       # a straggler shows here: `ms_per_step` is the MAX over ranks (the contract), this is every rank's own clock
         out['config']['ms_per_step_per_rank'] = {'min': round(min(per_rank_ms), 3), 'max': round(max(per_rank_ms), 3),
                                                  'all': [round(v, 3) for v in per_rank_ms]}

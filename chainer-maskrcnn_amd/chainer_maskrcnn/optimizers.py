@@ -26,11 +26,56 @@ def init_process_group(backend='nccl', **kw):
         except Exception:
             opts = None
     if opts is not None:
+        # decided from the signature, not by catching TypeError: a TypeError raised AFTER partial initialisation would lead to a
+        # second init call ("default process group initialised twice") that masks the real error
+        import inspect
         try:
+            takes = 'pg_options' in inspect.signature(torch.distributed.init_process_group).parameters
+        except (TypeError, ValueError):
+            takes = False
+        if takes:
             return torch.distributed.init_process_group(backend, pg_options=opts, **kw)
-        except TypeError:           # a torch build whose init_process_group does not take pg_options: default options
-            pass
     return torch.distributed.init_process_group(backend, **kw)
+
+
+def rccl_evidence(dev, world):
+    """What the collective library saw, gathered over the ranks (bench.py prints it as config.rccl for N > 1): world size, backend,
+    RCCL version, every rank's device index and PCI bus id, and - when NCCL_DEBUG=INFO was set and NCCL_DEBUG_FILE names a file - the
+    transport lines of rank 0's log.  Two ranks on one device without MRCNN_BENCH_SINGLE_DEVICE is an error (RuntimeError on every
+    rank, raised after the gather so that no rank is left waiting in a collective)."""
+    import os
+    backend = torch.distributed.get_backend()
+    prop = torch.cuda.get_device_properties(dev)
+    try:
+        bus = '%04x:%02x:%02x' % (getattr(prop, 'pci_domain_id', 0), prop.pci_bus_id, prop.pci_device_id)
+    except AttributeError:
+        bus = None
+    mine = {'rank': torch.distributed.get_rank(), 'local_rank': int(os.environ.get('LOCAL_RANK', 0)), 'device_index': dev.index,
+            'device_name': prop.name, 'pci_bus_id': bus, 'pid': os.getpid(),
+            'visible_devices': os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES')}
+    ranks = [None] * world
+    torch.distributed.all_gather_object(ranks, mine)
+    try:
+        ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    ev = {'world_size': world, 'backend': backend, 'rccl_version': ver, 'ranks': ranks,
+          'distinct_devices': len({(r['pci_bus_id'], r['device_index'], r['visible_devices']) for r in ranks}),
+          'nccl_debug': os.environ.get('NCCL_DEBUG'), 'transport': None}
+    log = os.environ.get('NCCL_DEBUG_FILE')
+    if ev['nccl_debug'] and log and mine['rank'] == 0:
+        try:
+            path = log.replace('%h', os.uname().nodename).replace('%p', str(os.getpid()))
+            keys = ('via P2P', 'via SHM', 'via NET', 'via direct', 'Connected all', 'comm ', 'nRanks', 'XGMI', 'Ring ', 'Tree ')
+            lines = [l.strip() for l in open(path, errors='replace') if any(k in l for k in keys)]
+            ev['transport'] = lines[:40]
+        except OSError as e:
+            ev['transport'] = ['(could not read %s: %s)' % (log, e)]
+    if ev['distinct_devices'] < world and os.environ.get('MRCNN_BENCH_SINGLE_DEVICE') != '1':
+        raise RuntimeError('data-parallel launch with %d ranks resolved to %d distinct device(s): %s - one process per GPU is '
+                           'required (set MRCNN_BENCH_SINGLE_DEVICE=1 only for the functional check on a one-GPU box)'
+                           % (world, ev['distinct_devices'], [(r['rank'], r['device_index'], r['pci_bus_id']) for r in ranks]))
+    return ev
 
 
 class WeightDecay(object):

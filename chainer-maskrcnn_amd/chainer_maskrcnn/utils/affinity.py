@@ -46,7 +46,10 @@ def rank_cpus(local_rank, n_local, allowed=None):
         nodes = _gpu_numa_nodes()
         visible = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES')
         if visible:
-            nodes = [nodes[int(v)] for v in visible.split(',') if v.strip().isdigit()]
+            toks = [v.strip() for v in visible.split(',') if v.strip()]
+            if not all(v.isdigit() for v in toks):        # UUIDs ("GPU-..."): the index -> node map is unknown, split evenly
+                raise ValueError('non-numeric visible-device list')
+            nodes = [nodes[int(v)] for v in toks]
         node = nodes[local_rank]
         if node >= 0:
             cpus = [c for c in _cpulist(open('/sys/devices/system/node/node%d/cpulist' % node).read()) if c in set(allowed)]

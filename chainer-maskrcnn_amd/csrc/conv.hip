@@ -26,6 +26,7 @@
 // Epilogue: 32x32 accumulator tiles are transposed through per-wave LDS tiles and stored as float4.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -818,6 +819,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     }
 }
 
+#include "planes_gemm.h"
+
 // ---- launch planning -------------------------------------------------------------------------------------
 // Workgroup slots of the chip for one kernel instantiation = resident workgroups per CU (runtime occupancy query,
 // cached) x CUs.  Tiles and split-K factors are chosen so that the grid is a whole number of slot "rounds": a grid of
@@ -1279,7 +1282,7 @@ WinoLayout wino_layout(int N, int H, int W, int Cin, int Cout, int pass) {
     L.g = wino_geom(N, H, W, pass);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t o = 0;
-    L.u = o; o += al((size_t)L.g.nk * Cout * Cin * 4);
+    L.u = o; o += al((size_t)L.g.nk * Cout * Cin * 6);          // float32, or three bf16 planes (plane GEMMs)
     L.v = o; o += al((size_t)L.g.nk * L.g.Tp * Cin * 4);
     L.m = o; o += al((size_t)L.g.nk * L.g.Tp * Cout * 4);
     L.inner = o; o += (size_t)4 * g_cus() * 128 * 128 * sizeof(float);              // tail-split slabs of the GEMM launch
@@ -1356,7 +1359,7 @@ template <int M_> __device__ __forceinline__ void wino_gt(const float (&D)[M_ + 
 // written as U[k][ci][co] (the GEMM's "Cout" axis is then Cin).
 template <int M_>
 __device__ __forceinline__ void wino_filter_body(const float *__restrict__ w, float *__restrict__ U, int Cout, int Cin,
-                                                 int transposed, unsigned blk) {
+                                                 int transposed, unsigned blk, int uplanes = 0) {
     constexpr int A_ = M_ + 2;
     const int i = (int)(blk * 256u + threadIdx.x);
     if (i >= Cout * Cin) return;
@@ -1377,6 +1380,31 @@ __device__ __forceinline__ void wino_filter_body(const float *__restrict__ w, fl
     }
     const size_t stride = (size_t)Cout * Cin;
     const size_t o = transposed ? (size_t)ci * Cout + co : (size_t)co * Cin + ci;
+    if (uplanes) {
+        // U as "P16R4" bf16 planes for the plane GEMMs (planes_gemm.h): matrix k has `rows` rows (the GEMM's N index) of `cols`
+        // values (its K index); hi + mid + lo == the float32 value exactly
+        const unsigned rows = transposed ? (unsigned)Cin : (unsigned)Cout, cols = transposed ? (unsigned)Cout : (unsigned)Cin;
+        const unsigned rr = transposed ? (unsigned)ci : (unsigned)co, cc = transposed ? (unsigned)co : (unsigned)ci;
+        unsigned short *Up = reinterpret_cast<unsigned short *>(U);
+#pragma unroll
+        for (int r = 0; r < A_; ++r) {
+            float row[A_];
+            wino_g<M_>(t[r], row);
+#pragma unroll
+            for (int q = 0; q < A_; ++q) {
+                const unsigned off = pg_off_r4((unsigned)(r * A_ + q) * rows + rr, cc & ~3u, cols) / 2u + (cc & 3u);
+                const float v = row[q];
+                const __bf16 h = (__bf16)v;
+                const float r1 = v - (float)h;
+                const __bf16 m = (__bf16)r1;
+                const __bf16 l = (__bf16)(r1 - (float)m);
+                Up[off] = __builtin_bit_cast(unsigned short, h);
+                Up[off + 64] = __builtin_bit_cast(unsigned short, m);
+                Up[off + 128] = __builtin_bit_cast(unsigned short, l);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < A_; ++r) {
         float row[A_];
@@ -1387,8 +1415,8 @@ __device__ __forceinline__ void wino_filter_body(const float *__restrict__ w, fl
 }
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_filter(const float *__restrict__ w, float *__restrict__ U, int Cout, int Cin,
-                                                     int transposed) {
-    wino_filter_body<M_>(w, U, Cout, Cin, transposed, blockIdx.x);
+                                                     int transposed, int uplanes) {
+    wino_filter_body<M_>(w, U, Cout, Cin, transposed, blockIdx.x, uplanes);
 }
 
 // V[k][t][c] = (B^T d B)[k], d = the a x a input patch of tile t (rows m*ty-1 .., zero outside).  Thread = (t, 4 channels).
@@ -1487,8 +1515,8 @@ template <int M_>
 __global__ __launch_bounds__(256) void k_wino_input_filter(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
                                                            int th, int tw, long long T, long long Tp, const float *__restrict__ w,
                                                            float *__restrict__ U, int Cout_w, int Cin_w, int transposed, unsigned fblocks,
-                                                           int banded) {
-    if (blockIdx.x < fblocks) wino_filter_body<M_>(w, U, Cout_w, Cin_w, transposed, blockIdx.x);
+                                                           int banded, int uplanes) {
+    if (blockIdx.x < fblocks) wino_filter_body<M_>(w, U, Cout_w, Cin_w, transposed, blockIdx.x, uplanes);
     else wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, fblocks, gridDim.x - fblocks, banded));
 }
 
@@ -1592,7 +1620,7 @@ __global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ M
 // when C/4 divides 256: the host passes bias_part only then); k_colsum_final adds the rows up.
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_gy(const float *__restrict__ gy, float *__restrict__ Wt, int N, int H, int W, int C,
-                                                 int th, int tw, long long T, long long Tp, float *__restrict__ bias_part) {
+                                                 int th, int tw, long long T, long long Tp, float *__restrict__ bias_part, int wplanes) {
     constexpr int A_ = M_ + 2;
     __shared__ float4 sred[256];
     const unsigned C4 = (unsigned)C / 4u;
@@ -1603,12 +1631,23 @@ __global__ __launch_bounds__(256) void k_wino_gy(const float *__restrict__ gy, f
     V4 bsum = v4zero();
     // buffer descriptors as in k_wino_input: unconditional loads (pixels outside the image = out-of-range offset = 0), plane
     // offsets of the stores in the VGPR offset (see the hardware note there)
-    const unsigned ks = (unsigned)((size_t)Tp * C * 4);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void *)Wt, 0, (unsigned)((size_t)A_ * A_ * Tp * C * 4), 0x00020000);
-    const unsigned vo = (unsigned)(((size_t)t * C + c) * 4);
+    // wplanes: W as bf16 planes in the "PR" layout [k][t][3][C] (hi, mid, lo rows of C values: a wave writes whole 512-byte rows) for
+    // the plane GEMM k_pgemm_gpp (planes_gemm.h) instead of float32 [k][t][C]
+    const unsigned ks = wplanes ? (unsigned)((size_t)Tp * C * 6) : (unsigned)((size_t)Tp * C * 4);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void *)Wt, 0, (unsigned)((size_t)A_ * A_ * ks), 0x00020000);
+    const unsigned vo = wplanes ? (unsigned)(((size_t)t * 3 * C + c) * 2) : (unsigned)(((size_t)t * C + c) * 4);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto put = [&](unsigned off, V4 v) {
+        if (!wplanes) { v4bufst(rsW, off, 0, v); return; }
+        uint2 hi, mid, lo;
+        split3_bf16x4(make_float4(v.x, v.y, v.z, v.w), hi, mid, lo);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{hi.x, hi.y}, rsW, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{mid.x, mid.y}, rsW, off + (unsigned)C * 2u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo.x, lo.y}, rsW, off + (unsigned)C * 4u, 0, 0);
+    };
     if (in_range && t >= (unsigned)T) {           // padded rows: zero
 #pragma unroll
-        for (int k = 0; k < A_ * A_; ++k) v4bufst(rsW, vo + (unsigned)k * ks, 0, v4zero());
+        for (int k = 0; k < A_ * A_; ++k) put(vo + (unsigned)k * ks, v4zero());
     } else if (in_range) {
         const unsigned trow = t / (unsigned)tw;
         const int tx = (int)(t - trow * (unsigned)tw);
@@ -1635,7 +1674,7 @@ __global__ __launch_bounds__(256) void k_wino_gy(const float *__restrict__ gy, f
             V4 row[A_];
             wino_a<M_, V4>(r[q], row, v4zero());
 #pragma unroll
-            for (int j = 0; j < A_; ++j) v4bufst(rsW, vo + (unsigned)(q * A_ + j) * ks, 0, row[j]);
+            for (int j = 0; j < A_; ++j) put(vo + (unsigned)(q * A_ + j) * ks, row[j]);
         }
     }
     if (bias_part) {            // block-uniform
@@ -1798,17 +1837,33 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restric
         MRCNN_LAUNCH_CHECK();                                                                        \
     } while (0)
 
-struct WinoFLayout { size_t v, w, slabs, du, total; WinoGeom g; int ksplit, kchunk; };
+int g_pg_big = 1, g_pg_min_tiles = 256;
+// Split mode 3 on the Winograd filter-gradient GEMMs of the big layers: k_pgemm_gpp (planes_gemm.h).  The transformed output
+// gradient W is written as bf16 planes by k_wino_gy, the transformed input V stays float32 (the forward pass's, or k_wino_input's).
+bool pg_big_g_ok(const WinoGeom &g, int Cin, int Cout) {
+    if (g_split_mode[PASS_BWD_FILTER] != 3 || !g_pg_big) return false;
+    if (Cout % PGB_BM || Cin % PGB_BN || g.Tp % 32) return false;
+    return g.Tp >= 2048 && (long long)g.nk * g.Tp * Cout * 6 < (1ll << 32) && (long long)g.nk * g.Tp * Cin * 4 < (1ll << 32);
+}
+struct WinoFLayout { size_t v, w, slabs, du, total; WinoGeom g; int ksplit, kchunk; int big; };
 WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
     WinoFLayout L;
     L.g = wino_geom(N, H, W, PASS_BWD_FILTER);
     ConvP p = make_p(1, 1, (int)L.g.Tp, Cin, Cout, 1, 1, 1, 0);
     p.wbatch_rows = (int)L.g.Tp; p.wbatch_n = L.g.nk;
     filter_plan(p, L.ksplit, L.kchunk);
+    L.big = pg_big_g_ok(L.g, Cin, Cout) ? 1 : 0;
+    if (L.big) {            // k_pgemm_gpp: one 256 x 256 tile per (batch, split), one workgroup per CU: the splits fill one round of CUs
+        const long long tiles = (long long)L.g.nk * (Cout / PGB_BM) * (Cin / PGB_BN);
+        long long ks = std::max(1ll, (long long)g_cus() / tiles);
+        ks = std::min(ks, std::max(1ll, L.g.Tp / 256));                 // at least 16 K steps per split
+        L.kchunk = (int)((L.g.Tp / 32 + ks - 1) / ks * 32);
+        L.ksplit = (int)((L.g.Tp + L.kchunk - 1) / L.kchunk);
+    }
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t o = 0;
     L.v = o; o += al((size_t)L.g.nk * L.g.Tp * Cin * 4);
-    L.w = o; o += al((size_t)L.g.nk * L.g.Tp * Cout * 4);
+    L.w = o; o += al((size_t)L.g.nk * L.g.Tp * Cout * 6);          // float32, or three bf16 planes (plane GEMM)
     L.slabs = o; o += al((size_t)L.ksplit * Cout * L.g.nk * Cin * 4);
     L.du = o; o += al((size_t)Cout * L.g.nk * Cin * 4);
     L.total = o;
@@ -1829,8 +1884,26 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     const int C4o = Cout / 4;
     const bool fuse_bias = bias_part && bias_rows && !w_cached && C4o <= 256 && 256 % C4o == 0 && !(g_debug_skip & 2);
     if (bias_rows) *bias_rows = fuse_bias ? (int)((nout + 255) / 256) : 0;
+    const int big = (L.big && !w_cached) ? 1 : 0;           // (a cached W is float32: the shared-transform path keeps k_conv_igemm)
     if (!w_cached) WINO_LAUNCH(k_wino_gy, g, dim3((unsigned)((nout + 255) / 256)), gy, Wt, N, H, W, Cout, g.th, g.tw, g.T, g.Tp,
-                               fuse_bias ? bias_part : (float *)nullptr);
+                               fuse_bias ? bias_part : (float *)nullptr, big);
+    if (big) {
+        PlaneGemmP q{};
+        q.a = reinterpret_cast<const unsigned short *>(Wt); q.b = reinterpret_cast<const unsigned short *>(V);
+        q.c = L.ksplit > 1 ? slabs : dU;
+        q.M = Cout; q.N = Cin; q.K = (int)g.Tp; q.batch_rows = (int)g.Tp; q.nbatch = g.nk; q.ksplit = L.ksplit; q.kchunk = L.kchunk;
+        q.bytes_a = (unsigned)((size_t)g.nk * g.Tp * Cout * 6); q.bytes_b = (unsigned)((size_t)g.nk * g.Tp * Cin * 4);
+        q.ldc = g.nk * Cin; q.dbg = 0; q.stamps = nullptr;
+        if (!(g_debug_skip & 1)) launch_pgemm<5>(q, PGB_BM, PGB_BN, st);
+        MRCNN_LAUNCH_CHECK();
+        if (L.ksplit > 1) {
+            const size_t n4 = (size_t)Cout * g.nk * Cin / 4;
+            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, L.ksplit, 0);
+            MRCNN_LAUNCH_CHECK();
+        }
+        WINO_LAUNCH(k_wino_filter_grad, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), dU, gw, Cout, Cin, accumulate, 1);
+        return 0;
+    }
     ConvP p = make_p(1, 1, (int)g.Tp, Cin, Cout, 1, 1, 1, 0);
     p.wbatch_rows = (int)g.Tp; p.wbatch_n = g.nk;
     p.ksplit = L.ksplit; p.kchunk = L.kchunk;
@@ -1849,6 +1922,16 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     return 0;
 }
 
+// Split mode 3 on the Winograd batched GEMMs of the big layers: the plane GEMM of planes_gemm.h (k_pgemm_pp: 256 x 256 tiles, the
+// transformed activations V stay float32 and are split when a wave reads its fragment, the transformed filters U are written as
+// bf16 planes by the filter transform).  g_pg_big: 0 = never (mrcnn_debug_conv_parts bit 8 of the high byte; A/B against k_conv_igemm).
+bool pg_big_ok(int pass, const WinoGeom &g, int K, int Nn) {
+    if (g_split_mode[pass] != 3 || !g_pg_big) return false;
+    if (g.Tp % PGB_BM || Nn % PGB_BN || K % 16) return false;
+    const long long tiles = (long long)g.nk * g.Tp / PGB_BM * (Nn / PGB_BN);
+    return tiles >= g_pg_min_tiles && (long long)g.nk * g.Tp * K * 4 < (1ll << 32) && (long long)g.nk * Nn * K * 6 < (1ll << 32);
+}
+
 // in (N,H,W,Cin) -> out (N,H,W,Cout); w is always the layer's (Cout_layer,3,3,Cin_layer) weight tensor: transposed selects
 // the backward-data filter (then Cin here = the layer's Cout and Cout here = the layer's Cin).
 int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, int Cin, int Cout, bool transposed,
@@ -1861,7 +1944,8 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
     // the layer's weight tensor is (Cout_layer, 3, 3, Cin_layer): forward Cout_layer = Cout; transposed Cout_layer = Cin
     const long long nin = g.Tp * (Cin / 4), nout = g.T * (Cout / 4);       // k_wino_input zeroes the padded rows of V
     const unsigned fblocks = (unsigned)mrcnn::cdiv(Cout * Cin, 256);
-    if (w_keep) WINO_LAUNCH(k_wino_filter, g, dim3(fblocks), w, U, transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0);
+    const int big = pg_big_ok(transposed ? PASS_BWD_DATA : PASS_FWD, g, Cin, Cout) ? 1 : 0;
+    if (w_keep) WINO_LAUNCH(k_wino_filter, g, dim3(fblocks), w, U, transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, big);
     if (w_keep) {           // backward pass: one read of gy feeds this GEMM, the filter-gradient GEMM and the bias gradient
         const bool wb = gbias && (256 % (Cin / 4)) == 0;
         const int nblk = (int)std::min<long long>((nin + 255) / 256, 512);
@@ -1881,7 +1965,19 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
         }
     } else
         WINO_LAUNCH(k_wino_input_filter, g, dim3(fblocks + (unsigned)((nin + 255) / 256)), in, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp, w, U,
-                    transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, fblocks, g_wino_banded);
+                    transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, fblocks, g_wino_banded, big);
+    if (big) {          // the plane GEMM: A = V (float32 rows), B = U (P16R4 planes), C = M
+        PlaneGemmP q{};
+        q.a = reinterpret_cast<const unsigned short *>(V); q.b = reinterpret_cast<const unsigned short *>(U); q.c = Mb;
+        q.M = (int)(g.nk * g.Tp); q.N = Cout; q.K = Cin; q.batch_rows = (int)g.Tp; q.nbatch = g.nk; q.ksplit = 1; q.kchunk = Cin;
+        q.bytes_a = (unsigned)((size_t)g.nk * g.Tp * Cin * 4); q.bytes_b = (unsigned)((size_t)g.nk * Cout * Cin * 6);
+        q.ldc = Cout; q.dbg = 0; q.stamps = nullptr;
+        if (!(g_debug_skip & 1)) launch_pgemm<4>(q, PGB_BM, PGB_BN, st);
+        MRCNN_LAUNCH_CHECK();
+        WINO_LAUNCH(k_wino_output, g, dim3((unsigned)((nout + 255) / 256)), Mb, out, N, H, W, Cout, g.th, g.tw, g.T, g.Tp, bias, relu,
+                    accumulate, relu_x, bn_part);
+        return 0;
+    }
     // batched GEMM: 1x1 "convolution" over nk*Tp pixels, weight matrix selected by the row block
     ConvP p = make_p(1, 1, (int)(g.nk * g.Tp), Cin, Cout, 1, 1, 1, 0);
     p.a = V; p.b = U; p.c = Mb;
@@ -1918,7 +2014,76 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
 }
 
 extern "C" int mrcnn_debug_conv_parts(int mask) {
-    g_dbg_parts = mask & 15;          // 8: the three-plane kernels run the plain K loop instead of the pipelined one
+    g_dbg_parts = mask & 0xff;
+    g_pg_big = (mask & 0x100) ? 0 : 1;        // 8: the three-plane kernels run the plain K loop instead of the pipelined one; 16..128: planes_gemm.h knobs
+    return 0;
+}
+
+// Measurement / test entry points of planes_gemm.h: float32 (R, C) -> P16 planes, and one plane-GEMM launch.
+extern "C" int mrcnn_debug_split_planes_f32(const float *x, void *planes, int R, int C, int r4, void *stream) {
+    if (!x || !planes || R <= 0 || C <= 0 || C % 16 || (long long)R * C * 6 >= (1ll << 32) || (r4 == 1 && R % 4))
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_split_planes: null pointer, C %% 16 != 0, R %% 4 != 0 (P16R4) or more than 4 GiB of planes");
+    hipLaunchKernelGGL(k_split_planes, dim3(mrcnn::cdiv((long long)R * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (unsigned short *)planes, (unsigned)R, (unsigned)C, r4);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+static unsigned long long *g_pg_stamps = nullptr;
+extern "C" int mrcnn_debug_planes_gemm_stamps(unsigned long long *stamps) {       // 5 x u64 per workgroup of the next debug_planes_gemm calls (F kinds); null = off
+    g_pg_stamps = stamps;
+    return 0;
+}
+extern "C" int mrcnn_debug_planes_gemm(int kind, const void *a, const void *b, float *c, int M, int N, int K, int batch_rows, int nbatch,
+                                       int ksplit, int bm, int bn, void *stream) {
+    if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || nbatch <= 0 || ksplit <= 0 || kind < 0 || kind > 5)
+        return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_planes_gemm: bad arguments");
+    PlaneGemmP p{};
+    p.a = (const unsigned short *)a; p.b = (const unsigned short *)b; p.c = c;
+    p.M = M; p.N = N; p.K = K; p.batch_rows = batch_rows; p.nbatch = nbatch; p.ksplit = ksplit;
+    long long ba, bb;
+    if (kind == 5) {      // G, big tile, ping-pong: A = W (nbatch * K, M) "PR" planes, B = V (nbatch * K, N) float32; K = batch_rows
+        if (K != batch_rows || K % 32 || M % 16 || N % 16 || bm != 256 || bn != 256)
+            return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_planes_gemm G big: K == batch_rows, K %% 32, tile 256 x 256");
+        ba = (long long)nbatch * K * M * 6; bb = (long long)nbatch * K * N * 4;
+        p.kchunk = (K / 32 + ksplit - 1) / ksplit * 32;         // the caller's slab array has `ksplit` slabs; all are written
+        if ((K + p.kchunk - 1) / p.kchunk != ksplit) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_planes_gemm G big: ksplit %d leaves an empty split", ksplit);
+        p.ldc = nbatch * N;
+    } else if (kind == 3 || kind == 4) {      // F, big tile (4: ping-pong halves): A (M, K) float32, B (nbatch * N, K) P16R4 planes; batch_rows % 256 == 0
+        if (K % 16 || batch_rows % 256 || M != nbatch * batch_rows || N % 16 || bm != 256 || bn != 256)
+            return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_planes_gemm big: K %% 16, batch_rows %% 256, tile 256 x 256");
+        ba = (long long)M * K * 4; bb = (long long)nbatch * N * K * 6;
+        p.ldc = N; p.ksplit = 1; p.kchunk = K;
+    } else if (kind == 0 || kind == 2) {        // F: A (M, K) planes (kind 2: float32), B (nbatch, N, K) planes; M = nbatch * batch_rows
+        if (K % 16 || batch_rows % 128 || M != nbatch * batch_rows || N % 16 || bm != 128 || (bn != 128 && bn != 64))
+            return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_planes_gemm F: K %% 16, batch_rows %% 128, M == nbatch * batch_rows, tile 128 x 128|64");
+        ba = (long long)M * K * (kind == 2 ? 4 : 6); bb = (long long)nbatch * N * K * 6;
+        p.ldc = N; p.ksplit = 1; p.kchunk = K;
+    } else {                // G: A (nbatch, K, M), B (nbatch, K, N); K = batch_rows
+        if (K != batch_rows || K % (16 * ksplit) || M % 16 || N % 16 || (bm != 128 && bm != 64) || (bn != 128 && bn != 64))
+            return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_planes_gemm G: K == batch_rows, K %% (16 * ksplit), tiles 128|64");
+        ba = (long long)nbatch * K * M * 6; bb = (long long)nbatch * K * N * 6;
+        p.ldc = nbatch * N; p.kchunk = K / ksplit;
+    }
+    if (ba >= (1ll << 32) || bb >= (1ll << 32)) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "debug_planes_gemm: operand of 4 GiB or more");
+    p.bytes_a = (unsigned)ba; p.bytes_b = (unsigned)bb;
+    p.dbg = g_dbg_parts >> 4;
+    p.stamps = g_pg_stamps;
+    if (getenv("MRCNN_PG_OCC")) {
+        int o0 = -1, o1 = -1, o2 = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&o0, reinterpret_cast<const void *>(&k_pgemm_f<128, 128>), PG_THREADS, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, reinterpret_cast<const void *>(&k_pgemm_fa<128, 128>), PG_THREADS, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, reinterpret_cast<const void *>(&k_pgemm_g<128, 128>), PG_THREADS, 0);
+        hipFuncAttributes fa;
+        hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_pgemm_f<128, 128>));
+        fprintf(stderr, "occupancy (workgroups per CU): f %d fa %d g %d; f: %d regs, %zu B static LDS, max dynamic %d\n", o0, o1, o2, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
+    }
+    if (kind == 0) launch_pgemm<0>(p, bm, bn, (hipStream_t)stream);
+    else if (kind == 2) launch_pgemm<2>(p, bm, bn, (hipStream_t)stream);
+    else if (kind == 3) launch_pgemm<3>(p, bm, bn, (hipStream_t)stream);
+    else if (kind == 4) launch_pgemm<4>(p, bm, bn, (hipStream_t)stream);
+    else if (kind == 5) launch_pgemm<5>(p, bm, bn, (hipStream_t)stream);
+    else launch_pgemm<1>(p, bm, bn, (hipStream_t)stream);
+    MRCNN_LAUNCH_CHECK();
     return 0;
 }
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 7
+#define MRCNN_ABI_VERSION 8
 
 enum {
     MRCNN_OK = 0,
@@ -211,6 +211,17 @@ int mrcnn_debug_wino_banded(int on);
  * 8 = the three-plane (bf16x6) kernels run the plain K loop (split + LDS stores between the barriers) instead of the pipelined one
  * (split in registers in the MFMAs' shadow, loads two steps ahead) - same results, for A/B.  Bits 1 and 2 act on the plain loop. */
 int mrcnn_debug_conv_parts(int mask);
+/* Test / measurement entry points of the plane GEMMs (csrc/planes_gemm.h), the kernels behind split mode 3 on the Winograd path.
+ * split_planes: float32 (R, C), C % 16 == 0 -> "P16" planes, unsigned short [R][C/16][3][16]: hi, mid, lo bf16 planes of 16
+ * consecutive channels in 96 contiguous bytes (hi + mid + lo == x exactly).
+ * planes_gemm, kind 0 (F): c (M, N) = sum_k a[m][k] b[batch(m)][n][k] - a = P16 (M, K), b = P16 (nbatch * N, K), batch(m) =
+ * m / batch_rows, M = nbatch * batch_rows, batch_rows % 128 == 0; tile bm x bn = 128 x 128 | 64.
+ * kind 1 (G): c (ksplit, M, nbatch, N) partial sums over the row ranges of a = P16 (nbatch * K, M), b = P16 (nbatch * K, N),
+ * K = batch_rows, K % (16 * ksplit) == 0; tiles 128 | 64 each way.  Six v_mfma_f32_32x32x16_bf16 per product, float32 accumulate. */
+int mrcnn_debug_split_planes_f32(const float *x, void *planes, int R, int C, int r4, void *stream);
+int mrcnn_debug_planes_gemm_stamps(unsigned long long *stamps);
+int mrcnn_debug_planes_gemm(int kind, const void *a, const void *b, float *c, int M, int N, int K, int batch_rows, int nbatch,
+                            int ksplit, int bm, int bn, void *stream);
 
 /* Measurement knob for bench.py's roofline split (never set on a product path): bit 0 skips the MFMA GEMM launches of
  * the convolution calls, bit 1 skips every other kernel they launch (Winograd transforms, slab / tail / column sums).

@@ -88,3 +88,8 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert d['roofline']['traffic_source']['file'].startswith('profiles/')
     assert abs(d['value'] - 4 * 1e3 / d['ms_per_step']) <= 1e-2 * d['value']          # whole-job images/s = global batch / step time
     assert d['roofline']['frac'] <= 1.0 and 'roi_align_microbench' in d
+    # the line says what the collective library saw: ranks, their devices, backend, library version
+    rc = d['config']['rccl']
+    assert rc['world_size'] == 2 and rc['backend'] == 'gloo' and len(rc['ranks']) == 2
+    assert sorted(r['rank'] for r in rc['ranks']) == [0, 1] and all(r['device_index'] == 0 and r['pci_bus_id'] for r in rc['ranks'])
+    assert rc['distinct_devices'] == 1          # both ranks on the one GPU: accepted only because MRCNN_BENCH_SINGLE_DEVICE=1
