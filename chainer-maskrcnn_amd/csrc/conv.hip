@@ -819,6 +819,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_igemm(ConvP p) {
     }
 }
 
+int g_cus();
 #include "planes_gemm.h"
 
 // ---- launch planning -------------------------------------------------------------------------------------

@@ -525,6 +525,29 @@ __global__ __launch_bounds__(PGB_THREADS, 2) void k_pgemm_big(PlaneGemmP p) {
     }
 }
 
+// split3_bf16x4 with the subtractions kept scalar: beside another wave's MFMAs a v_pk_add_f32 costs ~13 cycles more than the two
+// v_sub_f32 it replaces (MI355X_MICROARCH.md, cycle constants: packed f32 VALU is an anti-lever beside MFMAs); the empty asm
+// statements keep hipcc's SLP vectoriser from re-packing them.
+__device__ __forceinline__ void pg_split3x4(const float4 v, uint2 &hi, uint2 &mid, uint2 &lo) {
+    const f32x2_t v01 = {v.x, v.y}, v23 = {v.z, v.w};
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, bf16x2_t));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, bf16x2_t));
+    float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xffff0000u);
+    float r2 = v.z - __uint_as_float(h23 << 16), r3 = v.w - __uint_as_float(h23 & 0xffff0000u);
+    asm volatile("" : "+v"(r0)); asm volatile("" : "+v"(r1)); asm volatile("" : "+v"(r2)); asm volatile("" : "+v"(r3));
+    const f32x2_t r01 = {r0, r1}, r23 = {r2, r3};
+    const unsigned m01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2_t));
+    const unsigned m23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2_t));
+    float q0 = r0 - __uint_as_float(m01 << 16), q1 = r1 - __uint_as_float(m01 & 0xffff0000u);
+    float q2 = r2 - __uint_as_float(m23 << 16), q3 = r3 - __uint_as_float(m23 & 0xffff0000u);
+    asm volatile("" : "+v"(q0)); asm volatile("" : "+v"(q1)); asm volatile("" : "+v"(q2)); asm volatile("" : "+v"(q3));
+    const f32x2_t q01 = {q0, q1}, q23 = {q2, q3};
+    hi = make_uint2(h01, h23);
+    mid = make_uint2(m01, m23);
+    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(q01, bf16x2_t)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(q23, bf16x2_t)));
+}
+
 // ---- F kind, 256 x 256 tile, ping-pong halves --------------------------------------------------------------------------------
 // k_pgemm_big with its two wave groups (waves 0-3: rows 0..127 of the tile, waves 4-7: rows 128..255; a SIMD hosts one wave of each)
 // offset by half a K step: while one group runs the 48 MFMAs of step s ("Y"), the other issues its LDS-DMA pieces of stage s + 2,
@@ -534,45 +557,60 @@ __global__ __launch_bounds__(PGB_THREADS, 2) void k_pgemm_big(PlaneGemmP p) {
 // refilled (stage s + 3) from phase 2s + 2 on; a wave checks ITS pieces of stage s + 1 (counted vmcnt) at the end of its X(s), the
 // barriers up to the first read of that stage (phase 2s + 2) carry the rest.
 __global__ __launch_bounds__(PGB_THREADS, 2) void k_pgemm_pp(PlaneGemmP p) {
+    // PERSISTENT: workgroup b walks the tiles vid0 + j * gridDim.x; the ring runs on across tile boundaries (the first stages of the
+    // next tile are in flight while the last steps of this one compute, and its stores drain under the next tile's phases).
     __shared__ __attribute__((aligned(1024))) unsigned char smem[PGB_NSTAGE * PGB_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave >> 2, wm = half * 2 + ((wave >> 1) & 1), wn = wave & 1;
-    int vid = blockIdx.x;
+    int vid0 = blockIdx.x;
     {
-        const int q = p.remap_n >> 3, r = p.remap_n & 7, xcd = vid & 7;
-        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vid >> 3);
+        const int G = (int)gridDim.x, q = G >> 3, r = G & 7, xcd = vid0 & 7;
+        vid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vid0 >> 3);
     }
     unsigned long long st_t0 = 0, st_r0 = 0;
     if (p.stamps) { st_t0 = pg_now(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-    const int bx = vid / p.tiles_n, by = vid - bx * p.tiles_n;
-    const int m0 = bx * PGB_BM, n0 = by * PGB_BN;
-    const int batch = m0 / p.batch_rows;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nj = vid0 < ntiles ? (ntiles - vid0 + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const unsigned rowbytesA = (unsigned)p.K * 4u;
     const unsigned kblocks = (unsigned)p.K / 16u;
+    const int nsteps = (int)kblocks;
+    const int S = nj * nsteps;                  // stages of this workgroup's stream
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.a, 0, p.bytes_a, 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void *)p.b, 0, p.bytes_b, 0x00020000);
+    // issue side: the tile and K step of the next stage to load, and that tile's per-lane source offsets
     unsigned voffA[2], voffB[3];
+    int ij = 0, is = 0;
+    auto setup = [&](int j) {
+        const int tile = vid0 + j * (int)gridDim.x;
+        const int bx = tile / p.tiles_n, by = tile - bx * p.tiles_n;
+        const int m0 = bx * PGB_BM, n0 = by * PGB_BN, batch = m0 / p.batch_rows;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int f = 64 * (wave + 8 * i) + lane, row = f >> 2, pc = f & 3, lc = pc ^ ((row >> 2) & 3);
-        voffA[i] = (m0 + row < p.M) ? (unsigned)(m0 + row) * rowbytesA + (unsigned)lc * 16u : 0xFFFFFFFFu;
-    }
+        for (int i = 0; i < 2; ++i) {
+            const int f = 64 * (wave + 8 * i) + lane, row = f >> 2, pc = f & 3, lc = pc ^ ((row >> 2) & 3);
+            voffA[i] = (m0 + row < p.M) ? (unsigned)(m0 + row) * rowbytesA + (unsigned)lc * 16u : 0xFFFFFFFFu;
+        }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int piece = wave + 8 * i, pl = piece >> 3, rb = piece & 7;
-        const int row = 32 * rb + (lane >> 1), hf = (lane & 1) ^ ((row >> 3) & 1);
-        const int n = n0 + row;
-        voffB[i] = (n < p.N) ? ((unsigned)((batch * p.N + n) >> 2) * kblocks) * 384u + (unsigned)pl * 128u + (unsigned)(n & 3) * 32u + (unsigned)hf * 16u
-                             : 0xFFFFFFFFu;
-    }
-    auto issue = [&](unsigned buf, unsigned kstep) {
+        for (int i = 0; i < 3; ++i) {
+            const int piece = wave + 8 * i, pl = piece >> 3, rb = piece & 7;
+            const int row = 32 * rb + (lane >> 1), hf = (lane & 1) ^ ((row >> 3) & 1);
+            const int n = n0 + row;
+            voffB[i] = (n < p.N) ? ((unsigned)((batch * p.N + n) >> 2) * kblocks) * 384u + (unsigned)pl * 128u + (unsigned)(n & 3) * 32u + (unsigned)hf * 16u
+                                 : 0xFFFFFFFFu;
+        }
+    };
+    const bool loads = !(p.dbg & 8), mfma = !(p.dbg & 1);
+    auto issue_next = [&](unsigned buf) {
+        if (is == 0) setup(ij);
         unsigned char *sa = smem + buf, *sb = sa + PGB_A_STAGE;
-        const unsigned soffA = kstep * 64u, soffB = kstep * 384u;
+        const unsigned soffA = (unsigned)is * 64u, soffB = (unsigned)is * 384u;
+        if (loads) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pg_dma16(rsA, sa + (wave + 8 * i) * 1024, voffA[i], soffA);
+            for (int i = 0; i < 2; ++i) pg_dma16(rsA, sa + (wave + 8 * i) * 1024, voffA[i], soffA);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pg_dma16(rsB, sb + (wave + 8 * i) * 1024, voffB[i], soffB);
+            for (int i = 0; i < 3; ++i) pg_dma16(rsB, sb + (wave + 8 * i) * 1024, voffB[i], soffB);
+        }
+        if (++is == nsteps) { is = 0; ++ij; }
     };
 
     f32x16 acc[2][4];
@@ -590,34 +628,34 @@ __global__ __launch_bounds__(PGB_THREADS, 2) void k_pgemm_pp(PlaneGemmP p) {
     const unsigned fragA1 = smem_base + (unsigned)(wm * 64 + r) * 64u + (((unsigned)(2 * h + 1) ^ sA) * 16u);
     const unsigned fragB = smem_base + (unsigned)PGB_A_STAGE + (unsigned)(wn * 128 + r) * 32u + (unsigned)((h ^ ((r >> 3) & 1)) * 16);
 
-    const int nsteps = (int)kblocks;
-    const bool loads = !(p.dbg & 8), mfma = !(p.dbg & 1);
     unsigned b0 = 0, b1 = PGB_STAGE, b2 = 2 * PGB_STAGE;
-    if (loads) { issue(b0, 0); if (nsteps > 1) issue(b1, 1); }
-    if (nsteps > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if (S > 0) issue_next(b0);
+    if (S > 1) issue_next(b1);
+    if (S > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (half) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-    for (int s = 0; s < nsteps; ++s) {
-        // ---- X(s): the loads of stage s + 2, this step's fragments, the split of the A fragments
-        if (s + 2 < nsteps && loads) issue(b2, (unsigned)(s + 2));
+    int cs = 0, cj = 0;               // compute side: K step within the tile, tile ordinal
+    for (int g = 0; g < S; ++g) {
+        // ---- X(g): the loads of stage g + 2, this step's fragments, the split of the A fragments
+        if (g + 2 < S) issue_next(b2);
         const unsigned a0 = fragA0 + b0, a1 = fragA1 + b0, bb = fragB + b0;
         pg_u32x4 ra[2][2], b[4][3];
         PG_DSR128(ra[0][0], a0, 0); PG_DSR128(ra[0][1], a1, 0);
         PG_DSR128(ra[1][0], a0, 32 * 64); PG_DSR128(ra[1][1], a1, 32 * 64);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) PG_DSR128(b[t][pl], bb, pl * PGB_B_PLANE + t * 32 * 32);
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         uint4 a[2][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             uint2 h0, m0_, l0, h1, m1, l1;
-            split3_bf16x4(__builtin_bit_cast(float4, ra[t][0]), h0, m0_, l0);
-            split3_bf16x4(__builtin_bit_cast(float4, ra[t][1]), h1, m1, l1);
+            pg_split3x4(__builtin_bit_cast(float4, ra[t][0]), h0, m0_, l0);
+            pg_split3x4(__builtin_bit_cast(float4, ra[t][1]), h1, m1, l1);
             a[t][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
             a[t][1] = make_uint4(m0_.x, m0_.y, m1.x, m1.y);
             a[t][2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
@@ -628,17 +666,31 @@ __global__ __launch_bounds__(PGB_THREADS, 2) void k_pgemm_pp(PlaneGemmP p) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(a[t][pl].x), "+v"(a[t][pl].y), "+v"(a[t][pl].z), "+v"(a[t][pl].w));
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        if (g + 2 < S) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- Y(s)
+        // ---- Y(g): the MFMAs, at raised priority (the partner's X phase fills the issue slots they leave)
+        // (the B fragments of the wave's second pair of column tiles are read here, under the first 24 MFMAs: 24 registers fewer
+        // live across the barrier; the stage stays valid until X(g + 1) of this wave group refills it)
+#pragma unroll
+        for (int t = 2; t < 4; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) PG_DSR128(b[t][pl], bb, pl * PGB_B_PLANE + t * 32 * 32);
+        __builtin_amdgcn_s_setprio(1);
         if (mfma) {
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) PG_MMA6(acc[tm][tn], a[tm][0], a[tm][1], a[tm][2], b[tn][0], b[tn][1], b[tn][2]);
+                for (int tn = 0; tn < 2; ++tn) PG_MMA6(acc[tm][tn], a[tm][0], a[tm][1], a[tm][2], b[tn][0], b[tn][1], b[tn][2]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 2; tn < 4; ++tn) PG_MMA6(acc[tm][tn], a[tm][0], a[tm][1], a[tm][2], b[tn][0], b[tn][1], b[tn][2]);
         } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -648,25 +700,33 @@ __global__ __launch_bounds__(PGB_THREADS, 2) void k_pgemm_pp(PlaneGemmP p) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) asm volatile("" :: "v"(b[t][pl]));
         }
+        __builtin_amdgcn_s_setprio(0);
+        if (++cs == nsteps) {
+            // the tile is complete: straight from the accumulator layout - per register two rows of 32 consecutive floats
+            const int tile = vid0 + cj * (int)gridDim.x;
+            const int bx = tile / p.tiles_n, by = tile - bx * p.tiles_n;
+            const int m0 = bx * PGB_BM, n0 = by * PGB_BN;
+            const int col = n0 + wn * 128 + (lane & 31);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    float *dst = p.c + (size_t)m * p.ldc + col;
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) {
+                        if (!(p.dbg & 4) && m < p.M && col + tn * 32 < p.N) dst[tn * 32] = acc[tm][tn][e];
+                        acc[tm][tn][e] = 0.0f;
+                    }
+                }
+            cs = 0; ++cj;
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const unsigned t_ = b0; b0 = b1; b1 = b2; b2 = t_;
     }
     if (!half) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-    if (!(p.dbg & 4)) {
-        const int col = n0 + wn * 128 + (lane & 31);
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                float *dst = p.c + (size_t)m * p.ldc + col;
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-                    if (m < p.M && col + tn * 32 < p.N) dst[tn * 32] = acc[tm][tn][e];
-            }
-    }
     if (p.stamps && tid == 0) {
         unsigned long long *o = p.stamps + (size_t)blockIdx.x * 5;
         o[0] = st_t0; o[1] = pg_now(); o[2] = st_r0; o[3] = __builtin_amdgcn_s_memrealtime();
@@ -1042,8 +1102,8 @@ int launch_pgemm(PlaneGemmP &p, int bm, int bn, hipStream_t st) {
         else hipLaunchKernelGGL((k_pgemm_fa<128, 64>), grid, blk, 0, st, p);
     } else if (KIND == 3) {
         hipLaunchKernelGGL(k_pgemm_big, grid, dim3(PGB_THREADS), 0, st, p);
-    } else if (KIND == 4) {
-        hipLaunchKernelGGL(k_pgemm_pp, grid, dim3(PGB_THREADS), 0, st, p);
+    } else if (KIND == 4) {         // persistent: one workgroup per CU (122,880 B of LDS each), fewer when there are fewer tiles
+        hipLaunchKernelGGL(k_pgemm_pp, dim3(std::min(total, g_cus())), dim3(PGB_THREADS), 0, st, p);
     } else if (KIND == 5) {
         hipLaunchKernelGGL(k_pgemm_gpp, grid, dim3(PGB_THREADS), 0, st, p);
     } else {

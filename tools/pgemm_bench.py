@@ -153,6 +153,8 @@ def stamps_report(kind=0, dbg=0):
     torch.cuda.synchronize()
     check(lib.mrcnn_debug_planes_gemm_stamps(None)); check(lib.mrcnn_debug_conv_parts(0))
     s = st.cpu().numpy().astype(np.int64)
+    s = s[s[:, 3] > 0]
+    nwg = len(s)
     t0, t1, r0, r1, hw = s[:, 0], s[:, 1], s[:, 2], s[:, 3], s[:, 4]
     hwid, xcc = hw & 0xffffffff, (hw >> 32) & 0xf
     cu = ((hwid >> 8) & 0xf) | (((hwid >> 12) & 0x1) << 4) | (((hwid >> 13) & 0x7) << 5) | (xcc << 8)
