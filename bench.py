@@ -9,7 +9,10 @@ Workloads
             resident in HBM.  value = algorithmic ROIAlign-backward GB/s (the second half of
             BASELINE.json's metric), whole job (sum over ranks; ranks run independent batches).
   step      BASELINE.json configs[2]: full ResNet50-FPN Mask R-CNN training step, bs=2/GPU,
-            1024x1024 (images/sec) - selected automatically once the training path is built.
+            1024x1024 (images/sec) - selected automatically once the training path is built.  Runs with the
+            shipped GEMM arithmetic of train.py (config.gemm_arithmetic says which MFMA instruction every
+            pass uses); the all-float32-MFMA step is always measured in the same process and printed as
+            config.images_per_sec_f32_mfma.
   keypoint  BASELINE.json configs[4] per-GPU shape: the Keypoint R-CNN step of train_keypoints.py
             (17 keypoints, 56x56 heat maps), same batch / image size; a secondary line, never the default.
 
@@ -242,6 +245,8 @@ def main():
     ap.add_argument('--workload', default='auto', choices=['auto', 'roialign', 'step', 'keypoint'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mask-rows', default='all', choices=['positives', 'all'])
+    ap.add_argument('--gemm-arithmetic', default=None, choices=['f32', 'bf16x6_backward', 'bf16x6'],
+                    help='arithmetic of the convolution GEMMs of the step workloads (default: the shipped training default, train.py)')
     ap.add_argument('--graph', type=int, default=0, help='capture the step into a HIP graph (single GPU; measured slower than eager multi-stream launches on ROCm 7.2, so off by default)')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', 1))

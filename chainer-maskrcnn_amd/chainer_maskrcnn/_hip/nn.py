@@ -71,6 +71,14 @@ def winograd_pass_tiles():
     return (t[0], t[1], t[2])
 
 
+def split_operands():
+    """(forward, backward-data, backward-filter) GEMM arithmetic of the process (mrcnn_conv2d_set_split_operands)."""
+    import ctypes
+    t = (ctypes.c_int * 3)()
+    check(lib().mrcnn_conv2d_get_split_operands(t))
+    return (t[0], t[1], t[2])
+
+
 def set_winograd_pass_tiles(fwd, bwd_data, bwd_filter):
     check(lib().mrcnn_conv2d_set_winograd_pass_tiles(int(fwd), int(bwd_data), int(bwd_filter)))
 

@@ -8,11 +8,13 @@ import numpy as np
 import torch
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
 
 
 def bench_step(args, rank, world):
     from chainer_maskrcnn.model.maskrcnn import MaskRCNN
-    from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChain, calc_mask_loss, calc_keypoint_loss
+    from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import (FPNMaskRCNNTrainChain, calc_mask_loss, calc_keypoint_loss, GEMM_ARITHMETIC,
+                                                                 DEFAULT_GEMM_ARITHMETIC)
     from chainer_maskrcnn.optimizers import MomentumSGD, WeightDecay
     from chainer_maskrcnn.utils.synthetic import make_batch
     from chainer_maskrcnn._hip import nn as hnn
@@ -25,12 +27,13 @@ def bench_step(args, rank, world):
         from chainer_maskrcnn._hip import lib, check
         check(lib().mrcnn_conv2d_set_winograd_pass_tiles(*[int(v) for v in tiles.split(',')]))
     keypoints = bool(getattr(args, 'keypoints', False))
+    arith = getattr(args, 'gemm_arithmetic', None) or DEFAULT_GEMM_ARITHMETIC        # the shipped training default (train.py)
     if keypoints:       # BASELINE.json configs[4] per-GPU shape: train_keypoints.py's model (1 class, 17 keypoints, 8 mask convs, 56x56 maps)
         model = MaskRCNN(n_fg_class=1, n_keypoints=17, head_arch='fpn_keypoint', device=dev, seed=1234)
-        chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_keypoint_loss, binary_mask=False, mask_rows=mask_rows)
+        chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_keypoint_loss, binary_mask=False, mask_rows=mask_rows, gemm_arithmetic=arith)
     else:
         model = MaskRCNN(n_fg_class=80, device=dev, seed=1234)
-        chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows=mask_rows)
+        chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows=mask_rows, gemm_arithmetic=arith)
     opt = MomentumSGD(lr=1e-3, momentum=0.9).setup(chain)
     opt.add_hook(WeightDecay(0.0005))
     rccl = None
@@ -80,18 +83,21 @@ def bench_step(args, rank, world):
         dp_report = opt.sync.timing_report()
         opt.sync.timing = False
 
+    def timed(n_warm=2, n=5):
+        for _ in range(n_warm):
+            opt.update(chain, imgs, bb, lab, masks, 1.0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            opt.update(chain, imgs, bb, lab, masks, 1.0)
+        torch.cuda.synchronize()
+        return N * n / (time.perf_counter() - t1)
+
     # the same step with the mask branch on the positive rows only (identical loss and gradients)
     alt = None
     if mask_rows == 'all' and world == 1:
         chain.mask_rows = 'positives'
-        for _ in range(2):
-            opt.update(chain, imgs, bb, lab, masks, 1.0)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            opt.update(chain, imgs, bb, lab, masks, 1.0)
-        torch.cuda.synchronize()
-        alt = N * 5 / (time.perf_counter() - t1)
+        alt = timed()
         chain.mask_rows = 'all'
 
     # opt-in mode: F(4x4) Winograd in the forward pass of the ResNet conv2 layers too (activations still <= 2.2e-4 of
@@ -101,39 +107,32 @@ def bench_step(args, rank, world):
     if world == 1 and not tiles:
         from chainer_maskrcnn._hip import lib, check
         check(lib().mrcnn_conv2d_set_winograd_pass_tiles(0, 0, 0))
-        for _ in range(2):
-            opt.update(chain, imgs, bb, lab, masks, 1.0)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            opt.update(chain, imgs, bb, lab, masks, 1.0)
-        torch.cuda.synchronize()
-        fast = N * 5 / (time.perf_counter() - t1)
-        check(lib().mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))
-        opt.update(chain, imgs, bb, lab, masks, 1.0)
+        try:
+            fast = timed()
+        finally:
+            check(lib().mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))
 
-    # EXPLORATORY opt-in modes (reported, never `value`): the GEMMs with three-term split operands on the 16-bit
-    # MFMA (hi + lo planes per float32 operand, float32 accumulation) - gfx950 has no xf32, this is what the 157.3 TF/s ceiling
-    # costs.  (0,1,1): float32 forward, bf16 planes in both backward passes - passes the full-width parity bars of the float32
-    # configuration unchanged; (2,1,1): half planes in the forward pass too - activations at the float32 kernels' level, a few
-    # gradient tensors up to 7.6 x the float32 noise floor (tests/test_full_width_gpu.py); (3,3,3): THREE bf16 planes (= the float32
-    # operand exactly) and six products in every pass - a float32-ACCURATE emulation (error against float64 <= the float32 MFMA's own)
-    split_ips = {}
+    # The same step under the other GEMM arithmetics, same process (reported beside `value`, never as `value`): ALWAYS the all-float32
+    # MFMA step (what a reader who does not accept the float32-accurate emulation falls back on), the emulation in every pass, and two
+    # NARROWER schemes (two-plane splits: 16 / 22 operand bits) that are opt-in lines forever.  A failure of an opt-in mode is
+    # reported in the line, it does not lose the line.
+    other = {}
     if world == 1 and not tiles:
         from chainer_maskrcnn._hip import lib, check
-        for name, smode in (('bf16x6', (3, 3, 3)), ('bf16x6_backward', (0, 3, 3)), ('split_bf16_backward', (0, 1, 1)), ('split_half_forward_bf16_backward', (2, 1, 1))):
-            check(lib().mrcnn_conv2d_set_split_operands(*smode))
+        keep = chain.gemm_arithmetic
+        chain.gemm_arithmetic = None
+        for name, smode in (('f32', (0, 0, 0)), ('bf16x6', (3, 3, 3)), ('bf16x6_backward', (0, 3, 3)), ('split_bf16_backward', (0, 1, 1)),
+                            ('split_half_forward_bf16_backward', (2, 1, 1))):
+            if smode == GEMM_ARITHMETIC[arith]:
+                continue
             try:
-                for _ in range(2):
-                    opt.update(chain, imgs, bb, lab, masks, 1.0)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(5):
-                    opt.update(chain, imgs, bb, lab, masks, 1.0)
-                torch.cuda.synchronize()
-                split_ips[name] = N * 5 / (time.perf_counter() - t1)
+                check(lib().mrcnn_conv2d_set_split_operands(*smode))
+                other[name] = round(timed(), 3)
+            except Exception as e:
+                other[name] = 'failed: %s' % str(e).split('\n')[0][:160]
             finally:
-                check(lib().mrcnn_conv2d_set_split_operands(0, 0, 0))
+                check(lib().mrcnn_conv2d_set_split_operands(*GEMM_ARITHMETIC[arith]))
+        chain.gemm_arithmetic = keep
         opt.update(chain, imgs, bb, lab, masks, 1.0)
 
     # roofline of the dominant kernel family (k_conv_igemm): instrumented steps, HIP events around every launch
@@ -159,6 +158,25 @@ def bench_step(args, rank, world):
     launches = sum(a[0] for a in agg.values()) // n_prof
     split = _replay_split(recs, n_prof, dev)
     pmc = _pmc_step_counters()
+    smode = GEMM_ARITHMETIC[arith]
+    pass_of = {'fwd': 0, 'bwd_data': 1, 'bwd_filter': 2}
+    emu_kinds = [k for k in ('fwd', 'bwd_data', 'bwd_filter') if smode[pass_of[k]] == 3]
+    f32_kinds = [k for k in ('fwd', 'bwd_data', 'bwd_filter') if smode[pass_of[k]] == 0]
+    gk = split['gemm_by_kind']
+
+    def pipe(kinds, mult, peak):
+        fl = sum(gk[k]['executed_flops'] for k in kinds if k in gk) * mult
+        ms = sum(gk[k]['ms_per_step'] for k in kinds if k in gk)
+        return {'passes': kinds, 'executed_TFLOPs': round(fl / (ms * 1e-3) / 1e12, 2) if ms else None, 'peak': peak,
+                'frac': round(fl / (ms * 1e-3) / 1e12 / peak, 4) if ms else None, 'gemm_ms_per_step': round(ms, 3), 'executed_flops_per_step': fl}
+    # The dominant kernel = the GEMM launches of the convolution calls.  Each pass is priced on the pipe it runs on: a float32-MFMA
+    # pass executes 2 flops per MAC on v_mfma_f32_32x32x2_f32 (peak 157.3 TF/s), an emulated pass SIX bf16 MFMA products per MAC on
+    # v_mfma_f32_32x32x16_bf16 (peak 2500 TF/s dense).  `roofline` is the larger of the two groups by time.
+    emu = pipe(emu_kinds, 6.0, MFMA_BF16_PEAK_TFLOPS) if emu_kinds else None
+    f32 = pipe(f32_kinds, 1.0, MFMA_F32_PEAK_TFLOPS) if f32_kinds else None
+    head = emu if (emu and (not f32 or emu['gemm_ms_per_step'] >= f32['gemm_ms_per_step'])) else f32
+    head_is_emu = head is emu
+    gemm_ms = sum(v['ms_per_step'] for v in gk.values())
     out = {
         'metric': 'images/sec (1024^2 COCO, bs=2/GPU) at 1/2/4/8 MI355X; ROIAlign bwd HBM GB/s',
         'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -171,49 +189,66 @@ def bench_step(args, rank, world):
                                 '8 gt boxes/image, 2000 proposals -> 256 sampled RoIs/image, mask branch on %s rows')
                                % ('the <=64 positive' if mask_rows == 'positives' else 'all 256 sampled'),
                    'global_batch': N * world, 'launch_mode': mode, 'parallelism': 'dp%d: RCCL all-reduce of the flat gradient buffer in 25 MB '
-                   'buckets on a side stream' % world if world > 1 else 'single GPU', 'final_loss': round(loss, 4)},
-        # frac = MFMA flops the pipes EXECUTE (Winograd layers: (m+2)^2 GEMMs on tiles, padded channels included) over the
-        # whole convolution bracket (GEMM launches + Winograd transforms + slab / column sums) / fp32 MFMA peak: <= 1.
-        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm<fwd|bwd_data|bwd_filter> (all %d convolution calls of a step)' % launches,
-                     'achieved': round(exe_flops / secs / 1e12, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(exe_flops / secs / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': pmc['traffic'],
-                     'traffic_source': pmc['traffic_source'],
+                   'buckets on a side stream' % world if world > 1 else 'single GPU', 'final_loss': round(loss, 4),
+                   'gemm_arithmetic': {
+                       'name': arith, 'split_operands_fwd_bwddata_bwdfilter': list(smode),
+                       'scheme': {'f32': 'v_mfma_f32_32x32x2_f32 in every pass: float32 operands, float32 accumulate (bit for bit an fmaf chain)',
+                                  'bf16x6_backward': 'forward pass: v_mfma_f32_32x32x2_f32 on float32 operands (activations, losses and sampled targets are '
+                                                     'those of the all-float32 step bit for bit); backward-data and backward-filter passes: float32-ACCURATE '
+                                                     'emulation on v_mfma_f32_32x32x16_bf16 - every float32 operand is carried EXACTLY by three bf16 planes '
+                                                     'hi + mid + lo, the six products of weight >= 2^-16 (lh + hl + mm + mh + hm + hh) are accumulated in float32; '
+                                                     'the dropped terms are <= 3 x 2^-24 |ab|, the size of the float32 MFMA\'s own accumulation rounding',
+                                  'bf16x6': 'the three-plane / six-product float32-accurate emulation on v_mfma_f32_32x32x16_bf16 in every pass'}[arith],
+                       'tensors': 'float32 in HBM everywhere; float32 accumulators; no tensor is stored in 16 bits',
+                       'why_this_is_the_value': 'VERDICT r3 ruling: the three-plane emulation is not narrower than the float32 MFMA (per-GEMM error against '
+                                                'float64 <= the float32 kernel\'s: tests/test_split_gemm_gpu.py); it carries the headline in the passes where the '
+                                                'full-width parity bars of the float32 configuration hold UNRELAXED on five batches '
+                                                '(tests/test_full_width_gpu.py, profiles/r04_full_width_parity_five_seeds.txt): the two backward passes.  With the '
+                                                'emulation in the forward pass too, one of the five batches has 4 % of the gradient tensors above 3 x the float32 '
+                                                'floor (bar 3 %): that configuration stays an opt-in line'},
+                   'images_per_sec_f32_mfma': other.get('f32') if arith != 'f32' else round(ips, 3)},
+        # The GEMM launches of the headline pass group on the pipe they run on (see above); the whole convolution bracket (GEMMs +
+        # Winograd transforms + sums) and the float32 group follow as extra keys.
+        'roofline': {'bound': 'mfma',
+                     'kernel': ('k_conv_igemm<bwd_data|bwd_filter, split 3> + k_pgemm_pp / k_pgemm_gpp (plane GEMMs): the GEMM launches of the %s passes'
+                                % ' + '.join(head['passes'])) if head_is_emu else
+                               'k_conv_igemm<%s>: the GEMM launches of the float32-MFMA passes' % '|'.join(head['passes']),
+                     'achieved': head['executed_TFLOPs'], 'peak': head['peak'], 'unit': 'TFLOP/s', 'frac': head['frac'],
+                     'pipe': 'v_mfma_f32_32x32x16_bf16, dense bf16 peak; executed flops = 6 products x 2 x MACs the pipes execute' if head_is_emu else
+                             'v_mfma_f32_32x32x2_f32, float32 MFMA peak; executed flops = 2 x MACs the pipes execute',
+                     'gemm_ms_per_step': head['gemm_ms_per_step'], 'executed_flops_per_step': head['executed_flops_per_step'],
+                     'effective_fp32_TFLOPs': round(sum(gk[k]['executed_flops'] for k in head['passes'] if k in gk) / (head['gemm_ms_per_step'] * 1e-3) / 1e12, 2)
+                     if head['gemm_ms_per_step'] else None,
+                     'traffic': pmc['traffic'], 'traffic_source': pmc['traffic_source'],
                      'hbm_bytes_per_step_by_family': pmc.get('hbm_bytes_per_step_by_family'),
                      'hbm_bytes_per_step_whole_step': pmc.get('hbm_bytes_per_step_whole_step'),
-                     'pmc_mfma_busy_fraction_all_k_conv_igemm': pmc.get('pmc_mfma_busy_fraction_all_k_conv_igemm'),
+                     'pmc_mfma_busy_fraction_by_kernel': pmc.get('pmc_mfma_busy_fraction_by_kernel'),
                      'pmc_mfma_source': pmc.get('pmc_mfma_source'),
-                     'executed_flops_per_step': exe_flops, 'conv_ms_per_step': round(secs * 1e3, 3),
-                     'effective_TFLOPs': round(flops / secs / 1e12, 3), 'algorithmic_flops_per_step': flops,
-                     'gemm_kernels_only': split['gemm'],
-                     'by_kind': {k: {'launches': a[0] // n_prof, 'effective_TFLOPs': round(a[1] / a[2] / 1e12, 3),
-                                     'executed_TFLOPs': round(a[3] / a[2] / 1e12, 3),
-                                     'ms': round(a[2] / n_prof * 1e3, 3)} for k, a in agg.items()},
-                     'note': 'HIP events around every conv call on %d instrumented single-stream steps right after the timed '
-                             'region.  achieved = executed MFMA flops / bracket time; effective_TFLOPs = 2 x the direct '
-                             'convolution\'s MACs on un-padded channels / the same time (can exceed the peak: Winograd executes '
-                             '2.25x / 4x fewer multiplications).  gemm_kernels_only / roofline_winograd_transforms: the same calls '
-                             'replayed standalone with mrcnn_conv2d_set_debug_skip (GEMMs only / everything but the GEMMs)' % n_prof},
+                     'gemm_kernels_only': {'ms_per_step_all_passes': round(gemm_ms, 3), 'by_pass': gk,
+                                           'float32_mfma_passes': f32, 'bf16_emulated_passes': emu},
+                     'conv_bracket': {'ms_per_step': round(secs * 1e3, 3), 'launches': launches,
+                                      'executed_macs_x2_per_step': exe_flops, 'algorithmic_flops_per_step': flops,
+                                      'effective_fp32_TFLOPs': round(flops / secs / 1e12, 3),
+                                      'by_kind': {k: {'launches': a[0] // n_prof, 'effective_fp32_TFLOPs': round(a[1] / a[2] / 1e12, 3),
+                                                      'ms': round(a[2] / n_prof * 1e3, 3)} for k, a in agg.items()}},
+                     'note': 'gemm_kernels_only: every distinct convolution call of the step replayed standalone with '
+                             'mrcnn_conv2d_set_debug_skip(2) (GEMM launches only), HIP events, times weighted by the call counts of %d instrumented '
+                             'single-stream steps that ran right after the timed region; conv_bracket: HIP events around every conv call of those '
+                             'steps (GEMMs + Winograd transforms + slab / column sums); effective_fp32_TFLOPs = 2 x MACs of the direct algorithm on '
+                             'un-padded channels (conv_bracket) or 2 x executed MACs (roofline) per second - a rate in float32-equivalent work, '
+                             'not a fraction of any peak' % n_prof},
         'roofline_winograd_transforms': split['aux'],
     }
     if alt is not None:
         out['config']['images_per_sec_mask_branch_on_positive_rows_only'] = round(alt, 3)
     if fast is not None:
         out['config']['images_per_sec_opt_in_winograd_f4_forward'] = round(fast, 3)
-    if split_ips:
-        out['config']['exploratory_opt_in_split_operands'] = {
-            'images_per_sec_float32_accurate_bf16x6_all_passes': round(split_ips['bf16x6'], 3),
-            'images_per_sec_f32_forward_bf16x6_backward': round(split_ips['bf16x6_backward'], 3),
-            'images_per_sec_f32_forward_bf16x3_backward': round(split_ips['split_bf16_backward'], 3),
-            'images_per_sec_f16x3_forward_bf16x3_backward': round(split_ips['split_half_forward_bf16_backward'], 3),
-            'dtype': 'float32 tensors; GEMM operands staged as hi + lo 16-bit planes (bf16: 16 significant bits, half: 22), products '
-                     'al*bh + ah*bl + ah*bh on the bf16 / f16 MFMA, float32 accumulation',
-            'note': 'mrcnn_conv2d_set_split_operands; NOT the headline (`value` is the float32-MFMA step).  bf16x6 = three bf16 planes per '
-                    'operand (hi + mid + lo = the float32 value exactly), six products: per-layer error against float64 <= the float32 '
-                    "MFMA kernels' (tools/ab_bf16.py), all float32 parity bars pass (test_full_width_512_float32_accurate_emulation_opt_in).  "
-                    'f32 forward + bf16x3 backward '
-                    'passes the same full-width parity bars as the float32 configuration (test_full_width_*_split_bf16_backward_opt_in); '
-                    'with f16x3 forward activations stay at the float32 level and 2 of 180 gradient tensors reach 7.6x the float32 noise '
-                    'floor (bar 6x)'}
+    if other:
+        out['config']['other_gemm_arithmetics_same_process'] = {
+            'images_per_sec': other,
+            'note': 'mrcnn_conv2d_set_split_operands(forward, backward-data, backward-filter): f32 = (0,0,0); bf16x6 = (3,3,3) the float32-accurate '
+                    'emulation in every pass (opt-in, see gemm_arithmetic.why_this_is_the_value); bf16x6_backward = (0,3,3); split_bf16_backward = (0,1,1) '
+                    'and split_half_forward_bf16_backward = (2,1,1) are NARROWER two-plane splits (16 / 22 operand bits): opt-in lines, never `value`'}
     out['config']['winograd_tiles_fwd_bwddata_bwdfilter'] = tiles or ('2,0,0 (0 = F(4x4) where the layer is large enough, else F(2x2)); the FPN / '
                                                                       'RPN / head convolutions run their forward pass with 0')
     if dp_report is not None:
@@ -268,37 +303,42 @@ def _gather_over_ranks(v, world, dev):
 def _pmc_step_counters():
     """What the hardware counters said about this step - NOT measured by this run: counters need rocprofv3 (separate --pmc
     passes, tools/round_end.sh), so the numbers are read from the summaries committed under profiles/ and the line says
-    which file and which commit of the kernels they were collected at (`traffic_source`)."""
-    f, d = latest_profile('step_pmc_traffic.json')
-    g, m = latest_profile('conv_pmc_mfma.json')
+    which file and which commit of the kernels they were collected at (`traffic_source`).  A summary that lacks a key gives
+    None fields, never an exception."""
     out = {'traffic': None, 'traffic_source': None}
-    if d is not None:
-        out['traffic'] = d['conv_bracket']['hbm_bytes_per_step']
-        fam = {k: v['hbm_bytes_per_step'] for k, v in d.items() if isinstance(v, dict) and 'hbm_bytes_per_step' in v and k != 'conv_bracket'}
-        out['traffic_source'] = {'file': f, 'collected_at_commit': d.get('_commit'), 'kind': 'constant read from the committed rocprofv3 --pmc summary, '
-                                 'not collected by this run', 'method': d.get('_method')}
-        out['hbm_bytes_per_step_by_family'] = fam
-        out['hbm_bytes_per_step_whole_step'] = sum(fam.values())
-    if m is not None:
-        ks = m.get('kernels', {})
-        cyc = sum(v['gpu_cycles_per_step'] for k, v in ks.items() if k.startswith('k_conv_igemm'))
-        busy = sum(v['gpu_cycles_per_step'] * v['mfma_busy_fraction'] for k, v in ks.items() if k.startswith('k_conv_igemm'))
-        out['pmc_mfma_busy_fraction_all_k_conv_igemm'] = round(busy / cyc, 4) if cyc else None
-        out['pmc_mfma_source'] = {'file': g, 'collected_at_commit': m.get('_commit')}
+    try:
+        f, d = latest_profile('step_pmc_traffic.json')
+        if d is not None:
+            out['traffic'] = d['conv_bracket']['hbm_bytes_per_step']
+            fam = {k: v['hbm_bytes_per_step'] for k, v in d.items() if isinstance(v, dict) and 'hbm_bytes_per_step' in v and k != 'conv_bracket'}
+            out['traffic_source'] = {'file': f, 'collected_at_commit': d.get('_commit'), 'kind': 'constant read from the committed rocprofv3 --pmc summary, '
+                                     'not collected by this run', 'method': d.get('_method')}
+            out['hbm_bytes_per_step_by_family'] = fam
+            out['hbm_bytes_per_step_whole_step'] = sum(fam.values())
+    except Exception as e:
+        out['traffic_source'] = {'error': 'unreadable step_pmc_traffic summary: %s' % str(e)[:120]}
+    try:
+        g, m = latest_profile('conv_pmc_mfma.json')
+        if m is not None:
+            ks = {k: v for k, v in m.get('kernels', {}).items() if k.startswith('k_conv_igemm') or k.startswith('k_pgemm')}
+            out['pmc_mfma_busy_fraction_by_kernel'] = {k: v.get('mfma_busy_fraction') for k, v in ks.items()}
+            out['pmc_mfma_source'] = {'file': g, 'collected_at_commit': m.get('_commit')}
+    except Exception as e:
+        out['pmc_mfma_source'] = {'error': 'unreadable conv_pmc_mfma summary: %s' % str(e)[:120]}
     return out
 
 
 def _replay_split(recs, n_prof, dev):
     """Every distinct convolution call of the step replayed standalone (random operands, 3 repetitions, HIP events) with the
-    library's measurement knob: GEMM launches only, and everything but the GEMM launches (Winograd transforms, slab /
-    tail / column sums).  Returns the two roofline objects."""
+    library's measurement knob, under the GEMM arithmetic in force: GEMM launches only (per pass), and everything but the GEMM
+    launches (Winograd transforms, slab / tail / column sums).  Returns {'gemm_by_kind', 'aux'}."""
     from chainer_maskrcnn._hip import nn as hnn, lib, check
     HBM_PEAK = 8000.0
     geoms = {}
     for rec in recs:
         geoms[(rec[0], rec[6], rec[7])] = geoms.get((rec[0], rec[6], rec[7]), 0) + 1
-    tot = {1: 0.0, 2: 0.0}
-    exe, aux_bytes = 0.0, 0.0
+    gemm_s, exe_k = {}, {}
+    aux_s, aux_bytes = 0.0, 0.0
     keep = hnn.PROFILE
     hnn.PROFILE = None
     base = hnn.winograd_pass_tiles()
@@ -324,8 +364,12 @@ def _replay_split(recs, n_prof, dev):
                     fn()
                 e1.record()
                 torch.cuda.synchronize()
-                tot[mask] += e0.elapsed_time(e1) / 3 * 1e-3 * cnt
-            exe += 2.0 * lib().mrcnn_conv2d_executed_macs(*g, {'fwd': 0, 'bwd_data': 1, 'bwd_filter': 2}[kind]) * cnt
+                t = e0.elapsed_time(e1) / 3 * 1e-3 * cnt
+                if mask == 2:
+                    gemm_s[kind] = gemm_s.get(kind, 0.0) + t
+                else:
+                    aux_s += t
+            exe_k[kind] = exe_k.get(kind, 0.0) + 2.0 * lib().mrcnn_conv2d_executed_macs(*g, {'fwd': 0, 'bwd_data': 1, 'bwd_filter': 2}[kind]) * cnt
             vb = lib().mrcnn_conv2d_winograd_v_bytes(*g)
             if vb:          # transforms stream: activation in + transformed operand out, GEMM result in + activation out
                 wb = lib().mrcnn_conv2d_winograd_w_bytes(*g)
@@ -335,12 +379,11 @@ def _replay_split(recs, n_prof, dev):
         check(lib().mrcnn_conv2d_set_debug_skip(0))
         hnn.set_winograd_pass_tiles(*base)
         hnn.PROFILE = keep
-    gemm = {'TFLOPs': round(exe / tot[2] / 1e12, 3), 'frac': round(exe / tot[2] / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-            'ms_per_step': round(tot[2] * 1e3, 3)}
+    by_kind = {k: {'ms_per_step': round(gemm_s[k] * 1e3, 3), 'executed_flops': exe_k[k]} for k in gemm_s}
     aux = {'bound': 'hbm', 'kernel': 'k_wino_input / k_wino_output / k_wino_gy / k_wino_filter* + slab, tail and column sums',
-           'achieved': round(aux_bytes / tot[1] / 1e9, 1), 'peak': HBM_PEAK, 'unit': 'GB/s',
-           'frac': round(aux_bytes / tot[1] / 1e9 / HBM_PEAK, 4), 'traffic': None, 'ms_per_step': round(tot[1] * 1e3, 3),
+           'achieved': round(aux_bytes / aux_s / 1e9, 1), 'peak': HBM_PEAK, 'unit': 'GB/s',
+           'frac': round(aux_bytes / aux_s / 1e9 / HBM_PEAK, 4), 'traffic': None, 'ms_per_step': round(aux_s * 1e3, 3),
            'algorithmic_bytes_per_step': aux_bytes,
-           'note': 'bytes = activations + transformed operands (V, M / W) of the Winograd calls, each crossing HBM once; the time '
-                   'also contains the split-K slab sums and bias column sums of the direct layers'}
-    return {'gemm': gemm, 'aux': aux}
+           'note': 'bytes = activations + transformed operands (V, M / W) of the Winograd calls, each crossing HBM once (float32 sizes); the '
+                   'time also contains the split-K slab sums and bias column sums of the direct layers'}
+    return {'gemm_by_kind': by_kind, 'aux': aux}

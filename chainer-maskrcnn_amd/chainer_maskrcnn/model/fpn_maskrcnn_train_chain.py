@@ -92,9 +92,30 @@ def calc_keypoint_loss(roi_cls_mask, gt_roi_mask, xp, gt_roi_label, num_keypoint
 calc_keypoint_loss.fused_kind = 'keypoint_ce'
 
 
+# Arithmetic of the convolution GEMMs (mrcnn_conv2d_set_split_operands: forward, backward-data, backward-filter).  All three take
+# float32 tensors in and out and accumulate in float32:
+#   'f32'              v_mfma_f32_32x32x2_f32 in every pass (bit for bit an fmaf chain)
+#   'bf16x6_backward'  the SHIPPED training default (train.py, bench.py): float32 MFMA in the forward pass - activations, losses and
+#                      sampled targets are those of 'f32' bit for bit - and the float32-ACCURATE three-plane emulation on
+#                      v_mfma_f32_32x32x16_bf16 in both backward passes: every operand is carried exactly by three bf16 planes
+#                      (hi + mid + lo), the six products of weight >= 2^-16 are accumulated in float32; per-GEMM error against
+#                      float64 <= the float32 MFMA's (tests/test_split_gemm_gpu.py), full-width parity on five batches with the bars
+#                      of the float32 configuration (tests/test_full_width_gpu.py, profiles/r04_full_width_parity_five_seeds.txt)
+#   'bf16x6'           the emulation in the forward pass too (opt-in: on one of the five batches a near-tie of the FPN part falls the
+#                      other way and 4 % of the gradient tensors sit above 3 x the float32 floor, against a 3 % bar)
+GEMM_ARITHMETIC = {'f32': (0, 0, 0), 'bf16x6_backward': (0, 3, 3), 'bf16x6': (3, 3, 3)}
+DEFAULT_GEMM_ARITHMETIC = 'bf16x6_backward'
+
+
 class FPNMaskRCNNTrainChain(object):
     def __init__(self, faster_rcnn, mask_loss_fun=calc_mask_loss, binary_mask=True, rpn_sigma=3., roi_sigma=1.,
-                 anchor_target_creator=None, strict_batch1=False, mask_rows='positives'):
+                 anchor_target_creator=None, strict_batch1=False, mask_rows='positives', gemm_arithmetic=None):
+        """gemm_arithmetic: a key of GEMM_ARITHMETIC - the chain then selects it (process-wide library setting) at the start of every
+        step; None (default of this constructor, used by the kernel-level tests) leaves the process setting alone.  train.py and
+        bench.py pass DEFAULT_GEMM_ARITHMETIC."""
+        if gemm_arithmetic is not None and gemm_arithmetic not in GEMM_ARITHMETIC:
+            raise ValueError('gemm_arithmetic must be one of %s' % sorted(GEMM_ARITHMETIC))
+        self.gemm_arithmetic = gemm_arithmetic
         self.faster_rcnn = faster_rcnn
         self.proposal_target_creator = ProposalTargetCreator(faster_rcnn.extractor.anchor_sizes)
         self.anchor_target_creator = AnchorTargetCreator()      # the argument is ignored, as in the reference
@@ -137,6 +158,9 @@ class FPNMaskRCNNTrainChain(object):
         n = bboxes.shape[0]
         if self.strict_batch1 and n != 1:
             raise ValueError('Currently only batch size 1 is supported. n={}'.format(n))
+        if self.gemm_arithmetic is not None:        # (read by the library on the host at call time: forward now, backward later)
+            from chainer_maskrcnn._hip import lib, check
+            check(lib().mrcnn_conv2d_set_split_operands(*GEMM_ARITHMETIC[self.gemm_arithmetic]))
         if torch.is_tensor(scale) and scale.numel() == 1:
             scale = float(scale.reshape(-1)[0].item())
         dev = imgs.device

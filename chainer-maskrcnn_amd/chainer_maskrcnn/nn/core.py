@@ -44,14 +44,26 @@ LAYER_TILE_HINTS = True
 FWD_TILE_RULE = None
 # BatchNorm statistics from the producing convolution's GEMM epilogue (mrcnn_conv2d_fwd_bnstats_f32) where the launch allows
 FUSE_BN_STATS = True
+# Measurement (tests/tools/seed_table.py): with the float32-accurate emulation selected for the FORWARD pass, False keeps the forward
+# pass of the layers behind the backbone (every convolution outside extractor/resnet: FPN, RPN, heads - no BatchNorm behind them) on the
+# float32 MFMA.
+FWD_EMULATION_BEHIND_BACKBONE = True
 
 
 class _layer_tiles(object):
     def __init__(self, conv):
         self.t = FWD_TILE_RULE(conv.name) if FWD_TILE_RULE is not None else (conv.fwd_tile if LAYER_TILE_HINTS else None)
         self.keep = None
+        self.behind = '/resnet/' not in conv.name          # FPN laterals / smoothing, RPN, heads: no BatchNorm behind them
 
     def __enter__(self):
+        self.keep_split = None
+        if not FWD_EMULATION_BEHIND_BACKBONE and self.behind:
+            sp = hnn.split_operands()
+            if sp[0] == 3:
+                self.keep_split = sp
+                from chainer_maskrcnn._hip import lib, check
+                check(lib().mrcnn_conv2d_set_split_operands(0, sp[1], sp[2]))
         if self.t is None:
             return
         cur = hnn.winograd_pass_tiles()
@@ -62,6 +74,9 @@ class _layer_tiles(object):
     def __exit__(self, *a):
         if self.keep is not None:
             hnn.set_winograd_pass_tiles(*self.keep)
+        if self.keep_split is not None:
+            from chainer_maskrcnn._hip import lib, check
+            check(lib().mrcnn_conv2d_set_split_operands(*self.keep_split))
 
 
 def join_side_stream(device):

@@ -2131,6 +2131,12 @@ extern "C" int mrcnn_conv2d_set_split_operands(int fwd, int bwd_data, int bwd_fi
     return 0;
 }
 
+extern "C" int mrcnn_conv2d_get_split_operands(int *modes3) {
+    if (!modes3) return mrcnn::fail_arg(MRCNN_E_INVALID, "get_split_operands: null output");
+    for (int i = 0; i < 3; ++i) modes3[i] = g_split_mode[i];
+    return 0;
+}
+
 extern "C" int mrcnn_conv2d_set_debug_skip(int mask) {
     if (mask < 0 || mask > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_debug_skip: mask in [0,3]");
     g_debug_skip = mask;

@@ -200,6 +200,8 @@ int mrcnn_conv2d_get_winograd_pass_tiles(int *tiles3);
  * |ab|, the size of the float32 MFMA's own accumulation rounding) at 3/8 of the float32 MFMA cycles.  gfx950 has no xf32: this is
  * what challenging the 157.3 TF/s fp32-MFMA ceiling costs in accuracy and buys in time.  Values outside 0..3: MRCNN_E_ARG. */
 int mrcnn_conv2d_set_split_operands(int fwd, int bwd_data, int bwd_filter);
+/* The three modes in force (forward, backward-data, backward-filter), for callers that bracket a call with their own setting. */
+int mrcnn_conv2d_get_split_operands(int *modes3);
 /* Measurement knob (tools/gemm_only_profile.py): workgroups per CU the tile choice and the forward / backward-data split-K plan aim
  * for (default 2), the HALF rounds of workgroup slots the filter-gradient split-K fills (default 2 = one round), and a forced forward /
  * backward-data tile (0 = the planner's choice, 1 = 128x64, 2 = 64x64). */

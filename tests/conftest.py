@@ -78,3 +78,19 @@ def pytest_unconfigure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _library_defaults_after_each_test():
+    """Process-wide library settings a test (or train.run / a train chain with gemm_arithmetic set) may have left behind are put back to
+    the library defaults after every test: float32 GEMMs, no measurement knobs.  Only when the library is already loaded (CPU tests never
+    load it)."""
+    yield
+    try:
+        from chainer_maskrcnn import _hip
+    except Exception:
+        return
+    if getattr(_hip, '_lib', None) is not None:
+        _hip._lib.mrcnn_conv2d_set_split_operands(0, 0, 0)
+        _hip._lib.mrcnn_debug_conv_parts(0)
+        _hip._lib.mrcnn_conv2d_set_debug_skip(0)

@@ -46,10 +46,12 @@ MODES = {'direct': ((100000, 1 << 30, 0), (0, 0, 0)),
          'split_bf16': ((256, 2048, 0), (2, 0, 0)), 'split_f16_fwd': ((256, 2048, 0), (2, 0, 0)), 'split_f16': ((256, 2048, 0), (2, 0, 0)),
          'split_f16_fwd_only': ((256, 2048, 0), (2, 0, 0)), 'split_bf16_bwd_only': ((256, 2048, 0), (2, 0, 0)),
          'bf16x6': ((256, 2048, 0), (2, 0, 0)), 'bf16x6_fwd': ((256, 2048, 0), (2, 0, 0)),
-         'bf16x6_fwd_only': ((256, 2048, 0), (2, 0, 0)), 'bf16x6_bwd_only': ((256, 2048, 0), (2, 0, 0))}
+         'bf16x6_fwd_only': ((256, 2048, 0), (2, 0, 0)), 'bf16x6_bwd_only': ((256, 2048, 0), (2, 0, 0)),
+         # measurement: bf16x6 in every pass except the FORWARD pass of the layers behind the backbone (no BatchNorm behind them)
+         'bf16x6_backbone_fwd': ((256, 2048, 0), (2, 0, 0))}
 # split operands per pass (forward, backward-data, backward-filter) of the exploratory modes: 1 = bf16 hi / lo planes, 2 = half planes
 SPLIT = {'split_bf16': (1, 1, 1), 'split_f16_fwd': (2, 1, 1), 'split_f16': (2, 2, 2), 'split_f16_fwd_only': (2, 0, 0), 'split_bf16_bwd_only': (0, 1, 1),
-         'bf16x6': (3, 3, 3), 'bf16x6_fwd': (3, 1, 1), 'bf16x6_fwd_only': (3, 0, 0), 'bf16x6_bwd_only': (0, 3, 3)}
+         'bf16x6': (3, 3, 3), 'bf16x6_fwd': (3, 1, 1), 'bf16x6_fwd_only': (3, 0, 0), 'bf16x6_bwd_only': (0, 3, 3), 'bf16x6_backbone_fwd': (3, 3, 3)}
 DEFAULT = MODES['shipped']
 NAMES = ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
 TAP = 'extractor/resnet/res5/b2'
@@ -111,6 +113,7 @@ def _run(S, mode, keypoints=False, N=1, seed=11, G=6):
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(*MODES[mode][0]))
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(*MODES[mode][1]))
     core.LAYER_TILE_HINTS = MODES[mode][2] if len(MODES[mode]) > 2 else True
+    core.FWD_EMULATION_BEHIND_BACKBONE = mode != 'bf16x6_backbone_fwd'
     _hip.check(_hip.lib().mrcnn_conv2d_set_split_operands(*SPLIT.get(mode, (0, 0, 0))))
     try:
         chain.proposal_target_creator.set_seed(21)
@@ -167,6 +170,7 @@ def _run(S, mode, keypoints=False, N=1, seed=11, G=6):
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_thresholds(*DEFAULT[0]))
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(*DEFAULT[1]))
         core.LAYER_TILE_HINTS = True
+        core.FWD_EMULATION_BEHIND_BACKBONE = True
     # ---- report
     out_dir = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out_dir, exist_ok=True)
@@ -247,17 +251,37 @@ def test_full_width_1024_batch2_split_bf16_backward_opt_in():
     _check(1024, 'split_bf16_bwd_only', N=2, seed=100, G=8, iso_tol=1e-3)
 
 
-def test_full_width_1024_batch2_float32_accurate_emulation_opt_in():
-    """bf16x6 in every pass on the benchmarked configuration (two 1024x1024 images, bench.py's batch): activations, losses, the
-    every-tensor bar (< 6 x the float32 floor), the median bar and the isolated filter gradient as for the float32 configuration.
-    On THIS batch the forward pass in bf16x6 is another realisation of the rounding noise in which one near-tie decision of the
-    FPN / RPN part (no BatchNorm, F(4x4) forward) falls the other way: the ten tensors behind it (toplayer, lat_p2..p4, conv_p3,
-    rpn/conv/b: gradients of 1e-3 of their scale against floors of 3..7e-4) sit at 3.4 - 4.7 x the floor, 5 % of the tensors
-    against the 3 % bar of the float32 configuration, so that bar is 6 % here.  With another batch (seed 101) float32, bf16x6 and
-    (0,3,3) all pass the 3 % bar, bf16x6 with the smaller maximum (3.15 x against 3.37 x); with a float32 forward pass and bf16x6 in
-    both backward passes (0,3,3) this batch passes it too (profiles/r03_full_width_parity_1024_batch2_*bf16x6*.txt)."""
+# The SHIPPED training arithmetic (model/fpn_maskrcnn_train_chain.py DEFAULT_GEMM_ARITHMETIC = 'bf16x6_backward', what train.py runs and
+# bench.py reports as `value`): float32 MFMA forward, float32-accurate three-plane emulation on the bf16 MFMA in both backward passes.
+HEADLINE = 'bf16x6_bwd_only'
+
+
+def test_full_width_1024_batch2_shipped_arithmetic():
+    """The benchmarked batch (bench.py: make_batch(100, 2, 1024, 1024, G=8)) in the shipped arithmetic with EVERY bar of the float32
+    configuration unrelaxed: activations <= 1e-3, losses <= 1e-4, every gradient tensor < max(1e-3, 6 x floor),
+    at most 3 % of the tensors above 3 x floor, median ratio <= 1.3, isolated filter gradient <= 2e-5."""
+    _check(1024, HEADLINE, N=2, seed=100, G=8)
+
+
+def test_full_width_1024_batch2_float32_accurate_emulation_in_every_pass_opt_in():
+    """OPT-IN, not the shipped arithmetic: bf16x6 in the forward pass too.  On THIS batch the emulated forward pass is another
+    realisation of the rounding noise in which one near-tie decision of the FPN / RPN part (no BatchNorm, F(4x4) forward) falls the other
+    way: the tensors behind it (toplayer, lat_p2..p4, conv_p3, rpn/conv/b) sit at 3.4 - 4.7 x the floor, 4 - 5 % of the tensors against
+    the 3 % bar - which is why the forward pass of the shipped arithmetic stays on the float32 MFMA.  On four other batches (seeds
+    101 .. 104) this mode passes the 3 % bar too (profiles/r04_full_width_parity_five_seeds.txt); here the bar is 6 % and everything
+    else (activations, losses, every tensor < 6 x floor, median, isolated filter gradient) is held as for the float32 configuration."""
     _check(1024, 'bf16x6', N=2, seed=100, G=8, above3_frac=0.06)
     _cache.pop(('oracle', 1024, False, 2, 100, 8), None)       # ~10 GB of float64 gradients and activations
+
+
+@pytest.mark.parametrize('seed', [101, 102, 103, 104])
+def test_full_width_1024_batch2_shipped_arithmetic_other_batches(seed):
+    """Four more batches of the benchmarked shape, shipped arithmetic, the same unrelaxed bars (one float64 + two float32 oracle
+    evaluations per batch, ~2 minutes each on the GPU box's host cores)."""
+    try:
+        _check(1024, HEADLINE, N=2, seed=seed, G=8)
+    finally:
+        _cache.pop(('oracle', 1024, False, 2, seed, 8), None)
 
 
 @pytest.mark.parametrize('mode', ['bf16x6', 'bf16x6_fwd'])
@@ -285,6 +309,17 @@ def test_full_width_512_split_half_forward_opt_in():
     assert not [(n, e, fl) for n, e, fl in rows if not e < max(1e-3, 12 * fl)]
     ratios = sorted(e / max(fl, 1e-12) for n, e, fl in rows if e >= 1e-3)
     assert ratios[len(ratios) // 2] <= 1.3, ratios[len(ratios) // 2]
+
+
+def test_full_width_keypoint_1024_batch2_shipped():
+    """BASELINE.json configs[4]'s per-GPU shape: the Keypoint R-CNN of train_keypoints.py, TWO 1024x1024 images,
+    full width, bench.py's batch (make_batch(100, ...)), float32 kernels and then the shipped arithmetic on the same oracle: the bars
+    of the mask test."""
+    try:
+        _check(1024, 'shipped', keypoints=True, N=2, seed=100, G=8)
+        _check(1024, HEADLINE, keypoints=True, N=2, seed=100, G=8)
+    finally:
+        _cache.pop(('oracle', 1024, True, 2, 100, 8), None)
 
 
 def test_full_width_keypoint_512_shipped():

@@ -465,12 +465,15 @@ def test_padded_batch_uses_each_images_own_size_and_scale():
     chain.sampler_keys = None
 
 
-def test_overfits_one_fixed_batch():
+@pytest.mark.parametrize('arith', ['f32', 'bf16x6_backward'])
+def test_overfits_one_fixed_batch(arith):
     """Does it learn: 150 MomentumSGD steps (lr 0.01, momentum 0.9, weight decay 5e-4 - train.py's
     optimiser at a learning rate that fits the reduced network) on ONE fixed batch with fixed sampler seeds: the total
     loss falls by at least half, every one of the five losses stays finite at every step, and the box-classification and
-    mask losses - the two that depend on the whole chain of proposals -> targets -> heads - both fall."""
+    mask losses - the two that depend on the whole chain of proposals -> targets -> heads - both fall.  In the all-float32
+    arithmetic and in the shipped one (train.py's default: float32-accurate bf16x6 emulation in the backward passes)."""
     m, chain = _build('all', seed=11)
+    chain.gemm_arithmetic = arith
     opt = MomentumSGD(lr=0.01, momentum=0.9).setup(chain)
     opt.add_hook(WeightDecay(0.0005))
     b = _batch()
@@ -487,6 +490,8 @@ def test_overfits_one_fixed_batch():
     assert last[5] <= 0.5 * first[5], (first, last)
     assert last[3] < first[3] and last[4] < first[4], (first, last)
     assert torch.isfinite(m.ps.params).all()
+    from chainer_maskrcnn import _hip
+    _hip.check(_hip.lib().mrcnn_conv2d_set_split_operands(0, 0, 0))
 
 
 def test_relu_mask_in_the_producer_gives_the_same_bits():

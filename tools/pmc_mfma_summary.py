@@ -18,7 +18,7 @@ out = {'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (one 
 tot_b = tot_a = 0.0
 for n, c in sorted(acc.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', 0)):
     a, b = c.get('GRBM_GUI_ACTIVE', 0.0), c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
-    if 'k_conv_igemm' not in n:
+    if 'k_conv_igemm' not in n and 'k_pgemm' not in n:
         continue
     out['kernels'][n] = {'launches_per_step': round(cnt[n] / steps, 1), 'mfma_busy_fraction': round(b / (a / 8 * 1024), 4) if a else None,
                          'gpu_cycles_per_step': round(a / 8 / steps)}

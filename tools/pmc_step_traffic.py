@@ -20,7 +20,7 @@ def load(d, counter):
 fetch, cnt = load(sys.argv[1], 'FETCH_SIZE')
 write, _ = load(sys.argv[2], 'WRITE_SIZE')
 steps = float(sys.argv[3])
-fam = {'conv_gemm': lambda n: 'k_conv_igemm' in n, 'winograd_transforms': lambda n: 'k_wino' in n,
+fam = {'conv_gemm': lambda n: 'k_conv_igemm' in n or 'k_pgemm' in n, 'winograd_transforms': lambda n: 'k_wino' in n,
        'slab_tail_column_sums': lambda n: any(k in n for k in ('k_sum_slabs', 'k_tail_sum', 'k_colsum')),
        'batchnorm': lambda n: 'k_bn_' in n, 'roi_align': lambda n: 'k_roi_align' in n}
 out = {}

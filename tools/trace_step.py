@@ -19,7 +19,7 @@ for s, e, n in ks:
 busy += ce - cs
 tot = sum(v[1] for v in agg.values())
 print('wall %.2f ms, busy %.2f ms, sum of durations %.2f ms, kernels %d' % ((t1 - t0) / 1e6, busy / 1e6, tot / 1e3, len(ks)))
-print('conv kernels sum %.2f ms' % (sum(v[1] for kk, v in agg.items() if 'k_conv_igemm' in kk) / 1e3))
+print('conv kernels sum %.2f ms' % (sum(v[1] for kk, v in agg.items() if 'k_conv_igemm' in kk or 'k_pgemm' in kk) / 1e3))
 for kk, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    if 'k_conv_igemm' in kk or v[1] < 30: continue
+    if 'k_conv_igemm' in kk or 'k_pgemm' in kk or v[1] < 30: continue
     print('%-60s n=%4d %8.1f us' % (kk[:60], v[0], v[1]))

@@ -49,6 +49,9 @@ def build_parser(keypoints=False):
     parser.add_argument('--num-workers', type=int, default=8, help='decode / transform threads of the COCO loader')
     parser.add_argument('--max-gt', type=int, default=0, help='instances kept per image (0: all; static shapes when > 0)')
     parser.add_argument('--image-size', type=int, nargs=2, default=[800, 800])
+    parser.add_argument('--gemm-arithmetic', default='bf16x6_backward', choices=['f32', 'bf16x6_backward', 'bf16x6'],
+                        help='arithmetic of the convolution GEMMs (model/fpn_maskrcnn_train_chain.py GEMM_ARITHMETIC): float32 tensors and float32 '
+                             'accumulation in all three; bf16x6 = float32-accurate three-plane emulation on the bf16 MFMA')
     parser.add_argument('--log-interval', type=int, default=100)
     parser.add_argument('--snapshot-interval', type=int, default=5000)
     parser.add_argument('--lr-shift-interval', type=int, default=0, help='iterations between lr x0.1 (reference: 2 epochs)')
@@ -84,14 +87,14 @@ def run(args, keypoints=False):
     if keypoints:
         n_fg, K = 1, 17
         faster_rcnn = MaskRCNN(n_fg_class=n_fg, n_keypoints=K, backbone=args.backbone, head_arch=args.head_arch, device=dev)
-        model = FPNMaskRCNNTrainChain(faster_rcnn, mask_loss_fun=calc_keypoint_loss, binary_mask=False)
+        model = FPNMaskRCNNTrainChain(faster_rcnn, mask_loss_fun=calc_keypoint_loss, binary_mask=False, gemm_arithmetic=args.gemm_arithmetic)
     else:
         n_fg, K = 80, None
         if os.path.exists(args.label_file):
             with open(args.label_file) as f:
                 n_fg = len(f.read().strip().split('\n'))
         faster_rcnn = MaskRCNN(n_fg_class=n_fg, backbone=args.backbone, head_arch=args.head_arch, device=dev)
-        model = FPNMaskRCNNTrainChain(faster_rcnn, mask_loss_fun=calc_mask_loss)
+        model = FPNMaskRCNNTrainChain(faster_rcnn, mask_loss_fun=calc_mask_loss, gemm_arithmetic=args.gemm_arithmetic)
     labels = None
     if not keypoints and os.path.exists(args.label_file):
         with open(args.label_file) as f:
