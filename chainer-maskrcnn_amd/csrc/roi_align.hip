@@ -1295,6 +1295,26 @@ extern "C" int mrcnn_debug_roi_align_bwd3_stamps(const float *gy, int N, int C, 
     return launch_bwd3(lv, total, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, ws, ws_bytes, (hipStream_t)stream, stamps);
 }
 
+// Measurement: where does the hardware put the workgroups of a launch shaped like k_roi_align_bwd_waves (256 threads, every block
+// resident at once)?  out[b] = HW_ID | XCC_ID << 32 of block b's first wave, out[nblocks + b] = its s_memrealtime at start; every block
+// then spins for `spin_us` so that the whole grid is co-resident like the real kernel's.
+__global__ __launch_bounds__(BWD_THREADS, 4) void k_dispatch_census(unsigned long long *out, int nblocks, int spin_ticks) {
+    __shared__ float pad[WaveLds<8>::QC > 0 ? 1 : 1];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        out[nblocks + blockIdx.x] = t0;
+    }
+    pad[0] = 0.f;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin_ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int mrcnn_debug_dispatch_census(unsigned long long *out, int nblocks, int spin_us, void *stream) {
+    if (!out || nblocks <= 0 || spin_us < 0 || spin_us > 1000) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_dispatch_census: bad arguments");
+    hipLaunchKernelGGL(k_dispatch_census, dim3(nblocks), dim3(BWD_THREADS), 0, (hipStream_t)stream, out, nblocks, spin_us * 100);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int mrcnn_roi_align_set_bwd_variant(int variant) {
     if (variant < 1 || variant > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_set_bwd_variant: 1, 2 or 3");
     g_bwd_variant = variant;

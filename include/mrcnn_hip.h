@@ -142,6 +142,9 @@ int mrcnn_debug_roi_align_bwd3_stamps(const float *gy, int N, int C, int H, int 
 
 /* Measurement knobs of variant 3: extra dynamic LDS per workgroup (caps resident workgroups per CU) and s_setprio for heavy waves. */
 int mrcnn_debug_roi_align_bwd3_knobs(int pad_lds_bytes, int prio);
+/* Measurement: block -> (XCD, CU) placement of a launch shaped like the ROIAlign backward (256 threads per block, all blocks co-resident
+ * for spin_us): out[b] = HW_ID | XCC_ID << 32, out[nblocks + b] = s_memrealtime at the start of block b. */
+int mrcnn_debug_dispatch_census(unsigned long long *out, int nblocks, int spin_us, void *stream);
 
 /* Verification hook for the "ROIAlign indices bit-exact" contract: dumps, for every RoI and
  * both axes, the integer corner cells and float weights of every sample exactly as the
