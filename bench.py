@@ -78,7 +78,10 @@ def bench_roialign(args, rank, world):
     algo_bytes = 4 * (N * C * H * W + R * C * PH * PW) + 20 * R
 
     # caller-owned scratch of the forward: the map-order permutation of the RoIs (ranking kernel + forward kernel per call)
-    nbf = lib.mrcnn_roi_align_fwd_workspace_bytes(R)
+    # (ABI v8: with mrcnn_roi_align_plan_workspace_bytes() bytes the forward also builds the backward's work plan for these RoIs inside
+    # its own launch; the backward is handed the same buffer - in a training step the forward always precedes the backward on the same
+    # RoIs, and both are timed here: `roi_align_pair_us` is what the pair costs)
+    nbf = max(lib.mrcnn_roi_align_fwd_workspace_bytes(R), lib.mrcnn_roi_align_plan_workspace_bytes(N, H, W, R))
     wsf = torch.empty((max(nbf, 1),), dtype=torch.uint8, device=dev)
 
     def fwd(sr=2):
@@ -91,7 +94,7 @@ def bench_roialign(args, rank, world):
 
     def bwd(sr=2):
         _hip.check(lib.mrcnn_roi_align_bwd_ws_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
-                                                  0.25, sr, _hip.ptr(gx), _hip.ptr(ws), nb, _hip.stream_ptr()))
+                                                  0.25, sr, _hip.ptr(gx), _hip.ptr(wsf), nbf, _hip.stream_ptr()))
 
     for _ in range(args.warmup):
         fwd(); bwd()
@@ -136,6 +139,12 @@ def bench_roialign(args, rank, world):
         torch.cuda.synchronize()
         return np.array([es[g].elapsed_time(es[g + 1]) / GROUP for g in range(NG)])
     bwd_b2b, fwd_b2b = back_to_back(bwd), back_to_back(fwd)
+    # A/B in the same process: the same launches without the forward-built plan (round-3 launch order)
+    lib.mrcnn_roi_align_set_bwd_plan(0)
+    fwd(); bwd()
+    bwd_noplan, fwd_noplan = back_to_back(bwd), back_to_back(fwd)
+    lib.mrcnn_roi_align_set_bwd_plan(1)
+    fwd()
     bwd_avg_s = float(bwd_b2b.mean()) * 1e-3
     fwd_avg_s = float(fwd_b2b.mean()) * 1e-3
     bwd_gbps = algo_bytes / bwd_avg_s / 1e9
@@ -159,6 +168,11 @@ def bench_roialign(args, rank, world):
                           'frac': round(algo_bytes / fwd_avg_s / 1e9 / HBM_PEAK_GBPS, 4), 'kernel': 'k_roi_map_order + k_roi_align_fwd_rows (RoIs walked in map order)',
                           'traffic': _pmc_traffic('k_roi_align_fwd')[0]},
         'roi_align_adaptive_sampling': adaptive,
+        'roi_align_pair_us': {'fwd_plus_bwd': round((fwd_avg_s + bwd_avg_s) * 1e6, 3),
+                              'without_the_forward_built_plan': {'fwd': round(float(fwd_noplan.mean()) * 1e3, 3), 'bwd': round(float(bwd_noplan.mean()) * 1e3, 3),
+                                                                 'fwd_plus_bwd': round(float(fwd_noplan.mean() + bwd_noplan.mean()) * 1e3, 3)},
+                              'note': 'the forward call builds the backward\'s work plan inside its own launch (mrcnn_roi_align_plan_workspace_bytes); '
+                                      'without_the_forward_built_plan = mrcnn_roi_align_set_bwd_plan(0), same process'},
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_roialign(x, yx, gy, algo_bytes)

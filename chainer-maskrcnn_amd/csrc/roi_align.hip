@@ -90,11 +90,179 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_nhwc(Levels lv, const flo
 // result is the same bits in the same place.  Rank by counting (every thread compares its key with all R keys in LDS,
 // ties by index): R <= MAP_ORDER_MAX_R, sixteen lanes per RoI, any number of workgroups.
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// (r4) Backward PLAN, built by the forward call of the same RoIs (single level, no RoI split).
+// The backward kernel's time is the most loaded SIMD's work: every workgroup is resident at once, the work of a 4 x 4 patch
+// (900 + 55 x candidate RoIs + 48 x queue entries instructions) varies 10x over the map, and a CU gets whatever tiles the dispatcher
+// deals it - tools/dispatch_census.py: block b runs on CU slot b % 256 EXACTLY (XCD b % 8, then round robin over the XCD's 32 CUs
+// with period 32), a workgroup's four waves go to the four SIMDs from a varying start.  So the plan (i) estimates every patch's work
+// from the RoIs (count blocks), (ii) sorts the patches of an image by work and makes every workgroup out of FOUR PATCHES OF NEARLY
+// EQUAL WORK (any four patches of one image can share a workgroup: the segment table does not depend on the tile) - the SIMD a wave
+// lands on then does not matter -, (iii) sorts the groups by work and deals them serpentine over the 256 CU slots in four full rounds
+// (1024 blocks, the missing ones empty), so that every CU gets one heavy, two middle and one light group.  The extra blocks ride in
+// the forward kernel's launch (16 blocks in front of its grid: 8 count, 1 sort, 7 idle) and finish long before it does.
+// Correctness never depends on the estimates: `order` is a permutation of the patches, every patch is computed exactly once by the
+// same code in the same summation order (bit-identical gx); a header that does not validate = the launch order of round 3.
+// ------------------------------------------------------------------------------------------
+constexpr int PLAN_MAGIC = 0x504C414E, PLAN_GROUPS = 1024, PLAN_HDR = 64, PLAN_COUNT_BLOCKS = 8, PLAN_EXTRA_BLOCKS = 16;
+constexpr int PLAN_BUCKETS = 1024;
+// header ints
+enum { PH_MAGIC = 0, PH_N, PH_H, PH_W, PH_NPATCH, PH_VALID, PH_DONE, PH_TAIL };
+struct PlanLayout { int npatch, pyn, pxn, per_image, groups_per_image; size_t e, order, gimg, sp, sw, gwork, gpatch, gimg_t, total_ints; };
+inline PlanLayout plan_layout(int N, int H, int W) {
+    PlanLayout p;
+    p.pyn = (H + PT - 1) / PT; p.pxn = (W + PT - 1) / PT;
+    p.per_image = p.pyn * p.pxn;
+    p.npatch = N * p.per_image;
+    p.groups_per_image = (p.per_image + 3) / 4;
+    size_t o = PLAN_HDR;
+    p.e = o; o += (size_t)p.npatch;
+    p.order = o; o += 4 * PLAN_GROUPS;
+    p.gimg = o; o += PLAN_GROUPS;
+    p.sp = o; o += (size_t)p.per_image + 4;
+    p.sw = o; o += (size_t)p.per_image + 4;
+    p.gwork = o; o += PLAN_GROUPS;
+    p.gpatch = o; o += 4 * PLAN_GROUPS;
+    p.gimg_t = o; o += PLAN_GROUPS;
+    p.total_ints = o + 1;           // + tail guard
+    return p;
+}
+inline bool plan_ok(int N, int H, int W) {
+    const long long per = (long long)((H + PT - 1) / PT) * ((W + PT - 1) / PT);
+    return N >= 1 && per * N < (1 << 20) && N * ((per + 3) / 4) <= PLAN_GROUPS;
+}
+
+// count block `cb` of PLAN_COUNT_BLOCKS: one wave per RoI; E[patch] += 55 + 48 * (bins touching the patch's rows) * (bins touching its columns)
+__device__ __forceinline__ void plan_count(int *plan, const PlanLayout pl, const float *rois, int R, int N, int H, int W, int PH, int PW, int sr,
+                                           float scale, int cb) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *E = plan + pl.e;
+    for (int r = cb * 4 + wave; r < R; r += PLAN_COUNT_BLOCKS * 4) {
+        const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, PH, PW, sr);
+        if (g.n < 0 || g.n >= N) continue;
+        // lanes 0..15: bin ph = lane, rows; lanes 16..31: bin pw = lane - 16, columns: the range of patch rows / columns the bin's samples touch
+        const int axis = (lane >> 4) & 1, bin = lane & 15;
+        int a = 1 << 30, b = -1;
+        if (lane < 32 && bin < (axis ? PW : PH)) {
+            for (int i = 0; i < sr; ++i) {
+                const Samp sp = axis_sample(axis ? g.x1f : g.y1f, axis ? g.bw : g.bh, bin, i, sr, axis ? W : H);
+                if (sp.lo >= 0) { a = min(a, sp.lo / PT); b = max(b, sp.hi / PT); }
+            }
+        }
+        // candidate rectangle: the kernel's own (conservative) box test
+        const int py_lo = max(0, (int)floorf(g.y1f * (1.0f / PT))), py_hi = min(pl.pyn - 1, (int)floorf((g.y1f + g.rh + 1.0f) * (1.0f / PT)));
+        const int px_lo = max(0, (int)floorf(g.x1f * (1.0f / PT))), px_hi = min(pl.pxn - 1, (int)floorf((g.x1f + g.rw + 1.0f) * (1.0f / PT)));
+        const int npr = py_hi - py_lo + 1, npc = px_hi - px_lo + 1;
+        if (npr <= 0 || npc <= 0) continue;
+        for (int idx = lane; idx < npr * npc; idx += 64) {
+            const int pr = idx / npc, pyi = py_lo + pr, pxi = px_lo + (idx - pr * npc);
+            int rc = 0, cc = 0;
+            for (int q = 0; q < 16; ++q) {
+                const int ar = __shfl(a, q, 64), br = __shfl(b, q, 64), ac = __shfl(a, 16 + q, 64), bc = __shfl(b, 16 + q, 64);
+                rc += (ar <= pyi && pyi <= br) ? 1 : 0;
+                cc += (ac <= pxi && pxi <= bc) ? 1 : 0;
+            }
+            atomicAdd(&E[g.n * pl.per_image + pyi * pl.pxn + pxi], 55 + 48 * rc * cc);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&plan[PH_DONE], 1);
+}
+
+// descending counting sort of n keys (key(i), i < n) in `work` units: out_pos(i) -> position; 256 threads, LDS hist[PLAN_BUCKETS] + scan[256]
+template <typename KeyF, typename PutF>
+__device__ __forceinline__ void plan_sort_desc(int n, int *hist, int *scan, KeyF key, PutF put) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < PLAN_BUCKETS; i += 256) hist[i] = 0;
+    __syncthreads();
+    auto bucket = [&](int w) { return PLAN_BUCKETS - 1 - min(w >> 4, PLAN_BUCKETS - 1); };      // heavier first
+    for (int i = tid; i < n; i += 256) atomicAdd(&hist[bucket(key(i))], 1);
+    __syncthreads();
+    // exclusive scan: thread t owns buckets 4t .. 4t+3
+    int c[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c[j] = hist[4 * tid + j]; s += c[j]; }
+    scan[tid] = s;
+    __syncthreads();
+    if (tid == 0) { int a = 0; for (int i = 0; i < 256; ++i) { const int v = scan[i]; scan[i] = a; a += v; } }
+    __syncthreads();
+    int base = scan[tid];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hist[4 * tid + j] = base; base += c[j]; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int w = key(i);
+        put(i, atomicAdd(&hist[bucket(w)], 1), w);
+    }
+    __syncthreads();
+}
+
+// the sort block: waits for the count blocks, builds `order` / `gimg`, validates the header
+__device__ __forceinline__ void plan_sort(int *plan, const PlanLayout pl, int N, int H, int W) {
+    __shared__ int hist[PLAN_BUCKETS], scan[256], s_ok;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int ok = 0;
+        for (int spin = 0; spin < 200000; ++spin) {          // bounded: the count blocks are dispatched before this one
+            if (atomicAdd(&plan[PH_DONE], 0) >= PLAN_COUNT_BLOCKS) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;                                        // header stays invalid: the backward takes its own order
+    __threadfence();
+    int *E = plan + pl.e, *sp = plan + pl.sp, *sw = plan + pl.sw, *gwork = plan + pl.gwork, *gpatch = plan + pl.gpatch, *gimg_t = plan + pl.gimg_t;
+    int ng = 0;
+    for (int n = 0; n < N; ++n) {
+        // patches of image n by descending work (an untouched patch still costs its wave the scan: 900)
+        plan_sort_desc(pl.per_image, hist, scan,
+                       [&](int i) { return 900 + atomicAdd(&E[n * pl.per_image + i], 0); },
+                       [&](int i, int pos, int w) { sp[pos] = i; sw[pos] = w; });
+        __threadfence_block();
+        for (int g = tid; g < pl.groups_per_image; g += 256) {
+            int wsum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * g + j;
+                const bool v = k < pl.per_image;
+                gpatch[4 * (ng + g) + j] = v ? n * pl.per_image + sp[k] : -1;
+                wsum += v ? sw[k] : 0;
+            }
+            gwork[ng + g] = wsum;
+            gimg_t[ng + g] = n;
+        }
+        ng += pl.groups_per_image;
+        __syncthreads();
+    }
+    // groups by descending work (fillers of work 0 behind them), dealt serpentine over the 256 CU slots: position k -> block
+    int *order = plan + pl.order, *gimg = plan + pl.gimg;
+    plan_sort_desc(PLAN_GROUPS, hist, scan,
+                   [&](int i) { return i < ng ? gwork[i] >> 2 : 0; },
+                   [&](int i, int pos, int) {
+                       const int rnd = pos >> 8, p8 = pos & 255, b = rnd * 256 + ((rnd & 1) ? 255 - p8 : p8);
+#pragma unroll
+                       for (int j = 0; j < 4; ++j) order[4 * b + j] = i < ng ? gpatch[4 * i + j] : -1;
+                       gimg[b] = i < ng ? gimg_t[i] : -1;
+                   });
+    __threadfence();
+    if (tid == 0) {
+        plan[PH_N] = N; plan[PH_H] = H; plan[PH_W] = W; plan[PH_NPATCH] = pl.npatch;
+        plan[pl.total_ints - 1] = PLAN_MAGIC;
+        plan[PH_MAGIC] = PLAN_MAGIC;
+        __threadfence();
+        plan[PH_VALID] = 1;
+    }
+}
+
 constexpr int MAP_ORDER_MAX_R = 8192;
 int g_fwd_map_order = 1;
 __global__ __launch_bounds__(256) void k_roi_map_order(Levels lv, const float *__restrict__ rois, const int32_t *__restrict__ levels,
-                                                       int R, int32_t *__restrict__ perm) {
+                                                       int R, int32_t *__restrict__ perm, int *__restrict__ plan, int plan_zero_ints) {
     extern __shared__ unsigned mo_keys[];
+    // (the backward plan of this call, if any: header and work counters start from zero; the forward launch that follows fills them)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < plan_zero_ints; i += gridDim.x * 256) plan[i] = 0;
     for (int r = threadIdx.x; r < R; r += 256) {
         int l = levels ? levels[r] : 0;
         l = min(max(l, 0), lv.L - 1);
@@ -133,11 +301,18 @@ __global__ __launch_bounds__(256) void k_roi_map_order(Levels lv, const float *_
 __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(Levels lv, const float *__restrict__ rois,
                                                             const int32_t *__restrict__ levels, int R, int N, int C, int PH, int PW,
                                                             int sr, float *__restrict__ y, int chunk,
-                                                            const int32_t *__restrict__ perm) {
+                                                            const int32_t *__restrict__ perm, int *__restrict__ plan, PlanLayout pl) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk) return;
+    int bid = blockIdx.x;
+    if (plan) {             // PLAN_EXTRA_BLOCKS blocks in front of the forward's grid build the backward plan (single level)
+        if (bid < PLAN_COUNT_BLOCKS) { plan_count(plan, pl, rois, R, N, lv.H[0], lv.W[0], PH, PW, sr, lv.scale[0], bid); return; }
+        if (bid == PLAN_COUNT_BLOCKS) { plan_sort(plan, pl, N, lv.H[0], lv.W[0]); return; }
+        if (bid < PLAN_EXTRA_BLOCKS) return;
+        bid -= PLAN_EXTRA_BLOCKS;
+    }
+    const int wg = (bid & 7) * chunk + (bid >> 3);
+    if ((int)(bid >> 3) >= chunk) return;
     const int pos_id = wg * 4 + wave;                  // (position in processing order, ph)
     if (pos_id >= R * PH) return;
     int r, ph;
@@ -610,7 +785,9 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
                                                                         const float *__restrict__ rois,
                                                                         const int32_t *__restrict__ levels, int R, int N, int C,
                                                                         int PH, int PW, int sr, int chunk, int accumulate,
-                                                                        unsigned long long *__restrict__ stamps = nullptr) {
+                                                                        unsigned long long *__restrict__ stamps = nullptr,
+                                                                        const int *__restrict__ plan = nullptr, int plan_order_off = 0,
+                                                                        int plan_gimg_off = 0, int plan_tail = 0) {
     unsigned long long st0 = 0, st_scan = 0, st_drain = 0, st_tmp = 0, st_rt0 = 0, st_pre = 0, st_tab = 0, st_cnt = 0;
     if (STAMP) { st0 = stamp_now(); st_rt0 = __builtin_amdgcn_s_memrealtime(); }
     using LDS = WaveLds<PBT>;
@@ -647,17 +824,36 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
         }
     };
     load_rois(0, rv0, lv0);
-    const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);       // XCD-banded tile order (speed only)
-    if ((int)(blockIdx.x >> 3) >= chunk || tile_id >= lv.tile_begin[lv.L]) return;      // whole workgroup
-    int l = 0;
-    while (l + 1 < lv.L && tile_id >= lv.tile_begin[l + 1]) ++l;
-    int t = tile_id - lv.tile_begin[l];
-    const int nsplit = lv.split[l];
-    int zsplit = 0, n, tyi, txi;
-    if (nsplit > 1) divmod_u24(t, nsplit, t, zsplit);
-    divmod_u24(t, lv.tiles_x[l] * lv.tiles_y[l], n, t);
-    divmod_u24(t, lv.tiles_x[l], tyi, txi);
-    const int py0 = tyi * TH + (wave >> 1) * PT, px0 = txi * TW + (wave & 1) * PT;
+    // A plan built by the forward call of the same geometry (see plan_sort): block b computes the four patches order[4b .. 4b+3] of
+    // image gimg[b] - any four patches of an image, of nearly equal work.  The header decides (uniformly for the launch); without a
+    // valid one the blocks take the XCD-banded tile order.
+    bool planned = false;
+    if (plan) planned = plan[PH_MAGIC] == PLAN_MAGIC && plan[PH_VALID] == 1 && plan[PH_N] == N && plan[PH_H] == lv.H[0] && plan[PH_W] == lv.W[0] &&
+                        plan[plan_tail] == PLAN_MAGIC;
+    planned = __builtin_amdgcn_readfirstlane((int)planned) != 0;
+    int l = 0, nsplit = 1, zsplit = 0, n, py0, px0;
+    if (planned) {
+        if (blockIdx.x >= PLAN_GROUPS) return;
+        n = __builtin_amdgcn_readfirstlane(plan[plan_gimg_off + blockIdx.x]);
+        if (n < 0) return;                                   // an empty group
+        const int pid = __builtin_amdgcn_readfirstlane(plan[plan_order_off + 4 * blockIdx.x + wave]);
+        const int pxn = (lv.W[0] + PT - 1) / PT, pyn = (lv.H[0] + PT - 1) / PT;
+        int rem = 0, pyi = 0, pxi = 0;
+        if (pid >= 0) { rem = pid - n * (pxn * pyn); divmod_u24(rem, pxn, pyi, pxi); }
+        py0 = pid >= 0 ? pyi * PT : lv.H[0];                 // a missing patch = a wave outside the map: it only helps with the table
+        px0 = pid >= 0 ? pxi * PT : lv.W[0];
+    } else {
+        const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);       // XCD-banded tile order (speed only)
+        if ((int)(blockIdx.x >> 3) >= chunk || tile_id >= lv.tile_begin[lv.L]) return;      // whole workgroup
+        while (l + 1 < lv.L && tile_id >= lv.tile_begin[l + 1]) ++l;
+        int t = tile_id - lv.tile_begin[l];
+        nsplit = lv.split[l];
+        int tyi, txi;
+        if (nsplit > 1) divmod_u24(t, nsplit, t, zsplit);
+        divmod_u24(t, lv.tiles_x[l] * lv.tiles_y[l], n, t);
+        divmod_u24(t, lv.tiles_x[l], tyi, txi);
+        py0 = tyi * TH + (wave >> 1) * PT; px0 = txi * TW + (wave & 1) * PT;
+    }
     const int H = lv.H[l], W = lv.W[l];
     const int nrow = min(PT, H - py0), ncol = min(PT, W - px0);
     const bool live = nrow > 0 && ncol > 0;      // a wave whose patch lies outside the map only helps to fill the table
@@ -1063,6 +1259,12 @@ size_t bwd_ws_bytes(const int *Hs, const int *Ws, int L, int N, int C, int R, in
 }
 
 size_t fwd_ws_bytes(int R) { return R > 0 ? ((size_t)R * sizeof(int32_t) + 255) / 256 * 256 : 0; }
+// forward workspace that also holds the backward plan of the same RoIs: [perm][plan]
+size_t fwd_plan_ws_bytes(int N, int H, int W, int R) {
+    if (R <= 0 || !plan_ok(N, H, W)) return fwd_ws_bytes(R);
+    return fwd_ws_bytes(R) + (plan_layout(N, H, W).total_ints * sizeof(int) + 255) / 256 * 256;
+}
+int g_bwd_plan = 1;         // mrcnn_roi_align_set_bwd_plan: 0 = the forward builds no plan / the backward ignores one (A/B)
 
 // Forward: rows kernel when the x samples of a row fit one wave (fixed sampling grid, PW * grid <= 64) and every level is
 // within 32-bit buffer offsets; else the one-wave-per-bin kernel.
@@ -1074,11 +1276,21 @@ void launch_fwd(Levels &lv, const float *rois, const int32_t *levels, int R, int
         const int wgs = mrcnn::cdiv((long long)R * PH, 4), chunk = mrcnn::cdiv(wgs, 8);
         // map order (needs R ints of workspace; worth a second launch from a few waves per CU on)
         int32_t *perm = nullptr;
+        int *plan = nullptr;
+        PlanLayout pl{};
         if (g_fwd_map_order && ws && ws_bytes >= fwd_ws_bytes(R) && R >= 128 && R <= MAP_ORDER_MAX_R) {
             perm = reinterpret_cast<int32_t *>(ws);
-            hipLaunchKernelGGL(k_roi_map_order, dim3(mrcnn::cdiv(R, 16)), dim3(256), (size_t)R * sizeof(unsigned), st, lv, rois, levels, R, perm);
+            // the backward plan rides along when the workspace has room for it (single level, fixed sampling grid, pooled <= 16)
+            if (g_bwd_plan && lv.L == 1 && !levels && plan_ok(N, lv.H[0], lv.W[0]) && PH <= PB && PW <= PB &&
+                ws_bytes >= fwd_plan_ws_bytes(N, lv.H[0], lv.W[0], R)) {
+                plan = reinterpret_cast<int *>((char *)ws + fwd_ws_bytes(R));
+                pl = plan_layout(N, lv.H[0], lv.W[0]);
+            }
+            hipLaunchKernelGGL(k_roi_map_order, dim3(mrcnn::cdiv(R, 16)), dim3(256), (size_t)R * sizeof(unsigned), st, lv, rois, levels, R, perm,
+                               plan, plan ? (int)(PLAN_HDR + pl.npatch) : 0);
         }
-        hipLaunchKernelGGL(k_roi_align_fwd_rows, dim3(chunk * 8), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW, sr, y, chunk, perm);
+        hipLaunchKernelGGL(k_roi_align_fwd_rows, dim3(chunk * 8 + (plan ? PLAN_EXTRA_BLOCKS : 0)), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW,
+                           sr, y, chunk, perm, plan, pl);
     } else {
         const long long waves = (long long)R * PH * PW;
         hipLaunchKernelGGL(k_roi_align_fwd_nhwc, dim3(mrcnn::cdiv(waves, 4)), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW, sr, y);
@@ -1091,7 +1303,7 @@ void launch_fwd(Levels &lv, const float *rois, const int32_t *levels, int R, int
 int g_bwd_variant = 2;
 
 int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, const int32_t *levels, int R,
-                     int C, int PH, int PW, int sr, int accumulate, void *ws, size_t ws_bytes, hipStream_t st) {
+                     int C, int PH, int PW, int sr, int accumulate, void *ws, size_t ws_bytes, hipStream_t st, const void *plan_ws = nullptr) {
     int total = 0;
     const size_t need = slab_ws_bytes(lv.H, lv.W, lv.L, N, C);
     const bool can_split = ws && ws_bytes >= need && R > 0;
@@ -1117,12 +1329,23 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
     for (int l = 0; l < lv.L; ++l) waves_ok = waves_ok && (unsigned long long)lv.H[l] * lv.W[l] * C * 4ull < (1ull << 32);
     if (waves_ok && g_bwd_variant == 3 && ws3) {
         if (int e = launch_bwd3(lv, total, N, gy, rois, levels, R, C, PH, PW, sr, accumulate, ws3, need3, st)) return e;
-    } else if (waves_ok && PH <= 8 && PW <= 8)
-        hipLaunchKernelGGL((k_roi_align_bwd_waves<8, W2_DEPTH>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
-                           PH, PW, sr, chunk, accumulate);
-    else if (waves_ok)
-        hipLaunchKernelGGL((k_roi_align_bwd_waves<16, W2_DEPTH>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
-                           PH, PW, sr, chunk, accumulate);
+    } else if (waves_ok) {
+        // `plan_ws`: the caller handed in the workspace of the FORWARD call of these RoIs ([perm][plan], mrcnn_roi_align_plan_workspace_bytes):
+        // the kernel validates the plan's header on the device and takes the launch order when it does not hold
+        const int *plan = nullptr;
+        PlanLayout pl{};
+        if (g_bwd_plan && plan_ws && lv.L == 1 && !levels && lv.split[0] == 1 && plan_ok(N, lv.H[0], lv.W[0])) {
+            plan = reinterpret_cast<const int *>((const char *)plan_ws + fwd_ws_bytes(R));
+            pl = plan_layout(N, lv.H[0], lv.W[0]);
+        }
+        const dim3 grid(plan ? std::max(chunk * 8, PLAN_GROUPS) : chunk * 8);
+        if (PH <= 8 && PW <= 8)
+            hipLaunchKernelGGL((k_roi_align_bwd_waves<8, W2_DEPTH>), grid, dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
+                               PH, PW, sr, chunk, accumulate, (unsigned long long *)nullptr, plan, (int)pl.order, (int)pl.gimg, (int)pl.total_ints - 1);
+        else
+            hipLaunchKernelGGL((k_roi_align_bwd_waves<16, W2_DEPTH>), grid, dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
+                               PH, PW, sr, chunk, accumulate, (unsigned long long *)nullptr, plan, (int)pl.order, (int)pl.gimg, (int)pl.total_ints - 1);
+    }
     else if (PH <= 8 && PW <= 8)
         hipLaunchKernelGGL(k_roi_align_bwd_nhwc<8>, dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois,
                            levels, R, N, C, PH, PW, sr, chunk, accumulate);
@@ -1170,6 +1393,16 @@ extern "C" int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C,
 
 extern "C" size_t mrcnn_roi_align_fwd_workspace_bytes(int R) { return fwd_ws_bytes(R); }
 
+extern "C" size_t mrcnn_roi_align_plan_workspace_bytes(int N, int H, int W, int R) {
+    if (N <= 0 || H <= 0 || W <= 0 || R <= 0) return 0;
+    return fwd_plan_ws_bytes(N, H, W, R);
+}
+
+extern "C" int mrcnn_roi_align_set_bwd_plan(int on) {
+    g_bwd_plan = on ? 1 : 0;
+    return 0;
+}
+
 extern "C" int mrcnn_roi_align_set_fwd_map_order(int on) {
     g_fwd_map_order = on ? 1 : 0;
     return 0;
@@ -1183,6 +1416,10 @@ extern "C" int mrcnn_roi_align_bwd_ws_f32(const float *gy, int layout, int N, in
     if (layout == MRCNN_LAYOUT_NHWC && fast_bwd_ok(C, PH, PW, sampling_ratio, R)) {
         Levels lv{};
         lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
+        // a workspace of mrcnn_roi_align_plan_workspace_bytes() that went through the forward call of these RoIs carries the backward's
+        // plan (validated on the device); this entry needs no scratch of its own on that path (no RoI split on a single large level)
+        const bool has_plan = ws && plan_ok(N, H, W) && ws_bytes >= fwd_plan_ws_bytes(N, H, W, R) && level_split(H, W, N) == 1 && g_bwd_variant == 2;
+        if (has_plan) return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, nullptr, 0, st, ws);
         return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, ws, ws_bytes, st);
     }
     MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * C * H * W, st));

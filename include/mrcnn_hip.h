@@ -72,6 +72,15 @@ int mrcnn_roi_align_fwd_ws_f32(const float *x, int layout, int N, int C, int H, 
                                const float *rois, int R, int PH, int PW, float spatial_scale,
                                int sampling_ratio, float *y, void *ws, size_t ws_bytes, void *stream);
 size_t mrcnn_roi_align_fwd_workspace_bytes(int R);
+/* (ABI v8) Forward workspace that ALSO carries the backward's work plan for the same RoIs (single-level entry points, NHWC, fixed sampling
+ * grid, pooled size <= 16): [the map-order permutation][plan].  mrcnn_roi_align_fwd_ws_f32 given at least this many bytes estimates the
+ * work of every 4 x 4 patch of the gradient map from the RoIs (extra workgroups inside its own launch) and leaves a patch -> workgroup
+ * assignment in which every workgroup holds four patches of nearly equal work and every CU a balanced share; mrcnn_roi_align_bwd_ws_f32
+ * given the SAME buffer (unmodified in between, same N, H, W) validates the plan on the device and follows it - identical bits, every
+ * patch is computed once by the same code - and falls back to its launch order otherwise.  Replaces nothing in the reference: the
+ * per-RoI loops of model/head/fpn_roi_mask_head.py:59-61,75-77 have no scheduling.  mrcnn_roi_align_set_bwd_plan(0) switches it off (A/B). */
+size_t mrcnn_roi_align_plan_workspace_bytes(int N, int H, int W, int R);
+int mrcnn_roi_align_set_bwd_plan(int on);
 /* A/B switch of the map-order walk (process-wide; default 1 = on when scratch is given). */
 int mrcnn_roi_align_set_fwd_map_order(int on);
 
