@@ -78,9 +78,9 @@ def bench_roialign(args, rank, world):
     algo_bytes = 4 * (N * C * H * W + R * C * PH * PW) + 20 * R
 
     # caller-owned scratch of the forward: the map-order permutation of the RoIs (ranking kernel + forward kernel per call)
-    # (ABI v8: with mrcnn_roi_align_plan_workspace_bytes() bytes the forward also builds the backward's work plan for these RoIs inside
-    # its own launch; the backward is handed the same buffer - in a training step the forward always precedes the backward on the same
-    # RoIs, and both are timed here: `roi_align_pair_us` is what the pair costs)
+    # (ABI v8, OPT-IN: with mrcnn_roi_align_plan_workspace_bytes() bytes and mrcnn_roi_align_set_bwd_plan(1 | 2) the forward also builds the
+    # backward's work plan for these RoIs inside its own launch and the backward, handed the same buffer, follows it.  Off by default: the
+    # backward alone gains, the forward + backward PAIR a training step pays loses - `roi_align_pair_us` reports both, same process)
     nbf = max(lib.mrcnn_roi_align_fwd_workspace_bytes(R), lib.mrcnn_roi_align_plan_workspace_bytes(N, H, W, R))
     wsf = torch.empty((max(nbf, 1),), dtype=torch.uint8, device=dev)
 
@@ -139,11 +139,14 @@ def bench_roialign(args, rank, world):
         torch.cuda.synchronize()
         return np.array([es[g].elapsed_time(es[g + 1]) / GROUP for g in range(NG)])
     bwd_b2b, fwd_b2b = back_to_back(bwd), back_to_back(fwd)
-    # A/B in the same process: the same launches without the forward-built plan (round-3 launch order)
+    # A/B in the same process: the OPT-IN forward-built work plan of the backward (mrcnn_roi_align_set_bwd_plan; default 0 = off)
+    plan_ab = {}
+    for pm, nm in ((1, 'groups_of_four_patches_of_equal_work'), (2, 'whole_tiles_dealt_by_work')):
+        lib.mrcnn_roi_align_set_bwd_plan(pm)
+        fwd(); bwd()
+        b_, f_ = back_to_back(bwd), back_to_back(fwd)
+        plan_ab[nm] = {'fwd': round(float(f_.mean()) * 1e3, 3), 'bwd': round(float(b_.mean()) * 1e3, 3), 'fwd_plus_bwd': round(float(f_.mean() + b_.mean()) * 1e3, 3)}
     lib.mrcnn_roi_align_set_bwd_plan(0)
-    fwd(); bwd()
-    bwd_noplan, fwd_noplan = back_to_back(bwd), back_to_back(fwd)
-    lib.mrcnn_roi_align_set_bwd_plan(1)
     fwd()
     bwd_avg_s = float(bwd_b2b.mean()) * 1e-3
     fwd_avg_s = float(fwd_b2b.mean()) * 1e-3
@@ -169,10 +172,9 @@ def bench_roialign(args, rank, world):
                           'traffic': _pmc_traffic('k_roi_align_fwd')[0]},
         'roi_align_adaptive_sampling': adaptive,
         'roi_align_pair_us': {'fwd_plus_bwd': round((fwd_avg_s + bwd_avg_s) * 1e6, 3),
-                              'without_the_forward_built_plan': {'fwd': round(float(fwd_noplan.mean()) * 1e3, 3), 'bwd': round(float(bwd_noplan.mean()) * 1e3, 3),
-                                                                 'fwd_plus_bwd': round(float(fwd_noplan.mean() + bwd_noplan.mean()) * 1e3, 3)},
-                              'note': 'the forward call builds the backward\'s work plan inside its own launch (mrcnn_roi_align_plan_workspace_bytes); '
-                                      'without_the_forward_built_plan = mrcnn_roi_align_set_bwd_plan(0), same process'},
+                              'opt_in_forward_built_backward_plan': plan_ab,
+                              'note': 'shipped: no plan.  opt_in_...: mrcnn_roi_align_set_bwd_plan(1 | 2), the forward call builds the backward\'s work plan '
+                                      'inside its own launch (extra workgroups), same process: the backward alone gains, the pair loses'},
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_roialign(x, yx, gy, algo_bytes)

@@ -28,6 +28,11 @@ def _layout_of(x):
     return None
 
 
+# OPT-IN (with mrcnn_roi_align_set_bwd_plan(1 | 2)): the forward call also builds the backward's work plan for the same RoIs.  Measured: the
+# backward alone gains 7-9 % on configs[1], the forward + backward pair loses 9 % (csrc/roi_align.hip, g_bwd_plan) - off.
+USE_BWD_PLAN = False
+
+
 class _RoIAlign2D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rois, outh, outw, spatial_scale, sampling_ratio):
@@ -47,7 +52,7 @@ class _RoIAlign2D(torch.autograd.Function):
         y = torch.empty((R, C, outh, outw), dtype=torch.float32, device=x.device, memory_format=fmt)
         from chainer_maskrcnn._hip.nn import workspace
         nb = _hip.lib().mrcnn_roi_align_fwd_workspace_bytes(R)
-        npl = _hip.lib().mrcnn_roi_align_plan_workspace_bytes(N, H, W, R) if layout == _hip.LAYOUT_NHWC else 0
+        npl = _hip.lib().mrcnn_roi_align_plan_workspace_bytes(N, H, W, R) if (USE_BWD_PLAN and layout == _hip.LAYOUT_NHWC) else 0
         if npl > nb:
             # the forward also leaves the backward's work plan for these RoIs (patch -> workgroup assignment balanced over the CUs) in
             # its workspace: a buffer of its own, kept for the backward call (the shared scratch is reused by other layers in between)

@@ -99,12 +99,13 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_nhwc(Levels lv, const flo
 // from the RoIs (count blocks), (ii) sorts the patches of an image by work and makes every workgroup out of FOUR PATCHES OF NEARLY
 // EQUAL WORK (any four patches of one image can share a workgroup: the segment table does not depend on the tile) - the SIMD a wave
 // lands on then does not matter -, (iii) sorts the groups by work and deals them serpentine over the 256 CU slots in four full rounds
-// (1024 blocks, the missing ones empty), so that every CU gets one heavy, two middle and one light group.  The extra blocks ride in
-// the forward kernel's launch (16 blocks in front of its grid: 8 count, 1 sort, 7 idle) and finish long before it does.
+// (1024 blocks, the missing ones empty), so that every CU gets one heavy, two middle and one light group - per XCD band, so that the gy
+// rows of a band stay in its XCD's L2.  The extra blocks ride in the forward kernel's launch (16 blocks in front of its grid: 8 count,
+// 8 sort - one per band) and finish before it does.
 // Correctness never depends on the estimates: `order` is a permutation of the patches, every patch is computed exactly once by the
 // same code in the same summation order (bit-identical gx); a header that does not validate = the launch order of round 3.
 // ------------------------------------------------------------------------------------------
-constexpr int PLAN_MAGIC = 0x504C414E, PLAN_GROUPS = 1024, PLAN_HDR = 64, PLAN_COUNT_BLOCKS = 8, PLAN_EXTRA_BLOCKS = 16;
+constexpr int PLAN_MAGIC = 0x504C414E, PLAN_GROUPS = 1024, PLAN_HDR = 64, PLAN_COUNT_BLOCKS = 32, PLAN_EXTRA_BLOCKS = 40;
 constexpr int PLAN_BUCKETS = 1024;
 // header ints
 enum { PH_MAGIC = 0, PH_N, PH_H, PH_W, PH_NPATCH, PH_VALID, PH_DONE, PH_TAIL };
@@ -135,6 +136,7 @@ inline bool plan_ok(int N, int H, int W) {
 // count block `cb` of PLAN_COUNT_BLOCKS: one wave per RoI; E[patch] += 55 + 48 * (bins touching the patch's rows) * (bins touching its columns)
 __device__ __forceinline__ void plan_count(int *plan, const PlanLayout pl, const float *rois, int R, int N, int H, int W, int PH, int PW, int sr,
                                            float scale, int cb) {
+    __shared__ unsigned char s_cnt[4][2][128];          // per wave: bins per patch row / column of the RoI's rectangle (<= 128 each side)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int *E = plan + pl.e;
     for (int r = cb * 4 + wave; r < R; r += PLAN_COUNT_BLOCKS * 4) {
@@ -152,107 +154,142 @@ __device__ __forceinline__ void plan_count(int *plan, const PlanLayout pl, const
         // candidate rectangle: the kernel's own (conservative) box test
         const int py_lo = max(0, (int)floorf(g.y1f * (1.0f / PT))), py_hi = min(pl.pyn - 1, (int)floorf((g.y1f + g.rh + 1.0f) * (1.0f / PT)));
         const int px_lo = max(0, (int)floorf(g.x1f * (1.0f / PT))), px_hi = min(pl.pxn - 1, (int)floorf((g.x1f + g.rw + 1.0f) * (1.0f / PT)));
-        const int npr = py_hi - py_lo + 1, npc = px_hi - px_lo + 1;
+        const int npr = min(py_hi - py_lo + 1, 128), npc = min(px_hi - px_lo + 1, 128);      // (an estimate: a larger rectangle is cut)
         if (npr <= 0 || npc <= 0) continue;
-        for (int idx = lane; idx < npr * npc; idx += 64) {
-            const int pr = idx / npc, pyi = py_lo + pr, pxi = px_lo + (idx - pr * npc);
-            int rc = 0, cc = 0;
-            for (int q = 0; q < 16; ++q) {
-                const int ar = __shfl(a, q, 64), br = __shfl(b, q, 64), ac = __shfl(a, 16 + q, 64), bc = __shfl(b, 16 + q, 64);
-                rc += (ar <= pyi && pyi <= br) ? 1 : 0;
-                cc += (ac <= pxi && pxi <= bc) ? 1 : 0;
-            }
-            atomicAdd(&E[g.n * pl.per_image + pyi * pl.pxn + pxi], 55 + 48 * rc * cc);
+        // bins per patch row / column: one ballot per row (lanes 0-15 answer for the rows, 16-31 for the columns)
+        for (int k = 0; k < max(npr, npc); ++k) {
+            const int q = (axis ? px_lo : py_lo) + k;
+            const unsigned long long bal = __ballot(lane < 32 && a <= q && q <= b);
+            if (lane == 0) { s_cnt[wave][0][k] = (unsigned char)__popcll(bal & 0xFFFFull); s_cnt[wave][1][k] = (unsigned char)__popcll(bal & 0xFFFF0000ull); }
         }
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < npr * npc; idx += 64) {
+            const int pr = idx / npc, pc = idx - pr * npc;
+            atomicAdd(&E[g.n * pl.per_image + (py_lo + pr) * pl.pxn + px_lo + pc], 55 + 48 * (int)s_cnt[wave][0][pr] * (int)s_cnt[wave][1][pc]);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&plan[PH_DONE], 1);
 }
 
-// descending counting sort of n keys (key(i), i < n) in `work` units: out_pos(i) -> position; 256 threads, LDS hist[PLAN_BUCKETS] + scan[256]
-template <typename KeyF, typename PutF>
-__device__ __forceinline__ void plan_sort_desc(int n, int *hist, int *scan, KeyF key, PutF put) {
-    const int tid = threadIdx.x;
-    for (int i = tid; i < PLAN_BUCKETS; i += 256) hist[i] = 0;
-    __syncthreads();
-    auto bucket = [&](int w) { return PLAN_BUCKETS - 1 - min(w >> 4, PLAN_BUCKETS - 1); };      // heavier first
-    for (int i = tid; i < n; i += 256) atomicAdd(&hist[bucket(key(i))], 1);
-    __syncthreads();
-    // exclusive scan: thread t owns buckets 4t .. 4t+3
-    int c[4], s = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { c[j] = hist[4 * tid + j]; s += c[j]; }
-    scan[tid] = s;
-    __syncthreads();
-    if (tid == 0) { int a = 0; for (int i = 0; i < 256; ++i) { const int v = scan[i]; scan[i] = a; a += v; } }
-    __syncthreads();
-    int base = scan[tid];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { hist[4 * tid + j] = base; base += c[j]; }
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const int w = key(i);
-        put(i, atomicAdd(&hist[bucket(w)], 1), w);
+// Sort block of XCD band x (8 of them): waits for the count blocks, then for every image: the patches of the band's tiles (the tile
+// range the unplanned launch gives this XCD, so that a band's gy rows stay in its XCD's L2) by descending work, four consecutive ones =
+// a group; the band's groups by descending work, dealt serpentine over the band's 32 CU slots in four rounds:
+// group rank k -> block 8 * ((k / 32) * 32 + slot) + x.  Ranking = counting in LDS (<= 512 patches, <= 128 groups per band).
+constexpr int PLAN_BAND_PATCHES = 512, PLAN_BAND_GROUPS = 128;
+// rank of key `k` among the n keys in LDS (all distinct): the number of larger ones; four keys per LDS read, eight reads in flight
+__device__ __forceinline__ int plan_rank(const int *keys, int n4, int k) {
+    int rk = 0;
+    const int4 *k4 = reinterpret_cast<const int4 *>(keys);
+#pragma unroll 8
+    for (int j = 0; j < n4; ++j) {
+        const int4 v = k4[j];
+        rk += (v.x > k) + (v.y > k) + (v.z > k) + (v.w > k);
     }
-    __syncthreads();
+    return rk;
 }
-
-// the sort block: waits for the count blocks, builds `order` / `gimg`, validates the header
-__device__ __forceinline__ void plan_sort(int *plan, const PlanLayout pl, int N, int H, int W) {
-    __shared__ int hist[PLAN_BUCKETS], scan[256], s_ok;
+__device__ __forceinline__ void plan_sort(int *plan, const PlanLayout pl, int N, int H, int W, int x, int mode) {
+    __shared__ __attribute__((aligned(16))) int s_key[PLAN_BAND_PATCHES], s_gkey[PLAN_BAND_GROUPS];
+    __shared__ int s_pid[PLAN_BAND_PATCHES], s_sorted[PLAN_BAND_PATCHES], s_sw[PLAN_BAND_PATCHES];
+    __shared__ int s_gp[PLAN_BAND_GROUPS][4], s_gn[PLAN_BAND_GROUPS], s_ok;
     const int tid = threadIdx.x;
     if (tid == 0) {
         int ok = 0;
         for (int spin = 0; spin < 200000; ++spin) {          // bounded: the count blocks are dispatched before this one
             if (atomicAdd(&plan[PH_DONE], 0) >= PLAN_COUNT_BLOCKS) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_s_sleep(8);
         }
         s_ok = ok;
     }
     __syncthreads();
     if (!s_ok) return;                                        // header stays invalid: the backward takes its own order
     __threadfence();
-    int *E = plan + pl.e, *sp = plan + pl.sp, *sw = plan + pl.sw, *gwork = plan + pl.gwork, *gpatch = plan + pl.gpatch, *gimg_t = plan + pl.gimg_t;
+    const int *E = plan + pl.e;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, per_img_tiles = tiles_x * tiles_y;
+    const int total_tiles = per_img_tiles * N, chunk = (total_tiles + 7) / 8;
+    const int t0 = x * chunk, t1 = min(total_tiles, t0 + chunk);
     int ng = 0;
-    for (int n = 0; n < N; ++n) {
-        // patches of image n by descending work (an untouched patch still costs its wave the scan: 900)
-        plan_sort_desc(pl.per_image, hist, scan,
-                       [&](int i) { return 900 + atomicAdd(&E[n * pl.per_image + i], 0); },
-                       [&](int i, int pos, int w) { sp[pos] = i; sw[pos] = w; });
-        __threadfence_block();
-        for (int g = tid; g < pl.groups_per_image; g += 256) {
-            int wsum = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 4 * g + j;
-                const bool v = k < pl.per_image;
-                gpatch[4 * (ng + g) + j] = v ? n * pl.per_image + sp[k] : -1;
-                wsum += v ? sw[k] : 0;
+    bool fits = (t1 - t0) * 4 <= PLAN_BAND_PATCHES;
+    for (int n = 0; n < N && fits; ++n) {
+        const int a0 = max(t0, n * per_img_tiles), a1 = min(t1, (n + 1) * per_img_tiles);
+        if (a1 <= a0) continue;                                // (block-uniform)
+        // the band's patches of image n: slot i = (tile, quarter); key = work << 9 | (511 - i): distinct, a missing patch sorts last
+        const int ns = (a1 - a0) * 4, ns4 = (ns + 3) / 4;
+        int nvalid = 0;
+        for (int i0 = 0; i0 < PLAN_BAND_PATCHES; i0 += 256) {
+            const int i = i0 + tid;
+            int key = 0, pid = -1;
+            if (i < ns) {
+                const int t = a0 + (i >> 2) - n * per_img_tiles, q = i & 3;
+                const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+                const int pyi = 2 * tyi + (q >> 1), pxi = 2 * txi + (q & 1);
+                if (pyi < pl.pyn && pxi < pl.pxn) {
+                    pid = n * pl.per_image + pyi * pl.pxn + pxi;
+                    const int w = min(900 + __hip_atomic_load(&E[pid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (1 << 21) - 1);
+                    key = (w << 9) | (511 - i);
+                } else key = 511 - i;
             }
-            gwork[ng + g] = wsum;
-            gimg_t[ng + g] = n;
+            s_key[i] = key; s_pid[i] = pid;
+            nvalid += __syncthreads_count(pid >= 0);
         }
-        ng += pl.groups_per_image;
+        __syncthreads();
+        const int np = nvalid;
+        int gcount;
+        if (mode == 0) {
+            // patches by descending work; four consecutive ones = a group of nearly equal work
+            for (int i = tid; i < ns; i += 256) {
+                const int rk = plan_rank(s_key, ns4, s_key[i]);
+                s_sorted[rk] = s_pid[i]; s_sw[rk] = s_key[i] >> 9;
+            }
+            __syncthreads();
+            gcount = (np + 3) / 4;
+            if (ng + gcount > PLAN_BAND_GROUPS) { fits = false; break; }
+            for (int g = tid; g < gcount; g += 256) {
+                int wsum = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * g + j;
+                    s_gp[ng + g][j] = k < np ? s_sorted[k] : -1;
+                    wsum += k < np ? s_sw[k] : 0;
+                }
+                s_gkey[ng + g] = (min(wsum, (1 << 23) - 1) << 7) | (127 - (ng + g)); s_gn[ng + g] = n;
+            }
+        } else {
+            // groups = the 8 x 8 tiles themselves (their four patches share most of their RoIs: L1 reuse of the gy rows), only dealt by work
+            gcount = a1 - a0;
+            if (ng + gcount > PLAN_BAND_GROUPS) { fits = false; break; }
+            for (int g = tid; g < gcount; g += 256) {
+                int wsum = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s_gp[ng + g][j] = s_pid[4 * g + j]; wsum += s_pid[4 * g + j] >= 0 ? s_key[4 * g + j] >> 9 : 0; }
+                s_gkey[ng + g] = (min(wsum, (1 << 23) - 1) << 7) | (127 - (ng + g)); s_gn[ng + g] = n;
+            }
+        }
+        ng += gcount;
         __syncthreads();
     }
-    // groups by descending work (fillers of work 0 behind them), dealt serpentine over the 256 CU slots: position k -> block
+    if (!fits) return;
+    for (int i = ng + tid; i < PLAN_BAND_GROUPS; i += 256) s_gkey[i] = 127 - i;        // fillers: work 0, behind every group
+    __syncthreads();
     int *order = plan + pl.order, *gimg = plan + pl.gimg;
-    plan_sort_desc(PLAN_GROUPS, hist, scan,
-                   [&](int i) { return i < ng ? gwork[i] >> 2 : 0; },
-                   [&](int i, int pos, int) {
-                       const int rnd = pos >> 8, p8 = pos & 255, b = rnd * 256 + ((rnd & 1) ? 255 - p8 : p8);
+    // the band's groups by descending work, serpentine over the band's 32 CU slots: rank k -> block 8 * ((k / 32) * 32 + slot) + x
+    for (int i = tid; i < PLAN_BAND_GROUPS; i += 256) {
+        const int rk = plan_rank(s_gkey, PLAN_BAND_GROUPS / 4, s_gkey[i]);
+        const int rnd = rk >> 5, pos = rk & 31, b = 8 * (rnd * 32 + ((rnd & 1) ? 31 - pos : pos)) + x;
 #pragma unroll
-                       for (int j = 0; j < 4; ++j) order[4 * b + j] = i < ng ? gpatch[4 * i + j] : -1;
-                       gimg[b] = i < ng ? gimg_t[i] : -1;
-                   });
+        for (int j = 0; j < 4; ++j) order[4 * b + j] = i < ng ? s_gp[i][j] : -1;
+        gimg[b] = i < ng ? s_gn[i] : -1;
+    }
     __threadfence();
+    __syncthreads();
     if (tid == 0) {
         plan[PH_N] = N; plan[PH_H] = H; plan[PH_W] = W; plan[PH_NPATCH] = pl.npatch;
         plan[pl.total_ints - 1] = PLAN_MAGIC;
         plan[PH_MAGIC] = PLAN_MAGIC;
         __threadfence();
-        plan[PH_VALID] = 1;
+        atomicAdd(&plan[PH_VALID], 1);                       // valid when all 8 bands have arrived
     }
 }
 
@@ -301,14 +338,13 @@ __global__ __launch_bounds__(256) void k_roi_map_order(Levels lv, const float *_
 __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(Levels lv, const float *__restrict__ rois,
                                                             const int32_t *__restrict__ levels, int R, int N, int C, int PH, int PW,
                                                             int sr, float *__restrict__ y, int chunk,
-                                                            const int32_t *__restrict__ perm, int *__restrict__ plan, PlanLayout pl) {
+                                                            const int32_t *__restrict__ perm, int *__restrict__ plan, PlanLayout pl, int plan_mode) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bid = blockIdx.x;
     if (plan) {             // PLAN_EXTRA_BLOCKS blocks in front of the forward's grid build the backward plan (single level)
         if (bid < PLAN_COUNT_BLOCKS) { plan_count(plan, pl, rois, R, N, lv.H[0], lv.W[0], PH, PW, sr, lv.scale[0], bid); return; }
-        if (bid == PLAN_COUNT_BLOCKS) { plan_sort(plan, pl, N, lv.H[0], lv.W[0]); return; }
-        if (bid < PLAN_EXTRA_BLOCKS) return;
+        if (bid < PLAN_EXTRA_BLOCKS) { plan_sort(plan, pl, N, lv.H[0], lv.W[0], bid - PLAN_COUNT_BLOCKS, plan_mode); return; }
         bid -= PLAN_EXTRA_BLOCKS;
     }
     const int wg = (bid & 7) * chunk + (bid >> 3);
@@ -828,7 +864,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
     // image gimg[b] - any four patches of an image, of nearly equal work.  The header decides (uniformly for the launch); without a
     // valid one the blocks take the XCD-banded tile order.
     bool planned = false;
-    if (plan) planned = plan[PH_MAGIC] == PLAN_MAGIC && plan[PH_VALID] == 1 && plan[PH_N] == N && plan[PH_H] == lv.H[0] && plan[PH_W] == lv.W[0] &&
+    if (plan) planned = plan[PH_MAGIC] == PLAN_MAGIC && plan[PH_VALID] == 8 && plan[PH_N] == N && plan[PH_H] == lv.H[0] && plan[PH_W] == lv.W[0] &&
                         plan[plan_tail] == PLAN_MAGIC;
     planned = __builtin_amdgcn_readfirstlane((int)planned) != 0;
     int l = 0, nsplit = 1, zsplit = 0, n, py0, px0;
@@ -1264,7 +1300,13 @@ size_t fwd_plan_ws_bytes(int N, int H, int W, int R) {
     if (R <= 0 || !plan_ok(N, H, W)) return fwd_ws_bytes(R);
     return fwd_ws_bytes(R) + (plan_layout(N, H, W).total_ints * sizeof(int) + 255) / 256 * 256;
 }
-int g_bwd_plan = 1;         // mrcnn_roi_align_set_bwd_plan: 0 = the forward builds no plan / the backward ignores one (A/B)
+// mrcnn_roi_align_set_bwd_plan: 0 (DEFAULT) = the forward builds no plan and the backward ignores one; 1 = groups of four patches of equal
+// work; 2 = the 8 x 8 tiles themselves, dealt by work.  OPT-IN: measured on configs[1] (bench.py --workload roialign, same process) the
+// backward alone gains 7-9 % (27.8 -> 25.8 / 25.3 us) - a third of what the VALU-load model promises (tools/roi_balance_model.py: x0.75):
+// the scattered groups lose the tiles' L1 reuse of gy rows, and the kernel's latency chains (table fill, RoI loads) do not shrink with
+// the balance - while the forward pays 7.7 us for the plan (its blocks share the CUs with the forward's waves and finish after them):
+// the PAIR a training step pays goes 56.2 -> 61.4 us.  Kept as a tested option, not shipped.
+int g_bwd_plan = 0;
 
 // Forward: rows kernel when the x samples of a row fit one wave (fixed sampling grid, PW * grid <= 64) and every level is
 // within 32-bit buffer offsets; else the one-wave-per-bin kernel.
@@ -1290,7 +1332,7 @@ void launch_fwd(Levels &lv, const float *rois, const int32_t *levels, int R, int
                                plan, plan ? (int)(PLAN_HDR + pl.npatch) : 0);
         }
         hipLaunchKernelGGL(k_roi_align_fwd_rows, dim3(chunk * 8 + (plan ? PLAN_EXTRA_BLOCKS : 0)), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW,
-                           sr, y, chunk, perm, plan, pl);
+                           sr, y, chunk, perm, plan, pl, g_bwd_plan - 1);
     } else {
         const long long waves = (long long)R * PH * PW;
         hipLaunchKernelGGL(k_roi_align_fwd_nhwc, dim3(mrcnn::cdiv(waves, 4)), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW, sr, y);
@@ -1398,8 +1440,8 @@ extern "C" size_t mrcnn_roi_align_plan_workspace_bytes(int N, int H, int W, int 
     return fwd_plan_ws_bytes(N, H, W, R);
 }
 
-extern "C" int mrcnn_roi_align_set_bwd_plan(int on) {
-    g_bwd_plan = on ? 1 : 0;
+extern "C" int mrcnn_roi_align_set_bwd_plan(int on) {          // 0 off, 1 groups of four patches of equal work (default), 2 the tiles themselves, dealt by work
+    g_bwd_plan = on < 0 ? 0 : (on > 2 ? 2 : on);
     return 0;
 }
 

@@ -298,8 +298,9 @@ def test_forward_map_order_walk_gives_the_same_rows(R):
 @pytest.mark.parametrize('case', [(1, 200, 272, 256, 7, 2, 'config2'), (2, 100, 136, 64, 7, 2, 'rand'), (1, 61, 83, 128, 14, 2, 'rand'),
                                   (3, 37, 41, 32, 5, 3, 'rand'), (1, 200, 272, 256, 14, 2, 'config2')],
                          ids=lambda c: '%dx%dx%dx%d_P%d_sr%d_%s' % c)
-def test_backward_with_the_forward_built_plan_gives_the_same_bits(case):
-    """ABI v8: a forward call given mrcnn_roi_align_plan_workspace_bytes() bytes leaves the backward's work plan in the workspace (every
+@pytest.mark.parametrize('mode', [1, 2], ids=['equal_work_groups', 'whole_tiles'])
+def test_backward_with_the_forward_built_plan_gives_the_same_bits(case, mode):
+    """ABI v8, opt-in (mrcnn_roi_align_set_bwd_plan(1 | 2); off by default - the pair loses what the backward gains): a forward call given mrcnn_roi_align_plan_workspace_bytes() bytes leaves the backward's work plan in the workspace (every
     workgroup = four patches of nearly equal estimated work, groups dealt serpentine over the CU slots); the backward given the same
     buffer follows it.  Every patch is still computed exactly once by the same code: gx is bit-identical to the launch order of round 3
     (plan switched off), on configs[1] itself and on ragged maps, several images, bad image indices, 14x14 / odd pooled sizes.  The plan
@@ -340,12 +341,12 @@ def test_backward_with_the_forward_built_plan_gives_the_same_bits(case):
         y0 = y.clone()
         ref = bwd(ws)
         assert torch.isfinite(ref).all()
-        _hip.check(lib.mrcnn_roi_align_set_bwd_plan(1))
+        _hip.check(lib.mrcnn_roi_align_set_bwd_plan(mode))
         fwd(ws)
         assert torch.equal(y, y0)                               # the extra workgroups do not touch the forward's output
         hdr_off = lib.mrcnn_roi_align_fwd_workspace_bytes(R) // 4
         plan = ws.view(torch.int32)[hdr_off:].cpu().numpy()
-        assert plan[0] == 0x504C414E and plan[5] == 1, plan[:8]  # magic, valid
+        assert plan[0] == 0x504C414E and plan[5] == 8, plan[:8]  # magic, all eight XCD bands arrived
         pyn, pxn = (H + 3) // 4, (W + 3) // 4
         npatch = N * pyn * pxn
         assert plan[4] == npatch
@@ -370,4 +371,4 @@ def test_backward_with_the_forward_built_plan_gives_the_same_bits(case):
                                                       _hip.stream_ptr()))
             assert torch.equal(bwd(ws2), ref)
     finally:
-        _hip.check(lib.mrcnn_roi_align_set_bwd_plan(1))
+        _hip.check(lib.mrcnn_roi_align_set_bwd_plan(0))

@@ -142,3 +142,25 @@ for w, i in tw:
 m2, x2 = simd_loads(lpt)
 print('random SIMD start: shipped order max SIMD load %.0f | sorted serpentine %.0f (x%.2f) | LPT by CU %.0f (x%.2f); CU sums: shipped max %.0f, serpentine max %.0f, mean %.0f'
       % (m0, m1, m1 / m0, m2, m2 / m0, max(sum(units[i].sum() for i in t) for t in base), max(sum(units[i].sum() for i in t) for t in serp), np.mean([sum(units[i].sum() for i in t) for t in base])))
+
+# --- (r4) the plan as built: per XCD band (the shipped tile ranges, so that a band's gy rows stay in its XCD's L2): patches sorted by work,
+# groups of four patches of nearly equal work, groups sorted and dealt serpentine over the band's 32 CU slots
+pw_all = {}
+for ty in range(tiles_y):
+    for tx in range(tiles_x):
+        t = ty * tiles_x + tx
+        for s4 in range(4):
+            a, b = 2 * ty + (s4 >> 1), 2 * tx + (s4 & 1)
+            if a < TY and b < TX: pw_all.setdefault(t // chunk, []).append(work(E[a, b], Cn[a, b]))
+worst = 0; tot = []
+for x, ws in pw_all.items():
+    ws = sorted(ws, reverse=True)
+    groups = [sum(ws[i:i + 4]) for i in range(0, len(ws), 4)]
+    groups.sort(reverse=True)
+    slots = np.zeros(32)
+    for k, gw_ in enumerate(groups):
+        rnd, pos = divmod(k, 32)
+        slots[pos if rnd % 2 == 0 else 31 - pos] += gw_
+    worst = max(worst, slots.max() / 4); tot.append(sum(ws))
+print('per-XCD-band plan: max SIMD load %.0f (x%.2f of the shipped order); band work min %.0f max %.0f mean %.0f (a band bounds its XCD: max band / 128 SIMDs = %.0f)'
+      % (worst, worst / m0, min(tot), max(tot), np.mean(tot), max(tot) / 128))
