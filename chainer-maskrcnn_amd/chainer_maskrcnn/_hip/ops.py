@@ -248,12 +248,13 @@ def _loss_ws(dev):
     return workspace(lib().mrcnn_loss_workspace_bytes(), dev)
 
 
-def softmax_ce_fills_gradient(M, K, xmap):
-    """True when mrcnn_softmax_ce_f32 takes its channel-interleaved path for this element map (rows = (group, channel) over an NHWC
+def softmax_ce_fills_gradient(M, K, xmap, gmap=None, Kfill=0):
+    """True when mrcnn_softmax_ce_f32 takes its channel-interleaved path for these element maps (rows = (group, channel) over an NHWC
     (G, K, C) tensor: the keypoint loss) - the callee then writes EVERY element of gx (zeros in the padded channels and the ignored
-    rows), so the caller need not zero-fill it.  Mirrors the condition in csrc/loss.hip."""
+    rows), so the caller need not zero-fill it.  Asks the library's own dispatch predicate (mrcnn_softmax_ce_fills_gx)."""
     A, gs, rs, es = xmap
-    return rs == 1 and 4 <= es <= 256 and es % 4 == 0 and 256 % (es // 4) == 0 and A <= es and gs == K * es and M > 0 and M % A == 0 and K >= 64
+    _, ggs, grs, ges = gmap or xmap
+    return bool(lib().mrcnn_softmax_ce_fills_gx(int(M), int(K), int(A), int(gs), int(rs), int(es), int(ggs), int(grs), int(ges), int(Kfill)))
 
 
 def softmax_ce(x, t, M, K, xmap, gmap=None, Kfill=0, want_grad=True, gx=None, ignore_label=-1, out=None):

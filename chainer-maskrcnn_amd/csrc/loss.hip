@@ -370,6 +370,20 @@ extern "C" size_t mrcnn_loss_workspace_bytes(void) { return (size_t)MAXB * 2 * s
 
 // x: logically (M,K); element (r,j) at (r/A)*gs + (r%A)*rs + j*es floats.  gx uses the same map shape with its own
 // strides; columns K..Kfill-1 of gx are zero-filled (es must be 1 for Kfill > K).  loss_out[0] = loss, [1] = count.
+// The ONE statement of when mrcnn_softmax_ce_f32 takes the channel-interleaved kernel (k_sce_chan), which writes EVERY element of gx
+// (zeros in padded channels and ignored rows): used by the dispatch below and exported as mrcnn_softmax_ce_fills_gx, so that a caller
+// that skips zero-filling gx can never disagree with the callee.
+static bool sce_chan_path(int M, int K, int A, long long gs, long long rs, long long es, bool has_gx, long long ggs, long long grs,
+                          long long ges, int Kfill) {
+    if (Kfill < K) Kfill = K;
+    return rs == 1 && es >= 4 && es <= 256 && (es % 4) == 0 && (NT % (es / 4)) == 0 && A <= es && gs == (long long)K * es &&
+           (!has_gx || (grs == 1 && ges == es && ggs == gs)) && Kfill == K && M > 0 && (M % A) == 0 && K >= 64;
+}
+extern "C" int mrcnn_softmax_ce_fills_gx(int M, int K, int A, long long gs, long long rs, long long es, long long ggs, long long grs,
+                                         long long ges, int Kfill) {
+    return sce_chan_path(M, K, A, gs, rs, es, true, ggs, grs, ges, Kfill) ? 1 : 0;
+}
+
 extern "C" int mrcnn_softmax_ce_f32(const float *x, int A, long long gs, long long rs, long long es, const int32_t *t,
                                     int M, int K, int ignore_label, float *loss_out, float *gx, long long ggs,
                                     long long grs, long long ges, int Kfill, void *ws, size_t ws_bytes, void *stream) {
@@ -381,8 +395,7 @@ extern "C" int mrcnn_softmax_ce_f32(const float *x, int A, long long gs, long lo
     const RowMap xm{A, gs, rs, es}, gm{A, ggs, grs, ges};
     if (Kfill < K) Kfill = K;
     // channel-interleaved rows (the keypoint loss): one workgroup per group of A rows, coalesced (k_sce_chan)
-    const bool chan = rs == 1 && es >= 4 && es <= 256 && (es % 4) == 0 && (NT % (es / 4)) == 0 && A <= es && gs == (long long)K * es &&
-                      (!gx || (grs == 1 && ges == es && ggs == gs)) && Kfill == K && M > 0 && (M % A) == 0 && K >= 64;
+    const bool chan = sce_chan_path(M, K, A, gs, rs, es, gx != nullptr, ggs, grs, ges, Kfill);
     if (chan) {
         const int G = M / A, nbc = std::min(G, MAXB);
         if (gx) hipLaunchKernelGGL(k_sce_chan<true>, dim3(nbc), dim3(NT), 0, st, x, t, G, A, K, (int)es, ignore_label, part, gx);

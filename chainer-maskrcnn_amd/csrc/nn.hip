@@ -171,11 +171,22 @@ __global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_stats_final(const fl
     if (sredo) {            // block-uniform
         const double mc = smean[cl];
         double d1 = 0.0, d2 = 0.0;
-        if (c < C)
-            for (int r = slice; r < P; r += FIN_SLICES) {
+        if (c < C) {
+            // eight rows in flight per thread, added in row order (one dependent load per iteration made this rare path
+            // - a pretrained backbone's first BatchNorms, a dead channel - a step-time cliff of tens of ms at P ~ 5e5)
+            int r = slice;
+            for (; r + 7 * FIN_SLICES < P; r += 8 * FIN_SLICES) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = x[(size_t)(r + j * FIN_SLICES) * C + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const double d = (double)v[j] - mc; d1 += d; d2 += d * d; }
+            }
+            for (; r < P; r += FIN_SLICES) {
                 const double d = (double)x[(size_t)r * C + c] - mc;
                 d1 += d; d2 += d * d;
             }
+        }
         __syncthreads();
         sa[slice][cl] = d1; sb[slice][cl] = d2;
         __syncthreads();

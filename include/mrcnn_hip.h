@@ -389,6 +389,11 @@ size_t mrcnn_loss_workspace_bytes(void);
  * the keypoint loss of train_keypoints.py:21-27, 17 heat maps in 32 padded channels) take a coalesced kernel - one workgroup per group,
  * float4 loads over the (position, channel) plane, loss and gradient from one launch - which writes EVERY element of gx (zeros in the
  * channels >= A and in the ignored rows); on the other paths gx receives the K (Kfill) columns of its M rows only. */
+/* 1 when mrcnn_softmax_ce_f32 called with these maps writes EVERY element of gx itself (its channel-interleaved path: the keypoint loss),
+ * so that the caller need not zero-fill gx; 0 = the strided path writes only the K columns of the M rows.  The library's own dispatch
+ * predicate, exported (one source of truth). */
+int mrcnn_softmax_ce_fills_gx(int M, int K, int A, long long gs, long long rs, long long es, long long ggs, long long grs, long long ges,
+                              int Kfill);
 int mrcnn_softmax_ce_f32(const float *x, int A, long long gs, long long rs, long long es, const int32_t *t,
                          int M, int K, int ignore_label, float *loss_out, float *gx, long long ggs,
                          long long grs, long long ges, int Kfill, void *ws, size_t ws_bytes, void *stream);
