@@ -48,6 +48,8 @@ FUSE_BN_STATS = True
 # pass of the layers behind the backbone (every convolution outside extractor/resnet: FPN, RPN, heads - no BatchNorm behind them) on the
 # float32 MFMA.
 FWD_EMULATION_BEHIND_BACKBONE = True
+# ... and False here keeps the forward pass of the BACKBONE's convolutions (extractor/resnet) on the float32 MFMA.
+FWD_EMULATION_IN_BACKBONE = True
 
 
 class _layer_tiles(object):
@@ -58,7 +60,7 @@ class _layer_tiles(object):
 
     def __enter__(self):
         self.keep_split = None
-        if not FWD_EMULATION_BEHIND_BACKBONE and self.behind:
+        if (not FWD_EMULATION_BEHIND_BACKBONE and self.behind) or (not FWD_EMULATION_IN_BACKBONE and not self.behind):
             sp = hnn.split_operands()
             if sp[0] == 3:
                 self.keep_split = sp

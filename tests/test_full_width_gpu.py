@@ -48,10 +48,12 @@ MODES = {'direct': ((100000, 1 << 30, 0), (0, 0, 0)),
          'bf16x6': ((256, 2048, 0), (2, 0, 0)), 'bf16x6_fwd': ((256, 2048, 0), (2, 0, 0)),
          'bf16x6_fwd_only': ((256, 2048, 0), (2, 0, 0)), 'bf16x6_bwd_only': ((256, 2048, 0), (2, 0, 0)),
          # measurement: bf16x6 in every pass except the FORWARD pass of the layers behind the backbone (no BatchNorm behind them)
-         'bf16x6_backbone_fwd': ((256, 2048, 0), (2, 0, 0))}
+         'bf16x6_backbone_fwd': ((256, 2048, 0), (2, 0, 0)),
+         # ... and the other way round: float32 forward in the backbone (c2 .. c5 bit-identical to the float32 step), emulated forward behind it
+         'bf16x6_behind_backbone_fwd': ((256, 2048, 0), (2, 0, 0))}
 # split operands per pass (forward, backward-data, backward-filter) of the exploratory modes: 1 = bf16 hi / lo planes, 2 = half planes
 SPLIT = {'split_bf16': (1, 1, 1), 'split_f16_fwd': (2, 1, 1), 'split_f16': (2, 2, 2), 'split_f16_fwd_only': (2, 0, 0), 'split_bf16_bwd_only': (0, 1, 1),
-         'bf16x6': (3, 3, 3), 'bf16x6_fwd': (3, 1, 1), 'bf16x6_fwd_only': (3, 0, 0), 'bf16x6_bwd_only': (0, 3, 3), 'bf16x6_backbone_fwd': (3, 3, 3)}
+         'bf16x6': (3, 3, 3), 'bf16x6_fwd': (3, 1, 1), 'bf16x6_fwd_only': (3, 0, 0), 'bf16x6_bwd_only': (0, 3, 3), 'bf16x6_backbone_fwd': (3, 3, 3), 'bf16x6_behind_backbone_fwd': (3, 3, 3)}
 DEFAULT = MODES['shipped']
 NAMES = ('rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'mask_loss')
 TAP = 'extractor/resnet/res5/b2'
@@ -114,6 +116,7 @@ def _run(S, mode, keypoints=False, N=1, seed=11, G=6):
     _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(*MODES[mode][1]))
     core.LAYER_TILE_HINTS = MODES[mode][2] if len(MODES[mode]) > 2 else True
     core.FWD_EMULATION_BEHIND_BACKBONE = mode != 'bf16x6_backbone_fwd'
+    core.FWD_EMULATION_IN_BACKBONE = mode != 'bf16x6_behind_backbone_fwd'
     _hip.check(_hip.lib().mrcnn_conv2d_set_split_operands(*SPLIT.get(mode, (0, 0, 0))))
     try:
         chain.proposal_target_creator.set_seed(21)
@@ -171,6 +174,7 @@ def _run(S, mode, keypoints=False, N=1, seed=11, G=6):
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(*DEFAULT[1]))
         core.LAYER_TILE_HINTS = True
         core.FWD_EMULATION_BEHIND_BACKBONE = True
+        core.FWD_EMULATION_IN_BACKBONE = True
     # ---- report
     out_dir = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out_dir, exist_ok=True)
