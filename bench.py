@@ -261,7 +261,7 @@ def main():
     ap.add_argument('--workload', default='auto', choices=['auto', 'roialign', 'step', 'keypoint'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mask-rows', default='all', choices=['positives', 'all'])
-    ap.add_argument('--gemm-arithmetic', default=None, choices=['f32', 'bf16x6_backward', 'bf16x6'],
+    ap.add_argument('--gemm-arithmetic', default=None, choices=['f32', 'bf16x6_behind_backbone', 'bf16x6_backward', 'bf16x6'],
                     help='arithmetic of the convolution GEMMs of the step workloads (default: the shipped training default, train.py)')
     ap.add_argument('--graph', type=int, default=0, help='capture the step into a HIP graph (single GPU; measured slower than eager multi-stream launches on ROCm 7.2, so off by default)')
     args = ap.parse_args()

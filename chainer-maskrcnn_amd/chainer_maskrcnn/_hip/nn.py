@@ -29,7 +29,8 @@ class _prof(object):
                 cin, cout = LOGICAL
             self.rec = [kind, n_out_pix * KH * KW * cin * cout, torch.cuda.Event(enable_timing=True),
                         torch.cuda.Event(enable_timing=True), (n_out_pix, KH, cin, cout), executed, geom,
-                        winograd_pass_tiles()]      # the per-pass tiles in force for THIS call (layers may bracket their own)
+                        winograd_pass_tiles(),      # the per-pass tiles in force for THIS call (layers may bracket their own)
+                        split_operands()]           # ... and the GEMM arithmetic per pass (the backbone's forward pass may differ)
 
     def __enter__(self):
         if self.on:

@@ -119,19 +119,23 @@ def bench_step(args, rank, world):
     other = {}
     if world == 1 and not tiles:
         from chainer_maskrcnn._hip import lib, check
+        from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import select_gemm_arithmetic
         keep = chain.gemm_arithmetic
         chain.gemm_arithmetic = None
-        for name, smode in (('f32', (0, 0, 0)), ('bf16x6', (3, 3, 3)), ('bf16x6_backward', (0, 3, 3)), ('split_bf16_backward', (0, 1, 1)),
-                            ('split_half_forward_bf16_backward', (2, 1, 1))):
-            if smode == GEMM_ARITHMETIC[arith]:
+        for name in ('f32', 'bf16x6_behind_backbone', 'bf16x6_backward', 'bf16x6', 'split_bf16_backward', 'split_half_forward_bf16_backward'):
+            if name == arith:
                 continue
             try:
-                check(lib().mrcnn_conv2d_set_split_operands(*smode))
+                if name in GEMM_ARITHMETIC:
+                    select_gemm_arithmetic(name)
+                else:
+                    select_gemm_arithmetic('f32')
+                    check(lib().mrcnn_conv2d_set_split_operands(*{'split_bf16_backward': (0, 1, 1), 'split_half_forward_bf16_backward': (2, 1, 1)}[name]))
                 other[name] = round(timed(), 3)
             except Exception as e:
                 other[name] = 'failed: %s' % str(e).split('\n')[0][:160]
             finally:
-                check(lib().mrcnn_conv2d_set_split_operands(*GEMM_ARITHMETIC[arith]))
+                select_gemm_arithmetic(arith)
         chain.gemm_arithmetic = keep
         opt.update(chain, imgs, bb, lab, masks, 1.0)
 
@@ -158,22 +162,22 @@ def bench_step(args, rank, world):
     launches = sum(a[0] for a in agg.values()) // n_prof
     split = _replay_split(recs, n_prof, dev)
     pmc = _pmc_step_counters()
-    smode = GEMM_ARITHMETIC[arith]
-    pass_of = {'fwd': 0, 'bwd_data': 1, 'bwd_filter': 2}
-    emu_kinds = [k for k in ('fwd', 'bwd_data', 'bwd_filter') if smode[pass_of[k]] == 3]
-    f32_kinds = [k for k in ('fwd', 'bwd_data', 'bwd_filter') if smode[pass_of[k]] == 0]
-    gk = split['gemm_by_kind']
+    smode = GEMM_ARITHMETIC[arith][0]
+    gk = split['gemm_by_kind']          # keys: (pass, 'f32' | 'bf16x6' | ...) -> ms and executed flops of its GEMM launches
 
-    def pipe(kinds, mult, peak):
-        fl = sum(gk[k]['executed_flops'] for k in kinds if k in gk) * mult
-        ms = sum(gk[k]['ms_per_step'] for k in kinds if k in gk)
-        return {'passes': kinds, 'executed_TFLOPs': round(fl / (ms * 1e-3) / 1e12, 2) if ms else None, 'peak': peak,
+    def pipe(which, mult, peak):
+        keys = [k for k in gk if k.endswith('/' + which)]
+        fl = sum(gk[k]['executed_flops'] for k in keys) * mult
+        ms = sum(gk[k]['ms_per_step'] for k in keys)
+        return {'passes': sorted(k.split('/')[0] for k in keys), 'executed_TFLOPs': round(fl / (ms * 1e-3) / 1e12, 2) if ms else None, 'peak': peak,
                 'frac': round(fl / (ms * 1e-3) / 1e12 / peak, 4) if ms else None, 'gemm_ms_per_step': round(ms, 3), 'executed_flops_per_step': fl}
+    emu_kinds = [k for k in gk if k.endswith('/bf16x6')]
+    f32_kinds = [k for k in gk if k.endswith('/f32')]
     # The dominant kernel = the GEMM launches of the convolution calls.  Each pass is priced on the pipe it runs on: a float32-MFMA
     # pass executes 2 flops per MAC on v_mfma_f32_32x32x2_f32 (peak 157.3 TF/s), an emulated pass SIX bf16 MFMA products per MAC on
     # v_mfma_f32_32x32x16_bf16 (peak 2500 TF/s dense).  `roofline` is the larger of the two groups by time.
-    emu = pipe(emu_kinds, 6.0, MFMA_BF16_PEAK_TFLOPS) if emu_kinds else None
-    f32 = pipe(f32_kinds, 1.0, MFMA_F32_PEAK_TFLOPS) if f32_kinds else None
+    emu = pipe('bf16x6', 6.0, MFMA_BF16_PEAK_TFLOPS) if emu_kinds else None
+    f32 = pipe('f32', 1.0, MFMA_F32_PEAK_TFLOPS) if f32_kinds else None
     head = emu if (emu and (not f32 or emu['gemm_ms_per_step'] >= f32['gemm_ms_per_step'])) else f32
     head_is_emu = head is emu
     gemm_ms = sum(v['ms_per_step'] for v in gk.values())
@@ -192,7 +196,13 @@ def bench_step(args, rank, world):
                    'buckets on a side stream' % world if world > 1 else 'single GPU', 'final_loss': round(loss, 4),
                    'gemm_arithmetic': {
                        'name': arith, 'split_operands_fwd_bwddata_bwdfilter': list(smode),
-                       'scheme': {'f32': 'v_mfma_f32_32x32x2_f32 in every pass: float32 operands, float32 accumulate (bit for bit an fmaf chain)',
+                       'scheme': {'bf16x6_behind_backbone': 'float32-ACCURATE emulation on v_mfma_f32_32x32x16_bf16 - every float32 operand is carried EXACTLY by three bf16 '
+                                                            'planes hi + mid + lo, the six products of weight >= 2^-16 (lh + hl + mm + mh + hm + hh) are accumulated in float32; the '
+                                                            'dropped terms are <= 3 x 2^-24 |ab|, the size of the float32 MFMA\'s own accumulation rounding - in the backward-data and '
+                                                            'backward-filter passes of every layer and in the forward pass of every layer BEHIND the backbone (FPN, RPN, heads); the '
+                                                            'forward pass of the ResNet-50\'s convolutions runs on v_mfma_f32_32x32x2_f32 (c2 .. c5 are those of the all-float32 step '
+                                                            'bit for bit)',
+                                  'f32': 'v_mfma_f32_32x32x2_f32 in every pass: float32 operands, float32 accumulate (bit for bit an fmaf chain)',
                                   'bf16x6_backward': 'forward pass: v_mfma_f32_32x32x2_f32 on float32 operands (activations, losses and sampled targets are '
                                                      'those of the all-float32 step bit for bit); backward-data and backward-filter passes: float32-ACCURATE '
                                                      'emulation on v_mfma_f32_32x32x16_bf16 - every float32 operand is carried EXACTLY by three bf16 planes '
@@ -203,29 +213,29 @@ def bench_step(args, rank, world):
                        'why_this_is_the_value': 'VERDICT r3 ruling: the three-plane emulation is not narrower than the float32 MFMA (per-GEMM error against '
                                                 'float64 <= the float32 kernel\'s: tests/test_split_gemm_gpu.py); it carries the headline in the passes where the '
                                                 'full-width parity bars of the float32 configuration hold UNRELAXED on five batches '
-                                                '(tests/test_full_width_gpu.py, profiles/r04_full_width_parity_five_seeds.txt): the two backward passes.  With the '
-                                                'emulation in the forward pass too, one of the five batches has 4 % of the gradient tensors above 3 x the float32 '
-                                                'floor (bar 3 %): that configuration stays an opt-in line'},
+                                                '(tests/test_full_width_gpu.py, profiles/r04_full_width_parity_*.txt): both backward passes, and the forward pass '
+                                                'behind the backbone.  With the backbone\'s forward pass emulated too, one of the five batches has 4 % of the gradient '
+                                                'tensors above 3 x the float32 floor (bar 3 %): that configuration stays an opt-in line'},
                    'images_per_sec_f32_mfma': other.get('f32') if arith != 'f32' else round(ips, 3)},
         # The GEMM launches of the headline pass group on the pipe they run on (see above); the whole convolution bracket (GEMMs +
         # Winograd transforms + sums) and the float32 group follow as extra keys.
         'roofline': {'bound': 'mfma',
-                     'kernel': ('k_conv_igemm<bwd_data|bwd_filter, split 3> + k_pgemm_pp / k_pgemm_gpp (plane GEMMs): the GEMM launches of the %s passes'
-                                % ' + '.join(head['passes'])) if head_is_emu else
-                               'k_conv_igemm<%s>: the GEMM launches of the float32-MFMA passes' % '|'.join(head['passes']),
+                     'kernel': ('k_conv_igemm<..., split 3> + k_pgemm_pp / k_pgemm_gpp (plane GEMMs): the GEMM launches of every emulated convolution call (%s)'
+                                % ', '.join(head['passes'])) if head_is_emu else
+                               'k_conv_igemm<..., float32>: the GEMM launches of the float32-MFMA calls (%s)' % ', '.join(head['passes']),
                      'achieved': head['executed_TFLOPs'], 'peak': head['peak'], 'unit': 'TFLOP/s', 'frac': head['frac'],
                      'pipe': 'v_mfma_f32_32x32x16_bf16, dense bf16 peak; executed flops = 6 products x 2 x MACs the pipes execute' if head_is_emu else
                              'v_mfma_f32_32x32x2_f32, float32 MFMA peak; executed flops = 2 x MACs the pipes execute',
                      'gemm_ms_per_step': head['gemm_ms_per_step'], 'executed_flops_per_step': head['executed_flops_per_step'],
-                     'effective_fp32_TFLOPs': round(sum(gk[k]['executed_flops'] for k in head['passes'] if k in gk) / (head['gemm_ms_per_step'] * 1e-3) / 1e12, 2)
+                     'effective_fp32_TFLOPs': round(head['executed_flops_per_step'] / (6.0 if head_is_emu else 1.0) / (head['gemm_ms_per_step'] * 1e-3) / 1e12, 2)
                      if head['gemm_ms_per_step'] else None,
                      'traffic': pmc['traffic'], 'traffic_source': pmc['traffic_source'],
                      'hbm_bytes_per_step_by_family': pmc.get('hbm_bytes_per_step_by_family'),
                      'hbm_bytes_per_step_whole_step': pmc.get('hbm_bytes_per_step_whole_step'),
                      'pmc_mfma_busy_fraction_by_kernel': pmc.get('pmc_mfma_busy_fraction_by_kernel'),
                      'pmc_mfma_source': pmc.get('pmc_mfma_source'),
-                     'gemm_kernels_only': {'ms_per_step_all_passes': round(gemm_ms, 3), 'by_pass': gk,
-                                           'float32_mfma_passes': f32, 'bf16_emulated_passes': emu},
+                     'gemm_kernels_only': {'ms_per_step_all_passes': round(gemm_ms, 3), 'by_pass_and_arithmetic': gk,
+                                           'float32_mfma_calls': f32, 'bf16_emulated_calls': emu},
                      'conv_bracket': {'ms_per_step': round(secs * 1e3, 3), 'launches': launches,
                                       'executed_macs_x2_per_step': exe_flops, 'algorithmic_flops_per_step': flops,
                                       'effective_fp32_TFLOPs': round(flops / secs / 1e12, 3),
@@ -336,16 +346,21 @@ def _replay_split(recs, n_prof, dev):
     HBM_PEAK = 8000.0
     geoms = {}
     for rec in recs:
-        geoms[(rec[0], rec[6], rec[7])] = geoms.get((rec[0], rec[6], rec[7]), 0) + 1
+        key = (rec[0], rec[6], rec[7], rec[8] if len(rec) > 8 else (0, 0, 0))
+        geoms[key] = geoms.get(key, 0) + 1
     gemm_s, exe_k = {}, {}
     aux_s, aux_bytes = 0.0, 0.0
     keep = hnn.PROFILE
     hnn.PROFILE = None
     base = hnn.winograd_pass_tiles()
+    base_split = hnn.split_operands()
+    names = {0: 'f32', 1: 'bf16x3', 2: 'f16x3', 3: 'bf16x6'}
     try:
-        for (kind, g, tiles), cnt in geoms.items():
+        for (kind, g, tiles, sm), cnt in geoms.items():
             cnt = cnt / n_prof
             hnn.set_winograd_pass_tiles(*tiles)         # the call's own tiles (FPN / RPN / head layers bracket theirs)
+            check(lib().mrcnn_conv2d_set_split_operands(*sm))        # ... and its own arithmetic (the backbone's forward pass may differ)
+            kk = '%s/%s' % (kind, names[sm[{'fwd': 0, 'bwd_data': 1, 'bwd_filter': 2}[kind]]])
             N, H, W, Cin, Cout, KH, KW, stride, pad = g
             Ho, Wo = hnn.conv_out(H, KH, stride, pad), hnn.conv_out(W, KW, stride, pad)
             x = torch.empty((N, H, W, Cin), device=dev).normal_()
@@ -366,10 +381,10 @@ def _replay_split(recs, n_prof, dev):
                 torch.cuda.synchronize()
                 t = e0.elapsed_time(e1) / 3 * 1e-3 * cnt
                 if mask == 2:
-                    gemm_s[kind] = gemm_s.get(kind, 0.0) + t
+                    gemm_s[kk] = gemm_s.get(kk, 0.0) + t
                 else:
                     aux_s += t
-            exe_k[kind] = exe_k.get(kind, 0.0) + 2.0 * lib().mrcnn_conv2d_executed_macs(*g, {'fwd': 0, 'bwd_data': 1, 'bwd_filter': 2}[kind]) * cnt
+            exe_k[kk] = exe_k.get(kk, 0.0) + 2.0 * lib().mrcnn_conv2d_executed_macs(*g, {'fwd': 0, 'bwd_data': 1, 'bwd_filter': 2}[kind]) * cnt
             vb = lib().mrcnn_conv2d_winograd_v_bytes(*g)
             if vb:          # transforms stream: activation in + transformed operand out, GEMM result in + activation out
                 wb = lib().mrcnn_conv2d_winograd_w_bytes(*g)
@@ -377,6 +392,7 @@ def _replay_split(recs, n_prof, dev):
                 aux_bytes += cnt * ({'fwd': ain + vb + wb + aout, 'bwd_data': aout + wb + vb + ain, 'bwd_filter': aout + wb}[kind])
     finally:
         check(lib().mrcnn_conv2d_set_debug_skip(0))
+        check(lib().mrcnn_conv2d_set_split_operands(*base_split))
         hnn.set_winograd_pass_tiles(*base)
         hnn.PROFILE = keep
     by_kind = {k: {'ms_per_step': round(gemm_s[k] * 1e3, 3), 'executed_flops': exe_k[k]} for k in gemm_s}

@@ -92,19 +92,34 @@ def calc_keypoint_loss(roi_cls_mask, gt_roi_mask, xp, gt_roi_label, num_keypoint
 calc_keypoint_loss.fused_kind = 'keypoint_ce'
 
 
-# Arithmetic of the convolution GEMMs (mrcnn_conv2d_set_split_operands: forward, backward-data, backward-filter).  All three take
-# float32 tensors in and out and accumulate in float32:
-#   'f32'              v_mfma_f32_32x32x2_f32 in every pass (bit for bit an fmaf chain)
-#   'bf16x6_backward'  the SHIPPED training default (train.py, bench.py): float32 MFMA in the forward pass - activations, losses and
-#                      sampled targets are those of 'f32' bit for bit - and the float32-ACCURATE three-plane emulation on
-#                      v_mfma_f32_32x32x16_bf16 in both backward passes: every operand is carried exactly by three bf16 planes
-#                      (hi + mid + lo), the six products of weight >= 2^-16 are accumulated in float32; per-GEMM error against
-#                      float64 <= the float32 MFMA's (tests/test_split_gemm_gpu.py), full-width parity on five batches with the bars
-#                      of the float32 configuration (tests/test_full_width_gpu.py, profiles/r04_full_width_parity_five_seeds.txt)
-#   'bf16x6'           the emulation in the forward pass too (opt-in: on one of the five batches a near-tie of the FPN part falls the
-#                      other way and 4 % of the gradient tensors sit above 3 x the float32 floor, against a 3 % bar)
-GEMM_ARITHMETIC = {'f32': (0, 0, 0), 'bf16x6_backward': (0, 3, 3), 'bf16x6': (3, 3, 3)}
-DEFAULT_GEMM_ARITHMETIC = 'bf16x6_backward'
+# Arithmetic of the convolution GEMMs (mrcnn_conv2d_set_split_operands: forward, backward-data, backward-filter; + which layers' FORWARD
+# pass the setting applies to).  All of them take float32 tensors in and out and accumulate in float32:
+#   'f32'                     v_mfma_f32_32x32x2_f32 in every pass (bit for bit an fmaf chain)
+#   'bf16x6_behind_backbone'  the SHIPPED training default (train.py, bench.py): the float32-ACCURATE three-plane emulation on
+#                             v_mfma_f32_32x32x16_bf16 - every operand carried exactly by three bf16 planes (hi + mid + lo), the six
+#                             products of weight >= 2^-16 accumulated in float32; per-GEMM error against float64 <= the float32 MFMA's
+#                             (tests/test_split_gemm_gpu.py) - in both backward passes of every layer and in the forward pass of every
+#                             layer BEHIND the backbone (FPN, RPN, heads); the forward pass of the ResNet's convolutions stays on the
+#                             float32 MFMA, so c2 .. c5 - 50 layers of training-mode BatchNorm - are those of the float32 step bit for
+#                             bit.  Full-width parity with the UNRELAXED bars of the float32 configuration on five batches
+#                             (tests/test_full_width_gpu.py; profiles/r04_full_width_parity_behind_backbone_forward_emulated.txt)
+#   'bf16x6_backward'         float32 MFMA in the whole forward pass, the emulation in both backward passes (round 4's first choice: the
+#                             same five batches pass, activations / losses / sampled targets bit-identical to 'f32')
+#   'bf16x6'                  the emulation in every pass of every layer (opt-in: with the backbone's forward pass emulated, one of the
+#                             five batches has 4 % of the gradient tensors above 3 x the float32 floor, against a 3 % bar)
+# value = (split operands per pass, emulate the backbone's forward pass too)
+GEMM_ARITHMETIC = {'f32': ((0, 0, 0), True), 'bf16x6_behind_backbone': ((3, 3, 3), False), 'bf16x6_backward': ((0, 3, 3), True),
+                   'bf16x6': ((3, 3, 3), True)}
+DEFAULT_GEMM_ARITHMETIC = 'bf16x6_behind_backbone'
+
+
+def select_gemm_arithmetic(name):
+    """Process-wide: the library's split-operand modes and the per-layer rule of nn/core.py."""
+    from chainer_maskrcnn._hip import lib, check
+    from chainer_maskrcnn.nn import core
+    split, backbone_fwd = GEMM_ARITHMETIC[name]
+    check(lib().mrcnn_conv2d_set_split_operands(*split))
+    core.FWD_EMULATION_IN_BACKBONE = bool(backbone_fwd)
 
 
 class FPNMaskRCNNTrainChain(object):
@@ -159,8 +174,7 @@ class FPNMaskRCNNTrainChain(object):
         if self.strict_batch1 and n != 1:
             raise ValueError('Currently only batch size 1 is supported. n={}'.format(n))
         if self.gemm_arithmetic is not None:        # (read by the library on the host at call time: forward now, backward later)
-            from chainer_maskrcnn._hip import lib, check
-            check(lib().mrcnn_conv2d_set_split_operands(*GEMM_ARITHMETIC[self.gemm_arithmetic]))
+            select_gemm_arithmetic(self.gemm_arithmetic)
         if torch.is_tensor(scale) and scale.numel() == 1:
             scale = float(scale.reshape(-1)[0].item())
         dev = imgs.device

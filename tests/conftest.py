@@ -92,5 +92,7 @@ def _library_defaults_after_each_test():
         return
     if getattr(_hip, '_lib', None) is not None:
         _hip._lib.mrcnn_conv2d_set_split_operands(0, 0, 0)
+        from chainer_maskrcnn.nn import core
+        core.FWD_EMULATION_IN_BACKBONE = core.FWD_EMULATION_BEHIND_BACKBONE = True
         _hip._lib.mrcnn_debug_conv_parts(0)
         _hip._lib.mrcnn_conv2d_set_debug_skip(0)

@@ -255,9 +255,10 @@ def test_full_width_1024_batch2_split_bf16_backward_opt_in():
     _check(1024, 'split_bf16_bwd_only', N=2, seed=100, G=8, iso_tol=1e-3)
 
 
-# The SHIPPED training arithmetic (model/fpn_maskrcnn_train_chain.py DEFAULT_GEMM_ARITHMETIC = 'bf16x6_backward', what train.py runs and
-# bench.py reports as `value`): float32 MFMA forward, float32-accurate three-plane emulation on the bf16 MFMA in both backward passes.
-HEADLINE = 'bf16x6_bwd_only'
+# The SHIPPED training arithmetic (model/fpn_maskrcnn_train_chain.py DEFAULT_GEMM_ARITHMETIC = 'bf16x6_behind_backbone', what train.py runs
+# and bench.py reports as `value`): the float32-accurate three-plane emulation on the bf16 MFMA in both backward passes of every layer and
+# in the forward pass of every layer behind the backbone; float32 MFMA in the forward pass of the ResNet's convolutions.
+HEADLINE = 'bf16x6_behind_backbone_fwd'
 
 
 def test_full_width_1024_batch2_shipped_arithmetic():
@@ -267,11 +268,18 @@ def test_full_width_1024_batch2_shipped_arithmetic():
     _check(1024, HEADLINE, N=2, seed=100, G=8)
 
 
+def test_full_width_1024_batch2_emulation_in_the_backward_passes_only():
+    """The more conservative arithmetic 'bf16x6_backward' (float32 MFMA in the whole forward pass: activations, losses and sampled
+    targets bit-identical to the float32 step), same batch, same unrelaxed bars."""
+    _check(1024, 'bf16x6_bwd_only', N=2, seed=100, G=8)
+
+
 def test_full_width_1024_batch2_float32_accurate_emulation_in_every_pass_opt_in():
-    """OPT-IN, not the shipped arithmetic: bf16x6 in the forward pass too.  On THIS batch the emulated forward pass is another
-    realisation of the rounding noise in which one near-tie decision of the FPN / RPN part (no BatchNorm, F(4x4) forward) falls the other
-    way: the tensors behind it (toplayer, lat_p2..p4, conv_p3, rpn/conv/b) sit at 3.4 - 4.7 x the floor, 4 - 5 % of the tensors against
-    the 3 % bar - which is why the forward pass of the shipped arithmetic stays on the float32 MFMA.  On four other batches (seeds
+    """OPT-IN, not the shipped arithmetic: bf16x6 in the forward pass of the BACKBONE too.  On THIS batch the emulated ResNet forward is
+    another realisation of the rounding noise (50 layers of training-mode BatchNorm) in which one near-tie decision downstream falls the
+    other way: the tensors behind it (toplayer, lat_p2..p4, conv_p3, rpn/conv/b) sit at 3.4 - 4.7 x the floor, 4 - 5 % of the tensors
+    against the 3 % bar (emulating ONLY the backbone's forward pass reproduces it, emulating only the forward pass behind the backbone
+    does not: profiles/r04_full_width_parity_*backbone*.txt) - which is why the backbone's forward pass stays on the float32 MFMA.  On four other batches (seeds
     101 .. 104) this mode passes the 3 % bar too (profiles/r04_full_width_parity_five_seeds.txt); here the bar is 6 % and everything
     else (activations, losses, every tensor < 6 x floor, median, isolated filter gradient) is held as for the float32 configuration."""
     _check(1024, 'bf16x6', N=2, seed=100, G=8, above3_frac=0.06)

@@ -465,13 +465,13 @@ def test_padded_batch_uses_each_images_own_size_and_scale():
     chain.sampler_keys = None
 
 
-@pytest.mark.parametrize('arith', ['f32', 'bf16x6_backward'])
+@pytest.mark.parametrize('arith', ['f32', 'bf16x6_behind_backbone'])
 def test_overfits_one_fixed_batch(arith):
     """Does it learn: 150 MomentumSGD steps (lr 0.01, momentum 0.9, weight decay 5e-4 - train.py's
     optimiser at a learning rate that fits the reduced network) on ONE fixed batch with fixed sampler seeds: the total
     loss falls by at least half, every one of the five losses stays finite at every step, and the box-classification and
     mask losses - the two that depend on the whole chain of proposals -> targets -> heads - both fall.  In the all-float32
-    arithmetic and in the shipped one (train.py's default: float32-accurate bf16x6 emulation in the backward passes)."""
+    arithmetic and in the shipped one (train.py's default: the float32-accurate bf16x6 emulation everywhere but the backbone's forward pass)."""
     m, chain = _build('all', seed=11)
     chain.gemm_arithmetic = arith
     opt = MomentumSGD(lr=0.01, momentum=0.9).setup(chain)

@@ -11,7 +11,7 @@ from chainer_maskrcnn.utils.synthetic import make_batch
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 dev = torch.device('cuda:0')
 model = MaskRCNN(n_fg_class=80, device=dev, seed=1234)
-chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows='all', gemm_arithmetic=os.environ.get('MRCNN_GEMM_ARITHMETIC', 'bf16x6_backward'))
+chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows='all', gemm_arithmetic=os.environ.get('MRCNN_GEMM_ARITHMETIC', 'bf16x6_behind_backbone'))
 opt = MomentumSGD(lr=1e-3, momentum=0.9).setup(chain)
 opt.add_hook(WeightDecay(0.0005))
 b = make_batch(100, 2, 1024, 1024, G=8)

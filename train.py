@@ -49,7 +49,7 @@ def build_parser(keypoints=False):
     parser.add_argument('--num-workers', type=int, default=8, help='decode / transform threads of the COCO loader')
     parser.add_argument('--max-gt', type=int, default=0, help='instances kept per image (0: all; static shapes when > 0)')
     parser.add_argument('--image-size', type=int, nargs=2, default=[800, 800])
-    parser.add_argument('--gemm-arithmetic', default='bf16x6_backward', choices=['f32', 'bf16x6_backward', 'bf16x6'],
+    parser.add_argument('--gemm-arithmetic', default='bf16x6_behind_backbone', choices=['f32', 'bf16x6_behind_backbone', 'bf16x6_backward', 'bf16x6'],
                         help='arithmetic of the convolution GEMMs (model/fpn_maskrcnn_train_chain.py GEMM_ARITHMETIC): float32 tensors and float32 '
                              'accumulation in all three; bf16x6 = float32-accurate three-plane emulation on the bf16 MFMA')
     parser.add_argument('--log-interval', type=int, default=100)
