@@ -91,7 +91,10 @@ def bench_step(args, rank, world):
         for _ in range(n):
             opt.update(chain, imgs, bb, lab, masks, 1.0)
         torch.cuda.synchronize()
-        return N * n / (time.perf_counter() - t1)
+        el = time.perf_counter() - t1
+        if world > 1:       # every rank runs the same sequence (the gradient exchange is inside update): whole-job rate over the slowest rank
+            el = _max_over_ranks(el, world, dev)
+        return N * world * n / el
 
     # the same step with the mask branch on the positive rows only (identical loss and gradients)
     alt = None
@@ -117,12 +120,14 @@ def bench_step(args, rank, world):
     # NARROWER schemes (two-plane splits: 16 / 22 operand bits) that are opt-in lines forever.  A failure of an opt-in mode is
     # reported in the line, it does not lose the line.
     other = {}
-    if world == 1 and not tiles:
+    if not tiles:
         from chainer_maskrcnn._hip import lib, check
         from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import select_gemm_arithmetic
         keep = chain.gemm_arithmetic
         chain.gemm_arithmetic = None
-        for name in ('f32', 'bf16x6_behind_backbone', 'bf16x6_backward', 'bf16x6', 'split_bf16_backward', 'split_half_forward_bf16_backward'):
+        # N > 1: only the float32-MFMA step (the line's fallback number); it is a collective sequence, so a failure is not caught there
+        names = ('f32', 'bf16x6_behind_backbone', 'bf16x6_backward', 'bf16x6', 'split_bf16_backward', 'split_half_forward_bf16_backward') if world == 1 else ('f32',)
+        for name in names:
             if name == arith:
                 continue
             try:
@@ -133,6 +138,8 @@ def bench_step(args, rank, world):
                     check(lib().mrcnn_conv2d_set_split_operands(*{'split_bf16_backward': (0, 1, 1), 'split_half_forward_bf16_backward': (2, 1, 1)}[name]))
                 other[name] = round(timed(), 3)
             except Exception as e:
+                if world > 1:
+                    raise
                 other[name] = 'failed: %s' % str(e).split('\n')[0][:160]
             finally:
                 select_gemm_arithmetic(arith)

@@ -88,6 +88,8 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert d['roofline']['traffic_source']['file'].startswith('profiles/')
     assert abs(d['value'] - 4 * 1e3 / d['ms_per_step']) <= 1e-2 * d['value']          # whole-job images/s = global batch / step time
     assert d['roofline']['frac'] <= 1.0 and 'roi_align_microbench' in d
+    # the ruling's fallback number is in the N > 1 line too: the all-float32-MFMA step of the same processes, whole-job rate
+    assert d['config']['gemm_arithmetic']['name'] == 'bf16x6_behind_backbone' and d['config']['images_per_sec_f32_mfma'] > 0
     # the line says what the collective library saw: ranks, their devices, backend, library version
     rc = d['config']['rccl']
     assert rc['world_size'] == 2 and rc['backend'] == 'gloo' and len(rc['ranks']) == 2
