@@ -28,8 +28,9 @@ for rec in recs:
     geoms[(rec[0], rec[6], rec[7])] = geoms.get((rec[0], rec[6], rec[7]), 0) + 1
 rows = []
 check(lib().mrcnn_conv2d_set_split_operands(*SPLIT))
-if len(sys.argv) > 2:
-    check(lib().mrcnn_debug_conv_plan(*[int(v) for v in sys.argv[2].split(',')]))
+PLANS = [[int(v) for v in pl.split(',')] for pl in sys.argv[2].split(';')] if len(sys.argv) > 2 else []      # mrcnn_debug_conv_plan(fill, filter_rounds, force_tile)
+if len(PLANS) == 1:
+    check(lib().mrcnn_debug_conv_plan(*PLANS[0]))
 PARTS = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0]
 base = hnn.winograd_pass_tiles()
 for (kind, g, tiles), cnt in geoms.items():
@@ -53,6 +54,17 @@ for (kind, g, tiles), cnt in geoms.items():
         for _ in range(5): fn()
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 5 * 1e-3)
+    if len(PLANS) > 1:          # several plans: the first is the reference (ts[0]), the others are A/B columns
+        ts = []
+        for pl in PLANS:
+            check(lib().mrcnn_debug_conv_plan(*pl))
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): fn()
+            e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / 5 * 1e-3)
+        check(lib().mrcnn_debug_conv_plan(*PLANS[0]))
     check(lib().mrcnn_debug_conv_parts(0))
     check(lib().mrcnn_conv2d_set_debug_skip(0))
     t = ts[0]
@@ -64,6 +76,12 @@ print('split operands %s: GEMM-only total %.2f ms, %.1f TF/s executed (float32-e
 for kd in ('fwd', 'bwd_data', 'bwd_filter'):
     print('  %-10s %.2f ms' % (kd, 1e3 * sum(r[0] for r in rows if r[1] == kd)))
 print('%-10s %-38s %5s %3s %8s %7s %9s' % ('kind', 'N,H,W,Cin,Cout,KH,KW,s,p', 'tiles', 'n', 'ms', 'TF/s', 'lost@135'))
+if len(PLANS) > 1:
+    print('totals per plan %s: %s ms; best plan per call: %.2f ms' % (PLANS, ' '.join('%.2f' % (1e3 * sum(r[7][i] * r[4] for r in rows)) for i in range(len(PLANS))),
+                                                                      1e3 * sum(min(r[7]) * r[4] for r in rows)))
+    for kd in ('fwd', 'bwd_data', 'bwd_filter'):
+        print('  %-10s %s | best %.2f' % (kd, ' '.join('%.2f' % (1e3 * sum(r[7][i] * r[4] for r in rows if r[1] == kd)) for i in range(len(PLANS))),
+                                          1e3 * sum(min(r[7]) * r[4] for r in rows if r[1] == kd)))
 if len(PARTS) > 1:
     print('totals per debug_conv_parts mask %s: %s ms' % (PARTS, ' '.join('%.2f' % (1e3 * sum(r[7][i] * r[4] for r in rows)) for i in range(len(PARTS)))))
 for r in sorted(rows, key=lambda r: -(r[0] - r[6] * r[4] / 135e12)):
