@@ -308,6 +308,9 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        # every rank leaves together: rank 0 was still measuring the ROIAlign microbench while the others were done, and a rank that
+        # tears its communicator down early must not race rank 0's store
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -254,7 +254,8 @@ def bench_step(args, rank, world):
                              'steps (GEMMs + Winograd transforms + slab / column sums); effective_fp32_TFLOPs = 2 x MACs of the direct algorithm on '
                              'un-padded channels (conv_bracket) or 2 x executed MACs (roofline) per second - a rate in float32-equivalent work, '
                              'not a fraction of any peak' % n_prof},
-        'roofline_winograd_transforms': split['aux'],
+        'roofline_winograd_transforms': dict(split['aux'], traffic=(lambda fam: (fam['winograd_transforms'] + fam['slab_tail_column_sums'])
+                                                                     if fam and 'winograd_transforms' in fam and 'slab_tail_column_sums' in fam else None)(pmc.get('hbm_bytes_per_step_by_family'))),
     }
     if alt is not None:
         out['config']['images_per_sec_mask_branch_on_positive_rows_only'] = round(alt, 3)
@@ -407,6 +408,8 @@ def _replay_split(recs, n_prof, dev):
            'achieved': round(aux_bytes / aux_s / 1e9, 1), 'peak': HBM_PEAK, 'unit': 'GB/s',
            'frac': round(aux_bytes / aux_s / 1e9 / HBM_PEAK, 4), 'traffic': None, 'ms_per_step': round(aux_s * 1e3, 3),
            'algorithmic_bytes_per_step': aux_bytes,
-           'note': 'bytes = activations + transformed operands (V, M / W) of the Winograd calls, each crossing HBM once (float32 sizes); the '
-                   'time also contains the split-K slab sums and bias column sums of the direct layers'}
+           'note': 'bytes = activations + transformed operands (V, M / W) of the Winograd calls, each crossing HBM once (float32 sizes; the W operand '
+                   'of the large filter-gradient GEMMs is written as three bf16 planes, 6 B per element, which this count prices at 4); the time '
+                   'also contains the split-K slab sums and bias column sums of the direct layers; traffic = HBM bytes per step of the transform + '
+                   'sum kernel families from the committed rocprofv3 --pmc summary (roofline.traffic_source)'}
     return {'gemm_by_kind': by_kind, 'aux': aux}

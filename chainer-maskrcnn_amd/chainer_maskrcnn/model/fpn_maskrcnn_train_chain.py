@@ -123,6 +123,8 @@ def select_gemm_arithmetic(name):
 
 
 class FPNMaskRCNNTrainChain(object):
+    EARLY_RPN_BACKWARD = True       # A/B switch of the early RPN backward (see rpn_loss_branch in __call__)
+
     def __init__(self, faster_rcnn, mask_loss_fun=calc_mask_loss, binary_mask=True, rpn_sigma=3., roi_sigma=1.,
                  anchor_target_creator=None, strict_batch1=False, mask_rows='positives', gemm_arithmetic=None):
         """gemm_arithmetic: a key of GEMM_ARITHMETIC - the chain then selects it (process-wide library setting) at the start of every
@@ -146,6 +148,7 @@ class FPNMaskRCNNTrainChain(object):
         if self.mask_loss_kind not in ('mask_bce', 'keypoint_ce'):
             self.mask_loss_kind = 'generic'
         self.unit_upstream = False
+        self.backward_follows = False       # set by MomentumSGD.update around its forward call: loss.backward() comes next, with d loss = 1
         self.binary_mask = binary_mask
         self.strict_batch1 = strict_batch1
         self.mask_rows = mask_rows
@@ -214,6 +217,16 @@ class FPNMaskRCNNTrainChain(object):
                                                  n * A_, self.rpn_sigma, out=losses[0])
                 _, br1['g_scores'] = ops.softmax_ce(scores.view(n * A_, 2), br1['label'].view(-1), n * A_, 2, (1, 2, 0, 1),
                                                     out=losses[1])
+                # The RPN's own backward pass needs nothing but these two gradients: when a backward pass is known to follow
+                # (MomentumSGD.update) it is enqueued HERE, on the aux stream, and fills the chip while the main stream walks the
+                # latency-bound proposal chain (decode, select, sort, NMS, target sampling: small kernels on a few CUs).  Its
+                # per-level feature gradients are kept and added in backward() where rpn.backward() used to run.
+                if self.EARLY_RPN_BACKWARD and self.backward_follows and aux is not main:
+                    for c1, c2, _, _ in m.rpn.tape:         # saved activations were allocated on the main stream and are released by
+                        for t_ in tuple(c1) + tuple(c2):    # this call: the allocator must not hand them out again before aux is done
+                            if torch.is_tensor(t_):
+                                t_.record_stream(aux)
+                    br1['g_feats'] = m.rpn.backward(br1['g_locs'].view(n, A_, 4), br1['g_scores'].view(n, A_, 2), None)
 
         r = m.rpn.forward_padded(features, per_hw if per_hw is not None else img_size, scale, after_heads=rpn_loss_branch, batch_size=img_size)
         A = r['anchors'].shape[0]
@@ -273,6 +286,7 @@ class FPNMaskRCNNTrainChain(object):
         self.observation = {'rpn_loc_loss': losses[0, 0], 'rpn_cls_loss': losses[1, 0], 'roi_loc_loss': losses[2, 0],
                             'roi_cls_loss': losses[3, 0], 'mask_loss': losses[4, 0], 'loss': total[0]}
         self._bwd = (features, g_locs.view(n, A, 4), g_scores.view(n, A, 2), g_box, g_mask)
+        self._early_rpn = br1.get('g_feats')
         self.targets = t
         if self.keep_outputs:
             self.outputs = dict(features=features, locs=r['locs'], scores=r['scores'], box=box, mask=mask_out)
@@ -338,7 +352,14 @@ class FPNMaskRCNNTrainChain(object):
         m.head.backward_mask_pool(g_pool, g_feats)        # accumulates into g_feats (second pooled size)
         if hook:
             hook(self._offset_of('head/'))
-        m.rpn.backward(g_locs, g_scores, g_feats)
+        if self._early_rpn is not None:     # computed beside the proposal chain of the forward pass (aux stream, joined at its end)
+            assert upstream is None, 'the early RPN backward assumes d(objective)/d(loss) = 1'
+            for gf, g in zip(g_feats, self._early_rpn):
+                gf.add_(g)
+                g.record_stream(main)
+            self._early_rpn = None
+        else:
+            m.rpn.backward(g_locs, g_scores, g_feats)
         if hook:
             hook(self._offset_of('rpn/'))
         m.extractor.backward(g_feats, progress=(lambda prefix: hook(self._offset_of(prefix))) if hook else None)

@@ -123,11 +123,15 @@ class MultilevelRegionProposalNetwork(object):
 
     def backward(self, g_locs, g_scores, g_feats):
         """g_locs (N,A,4), g_scores (N,A,2): loss gradients.  g_feats: per-level gradient tensors that are
-        accumulated into (they already hold the ROIAlign gradients)."""
+        accumulated into (they already hold the ROIAlign gradients); None = the RPN's own contribution is RETURNED as a
+        list of new per-level tensors (the train chain runs this branch early, beside the proposal chain, and adds the
+        contributions where this call used to be)."""
         first = True
-        for (c1, c2, oshape, a_off), gf in zip(self.tape, g_feats):
+        out = []
+        for i, (c1, c2, oshape, a_off) in enumerate(self.tape):
             g_o = ops.rpn_unpack_grad(g_locs, g_scores, oshape, self.n_anchor, a_off)
             g_h = self.head.bwd(c2, g_o, accumulate_params=not first, mask_gx=True)     # + ReLU backward of self.conv
-            self.conv.bwd(c1, g_h, gx_acc=gf, accumulate_params=not first, gy_masked=True)
+            out.append(self.conv.bwd(c1, g_h, gx_acc=None if g_feats is None else g_feats[i], accumulate_params=not first, gy_masked=True))
             first = False
         self.tape = None
+        return out if g_feats is None else None

@@ -285,7 +285,13 @@ class MomentumSGD(object):
         if lossfun is not None:
             if self.sync is not None:
                 self.sync.begin()
-            loss = lossfun(*args, **kwds)
+            if hasattr(lossfun, 'backward_follows'):    # the train chain may start branches of the backward pass inside its forward call
+                lossfun.backward_follows = True
+            try:
+                loss = lossfun(*args, **kwds)
+            finally:
+                if hasattr(lossfun, 'backward_follows'):
+                    lossfun.backward_follows = False
             if hasattr(lossfun, 'unit_upstream'):       # the train chain: d loss = 1 here, no gradient-scaling pass
                 lossfun.unit_upstream = True
             try:

@@ -513,3 +513,39 @@ def test_relu_mask_in_the_producer_gives_the_same_bits():
     assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 50
     for n in grads[True]:
         assert torch.equal(grads[True][n], grads[False][n]), n
+
+
+def test_early_rpn_backward_gives_the_same_gradients():
+    """MomentumSGD.update() tells the chain that a backward pass follows; the chain then runs the RPN's own backward pass on the aux
+    stream right after the RPN losses, beside the proposal chain of the forward pass, and adds its per-level feature gradients where
+    rpn.backward() used to run.  Same losses bit for bit; gradients: the RPN's own parameters bit for bit (same kernels, same order),
+    everything below the pyramid to float32 rounding of ONE addition per feature element (old + (s0 + s1) instead of (old + s0) + s1
+    on the levels whose data gradient is a split-K sum)."""
+    res = {}
+    for early in (False, True):
+        m, chain = _build('all')
+        b = _batch()
+        chain.sampler_keys = None
+        chain.proposal_target_creator.set_seed(5)
+        chain.anchor_target_creator.set_seed(9)
+        FPNMaskRCNNTrainChain.EARLY_RPN_BACKWARD = early
+        try:
+            opt = MomentumSGD(lr=0.0, momentum=0.0).setup(chain)       # lr 0: update() runs forward + backward and leaves the parameters alone
+            opt.update(chain, b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+            torch.cuda.synchronize()
+        finally:
+            FPNMaskRCNNTrainChain.EARLY_RPN_BACKWARD = True
+        res[early] = (float(chain.observation['loss']), m.ps.grads.clone(), m.ps)
+    assert res[False][0] == res[True][0]
+    ps = res[True][2]
+    bad = []
+    for name, (o, shape) in ps.offsets.items():
+        n_ = int(np.prod(shape))
+        a, c = res[False][1][o:o + n_], res[True][1][o:o + n_]
+        if name.startswith('rpn/') or name.startswith('head/'):
+            assert torch.equal(a, c), name
+        else:
+            scale = max(float(a.abs().max()), 1e-4)      # (conv1/b sits in front of a BatchNorm: its gradient is rounding noise around zero)
+            if float((a - c).abs().max()) > 1e-5 * scale:
+                bad.append((name, float((a - c).abs().max()) / scale))
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:10]

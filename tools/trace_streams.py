@@ -32,3 +32,34 @@ for b in range(nb):
         else: ce = max(ce, e)
     if ce is not None: u += ce - cs
     print('%3d  ' % b + ' '.join('%8.2f' % v for v in row) + '  %5.2f' % (u / 1e6))
+
+
+# forward / backward phases of the step: the backward pass begins with the first loss-gradient or *bwd* kernel
+def cat(n):
+    if 'k_conv_igemm' in n or 'k_pgemm' in n: return 'gemm'
+    if 'k_wino' in n: return 'winograd transforms'
+    if 'k_bn_' in n: return 'batchnorm'
+    if 'slab' in n or 'colsum' in n or 'k_tail_sum' in n: return 'slab / column sums'
+    return 'other'
+tb = min((e[0] for e in ks if 'bwd' in e[2] or 'k_sgd' in e[2]), default=t1)
+for nm, lo, hi in (('forward', t0, tb), ('backward + update', tb, t1)):
+    es = [e for e in ks if lo <= e[0] < hi]
+    segs = sorted((e[0], e[1]) for e in es)
+    u = 0; cs = ce = None
+    for s, e in segs:
+        if ce is None: cs, ce = s, e
+        elif s > ce: u += ce - cs; cs, ce = s, e
+        else: ce = max(ce, e)
+    if ce is not None: u += ce - cs
+    print('%s: wall %.2f ms, chip busy %.2f ms, %d kernels, sum of durations %.2f ms' % (nm, (hi - lo) / 1e6, u / 1e6, len(es), sum(e[1] - e[0] for e in es) / 1e6))
+    agg = collections.defaultdict(lambda: [0, 0])
+    for e in es:
+        a = agg[cat(e[2])]; a[0] += 1; a[1] += e[1] - e[0]
+    for c, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print('    %-22s n=%4d  %7.2f ms' % (c, n, d / 1e6))
+    oth = collections.defaultdict(lambda: [0, 0])
+    for e in es:
+        if cat(e[2]) == 'other':
+            a = oth[re.sub(r'\(.*', '', e[2])[:50]]; a[0] += 1; a[1] += e[1] - e[0]
+    for c, (n, d) in sorted(oth.items(), key=lambda kv: -kv[1][1])[:12]:
+        print('        %-50s n=%3d %7.1f us' % (c, n, d / 1e3))
