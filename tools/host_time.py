@@ -9,7 +9,7 @@ from chainer_maskrcnn.optimizers import MomentumSGD, WeightDecay
 from chainer_maskrcnn.utils.synthetic import make_batch
 dev = torch.device('cuda:0')
 model = MaskRCNN(n_fg_class=80, device=dev)
-chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows='all')
+chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows='all', gemm_arithmetic=os.environ.get('MRCNN_GEMM_ARITHMETIC', 'bf16x6_behind_backbone'))
 opt = MomentumSGD(lr=1e-3).setup(chain); opt.add_hook(WeightDecay(5e-4))
 b = make_batch(100, 2, 1024, 1024, G=8)
 args = [torch.from_numpy(b[k]).to(dev) for k in ('imgs', 'bboxes', 'labels', 'masks')]
