@@ -29,5 +29,6 @@ rm -rf $O/pmc_f $O/pmc_w $O/pmc_m
 for d in prof_step prof_roi; do f=$(ls $O/$d/*/*_kernel_stats.csv 2>/dev/null | tail -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
 python tools/trace_step.py $O/prof_step 5 > $O/step_breakdown.txt 2>&1
 python tools/trace_streams.py $O/prof_step 5 > $O/step_streams.txt 2>&1
+python tools/trace_fill.py $O/prof_step 5 > $O/step_fill.txt 2>&1
 rm -rf $O/prof_step $O/prof_roi
 ls -la $O

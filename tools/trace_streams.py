@@ -60,6 +60,6 @@ for nm, lo, hi in (('forward', t0, tb), ('backward + update', tb, t1)):
     oth = collections.defaultdict(lambda: [0, 0])
     for e in es:
         if cat(e[2]) == 'other':
-            a = oth[re.sub(r'\(.*', '', e[2])[:50]]; a[0] += 1; a[1] += e[1] - e[0]
+            mm = re.search(r'(k_[a-z0-9_]+|[A-Za-z_]+Buffer[A-Za-z]*|elementwise_kernel)', e[2]); a = oth[mm.group(1) if mm else e[2][:50]]; a[0] += 1; a[1] += e[1] - e[0]
     for c, (n, d) in sorted(oth.items(), key=lambda kv: -kv[1][1])[:12]:
         print('        %-50s n=%3d %7.1f us' % (c, n, d / 1e3))
