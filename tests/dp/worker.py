@@ -82,7 +82,11 @@ def run_emu(out):
     for s in range(STEPS):
         gs = []
         for c, b in zip(chains, batches):
-            c(*b, 1.0).backward()
+            c.backward_follows = c.unit_upstream = True        # what MomentumSGD.update tells the chain (the ranks go through update):
+            try:                                               # the RPN's backward runs early, the loss seed is 1
+                c(*b, 1.0).backward()
+            finally:
+                c.backward_follows = c.unit_upstream = False
             torch.cuda.synchronize()
             gs.append(model.ps.grads.clone())
             if s == 0:

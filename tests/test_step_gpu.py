@@ -544,8 +544,10 @@ def test_early_rpn_backward_gives_the_same_gradients():
         a, c = res[False][1][o:o + n_], res[True][1][o:o + n_]
         if name.startswith('rpn/') or name.startswith('head/'):
             assert torch.equal(a, c), name
+        elif name == 'extractor/resnet/conv1/b':
+            continue            # a bias in front of a BatchNorm: its gradient is mathematically zero, what is stored is rounding noise
         else:
-            scale = max(float(a.abs().max()), 1e-4)      # (conv1/b sits in front of a BatchNorm: its gradient is rounding noise around zero)
+            scale = float(a.abs().max()) + 1e-30
             if float((a - c).abs().max()) > 1e-5 * scale:
                 bad.append((name, float((a - c).abs().max()) / scale))
     assert not bad, sorted(bad, key=lambda t: -t[1])[:10]

@@ -77,6 +77,19 @@ def run_g(nb, rows, M, N, ks, bm, bn, check_batches=(0,), kind=1):
     return us
 
 
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'small':
+    # the direct 1x1 layers of the ResNet-50 at batch 2 x 1024^2 as plain GEMMs (rows = pixels): what would the 128-wide plane GEMMs do on
+    # them?  (k_conv_igemm<.., 3> takes 36-46 us for every one of these: tools/gemm_only_profile.py 3,3,3)
+    for rows, K, N in ((131072, 64, 256), (131072, 256, 64), (32768, 128, 512), (32768, 512, 128), (8192, 256, 1024), (8192, 1024, 256),
+                       (2048, 512, 2048), (2048, 2048, 512), (2048, 1024, 2048)):
+        for kind in (2, 0):
+            for bn in (128, 64):
+                if N % bn == 0:
+                    run_f(1, rows, K, N, bn, kind=kind)
+        if rows % 256 == 0 and N % 256 == 0:
+            run_f(1, rows, K, N, 256, kind=4)
+    sys.exit(0)
+
 if __name__ == '__main__' and not (len(sys.argv) > 1 and sys.argv[1] == 'stamps'):
     quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
     # edge shapes first (correctness): N not a multiple of the tile, 64-wide tiles, short K
