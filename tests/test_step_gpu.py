@@ -551,3 +551,31 @@ def test_early_rpn_backward_gives_the_same_gradients():
             if float((a - c).abs().max()) > 1e-5 * scale:
                 bad.append((name, float((a - c).abs().max()) / scale))
     assert not bad, sorted(bad, key=lambda t: -t[1])[:10]
+
+
+def test_graphed_step_replays_the_eager_step():
+    """optimizers.GraphedStep (bench.py --graph 1): the whole step - forward on three streams with the early RPN backward on the aux
+    stream, backward with the filter gradients on the side stream, SGD - captured once into a HIP graph; replays must walk the same
+    parameter trajectory as eager steps, bit for bit (sampler seeds live on the device and are advanced by the captured kernels)."""
+    from chainer_maskrcnn.optimizers import GraphedStep
+    res = []
+    for graphed in (False, True):
+        m, chain = _build('all')
+        b = _batch()
+        chain.sampler_keys = None
+        chain.proposal_target_creator.set_seed(5)
+        chain.anchor_target_creator.set_seed(9)
+        opt = MomentumSGD(lr=1e-2, momentum=0.9, high_priority_stream=False).setup(chain)
+        opt.add_hook(WeightDecay(0.0005))
+        batch = [b['imgs'], b['bboxes'], b['labels'], b['masks']]
+        if graphed:
+            g = GraphedStep(opt, chain, batch, 1.0, warmup=3)
+            for _ in range(2):
+                g(*batch)
+        else:
+            for _ in range(5):
+                opt.update(chain, *batch, 1.0)
+        torch.cuda.synchronize()
+        res.append((m.ps.params.clone(), float(chain.observation['loss'])))
+    assert res[0][1] == res[1][1]
+    assert torch.equal(res[0][0], res[1][0])
