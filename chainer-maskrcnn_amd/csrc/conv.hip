@@ -2055,13 +2055,13 @@ extern "C" int mrcnn_debug_planes_gemm(int kind, const void *a, const void *b, f
         ba = (long long)M * K * 4; bb = (long long)nbatch * N * K * 6;
         p.ldc = N; p.ksplit = 1; p.kchunk = K;
     } else if (kind == 0 || kind == 2) {        // F: A (M, K) planes (kind 2: float32), B (nbatch, N, K) planes; M = nbatch * batch_rows
-        if (K % 16 || batch_rows % 128 || M != nbatch * batch_rows || N % 16 || bm != 128 || (bn != 128 && bn != 64))
-            return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_planes_gemm F: K %% 16, batch_rows %% 128, M == nbatch * batch_rows, tile 128 x 128|64");
+        if (K % 32 || batch_rows % 128 || M != nbatch * batch_rows || N % 16 || bm != 128 || (bn != 128 && bn != 64))       // (two-stage ring, steps in pairs)
+            return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_planes_gemm F: K %% 32, batch_rows %% 128, M == nbatch * batch_rows, tile 128 x 128|64");
         ba = (long long)M * K * (kind == 2 ? 4 : 6); bb = (long long)nbatch * N * K * 6;
         p.ldc = N; p.ksplit = 1; p.kchunk = K;
     } else {                // G: A (nbatch, K, M), B (nbatch, K, N); K = batch_rows
-        if (K != batch_rows || K % (16 * ksplit) || M % 16 || N % 16 || (bm != 128 && bm != 64) || (bn != 128 && bn != 64))
-            return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_planes_gemm G: K == batch_rows, K %% (16 * ksplit), tiles 128|64");
+        if (K != batch_rows || K % (32 * ksplit) || M % 16 || N % 16 || (bm != 128 && bm != 64) || (bn != 128 && bn != 64))   // (steps in pairs per split)
+            return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_planes_gemm G: K == batch_rows, K %% (32 * ksplit), tiles 128|64");
         ba = (long long)nbatch * K * M * 6; bb = (long long)nbatch * K * N * 6;
         p.ldc = nbatch * N; p.kchunk = K / ksplit;
     }

@@ -297,3 +297,49 @@ def test_emulation_keeps_non_finite_values_non_finite(case):
     finally:
         _hip.check(lib.mrcnn_conv2d_set_split_operands(0, 0, 0))
         hnn.set_winograd_pass_tiles(*keep)
+
+
+def _planes(x, layout):
+    """float32 (R, C) -> three bf16 planes through the library's own split kernel (layout 0 = P16, 1 = P16R4, 2 = PR)."""
+    R_, C_ = x.shape
+    out = torch.empty((R_ * C_ * 3,), dtype=torch.int16, device=x.device)
+    _hip.check(_hip.lib().mrcnn_debug_split_planes_f32(_hip.ptr(x), _hip.ptr(out), R_, C_, layout, _hip.stream_ptr()))
+    return out
+
+
+@pytest.mark.parametrize('nb,rows,K,N', [(1, 256, 16, 256), (3, 256, 48, 256), (2, 512, 80, 512), (1, 768, 272, 256), (5, 256, 32, 256)])
+def test_plane_gemm_forward_kind_edge_shapes(nb, rows, K, N):
+    """k_pgemm_pp (the Winograd forward / backward-data GEMM of the emulated arithmetic) called directly through the measurement entry
+    on shapes the step does not have: one K step per tile, odd numbers of K steps (the three-stage ring wraps inside a tile and across
+    the tiles of the persistent walk), more tiles than one round, several batches.  C[b] = A[b] B[b]^T against float64."""
+    g = torch.Generator(device='cpu').manual_seed(1000 * nb + K)
+    A = (torch.randn((nb * rows, K), generator=g) * torch.exp2(torch.randint(-6, 6, (nb * rows, 1), generator=g).float())).to(DEV)
+    B = (torch.randn((nb * N, K), generator=g) / K ** 0.5).to(DEV)
+    C = torch.full((nb * rows, N), float('nan'), device=DEV)
+    _hip.check(_hip.lib().mrcnn_debug_planes_gemm(4, _hip.ptr(A), _hip.ptr(_planes(B, 1)), _hip.ptr(C), nb * rows, N, K, rows, nb, 1, 256, 256,
+                                                  _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(C).all(), 'unwritten output'
+    for b in range(nb):
+        ref = A[b * rows:(b + 1) * rows].double() @ B[b * N:(b + 1) * N].double().t()
+        err = float((C[b * rows:(b + 1) * rows].double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (b, err)
+
+
+@pytest.mark.parametrize('nb,rows,M,N,ks', [(1, 32, 256, 256, 1), (2, 96, 256, 512, 3), (3, 544, 512, 256, 2), (1, 2080, 256, 256, 5)])
+def test_plane_gemm_filter_gradient_kind_edge_shapes(nb, rows, M, N, ks):
+    """k_pgemm_gpp (the Winograd filter-gradient GEMM): dU[b] = W[b]^T V[b] summed over `rows` tiles in `ks` splits - a single pair
+    of K steps, splits of unequal length (the last one shorter), several batches - against float64."""
+    g = torch.Generator(device='cpu').manual_seed(17 * nb + rows)
+    A = (torch.randn((nb * rows, M), generator=g) * 1e-3).to(DEV)
+    B = torch.randn((nb * rows, N), generator=g).to(DEV)
+    C = torch.full((ks, M, nb, N), float('nan'), device=DEV)
+    _hip.check(_hip.lib().mrcnn_debug_planes_gemm(5, _hip.ptr(_planes(A, 2)), _hip.ptr(B), _hip.ptr(C), M, N, rows, rows, nb, ks, 256, 256,
+                                                  _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(C).all(), 'unwritten output'
+    Cs = C.double().sum(dim=0)
+    for b in range(nb):
+        ref = A[b * rows:(b + 1) * rows].double().t() @ B[b * rows:(b + 1) * rows].double()
+        err = float((Cs[:, b, :] - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (b, err)
