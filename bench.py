@@ -234,8 +234,12 @@ def cpu_baseline_step(model, dev):
 
 
 def _local_device():
-    """LOCAL_RANK, or 0 for every rank when MRCNN_BENCH_SINGLE_DEVICE=1 (functional check on a 1-GPU box)."""
-    return 0 if os.environ.get('MRCNN_BENCH_SINGLE_DEVICE') == '1' else int(os.environ.get('LOCAL_RANK', 0))
+    """LOCAL_RANK, or 0 for every rank when MRCNN_BENCH_SINGLE_DEVICE=1 (functional check on a 1-GPU box).  A launcher that shows every
+    rank only its own GPU (HIP_VISIBLE_DEVICES=k per rank) leaves one visible device: LOCAL_RANK is taken modulo the visible count, and
+    two ranks that really share a device are refused with a clear message by optimizers.rccl_evidence, not by an invalid ordinal here."""
+    if os.environ.get('MRCNN_BENCH_SINGLE_DEVICE') == '1':
+        return 0
+    return int(os.environ.get('LOCAL_RANK', 0)) % max(1, torch.cuda.device_count())
 
 
 def sync_all(world):

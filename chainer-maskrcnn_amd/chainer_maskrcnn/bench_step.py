@@ -18,7 +18,7 @@ def bench_step(args, rank, world):
     from chainer_maskrcnn.optimizers import MomentumSGD, WeightDecay
     from chainer_maskrcnn.utils.synthetic import make_batch
     from chainer_maskrcnn._hip import nn as hnn
-    dev = torch.device('cuda', 0 if os.environ.get('MRCNN_BENCH_SINGLE_DEVICE') == '1' else int(os.environ.get('LOCAL_RANK', 0)))
+    dev = torch.device('cuda', 0 if os.environ.get('MRCNN_BENCH_SINGLE_DEVICE') == '1' else int(os.environ.get('LOCAL_RANK', 0)) % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     N, H, W = 2, 1024, 1024
     mask_rows = getattr(args, 'mask_rows', 'all')

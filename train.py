@@ -73,7 +73,7 @@ def run(args, keypoints=False):
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', args.gpu))
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local % max(1, torch.cuda.device_count()) if 'LOCAL_RANK' in os.environ else local)      # (a launcher may show every rank only its own GPU)
     if world > 1:       # one process per GPU: host threads (enqueue loop, loader workers, RCCL proxy) on the GPU's NUMA node
         from chainer_maskrcnn.utils.affinity import pin_rank
         cpus = pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
