@@ -1930,6 +1930,10 @@ bool pg_big_ok(int pass, const WinoGeom &g, int K, int Nn) {
     if (g_split_mode[pass] != 3 || !g_pg_big) return false;
     if (g.Tp % PGB_BM || Nn % PGB_BN || K % 16) return false;
     const long long tiles = (long long)g.nk * g.Tp / PGB_BM * (Nn / PGB_BN);
+    // the persistent grid walks the tiles in rounds of one per CU: a last round that is mostly empty (288 tiles = 2 rounds at 0.56) loses
+    // to k_conv_igemm's 128 x 128 tiles (tools/gemm_only_profile.py 3,3,3 2,2,0 0,256: 67 against 57 us on the p3 layers)
+    const long long rounds = (tiles + g_cus() - 1) / g_cus();
+    if (tiles * 10 < rounds * g_cus() * 8) return false;
     return tiles >= g_pg_min_tiles && (long long)g.nk * g.Tp * K * 4 < (1ll << 32) && (long long)g.nk * Nn * K * 6 < (1ll << 32);
 }
 
