@@ -7,7 +7,7 @@ src = os.path.join(R, 'gpurun_out', 'round_end')
 commit = subprocess.check_output(['git', '-C', R, 'rev-parse', '--short', 'HEAD']).decode().strip()
 dirty = bool(subprocess.check_output(['git', '-C', R, 'status', '--porcelain', '--', 'chainer-maskrcnn_amd', 'include', 'bench.py']).decode().strip())
 names = {'bench_step_n1.json': 1, 'bench_roialign_n1.json': 1, 'bench_keypoint_n1.json': 1, 'prof_step_kernel_stats.csv': 'step_kernel_stats.csv',
-         'prof_roi_kernel_stats.csv': 'roialign_kernel_stats.csv', 'step_breakdown.txt': 1, 'step_streams.txt': 1, 'step_fill.txt': 1, 'gpu_tests.txt': 1,
+         'prof_roi_kernel_stats.csv': 'roialign_kernel_stats.csv', 'step_breakdown.txt': 1, 'step_streams.txt': 1, 'step_fill.txt': 1, 'step_pmc_by_kernel.txt': 1, 'gpu_tests.txt': 1,
          'step_pmc_traffic.json': 1, 'conv_pmc_mfma.json': 1, 'roialign_pmc_traffic.json': 1}
 for n, dst in names.items():
     a = os.path.join(src, n)

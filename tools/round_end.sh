@@ -24,6 +24,7 @@ cd $R
 python tools/pmc_roi_traffic.py $O/pmc_rf $O/pmc_rw > $O/roialign_pmc_traffic.json 2> $O/pmc_roi.err
 rm -rf $O/pmc_rf $O/pmc_rw
 python tools/pmc_step_traffic.py $O/pmc_f $O/pmc_w 2 > $O/step_pmc_traffic.json 2> $O/pmc_traffic.err
+python tools/pmc_step_by_kernel.py $O/pmc_f $O/pmc_w 2 > $O/step_pmc_by_kernel.txt 2>&1
 python tools/pmc_mfma_summary.py $O/pmc_m 2 > $O/conv_pmc_mfma.json 2> $O/pmc_mfma.err
 rm -rf $O/pmc_f $O/pmc_w $O/pmc_m
 for d in prof_step prof_roi; do f=$(ls $O/$d/*/*_kernel_stats.csv 2>/dev/null | tail -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
