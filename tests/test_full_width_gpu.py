@@ -121,9 +121,15 @@ def _run(S, mode, keypoints=False, N=1, seed=11, G=6):
     try:
         chain.proposal_target_creator.set_seed(21)
         chain.anchor_target_creator.set_seed(22)
-        loss = chain(bt['imgs'], bt['bboxes'], bt['labels'], bt['keypoints' if keypoints else 'masks'], 1.0)
-        outs = {k: ([f.clone() for f in v] if k == 'features' else v.clone()) for k, v in chain.outputs.items()}
-        loss.backward()
+        # the step as MomentumSGD.update runs it: the chain knows that a backward pass with d loss = 1 follows and starts the RPN's
+        # backward pass early, beside the proposal chain - the summation order of the shipped training step
+        chain.backward_follows = chain.unit_upstream = True
+        try:
+            loss = chain(bt['imgs'], bt['bboxes'], bt['labels'], bt['keypoints' if keypoints else 'masks'], 1.0)
+            outs = {k: ([f.clone() for f in v] if k == 'features' else v.clone()) for k, v in chain.outputs.items()}
+            loss.backward()
+        finally:
+            chain.backward_follows = chain.unit_upstream = False
         obs = {k: float(v) for k, v in chain.observation.items()}
         t = _targets(chain)
         img4 = torch.cat([bt['imgs'].cpu().permute(0, 2, 3, 1), torch.zeros((N, S, S, 1))], -1)
