@@ -75,3 +75,22 @@ def test_host_side_under_address_sanitizer():
     r = subprocess.run([os.path.join(csrc, 'asan', 'abi_host_check')], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0 and 'AddressSanitizer' not in out and ' 0 failure(s)' in out, out[-3000:]
+
+
+def test_gemm_arithmetic_names_are_the_same_everywhere():
+    """The training arithmetic is chosen by name in three places (train.py --gemm-arithmetic, bench.py --gemm-arithmetic, the chain's
+    GEMM_ARITHMETIC table): the names and the default must agree, the float32-MFMA fallback must exist, and only the float32-ACCURATE
+    schemes (library split modes 0 and 3) may be selectable there - the narrower two-plane splits (modes 1, 2) are never a training default."""
+    import re
+    from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import GEMM_ARITHMETIC, DEFAULT_GEMM_ARITHMETIC
+    assert DEFAULT_GEMM_ARITHMETIC in GEMM_ARITHMETIC and 'f32' in GEMM_ARITHMETIC
+    assert GEMM_ARITHMETIC['f32'][0] == (0, 0, 0)
+    assert all(set(modes) <= {0, 3} for modes, _ in GEMM_ARITHMETIC.values())
+    for path in ('train.py', 'bench.py'):
+        src = open(os.path.join(ROOT, path)).read()
+        m = re.search(r"'--gemm-arithmetic',\s*default=([^,]+),\s*choices=\[([^\]]+)\]", src)
+        assert m, path
+        choices = set(re.findall(r"'([^']+)'", m.group(2)))
+        assert choices == set(GEMM_ARITHMETIC), (path, choices)
+        default = m.group(1).strip().strip("'")
+        assert default in ('None', DEFAULT_GEMM_ARITHMETIC), (path, default)      # bench.py: None = the shipped training default
