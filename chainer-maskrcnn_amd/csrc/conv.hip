@@ -2073,15 +2073,6 @@ extern "C" int mrcnn_debug_planes_gemm(int kind, const void *a, const void *b, f
     p.bytes_a = (unsigned)ba; p.bytes_b = (unsigned)bb;
     p.dbg = g_dbg_parts >> 4;
     p.stamps = g_pg_stamps;
-    if (getenv("MRCNN_PG_OCC")) {
-        int o0 = -1, o1 = -1, o2 = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&o0, reinterpret_cast<const void *>(&k_pgemm_f<128, 128>), PG_THREADS, 0);
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, reinterpret_cast<const void *>(&k_pgemm_fa<128, 128>), PG_THREADS, 0);
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, reinterpret_cast<const void *>(&k_pgemm_g<128, 128>), PG_THREADS, 0);
-        hipFuncAttributes fa;
-        hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_pgemm_f<128, 128>));
-        fprintf(stderr, "occupancy (workgroups per CU): f %d fa %d g %d; f: %d regs, %zu B static LDS, max dynamic %d\n", o0, o1, o2, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
-    }
     if (kind == 0) launch_pgemm<0>(p, bm, bn, (hipStream_t)stream);
     else if (kind == 2) launch_pgemm<2>(p, bm, bn, (hipStream_t)stream);
     else if (kind == 3) launch_pgemm<3>(p, bm, bn, (hipStream_t)stream);
