@@ -579,3 +579,33 @@ def test_graphed_step_replays_the_eager_step():
         res.append((m.ps.params.clone(), float(chain.observation['loss'])))
     assert res[0][1] == res[1][1]
     assert torch.equal(res[0][0], res[1][0])
+
+
+def test_laterals_off_the_chain_give_the_same_bits():
+    """feature_pyramid_network.LATERALS_OFF_THE_CHAIN (off by default): the lateral 1x1 convolutions run beside the later ResNet stages in
+    the forward pass and their data gradients beside the top-down chain of the backward pass - other streams, the same kernels on the same
+    operands in the same summation order.  Losses, every gradient and the parameters after three updates must be the same bits."""
+    from chainer_maskrcnn.model.extractor import feature_pyramid_network as fpn
+    res = []
+    for on in (False, True):
+        fpn.LATERALS_OFF_THE_CHAIN = on
+        try:
+            m, chain = _build('all')
+            b = _batch()
+            chain.sampler_keys = None
+            chain.proposal_target_creator.set_seed(5)
+            chain.anchor_target_creator.set_seed(9)
+            chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0).backward()
+            torch.cuda.synchronize()
+            g, l = m.ps.grads.clone(), float(chain.observation['loss'])
+            opt = MomentumSGD(lr=1e-2, momentum=0.9).setup(chain)
+            opt.add_hook(WeightDecay(0.0005))
+            for _ in range(3):
+                opt.update(chain, b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+            torch.cuda.synchronize()
+            res.append((l, g, m.ps.params.clone()))
+        finally:
+            fpn.LATERALS_OFF_THE_CHAIN = False
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2])
