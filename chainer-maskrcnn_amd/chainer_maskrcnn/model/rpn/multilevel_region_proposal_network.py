@@ -11,11 +11,15 @@ Mirror of chainer_maskrcnn/model/rpn/multilevel_region_proposal_network.py:16-31
     ``__call__`` returns exact-size arrays like the reference (one host sync); ``forward_padded``
     is the sync-free form the train chain uses.
 """
+import contextlib
+
 import numpy as np
 import torch
 
 from chainer_maskrcnn.nn.core import Conv, ParamStore, normal
-from chainer_maskrcnn._hip import ops
+from chainer_maskrcnn._hip import ops, nn as hnn
+
+SMALL_LEVELS_BESIDE_P2 = False      # A/B switch, see forward_padded
 from chainer_maskrcnn.utils.anchors import generate_anchor_base, enumerate_shifted_anchor
 
 
@@ -95,12 +99,25 @@ class MultilevelRegionProposalNetwork(object):
         locs = torch.empty((N, Atot, 4), dtype=torch.float32, device=dev)
         scores = torch.empty((N, Atot, 2), dtype=torch.float32, device=dev)
         tape, a_off = [], 0
-        for x in xs:
-            h, c1 = self.conv.fwd(x)
-            o, c2 = self.head.fwd(h)
-            ops.rpn_pack(o, self.n_anchor, locs, scores, a_off)
+        # SMALL_LEVELS_BESIDE_P2 (off by default): the levels are independent and p3 .. p6 are latency-bound launches
+        # that do not fill the chip - they run on the weight-gradient stream (idle in the forward pass) beside p2's two large kernels
+        beside = SMALL_LEVELS_BESIDE_P2 and dev.type == 'cuda' and hnn.PROFILE is None and len(xs) > 1
+        if beside:
+            main, side = torch.cuda.current_stream(dev), hnn.side_stream(dev)
+            side.wait_stream(main)
+        for i, x in enumerate(xs):
+            with (torch.cuda.stream(side) if (beside and i > 0) else contextlib.nullcontext()):
+                h, c1 = self.conv.fwd(x)
+                o, c2 = self.head.fwd(h)
+                ops.rpn_pack(o, self.n_anchor, locs, scores, a_off)
+            if beside and i > 0:
+                for t_ in tuple(c1) + tuple(c2):        # saved for the backward pass, which runs on other streams
+                    if torch.is_tensor(t_):
+                        t_.record_stream(main)
             tape.append((c1, c2, tuple(o.shape), a_off))
             a_off += x.shape[1] * x.shape[2] * self.n_anchor
+        if beside:
+            main.wait_stream(side)
         self.tape = tape
         if after_heads is not None:
             after_heads(locs, scores, anchors)

@@ -609,3 +609,32 @@ def test_laterals_off_the_chain_give_the_same_bits():
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][2], res[1][2])
+
+
+def test_small_rpn_levels_beside_p2_give_the_same_bits():
+    """multilevel_region_proposal_network.SMALL_LEVELS_BESIDE_P2 (off by default): the RPN convolutions of p3 .. p6 on the weight-gradient
+    stream beside those of p2 - the same kernels on the same operands: same losses, gradients and parameters after three updates."""
+    from chainer_maskrcnn.model.rpn import multilevel_region_proposal_network as rpn
+    res = []
+    for on in (False, True):
+        rpn.SMALL_LEVELS_BESIDE_P2 = on
+        try:
+            m, chain = _build('all')
+            b = _batch()
+            chain.sampler_keys = None
+            chain.proposal_target_creator.set_seed(5)
+            chain.anchor_target_creator.set_seed(9)
+            chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0).backward()
+            torch.cuda.synchronize()
+            g, l = m.ps.grads.clone(), float(chain.observation['loss'])
+            opt = MomentumSGD(lr=1e-2, momentum=0.9).setup(chain)
+            opt.add_hook(WeightDecay(0.0005))
+            for _ in range(3):
+                opt.update(chain, b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+            torch.cuda.synchronize()
+            res.append((l, g, m.ps.params.clone()))
+        finally:
+            rpn.SMALL_LEVELS_BESIDE_P2 = False
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2])
