@@ -94,3 +94,37 @@ def test_gemm_arithmetic_names_are_the_same_everywhere():
         assert choices == set(GEMM_ARITHMETIC), (path, choices)
         default = m.group(1).strip().strip("'")
         assert default in ('None', DEFAULT_GEMM_ARITHMETIC), (path, default)      # bench.py: None = the shipped training default
+
+
+def test_shipped_arithmetic_brackets_the_backbone_forward_calls():
+    """'bf16x6_behind_backbone' = library split modes (3, 3, 3) with the FORWARD call of every extractor/resnet convolution bracketed back to
+    the float32 MFMA by the host layer (nn/core.py: _layer_tiles).  The split-mode setting is host state of the library (no device needed):
+    inside the bracket of a backbone layer the forward mode reads 0 and the backward modes stay 3; a layer behind the backbone keeps 3; the
+    setting is restored on exit; 'f32' and 'bf16x6' do not bracket anything."""
+    from chainer_maskrcnn._hip import nn as hnn
+    from chainer_maskrcnn.nn import core
+    from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import select_gemm_arithmetic
+
+    class L(object):            # what _layer_tiles reads of a Conv
+        fwd_tile = None
+
+        def __init__(self, name):
+            self.name = name
+    backbone, behind = L('extractor/resnet/res3/a/conv2'), L('extractor/lat_p3')
+    try:
+        select_gemm_arithmetic('bf16x6_behind_backbone')
+        assert tuple(hnn.split_operands()) == (3, 3, 3) and core.FWD_EMULATION_IN_BACKBONE is False
+        with core._layer_tiles(backbone):
+            assert tuple(hnn.split_operands()) == (0, 3, 3)
+        assert tuple(hnn.split_operands()) == (3, 3, 3)
+        with core._layer_tiles(behind):
+            assert tuple(hnn.split_operands()) == (3, 3, 3)
+        for name, want in (('bf16x6', (3, 3, 3)), ('bf16x6_backward', (0, 3, 3)), ('f32', (0, 0, 0))):
+            select_gemm_arithmetic(name)
+            assert core.FWD_EMULATION_IN_BACKBONE is True
+            for layer in (backbone, behind):
+                with core._layer_tiles(layer):
+                    assert tuple(hnn.split_operands()) == want, (name, layer.name)
+    finally:
+        select_gemm_arithmetic('f32')
+        core.FWD_EMULATION_IN_BACKBONE = core.FWD_EMULATION_BEHIND_BACKBONE = True
