@@ -17,13 +17,49 @@ _DP = {'proc': None, 'dir': None}
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'gpu_long: sweeps over modes / seeds / geometries on the GPU box; NOT part of `-m gpu` '
+                            '(they carry the gpu marker too and are deselected below) - run them with `-m gpu_long`')
     _start_dp_workers(config)
+
+
+# `-m gpu` runs the files in this order: the cheap index- / bit-exact kernel-vs-oracle and kernel-vs-golden files first, the files whose
+# time is a float64 CPU oracle of whole images last, the data-parallel children's results at the very end - a time limit can then only
+# ever cut the sweeps, never an index-exact row.  Files not listed keep their alphabetical place after the listed ones.
+GPU_FILE_ORDER = ['test_roi_align_gpu.py', 'test_rpn_gpu.py', 'test_targets_gpu.py', 'test_step_reference_gpu.py', 'test_loss_gpu.py',
+                  'test_predict_reference_gpu.py', 'test_legacy_reference_gpu.py', 'test_predict_gpu.py', 'test_nn_gpu.py',
+                  'test_dataset_gpu.py', 'test_chainer_npz_gpu.py', 'test_conv_gpu.py', 'test_split_gemm_gpu.py', 'test_step_gpu.py',
+                  'test_legacy_gpu.py', 'test_train_gpu.py', 'test_config0_gpu.py', 'test_full_width_gpu.py', 'test_dp_gpu.py']
+# the data-parallel children (tests/dp/launcher.py) start their GPU work when the first test of one of these files is set up: they
+# then share the GPU with tests whose time is spent in the CPU oracle, not with the kernel tests before them
+DP_GO_FILES = ('test_config0_gpu.py', 'test_full_width_gpu.py', 'test_dp_gpu.py')
+
+
+def _wants_long(config):
+    return 'gpu_long' in (config.getoption('markexpr', '') or '')
+
+
+def pytest_collection_modifyitems(config, items):
+    if not _wants_long(config):
+        long_ones = [it for it in items if it.get_closest_marker('gpu_long') is not None]
+        if long_ones:
+            config.hook.pytest_deselected(items=long_ones)
+            items[:] = [it for it in items if it.get_closest_marker('gpu_long') is None]
+    rank = {f: i for i, f in enumerate(GPU_FILE_ORDER)}
+    items.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), rank['test_config0_gpu.py'] - 0.5 if str(it.fspath).endswith('_gpu.py') else -1))
+
+
+def pytest_runtest_setup(item):
+    out = _DP['dir']
+    if out is not None and os.path.basename(str(item.fspath)) in DP_GO_FILES:
+        go = os.path.join(out, 'go')
+        if not os.path.exists(go):
+            open(go, 'w').close()
 
 
 def _selects_dp_tests(config):
     """True when this session can run tests/test_dp_gpu.py: -m gpu, and the file is among (or below) the given paths."""
     expr = config.getoption('markexpr', '') or ''
-    if 'gpu' not in expr or 'not gpu' in expr:
+    if 'gpu' not in expr or 'not gpu' in expr or 'gpu_long' in expr:
         return False
     target = os.path.join(ROOT, 'tests', 'test_dp_gpu.py')
     args = [a for a in (config.args or []) if not a.startswith('-')] or [os.path.join(ROOT, 'tests')]

@@ -4,6 +4,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -19,6 +20,12 @@ def _free_port():
 def main(out):
     w = os.path.join(HERE, 'worker.py')
     log = open(os.path.join(out, 'log.txt'), 'w')
+    # tests/conftest.py writes `go` when the first test of the oracle-heavy files (or of test_dp_gpu.py) is set up: until then the GPU
+    # belongs to the kernel tests alone
+    while not os.path.exists(os.path.join(out, 'go')):
+        if not os.path.isdir(out):
+            return
+        time.sleep(0.5)
     rc = subprocess.call([sys.executable, w, 'emu', out], stdout=log, stderr=subprocess.STDOUT)
     for attempt in range(3):       # the rendezvous port is picked and released here, re-bound by rank 0: retried on a collision
         port = _free_port()

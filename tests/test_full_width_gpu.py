@@ -135,6 +135,8 @@ def _run(S, mode, keypoints=False, N=1, seed=11, G=6):
         img4 = torch.cat([bt['imgs'].cpu().permute(0, 2, 3, 1), torch.zeros((N, S, S, 1))], -1)
         key = ('oracle', S, keypoints, N, seed, G)
         if not (key in _cache and _same_targets(_cache[key]['t'], t)):      # proposals can differ between conv paths
+            for k in [k for k in _cache if isinstance(k, tuple) and k[0] == 'oracle']:      # one oracle at a time: ~10 GB each at bs 2, 1024^2
+                del _cache[k]
             t0 = time.time()
             o64, out64, g64 = _oracle(m, t, img4, torch.float64, tap=TAP, keypoints=keypoints)
             _, out32, g32 = _oracle(m, t, img4, torch.float32, keypoints=keypoints)
@@ -228,11 +230,13 @@ def _check(S, mode, keypoints=False, iso_tol=2e-5, above3_frac=0.03, **kw):
     assert ratios[len(ratios) // 2] <= 1.3, ratios[len(ratios) // 2]
 
 
-@pytest.mark.parametrize('mode', ['direct', 'winograd_f2', 'uniform_f2_forward', 'shipped', 'fast'])
+@pytest.mark.parametrize('mode', [pytest.param('direct', marks=pytest.mark.gpu_long), pytest.param('winograd_f2', marks=pytest.mark.gpu_long),
+                                  pytest.param('uniform_f2_forward', marks=pytest.mark.gpu_long), 'shipped', pytest.param('fast', marks=pytest.mark.gpu_long)])
 def test_full_width_512(mode):
     _check(512, mode)
 
 
+@pytest.mark.gpu_long
 def test_full_width_1024_shipped():
     """BASELINE.json configs[2]'s image size with the shipped (benchmarked) kernel selection."""
     _check(1024, 'shipped')
@@ -246,6 +250,7 @@ def test_full_width_1024_batch2_shipped():
     _check(1024, 'shipped', N=2, seed=100, G=8)        # (the oracle stays cached for the split-bf16 variant of the same batch below)
 
 
+@pytest.mark.gpu_long
 def test_full_width_512_split_bf16_backward_opt_in():
     """EXPLORATORY opt-in, validated by the SAME bars as the shipped float32 configuration: float32 MFMA in the
     forward pass, three-term split-bf16 operands on the bf16 MFMA in BOTH backward passes (every backward-data and
@@ -254,6 +259,7 @@ def test_full_width_512_split_bf16_backward_opt_in():
     _check(512, 'split_bf16_bwd_only')      # (this layer takes the direct kernel at 512^2: 9.5e-6)
 
 
+@pytest.mark.gpu_long
 def test_full_width_1024_batch2_split_bf16_backward_opt_in():
     """The same on the benchmarked configuration (two 1024x1024 images, bench.py's batch)."""
     # the isolated res5 filter gradient takes the F(4x4) Winograd path here: the transforms amplify the bf16 planes' 4e-6 to 2.7e-4
@@ -274,12 +280,14 @@ def test_full_width_1024_batch2_shipped_arithmetic():
     _check(1024, HEADLINE, N=2, seed=100, G=8)
 
 
+@pytest.mark.gpu_long
 def test_full_width_1024_batch2_emulation_in_the_backward_passes_only():
     """The more conservative arithmetic 'bf16x6_backward' (float32 MFMA in the whole forward pass: activations, losses and sampled
     targets bit-identical to the float32 step), same batch, same unrelaxed bars."""
     _check(1024, 'bf16x6_bwd_only', N=2, seed=100, G=8)
 
 
+@pytest.mark.gpu_long
 def test_full_width_1024_batch2_float32_accurate_emulation_in_every_pass_opt_in():
     """OPT-IN, not the shipped arithmetic: bf16x6 in the forward pass of the BACKBONE too.  On THIS batch the emulated ResNet forward is
     another realisation of the rounding noise (50 layers of training-mode BatchNorm) in which one near-tie decision downstream falls the
@@ -292,6 +300,7 @@ def test_full_width_1024_batch2_float32_accurate_emulation_in_every_pass_opt_in(
     _cache.pop(('oracle', 1024, False, 2, 100, 8), None)       # ~10 GB of float64 gradients and activations
 
 
+@pytest.mark.gpu_long
 @pytest.mark.parametrize('seed', [101, 102, 103, 104])
 def test_full_width_1024_batch2_shipped_arithmetic_other_batches(seed):
     """Four more batches of the benchmarked shape, shipped arithmetic, the same unrelaxed bars (one float64 + two float32 oracle
@@ -302,6 +311,7 @@ def test_full_width_1024_batch2_shipped_arithmetic_other_batches(seed):
         _cache.pop(('oracle', 1024, False, 2, seed, 8), None)
 
 
+@pytest.mark.gpu_long
 @pytest.mark.parametrize('mode', ['bf16x6', 'bf16x6_fwd'])
 def test_full_width_512_float32_accurate_emulation_opt_in(mode):
     """EXPLORATORY opt-in: three bf16 planes per operand (hi + mid + lo = the float32 value exactly) and the six products of weight
@@ -311,6 +321,7 @@ def test_full_width_512_float32_accurate_emulation_opt_in(mode):
     _check(512, mode)
 
 
+@pytest.mark.gpu_long
 def test_full_width_512_split_half_forward_opt_in():
     """EXPLORATORY opt-in, the fastest combination: half hi / lo planes in the forward pass (22 significant bits, weights scaled by
     2^12 into half's normal range), bf16 planes in the backward passes.  Activations <= 1e-3 and losses <= 1e-4 like the shipped
@@ -340,6 +351,7 @@ def test_full_width_keypoint_1024_batch2_shipped():
         _cache.pop(('oracle', 1024, True, 2, 100, 8), None)
 
 
+@pytest.mark.gpu_long
 def test_full_width_keypoint_512_shipped():
     """BASELINE.json configs[4]'s model at full width (train_keypoints.py: 1 class, 17 keypoints, 8 keypoint convolutions,
     56x56 heat maps, softmax cross-entropy over positions), one 512x512 image, shipped kernel selection: the same bars."""

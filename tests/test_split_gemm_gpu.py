@@ -162,7 +162,17 @@ def _errors(kind, geom, x, w, gy, seed):
     return st(got[0] - ref), st(got[3] - ref), float(ref.abs().max())
 
 
-@pytest.mark.parametrize('case', STEP_GEOMS, ids=lambda c: 'x'.join(str(v) for v in c[0]) + '_' + c[2])
+# `-m gpu` runs one geometry per kernel family / plan kind of the step (the rows below); the other 27 carry `gpu_long` (tests/conftest.py)
+SHORT = {(512, 14, 14, 256, 256, 3, 3, 1, 1), (512, 14, 14, 256, 384, 1, 1, 1, 0), (512, 7, 7, 256, 256, 3, 3, 1, 1), (512, 1, 1, 12544, 1024, 1, 1, 1, 0),
+         (512, 1, 1, 1024, 96, 1, 1, 1, 0), (2, 256, 256, 256, 256, 3, 3, 1, 1), (2, 16, 16, 256, 256, 3, 3, 1, 1), (2, 256, 256, 256, 32, 1, 1, 1, 0),
+         (2, 256, 256, 256, 256, 1, 1, 1, 0), (2, 32, 32, 2048, 256, 1, 1, 1, 0), (2, 1024, 1024, 4, 64, 7, 7, 2, 3), (2, 256, 256, 64, 64, 3, 3, 1, 1),
+         (2, 256, 256, 256, 512, 1, 1, 2, 0), (2, 64, 64, 512, 1024, 1, 1, 1, 0), (2, 32, 32, 512, 512, 3, 3, 1, 1), (2, 32, 32, 2048, 512, 1, 1, 1, 0),
+         (2, 32, 32, 256, 256, 1, 1, 2, 0)}
+assert SHORT <= {c[0] for c in STEP_GEOMS}
+
+
+@pytest.mark.parametrize('case', [c if c[0] in SHORT else pytest.param(c, marks=pytest.mark.gpu_long) for c in STEP_GEOMS],
+                         ids=lambda c: 'x'.join(str(v) for v in c[0]) + '_' + c[2])
 def test_emulation_is_as_accurate_as_the_float32_mfma_on_every_step_geometry(case):
     geom, tiles, passes = case
     lib = _hip.lib()

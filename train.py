@@ -32,10 +32,17 @@ def build_parser(keypoints=False):
     parser.add_argument('--weight', '-w', type=str, default='')
     parser.add_argument('--resnet50-npz', type=str, default='', help="a chainer.links.ResNet50Layers snapshot for the bottom-up pathway (what ResNet50Layers('auto') loads in the reference, feature_pyramid_network.py:22)")
     if keypoints:   # train_keypoints.py spells its flags with underscores (train_keypoints.py:73-89)
+        parser.add_argument('--label_file', '-f', type=str, default='data/label_coco.txt')      # (:79-80; unused there too: n_fg_class is 1)
         parser.add_argument('--backbone', type=str, default='fpn')
         parser.add_argument('--head_arch', '-a', type=str, default='fpn_keypoint')
         parser.add_argument('--multi_gpu', '-m', type=int, default=0)
         parser.add_argument('--batch_size', '-b', type=int, default=1)
+        parser.add_argument('--dataset', default='coco', choices=['coco', 'depth'])               # :86
+        parser.add_argument('--n_mask_convs', type=int, default=None)                             # :87 (None: the model's 8, maskrcnn.py:110-111)
+        parser.add_argument('--min_size', type=int, default=600)                                  # :88
+        parser.add_argument('--max_size', type=int, default=1000)                                 # :89
+        parser.add_argument('--depth-list', default='data/rgbd/train.txt', help='--dataset depth: the list file (train_keypoints.py:105)')
+        parser.add_argument('--depth-root', default='data/rgbd/', help='--dataset depth: directory the listed .npz paths are relative to')
     else:
         parser.add_argument('--label_file', '-f', type=str, default='data/label_coco.txt')
         parser.add_argument('--backbone', type=str, default='fpn')
@@ -85,9 +92,14 @@ def run(args, keypoints=False):
         from chainer_maskrcnn.optimizers import init_process_group
         init_process_group('nccl')
     if keypoints:
-        n_fg, K = 1, 17
-        faster_rcnn = MaskRCNN(n_fg_class=n_fg, n_keypoints=K, backbone=args.backbone, head_arch=args.head_arch, device=dev)
-        model = FPNMaskRCNNTrainChain(faster_rcnn, mask_loss_fun=calc_keypoint_loss, binary_mask=False, gemm_arithmetic=args.gemm_arithmetic)
+        n_fg, K = 1, 20 if args.dataset == 'depth' else 17          # DepthDataset.n_keypoints / COCOKeypointsLoader.n_keypoints
+        faster_rcnn = MaskRCNN(n_fg_class=n_fg, n_keypoints=K, backbone=args.backbone, head_arch=args.head_arch, n_mask_convs=args.n_mask_convs,
+                               min_size=args.min_size, max_size=args.max_size, device=dev)
+        loss_fun = calc_keypoint_loss
+        if K != 17:         # train_keypoints.py:122: lambda x, y, z, w: calc_mask_loss(x, y, z, w, num_keypoints=n_keypoints)
+            loss_fun = lambda x, y, z, w: calc_keypoint_loss(x, y, z, w, num_keypoints=K)
+            loss_fun.fused_kind = calc_keypoint_loss.fused_kind
+        model = FPNMaskRCNNTrainChain(faster_rcnn, mask_loss_fun=loss_fun, binary_mask=False, gemm_arithmetic=args.gemm_arithmetic)
     else:
         n_fg, K = 80, None
         if os.path.exists(args.label_file):
@@ -124,7 +136,13 @@ def run(args, keypoints=False):
         from chainer_maskrcnn.dataset.coco_dataset import COCOMaskLoader, COCOKeypointsLoader
         from chainer_maskrcnn.dataset.transforms import RawTransform
         from chainer_maskrcnn.dataset.loader import BatchLoader
-        if keypoints:
+        if keypoints and args.dataset == 'depth':       # train_keypoints.py:103-109, 135: DepthDataset -> DepthTransformer -> Transform, on the host
+            from chainer_maskrcnn.dataset.depth_dataset import DepthDataset, DepthTransformer
+            from chainer_maskrcnn.dataset.transforms import KeypointTransform
+            data = DepthDataset(path=args.depth_list, root=args.depth_root)
+            jitter, kt = DepthTransformer(np.random.RandomState(4321 + rank)), KeypointTransform(faster_rcnn)
+            tf = lambda ex: kt(jitter(ex))
+        elif keypoints:
             data = COCOKeypointsLoader(anno_dir=args.anno_dir, img_dir=args.img_dir, data_type=args.data_type)
             tf = RawTransform(faster_rcnn, keypoints=True)      # host decodes, the GPU resizes (dataset/loader.py)
         else:
