@@ -191,8 +191,8 @@ def test_reference_api_surface():
     assert roi_indices.shape == (R,) and R <= 2000
 
 
-@pytest.mark.parametrize('name,tile,pass_tiles,grad_tol', [('f2', 2, (0, 0, 0), 1e-3), ('shipped', 0, (2, 0, 0), 1e-3),
-                                                           ('fast_f4', 4, (0, 0, 0), 3e-3)])
+@pytest.mark.parametrize('name,tile,pass_tiles,grad_tol', [pytest.param('f2', 2, (0, 0, 0), 1e-3, marks=pytest.mark.gpu_long), ('shipped', 0, (2, 0, 0), 1e-3),
+                                                           pytest.param('fast_f4', 4, (0, 0, 0), 3e-3, marks=pytest.mark.gpu_long)])
 def test_step_matches_oracle_with_winograd_everywhere(name, tile, pass_tiles, grad_tol):
     """The same whole-step parity check with the Winograd thresholds lowered so that every 3x3 / stride-1 layer of the
     small test network (ResNet conv2's, FPN, RPN, box and mask heads) takes the Winograd kernels in all three passes:
