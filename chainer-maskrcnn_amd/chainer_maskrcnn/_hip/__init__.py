@@ -65,7 +65,7 @@ def _parse_header(path):
 SIGNATURES = _parse_header(HEADER_PATH)
 
 _lib = None
-ABI_VERSION = 8          # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
+ABI_VERSION = 9          # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
 
 
 class MrcnnHipError(RuntimeError):
@@ -115,3 +115,24 @@ def ptr(t):
 
 
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+
+
+# ---- host structs of the composite entry points (include/mrcnn_hip.h, ABI v9) --------------------------------------------------------
+_F4 = c_void_p * 4
+
+
+class Bottleneck(ctypes.Structure):
+    """mrcnn_bottleneck_t: geometry, parameter and gradient pointers of one ResNet bottleneck."""
+    _fields_ = [('N', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('cin', ctypes.c_int32), ('mid', ctypes.c_int32),
+                ('cout', ctypes.c_int32), ('stride', ctypes.c_int32), ('project', ctypes.c_int32), ('fwd_split', ctypes.c_int32),
+                ('eps', c_float), ('decay', c_float), ('w', _F4), ('gamma', _F4), ('beta', _F4), ('run_mean', _F4), ('run_var', _F4),
+                ('gw', _F4), ('ggamma', _F4), ('gbeta', _F4)]
+
+
+BN_SLOTS = 23
+
+
+class BottleneckPlan(ctypes.Structure):
+    """mrcnn_bottleneck_plan_t: the forward arena's layout for the convolution settings in force when it was made."""
+    _fields_ = [('arena_bytes', ctypes.c_uint64), ('ws_bytes', ctypes.c_uint64), ('off', ctypes.c_uint64 * BN_SLOTS),
+                ('v_bytes', ctypes.c_uint64 * 4), ('part_rows', ctypes.c_int32 * 4)]

@@ -54,9 +54,11 @@ def side_stream(device):
     return _side[key]
 
 
-def workspace(nbytes, device):
-    """Grow-only scratch buffer per (device, current stream): the caller-owned workspace of the C ABI."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+def workspace(nbytes, device, stream=None):
+    """Grow-only scratch buffer per (device, stream - the current one unless given): the caller-owned workspace of the C ABI."""
+    if stream is None:
+        stream = torch.cuda.current_stream(device) if device.type == 'cuda' else None
+    key = (device.type, device.index, stream.cuda_stream if stream is not None else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

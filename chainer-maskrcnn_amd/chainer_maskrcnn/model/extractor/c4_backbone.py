@@ -22,7 +22,7 @@ class C4Backbone(object):
         self._own_ps = ps is None
         p = prefix + '/'
         d = width_div
-        self.conv1 = Conv(self.ps, p + 'conv1', 3, 64 // d, 7, 2, 3, bias=True)
+        self.conv1 = Conv(self.ps, p + 'conv1', 3, 64 // d, 7, 2, 3, bias=True, in_backbone=True)
         self.bn1 = BatchNorm(self.ps, p + 'bn1', 64 // d)
         self.stages = []
         for si, (name, n, cin, mid, cout, stride) in enumerate(self.STAGES):

@@ -12,7 +12,7 @@ class ConvBatch(object):
     def __init__(self, ps, name, in_channels, out_channels, ksize, stride, pad, activation='relu'):
         if activation not in ('relu', None):
             raise ValueError('ConvBatch: activation must be "relu" or None on this path')
-        self.c = Conv(ps, name + '/c', in_channels, out_channels, ksize, stride, pad, bias=True)
+        self.c = Conv(ps, name + '/c', in_channels, out_channels, ksize, stride, pad, bias=True, in_backbone=True)
         self.bn = BatchNorm(ps, name + '/bn', self.c.cout_p)
         self.activation = activation
 

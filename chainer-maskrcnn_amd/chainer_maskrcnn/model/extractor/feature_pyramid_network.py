@@ -48,7 +48,7 @@ class FeaturePyramidNetwork(object):
         self.ps = ps if ps is not None else ParamStore()
         p = prefix + '/'
         d = width_div
-        self.conv1 = Conv(self.ps, p + 'resnet/conv1', 3, 64 // d, 7, 2, 3, bias=True)
+        self.conv1 = Conv(self.ps, p + 'resnet/conv1', 3, 64 // d, 7, 2, 3, bias=True, in_backbone=True)
         self.bn1 = BatchNorm(self.ps, p + 'resnet/bn1', 64 // d)
         self.stages = []
         for si, (name, n, cin, mid, cout, stride) in enumerate(self.STAGES):

@@ -50,13 +50,18 @@ FUSE_BN_STATS = True
 FWD_EMULATION_BEHIND_BACKBONE = True
 # ... and False here keeps the forward pass of the BACKBONE's convolutions (extractor/resnet) on the float32 MFMA.
 FWD_EMULATION_IN_BACKBONE = True
+# One foreign call per ResNet bottleneck and pass (csrc/blocks.hip: mrcnn_bottleneck_fwd_f32 / _bwd_f32 enqueue the block's whole chain of
+# launches, same kernels / operands / order / streams as the per-layer path below - the same bits) instead of ~25 calls and ~20
+# allocations: the host side of the step (train.py:117-132) was 16.4 ms of Python per 21.7 ms step (profiles/r04_host_time.txt).
+# False = the per-layer path (also taken under bench instrumentation, evaluation mode and the measurement knobs it has no notion of).
+COMPOSITE_BLOCKS = True
 
 
 class _layer_tiles(object):
     def __init__(self, conv):
         self.t = FWD_TILE_RULE(conv.name) if FWD_TILE_RULE is not None else (conv.fwd_tile if LAYER_TILE_HINTS else None)
         self.keep = None
-        self.behind = '/resnet/' not in conv.name          # FPN laterals / smoothing, RPN, heads: no BatchNorm behind them
+        self.behind = not conv.in_backbone                 # FPN laterals / smoothing, RPN, heads: no BatchNorm behind them
 
     def __enter__(self):
         self.keep_split = None
@@ -159,8 +164,11 @@ class Conv(object):
     """
 
     def __init__(self, ps, name, cin, cout, k=1, stride=1, pad=0, bias=True, relu=False, init=None,
-                 cin_p=None, cout_p=None, cout_index=None, fwd_tile=None):
+                 cin_p=None, cout_p=None, cout_index=None, fwd_tile=None, in_backbone=None):
         self.ps, self.name, self.fwd_tile = ps, name, fwd_tile
+        # a convolution whose output feeds a training-mode BatchNorm (every backbone's: FPN ResNet, C4, Darknet, the res5 head) keeps its
+        # FORWARD pass on the float32 MFMA under 'bf16x6_behind_backbone'; set by the extractor that builds it (default: by the FPN's names)
+        self.in_backbone = ('/resnet/' in name) if in_backbone is None else bool(in_backbone)
         self.cin, self.cout, self.k, self.stride, self.pad, self.relu = cin, cout, k, stride, pad, relu
         self.cin_p = cin_p or (4 if cin <= 4 else pad_to(cin, 32))
         self.cout_p = cout_p or pad_to(cout, 32)
@@ -331,17 +339,89 @@ class Bottleneck(object):
     def __init__(self, ps, name, cin, mid, cout, stride, project):
         self.project, self.stride = project, stride
         he = lambda fan_in: (lambda shape: (lambda rs: rs.standard_normal(shape) * math.sqrt(2.0 / fan_in)))
-        self.conv1 = Conv(ps, name + '/conv1', cin, mid, 1, stride, 0, bias=False, init=he(cin))
+        self.conv1 = Conv(ps, name + '/conv1', cin, mid, 1, stride, 0, bias=False, init=he(cin), in_backbone=True)
         self.bn1 = BatchNorm(ps, name + '/bn1', mid)
-        self.conv2 = Conv(ps, name + '/conv2', mid, mid, 3, 1, 1, bias=False, init=he(mid * 9))
+        self.conv2 = Conv(ps, name + '/conv2', mid, mid, 3, 1, 1, bias=False, init=he(mid * 9), in_backbone=True)
         self.bn2 = BatchNorm(ps, name + '/bn2', mid)
-        self.conv3 = Conv(ps, name + '/conv3', mid, cout, 1, 1, 0, bias=False, init=he(mid))
+        self.conv3 = Conv(ps, name + '/conv3', mid, cout, 1, 1, 0, bias=False, init=he(mid), in_backbone=True)
         self.bn3 = BatchNorm(ps, name + '/bn3', cout)
         if project:
-            self.conv4 = Conv(ps, name + '/conv4', cin, cout, 1, stride, 0, bias=False, init=he(cin))
+            self.conv4 = Conv(ps, name + '/conv4', cin, cout, 1, stride, 0, bias=False, init=he(cin), in_backbone=True)
             self.bn4 = BatchNorm(ps, name + '/bn4', cout)
 
+    def _composite_ok(self, x):
+        return (COMPOSITE_BLOCKS and TRAIN and FUSE_BN_STATS and x.is_cuda and hnn.PROFILE is None and FWD_TILE_RULE is None
+                and not WINOGRAD_SHARED_GY_TRANSFORM)
+
+    def _descriptor(self, x):
+        """mrcnn_bottleneck_t for this block on input x (cached: the parameter / gradient pointers are views of the flat buffers)."""
+        ps = self.conv1.ps
+        N, H, W, _ = x.shape
+        fwd_split = -1 if FWD_EMULATION_IN_BACKBONE else 0
+        key = (N, H, W, ps.params.data_ptr(), ps.grads.data_ptr(), fwd_split)
+        if getattr(self, '_desc_key', None) != key:
+            from chainer_maskrcnn import _hip
+            d = _hip.Bottleneck()
+            d.N, d.H, d.W = N, H, W
+            d.cin, d.mid, d.cout = self.conv1.cin_p, self.conv1.cout_p, self.conv3.cout_p
+            d.stride, d.project, d.fwd_split = self.stride, int(self.project), fwd_split
+            d.eps, d.decay = 2e-5, 0.9
+            layers = [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)] + ([(self.conv4, self.bn4)] if self.project else [])
+            for i, (c, b) in enumerate(layers):
+                d.w[i], d.gw[i] = c.W.data_ptr(), ps.g(c.name + '/W').data_ptr()
+                d.gamma[i], d.beta[i] = ps.p(b.name + '/gamma').data_ptr(), ps.p(b.name + '/beta').data_ptr()
+                d.ggamma[i], d.gbeta[i] = ps.g(b.name + '/gamma').data_ptr(), ps.g(b.name + '/beta').data_ptr()
+                d.run_mean[i], d.run_var[i] = ps.buffers[b.name + '/avg_mean'].data_ptr(), ps.buffers[b.name + '/avg_var'].data_ptr()
+            self._desc, self._desc_key = d, key
+        return self._desc
+
+    def _fwd_composite(self, x):
+        import ctypes
+        from chainer_maskrcnn import _hip
+        lib = _hip.lib()
+        d = self._descriptor(x)
+        plan = _hip.BottleneckPlan()
+        _hip.check(lib.mrcnn_bottleneck_fwd_plan(ctypes.byref(d), ctypes.byref(plan)))
+        N, H, W, _ = x.shape
+        s = self.stride
+        y = torch.empty((N, (H - 1) // s + 1, (W - 1) // s + 1, d.cout), dtype=torch.float32, device=x.device)
+        arena = torch.empty((plan.arena_bytes,), dtype=torch.uint8, device=x.device)
+        ws = hnn.workspace(plan.ws_bytes, x.device)
+        _hip.check(lib.mrcnn_bottleneck_fwd_f32(ctypes.byref(d), ctypes.byref(plan), x.data_ptr(), y.data_ptr(), arena.data_ptr(), arena.numel(),
+                                                ws.data_ptr(), ws.numel(), _hip.stream_ptr()))
+        return y, ('composite', x, y, arena, plan)
+
+    def _bwd_composite(self, ctx, gy, gx_acc, gy_masked, mask_gx):
+        import ctypes
+        from chainer_maskrcnn import _hip
+        lib = _hip.lib()
+        _, x, y, fwd_arena, plan = ctx
+        d = self._descriptor(x)
+        dev = x.device
+        sizes = (ctypes.c_size_t * 3)()
+        _hip.check(lib.mrcnn_bottleneck_bwd_sizes(ctypes.byref(d), sizes))
+        main = torch.cuda.current_stream(dev)
+        side = hnn.side_stream(dev) if FILTER_GRAD_ON_SIDE_STREAM else main
+        arena = torch.empty((max(int(sizes[0]), 1),), dtype=torch.uint8, device=dev)
+        ws_main, ws_side = hnn.workspace(sizes[1], dev, main), hnn.workspace(sizes[2], dev, side)
+        g_r = None if gy_masked else torch.empty_like(y)
+        gx_new = torch.empty_like(x) if (self.project and gx_acc is None) else None
+        _hip.check(lib.mrcnn_bottleneck_bwd_f32(ctypes.byref(d), ctypes.byref(plan), x.data_ptr(), y.data_ptr(), fwd_arena.data_ptr(), gy.data_ptr(),
+                                                int(bool(gy_masked)), _hip.ptr(g_r), _hip.ptr(gx_acc), _hip.ptr(gx_new), int(bool(mask_gx)),
+                                                arena.data_ptr(), arena.numel(), ws_main.data_ptr(), ws_main.numel(), ws_side.data_ptr(),
+                                                ws_side.numel(), main.cuda_stream, side.cuda_stream))
+        if side is not main:            # the filter gradients read these on the side stream: the allocator must not recycle them before
+            for t_ in (x, fwd_arena, arena):
+                t_.record_stream(side)
+        if gx_acc is not None:
+            return gx_acc
+        if self.project:
+            return gx_new
+        return gy if gy_masked else g_r          # identity shortcut: accumulated into the shortcut gradient in place
+
     def fwd(self, x):
+        if self._composite_ok(x):
+            return self._fwd_composite(x)
         h1, c1 = self.conv1.fwd(x, bn_stats=True)
         a1, b1 = self.bn1.fwd(h1, relu=True, partials=self.conv1.last_bn_part)
         h2, c2 = self.conv2.fwd(a1, bn_stats=True)
@@ -361,6 +441,8 @@ class Bottleneck(object):
         bn3's backward then reads two streams instead of three and writes no separate shortcut gradient (it IS gy).
         mask_gx: the block's input is itself a ReLU output (the previous block's): the returned gradient - the sum of all its
         contributions - is zeroed where that input is <= 0, in the epilogue of the kernel that writes it last."""
+        if ctx[0] == 'composite':
+            return self._bwd_composite(ctx, gy, gx_acc, gy_masked, mask_gx)
         c1, b1, c2, b2, c3, b3, c4, b4 = ctx
         if gy_masked:
             g_h3, _ = self.bn3.bwd(b3, gy, gy_masked=True)

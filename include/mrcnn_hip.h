@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 8
+#define MRCNN_ABI_VERSION 9
 
 enum {
     MRCNN_OK = 0,
@@ -376,6 +376,73 @@ int mrcnn_random_keys_dev_u32(uint32_t *out, size_t n, unsigned long long *state
 /* g += wd*p; v = momentum*v - lr*g; p += v  over a flat parameter buffer (train.py:107-109). */
 int mrcnn_sgd_momentum_wd_f32(float *p, const float *g, float *v, size_t n, float lr, float momentum,
                               float weight_decay, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (ABI v9) One whole ResNet bottleneck per call.  Replaces the Python-issued chain of Chainer's ResNet50Layers building block
+ * (BottleneckA / BottleneckB: conv1x1 -> BN -> ReLU -> conv3x3 -> BN -> ReLU -> conv1x1 -> BN (+ shortcut, itself conv1x1 -> BN in
+ * the first block of a stage) -> ReLU) as the reference runs it in training mode, extractor/feature_pyramid_network.py:22,48-66, and its
+ * backward - the host side of the updater loop, train.py:117-132.  The call ENQUEUES exactly the launches the separate entry points
+ * above would (mrcnn_conv2d_fwd_bnstats_f32 / mrcnn_conv2d_fwd_f32, mrcnn_bn_train_fwd_stats_f32 / mrcnn_bn_train_fwd_f32,
+ * mrcnn_bn_train_bwd_f32, mrcnn_conv2d_bwd_filter_f32, mrcnn_conv2d_bwd_data_f32, mrcnn_subsample_bwd_f32, mrcnn_add_f32), in the same
+ * order with the same operands: the results are the same bits; what changes is the host cost (one foreign call and two or three
+ * allocations per block instead of ~25 calls and ~20 allocations).
+ *
+ * Descriptor (host memory, read during the call only).  Channel counts are the padded ones of the tensors (multiples of 32).
+ *   x (N,H,W,cin) NHWC;  conv1: 1x1 stride `stride` cin->mid;  conv2: 3x3 pad 1 mid->mid;  conv3: 1x1 mid->cout;
+ *   project != 0: shortcut conv4 1x1 stride `stride` cin->cout + bn4, else identity (cin == cout, stride 1).
+ *   w[i] filters (Cout,KH,KW,Cin); gamma/beta/run_mean/run_var of bn1..bn4; gw/ggamma/gbeta: where the backward writes the gradients.
+ *   fwd_split: -1 = the process setting (mrcnn_conv2d_set_split_operands); 0..3 = that arithmetic for the FORWARD convolutions of this
+ *   call (the setting is restored before return).
+ * Forward: mrcnn_bottleneck_fwd_plan fills `plan` (offsets of the saved tensors inside the caller's arena: pre-BN / post-BN
+ * activations, kept Winograd input transforms, statistics partials, saved mean / invstd) and returns the arena and scratch sizes for
+ * the CURRENT convolution settings; mrcnn_bottleneck_fwd_f32 follows that plan.  The arena is what the backward needs: keep it, with the
+ * plan, until mrcnn_bottleneck_bwd_f32 has been enqueued.  y (N,Ho,Wo,cout) is the block's output.
+ * Backward: gy = gradient of y.  gy_masked != 0: gy already carries the block's output ReLU mask (its producer applied it), the shortcut
+ * gradient is gy itself; else g_r (N,Ho,Wo,cout, required) receives the masked gradient.  The block's input gradient:
+ *   identity shortcut: accumulated into gx_acc when given (gx_acc = g_r + gx_acc first), else into g_r / gy IN PLACE (as the Python chain);
+ *   projection: accumulated into gx_acc when given, else written to gx_new (N,H,W,cin, required then).
+ * mask_gx != 0: that gradient is zeroed where x <= 0 (x is a ReLU output: the ReLU backward of the block before).
+ * side_stream (nullable): the four filter gradients are enqueued there, each behind an event recorded on `stream` when its operands are
+ * complete (the library keeps a small pool of timing-disabled events per device for this; no device memory); NULL = everything on
+ * `stream`.  ws_side is the side stream's own scratch.  The caller joins the side stream when it needs the filter gradients.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mrcnn_bottleneck {
+    int32_t N, H, W;
+    int32_t cin, mid, cout;
+    int32_t stride, project;
+    int32_t fwd_split;
+    float eps, decay;
+    const float *w[4];
+    const float *gamma[4];
+    const float *beta[4];
+    float *run_mean[4];
+    float *run_var[4];
+    float *gw[4];
+    float *ggamma[4];
+    float *gbeta[4];
+} mrcnn_bottleneck_t;
+
+enum { MRCNN_BN_H1 = 0, MRCNN_BN_A1, MRCNN_BN_H2, MRCNN_BN_A2, MRCNN_BN_H3, MRCNN_BN_H4, MRCNN_BN_R,
+       MRCNN_BN_V = 7 /* +0..3 */, MRCNN_BN_PART = 11 /* +0..3 */, MRCNN_BN_MEAN = 15 /* +0..3 */, MRCNN_BN_INVSTD = 19 /* +0..3 */,
+       MRCNN_BN_SLOTS = 23 };
+
+typedef struct mrcnn_bottleneck_plan {
+    uint64_t arena_bytes;               /* forward arena */
+    uint64_t ws_bytes;                  /* forward scratch on `stream` */
+    uint64_t off[MRCNN_BN_SLOTS];       /* byte offsets into the arena (256-B aligned); unused slots 0 */
+    uint64_t v_bytes[4];                /* kept Winograd input transform of conv1..4 (0: none) */
+    int32_t part_rows[4];               /* statistics partial rows of conv1..4 (0: BatchNorm runs its own statistics pass) */
+} mrcnn_bottleneck_plan_t;
+
+int mrcnn_bottleneck_fwd_plan(const mrcnn_bottleneck_t *b, mrcnn_bottleneck_plan_t *plan);
+int mrcnn_bottleneck_fwd_f32(const mrcnn_bottleneck_t *b, const mrcnn_bottleneck_plan_t *plan, const float *x, float *y,
+                             void *arena, size_t arena_bytes, void *ws, size_t ws_bytes, void *stream);
+/* sizes3 (host, 3 x size_t): backward arena (the intermediate gradients), scratch on `stream`, scratch on `side_stream` */
+int mrcnn_bottleneck_bwd_sizes(const mrcnn_bottleneck_t *b, size_t *sizes3);
+int mrcnn_bottleneck_bwd_f32(const mrcnn_bottleneck_t *b, const mrcnn_bottleneck_plan_t *plan, const float *x, const float *y,
+                             const void *fwd_arena, const float *gy, int gy_masked, float *g_r, float *gx_acc, float *gx_new,
+                             int mask_gx, void *arena, size_t arena_bytes, void *ws_main, size_t ws_main_bytes, void *ws_side,
+                             size_t ws_side_bytes, void *stream, void *side_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Losses (loss.hip).  Replace F.softmax_cross_entropy, _fast_rcnn_loc_loss/_smooth_l1_loss and

@@ -143,6 +143,40 @@ int main() {
     EXPECT_ERR(mrcnn_detect_decode_f32(CF, 10, CF, 96, 81, 88, 1.f, CF, CF, 64.f, 64.f, F, F, V));
     EXPECT_ERR(mrcnn_class_nms_f32(CF, CF, 10, 81, 1, 81, 0.5f, 0.5f, I, I, V));
     EXPECT_ERR(mrcnn_mask_paste_f32(CF, 2, 28, 96, CI, CF, 64, 64, U, V));
+    // ---- composite bottleneck (ABI v9): the plans are host arithmetic; the compute calls reject null buffers / short arenas first
+    {
+        mrcnn_bottleneck_t b{};
+        mrcnn_bottleneck_plan_t plan{};
+        size_t s3[3] = {0, 0, 0};
+        static float host[16];          // non-null stand-ins: every call below must be rejected before anything could touch them
+        float *NF = host; const float *NCF = host; void *NV = host;
+        EXPECT_ERR(mrcnn_bottleneck_fwd_plan(nullptr, &plan));
+        EXPECT_ERR(mrcnn_bottleneck_fwd_plan(&b, &plan));                  // all-zero descriptor
+        for (int stride = 1; stride <= 2; ++stride) for (int project = 0; project <= 1; ++project) for (int H : {7, 32, 100}) {
+            b = mrcnn_bottleneck_t{};
+            b.N = 2; b.H = H; b.W = H + 3; b.cin = project ? 64 : 256; b.mid = 64; b.cout = 256; b.stride = stride; b.project = project; b.fwd_split = -1;
+            b.eps = 2e-5f; b.decay = 0.9f;
+            if (!project && stride != 1) { EXPECT_ERR(mrcnn_bottleneck_fwd_plan(&b, &plan)); continue; }
+            EXPECT(mrcnn_bottleneck_fwd_plan(&b, &plan) == 0 && plan.arena_bytes > 0);
+            EXPECT_ERR(mrcnn_bottleneck_fwd_plan(&b, nullptr));
+            EXPECT(mrcnn_bottleneck_bwd_sizes(&b, s3) == 0 && s3[0] > 0 && s3[2] > 0);
+            EXPECT_ERR(mrcnn_bottleneck_bwd_sizes(&b, nullptr));
+            acc += plan.arena_bytes + plan.ws_bytes + s3[0] + s3[1] + s3[2];
+            EXPECT_ERR(mrcnn_bottleneck_fwd_f32(&b, &plan, nullptr, NF, NV, 0, NV, 0, V));                // null x
+            EXPECT_ERR(mrcnn_bottleneck_fwd_f32(&b, &plan, NCF, NF, NV, 16, NV, (size_t)1 << 40, V));  // arena too small
+            EXPECT_ERR(mrcnn_bottleneck_fwd_f32(&b, &plan, NCF, NF, NV, (size_t)1 << 40, NV, (size_t)1 << 40, V));   // null parameters
+            EXPECT_ERR(mrcnn_bottleneck_bwd_f32(&b, &plan, NCF, NCF, nullptr, NCF, 1, nullptr, nullptr, NF, 0, NV, (size_t)1 << 40, NV,
+                                                (size_t)1 << 40, NV, (size_t)1 << 40, V, V));              // null forward arena
+            EXPECT_ERR(mrcnn_bottleneck_bwd_f32(&b, &plan, NCF, NCF, NV, NCF, 0, nullptr, nullptr, NF, 0, NV, (size_t)1 << 40, NV,
+                                                (size_t)1 << 40, NV, (size_t)1 << 40, V, V));              // unmasked gy without g_r
+            EXPECT_ERR(mrcnn_bottleneck_bwd_f32(&b, &plan, NCF, NCF, NV, NCF, 1, nullptr, NF, NF, 0, NV, 16, NV,
+                                                (size_t)1 << 40, NV, (size_t)1 << 40, V, V));              // backward arena too small
+            EXPECT_ERR(mrcnn_bottleneck_bwd_f32(&b, &plan, NCF, NCF, NV, NCF, 1, nullptr, NF, NF, 0, NV, (size_t)1 << 40, NV,
+                                                (size_t)1 << 40, NV, (size_t)1 << 40, V, V));              // null parameter / gradient pointers
+        }
+        b.fwd_split = 7;
+        EXPECT_ERR(mrcnn_bottleneck_fwd_plan(&b, &plan));
+    }
     std::printf("planning checksum %llu, %d failure(s)\n", acc, failures);
     return failures ? 1 : 0;
 }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'libmrcnn_hip.so lacks %s' % n
         assert n in _hip.SIGNATURES, 'ctypes binding lacks %s' % n
     assert set(_hip.SIGNATURES) == set(names)
-    assert lib.mrcnn_abi_version() == _hip.ABI_VERSION == 8
+    assert lib.mrcnn_abi_version() == _hip.ABI_VERSION == 9
 
 
 def test_argument_errors_do_not_need_a_device():
@@ -105,12 +105,9 @@ def test_shipped_arithmetic_brackets_the_backbone_forward_calls():
     from chainer_maskrcnn.nn import core
     from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import select_gemm_arithmetic
 
-    class L(object):            # what _layer_tiles reads of a Conv
-        fwd_tile = None
-
-        def __init__(self, name):
-            self.name = name
-    backbone, behind = L('extractor/resnet/res3/a/conv2'), L('extractor/lat_p3')
+    ps = core.ParamStore()
+    backbone, behind = core.Bottleneck(ps, 'extractor/resnet/res3/a', 64, 32, 128, 2, True).conv2, core.Conv(ps, 'extractor/lat_p3', 64, 32, 1)
+    assert backbone.in_backbone and not behind.in_backbone
     try:
         select_gemm_arithmetic('bf16x6_behind_backbone')
         assert tuple(hnn.split_operands()) == (3, 3, 3) and core.FWD_EMULATION_IN_BACKBONE is False
@@ -128,3 +125,71 @@ def test_shipped_arithmetic_brackets_the_backbone_forward_calls():
     finally:
         select_gemm_arithmetic('f32')
         core.FWD_EMULATION_IN_BACKBONE = core.FWD_EMULATION_BEHIND_BACKBONE = True
+
+
+def test_every_backbone_marks_its_convolutions():
+    """the 'behind the backbone' decision is an attribute set by the extractor that builds the layer, not a match on the FPN's
+    parameter names - the C4 backbone, Darknet and the res5 head (BatchNorm behind every convolution) keep their forward pass on the float32
+    MFMA under 'bf16x6_behind_backbone' like the FPN's ResNet; FPN laterals / smoothing, RPN and head convolutions do not."""
+    from chainer_maskrcnn.nn import core
+    from chainer_maskrcnn.model.extractor.c4_backbone import C4Backbone
+    from chainer_maskrcnn.model.extractor.darknet import Darknet
+    from chainer_maskrcnn.model.extractor.feature_pyramid_network import FeaturePyramidNetwork
+    from chainer_maskrcnn.model.head.resnet_roi_mask_head import ResnetRoIMaskHead
+
+    def convs_of(obj, seen=None):
+        seen = set() if seen is None else seen
+        out = []
+        for v in vars(obj).values():
+            for o in (v if isinstance(v, (list, tuple)) else [v]):
+                for o2 in (o if isinstance(o, (list, tuple)) else [o]):
+                    if isinstance(o2, core.Conv):
+                        out.append(o2)
+                    elif hasattr(o2, '__dict__') and type(o2).__module__.startswith('chainer_maskrcnn') and id(o2) not in seen:
+                        seen.add(id(o2))
+                        out += convs_of(o2, seen)
+        return out
+    c4 = convs_of(C4Backbone(stages=(1, 1, 1), width_div=4))
+    assert len(c4) == 1 + 3 * 4 and all(c.in_backbone for c in c4)
+    dk = convs_of(Darknet())
+    assert len(dk) == 5 and all(c.in_backbone for c in dk)
+    fpn = FeaturePyramidNetwork(stages=(1, 1, 1, 1), width_div=4)
+    by = {c.name: c.in_backbone for c in convs_of(fpn)}
+    assert all(v == ('/resnet/' in k) for k, v in by.items()) and sum(by.values()) == 1 + 4 * 4 and len(by) == 17 + 8
+    head = ResnetRoIMaskHead(81, 7, 1 / 16., width_div=4)
+    assert all(c.in_backbone for b in head.res5 for c in (b.conv1, b.conv2, b.conv3)) and not head.conv1.in_backbone
+
+
+def test_composite_bottleneck_plan_is_host_arithmetic():
+    """mrcnn_bottleneck_fwd_plan / _bwd_sizes (ABI v9, csrc/blocks.hip) need no device: the forward arena holds the seven activations of a
+    projection block, 256-byte aligned and disjoint; fwd_split brackets the plan like the forward call and is restored; bad descriptors are
+    argument errors."""
+    import ctypes
+    from chainer_maskrcnn import _hip
+    from chainer_maskrcnn._hip import nn as hnn
+    lib = _hip.lib()
+    d = _hip.Bottleneck()
+    d.N, d.H, d.W, d.cin, d.mid, d.cout, d.stride, d.project, d.fwd_split = 2, 64, 64, 512, 256, 1024, 2, 1, 0
+    plan = _hip.BottleneckPlan()
+    _hip.check(lib.mrcnn_conv2d_set_split_operands(3, 3, 3))
+    try:
+        _hip.check(lib.mrcnn_bottleneck_fwd_plan(ctypes.byref(d), ctypes.byref(plan)))
+        assert tuple(hnn.split_operands()) == (3, 3, 3)
+    finally:
+        _hip.check(lib.mrcnn_conv2d_set_split_operands(0, 0, 0))
+    P = 2 * 32 * 32
+    sizes = [P * 256 * 4] * 4 + [P * 1024 * 4] * 3
+    offs = [plan.off[i] for i in range(7)]
+    assert all(o % 256 == 0 for o in plan.off) and offs == [sum(sizes[:i]) for i in range(7)]
+    used = sorted((plan.off[i], i) for i in range(_hip.BN_SLOTS) if i < 7 or plan.off[i])
+    assert all(a[0] < b[0] for a, b in zip(used, used[1:])) and plan.arena_bytes > used[-1][0]
+    assert plan.v_bytes[1] == lib.mrcnn_conv2d_winograd_v_bytes(2, 32, 32, 256, 256, 3, 3, 1, 1) and plan.v_bytes[0] == 0
+    assert plan.part_rows[1] == lib.mrcnn_conv2d_bnstats_rows(2, 32, 32, 256, 256, 3, 3, 1, 1)
+    s3 = (ctypes.c_size_t * 3)()
+    _hip.check(lib.mrcnn_bottleneck_bwd_sizes(ctypes.byref(d), s3))
+    assert s3[0] >= P * (1024 * 2 + 256 * 4 + 512) * 4 and s3[1] > 0 and s3[2] >= 1024 * 256 * 4
+    d.project, d.stride = 0, 2          # an identity shortcut cannot be strided
+    assert lib.mrcnn_bottleneck_fwd_plan(ctypes.byref(d), ctypes.byref(plan)) == -1 and b'identity' in lib.mrcnn_last_error()
+    d.stride, d.cin = 1, 100
+    assert lib.mrcnn_bottleneck_fwd_plan(ctypes.byref(d), ctypes.byref(plan)) == -1
+    assert lib.mrcnn_bottleneck_fwd_plan(None, ctypes.byref(plan)) == -1

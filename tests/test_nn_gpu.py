@@ -260,3 +260,47 @@ def test_bn_statistics_from_the_epilogue_with_a_large_mean(ratio):
     assert float((mean.double().cpu() - m64).abs().max()) <= 2e-6 * float(m64.abs().max())
     want = (yd - m64) * want_is
     assert float((o.double().cpu().reshape(P, Co) - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('case', [(2, 40, 56, 64, 64, 256, 1, True), (2, 40, 56, 256, 64, 256, 1, False), (2, 41, 57, 256, 128, 512, 2, True),
+                                  (2, 64, 64, 1024, 256, 1024, 1, False), (1, 64, 64, 512, 256, 1024, 2, True)],
+                         ids=['res2a', 'res2b', 'res3a_odd', 'res4b_winograd', 'res4a'])
+@pytest.mark.parametrize('flags', [(False, False, False), (True, True, False), (True, False, True), (False, True, True)],
+                         ids=['plain', 'masked_in_out', 'masked_acc', 'mask_gx_acc'])
+def test_composite_bottleneck_equals_the_per_layer_path(case, flags):
+    """mrcnn_bottleneck_fwd_f32 / _bwd_f32 (csrc/blocks.hip) against the per-layer calls of nn/core.py Bottleneck on full-width blocks
+    (identity and projection shortcuts, stride 1 and 2 on odd maps, a Winograd conv2 with its kept input transform): output, saved
+    statistics, every gradient and the input gradient are the same bits for every combination of gy_masked / mask_gx / gx_acc."""
+    from chainer_maskrcnn.nn import core
+    N, H, W, cin, mid, cout, stride, project = case
+    gy_masked, mask_gx, with_acc = flags
+    ps = core.ParamStore()
+    blk = core.Bottleneck(ps, 'b', cin, mid, cout, stride, project)
+    ps.materialise(torch.device(DEV), seed=11)
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = torch.relu(torch.randn((N, H, W, cin), generator=g)).to(DEV)            # a ReLU output, as in the network
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    gy0 = (torch.randn((N, Ho, Wo, cout), generator=g) * 1e-3).to(DEV)
+    acc0 = (torch.randn((N, H, W, cin), generator=g) * 1e-3).to(DEV)
+    out = []
+    for on in (False, True):
+        core.COMPOSITE_BLOCKS = on
+        try:
+            ps.grads.zero_()
+            for k in ps.buffers:
+                ps.buffers[k].copy_(torch.zeros_like(ps.buffers[k]) if k.endswith('avg_mean') else torch.ones_like(ps.buffers[k]))
+            y, ctx = blk.fwd(x)
+            assert (ctx[0] == 'composite') == on
+            gy = gy0.clone()
+            if gy_masked:
+                gy = gy * (y > 0)
+            acc = acc0.clone() if with_acc else None
+            gx = blk.bwd(ctx, gy, gx_acc=acc, gy_masked=gy_masked, mask_gx=mask_gx)
+            core.join_side_stream(torch.device(DEV))
+            torch.cuda.synchronize()
+            out.append((y.clone(), gx.clone(), ps.grads.clone(), torch.cat([v.flatten() for _, v in sorted(ps.buffers.items())])))
+        finally:
+            core.COMPOSITE_BLOCKS = True
+    for a, b_ in zip(out[0], out[1]):
+        assert torch.isfinite(a).all() and torch.equal(a, b_)
+    assert float(out[0][2].abs().max()) > 0 and float(out[0][1].abs().max()) > 0

@@ -638,3 +638,41 @@ def test_small_rpn_levels_beside_p2_give_the_same_bits():
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize('arith', ['f32', 'bf16x6_behind_backbone'])
+def test_composite_bottleneck_calls_give_the_same_bits(arith):
+    """nn/core.py COMPOSITE_BLOCKS (on by default): one foreign call per ResNet bottleneck and pass (csrc/blocks.hip) enqueues the launches
+    of the per-layer host path - same kernels, operands, order and streams.  Features, losses, every gradient and the parameters after
+    three updates must be the same bits, in the float32 arithmetic and in the shipped one (forward split bracket of the backbone)."""
+    from chainer_maskrcnn.nn import core
+    res = []
+    for on in (False, True):
+        core.COMPOSITE_BLOCKS = on
+        try:
+            m = MaskRCNN(n_fg_class=80, device=DEV, seed=7, _test_shrink=dict(stages=STAGES, width_div=2))
+            chain = FPNMaskRCNNTrainChain(m, mask_loss_fun=calc_mask_loss, mask_rows='all', gemm_arithmetic=arith)
+            chain.keep_outputs = True
+            b = _batch()
+            chain.sampler_keys = None
+            chain.proposal_target_creator.set_seed(5)
+            chain.anchor_target_creator.set_seed(9)
+            chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0).backward()
+            torch.cuda.synchronize()
+            feats = [f.clone() for f in chain.outputs['features']]
+            g, l = m.ps.grads.clone(), float(chain.observation['loss'])
+            stats = torch.cat([v.flatten() for _, v in sorted(m.ps.buffers.items())])       # BatchNorm running statistics
+            opt = MomentumSGD(lr=1e-2, momentum=0.9).setup(chain)
+            opt.add_hook(WeightDecay(0.0005))
+            for _ in range(3):
+                opt.update(chain, b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+            torch.cuda.synchronize()
+            res.append((l, g, m.ps.params.clone(), feats, stats))
+        finally:
+            core.COMPOSITE_BLOCKS = True
+    assert res[0][0] == res[1][0]
+    for a, b_ in zip(res[0][3], res[1][3]):
+        assert torch.equal(a, b_)
+    assert torch.equal(res[0][4], res[1][4])
+    assert torch.equal(res[0][1], res[1][1]) and float(res[0][1].abs().max()) > 0
+    assert torch.equal(res[0][2], res[1][2])

@@ -26,8 +26,19 @@ for rep in range(3):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print('10 steps: host enqueue %.1f ms/step (min %.1f max %.1f), wall incl. final sync %.1f ms/step, tail wait %.1f ms'
-          % ((t1 - t0) * 100, min(enq) * 1e3, max(enq) * 1e3, (t2 - t0) * 100, (t2 - t1) * 1e3))
+    print('10 steps back to back: host enqueue %.1f ms/step (min %.1f max %.1f; includes waiting for a free queue slot once the host is a step ahead), '
+          'wall incl. final sync %.1f ms/step, tail wait %.1f ms' % ((t1 - t0) * 100, min(enq) * 1e3, max(enq) * 1e3, (t2 - t0) * 100, (t2 - t1) * 1e3))
+# the host's own cost: every step enqueued into an EMPTY queue (device idle at the start), so no launch ever waits for the device
+for rep in range(3):
+    enq = []
+    for _ in range(10):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        opt.update(chain, *args, 1.0)
+        enq.append(time.perf_counter() - a)
+    torch.cuda.synchronize()
+    enq.sort()
+    print('10 steps, each into an empty queue: host enqueue median %.1f ms/step (min %.1f max %.1f)' % (enq[5] * 1e3, enq[0] * 1e3, enq[-1] * 1e3))
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5):
