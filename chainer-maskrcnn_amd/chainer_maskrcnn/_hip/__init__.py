@@ -98,9 +98,21 @@ def check(rc):
         raise MrcnnHipError('libmrcnn_hip call failed (code %d): %s' % (rc, msg))
 
 
-def stream_ptr():
+_raw_stream = None
+
+
+def raw_stream(device_index=None):
+    """hipStream_t of torch's current stream on the (current) device as an int - the stream every launch of this layer goes to.  Through
+    torch's C entry point (0.3 us) instead of building a torch.cuda.Stream object per call (7 us x ~200 calls per step)."""
+    global _raw_stream
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
+    return _raw_stream(torch._C._cuda_getDevice() if device_index is None else device_index)
+
+
+def stream_ptr():
+    return ctypes.c_void_p(raw_stream())
 
 
 def require_cuda(*tensors):

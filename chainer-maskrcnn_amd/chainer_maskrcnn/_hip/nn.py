@@ -56,9 +56,13 @@ def side_stream(device):
 
 def workspace(nbytes, device, stream=None):
     """Grow-only scratch buffer per (device, stream - the current one unless given): the caller-owned workspace of the C ABI."""
-    if stream is None:
-        stream = torch.cuda.current_stream(device) if device.type == 'cuda' else None
-    key = (device.type, device.index, stream.cuda_stream if stream is not None else 0)
+    if device.type != 'cuda':
+        sid = 0
+    elif stream is None:
+        sid = _hip.raw_stream(device.index)
+    else:
+        sid = stream.cuda_stream
+    key = (device.type, device.index, sid)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -105,6 +105,7 @@ class ParamStore(object):
         self.params = self.grads = self.momentum = None
         self.size = 0
         self.buffers = {}       # non-trainable state (BN running statistics)
+        self._views = {}        # id(flat buffer) -> (flat buffer, {name: view})
 
     def register(self, name, shape, init, trainable=True):
         if name in self.offsets:
@@ -131,8 +132,15 @@ class ParamStore(object):
         return self
 
     def _view(self, flat, name):
-        o, shape = self.offsets[name]
-        return flat[o:o + int(np.prod(shape))].view(shape)
+        # (views are cached per flat buffer: ~250 parameter / gradient lookups per step were 1.6 ms of slicing)
+        cache = self._views.get(id(flat))
+        if cache is None or cache[0] is not flat:
+            cache = self._views[id(flat)] = (flat, {})
+        v = cache[1].get(name)
+        if v is None:
+            o, shape = self.offsets[name]
+            v = cache[1][name] = flat[o:o + int(np.prod(shape))].view(shape)
+        return v
 
     def p(self, name):
         return self._view(self.params, name)

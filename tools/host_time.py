@@ -45,3 +45,4 @@ for _ in range(5):
     opt.update(chain, *args, 1.0)
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats('tottime').print_stats(18)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(70)
