@@ -44,11 +44,69 @@ def roi_align_fpn_fwd(xs, rois_xy5, levels, out_size, scales, sampling_ratio=2):
     return y
 
 
-def roi_align_fpn_bwd(gy, gxs, rois_xy5, levels, out_size, scales, accumulate, sampling_ratio=2):
+# The backward's entry lists are built beside the FORWARD pass (the RoIs are all they need): mrcnn_roi_align_fpn_bwd_plan_f32 on the
+# weight-gradient stream, idle then; the backward follows them (mrcnn_roi_align_fpn_bwd_planned_f32: same bits, the geometry two thirds of
+# the fused kernel's critical path gone from the backward).  False = the fused backward.
+PLAN_BWD_IN_FORWARD = True
+
+
+def roi_align_fpn_bwd_plan(xs, rois_xy5, levels, out_size, scales, sampling_ratio=2, stream=None):
+    """Entry-list plan of the ROIAlign backward for these RoIs over maps shaped like xs (NHWC levels), enqueued on `stream` (default: the
+    current one).  Returns the plan buffer (uint8) for roi_align_fpn_bwd(..., plan=)."""
+    L, _, Hs, Ws, sc = _level_args(xs, scales)
+    N, C = xs[0].shape[0], xs[0].shape[3]
+    R = rois_xy5.shape[0]
+    nb = lib().mrcnn_roi_align_fpn_bwd_plan_bytes(Hs, Ws, L, N, R, out_size, out_size, 1)
+    if nb == 0:
+        return None
+    plan = torch.empty((nb,), dtype=torch.uint8, device=rois_xy5.device)
+    st = _hip.raw_stream(rois_xy5.device.index) if stream is None else stream.cuda_stream
+    check(lib().mrcnn_roi_align_fpn_bwd_plan_f32(Hs, Ws, sc, L, N, C, ptr(rois_xy5), ptr(levels), R, out_size, out_size, sampling_ratio, 1,
+                                                 ptr(plan), plan.numel(), ctypes.c_void_p(st)))
+    return plan
+
+
+def _plan_beside_forward(xs, rois_xy5, levels, out_size, scales):
+    """The plan on the weight-gradient stream, behind everything enqueued on the current stream so far (the RoIs); returns (plan, event)."""
+    if not PLAN_BWD_IN_FORWARD or not rois_xy5.is_cuda or rois_xy5.shape[0] == 0:
+        return None
+    from chainer_maskrcnn._hip import nn as hnn
+    dev = rois_xy5.device
+    main, side = torch.cuda.current_stream(dev), hnn.side_stream(dev)
+    side.wait_stream(main)
+    plan = roi_align_fpn_bwd_plan(xs, rois_xy5, levels, out_size, scales, stream=side)
+    if plan is None:
+        return None
+    ev = torch.cuda.Event()
+    ev.record(side)
+    for t_ in (plan, rois_xy5, levels):
+        if t_ is not None:
+            t_.record_stream(side)
+    return plan, ev
+
+
+def roi_align_bwd_plan_status(plan):
+    """(header valid, tiles flagged, pool nodes used) of a plan buffer - WAITS for the device (mrcnn_roi_align_bwd_plan_status).  A caller
+    that found (True, 0, _) may pass verified=True to roi_align_fpn_bwd: the lean kernel alone, without the launch behind it."""
+    st3 = (ctypes.c_int * 3)()
+    check(lib().mrcnn_roi_align_bwd_plan_status(ptr(plan), plan.numel(), st3, stream_ptr()))
+    return bool(st3[0]), int(st3[1]), int(st3[2])
+
+
+def roi_align_fpn_bwd(gy, gxs, rois_xy5, levels, out_size, scales, accumulate, sampling_ratio=2, plan=None, verified=False):
+    """plan: (buffer, event) of _plan_beside_forward / a buffer of roi_align_fpn_bwd_plan for the SAME rois, levels, maps: the lean backward."""
     L, arr_p, Hs, Ws, sc = _level_args(gxs, scales)
     N, C = gxs[0].shape[0], gxs[0].shape[3]
     nb = lib().mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, N, C, rois_xy5.shape[0], out_size, out_size, sampling_ratio)
     ws = workspace(nb, gy.device) if nb else None
+    if plan is not None:
+        if isinstance(plan, tuple):
+            plan, ev = plan
+            torch.cuda.current_stream(gy.device).wait_event(ev)
+        check(lib().mrcnn_roi_align_fpn_bwd_planned_f32(ptr(gy), arr_p, Hs, Ws, sc, L, N, C, ptr(rois_xy5), ptr(levels), rois_xy5.shape[0], out_size,
+                                                        out_size, sampling_ratio, int(accumulate), ptr(ws), ws.numel() if ws is not None else 0,
+                                                        ptr(plan), plan.numel(), int(bool(verified)), stream_ptr()))
+        return
     check(lib().mrcnn_roi_align_fpn_bwd_f32(ptr(gy), arr_p, Hs, Ws, sc, L, N, C, ptr(rois_xy5), ptr(levels),
                                             rois_xy5.shape[0], out_size, out_size, sampling_ratio, int(accumulate),
                                             ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()))
@@ -99,7 +157,9 @@ class FPNRoIMaskHead(object):
         h, t2 = self.fc1.fwd(h.view(R, 1, 1, -1))
         h, t3 = self.fc2.fwd(h)
         o, t4 = self.box_out.fwd(h)
-        self.box_tape = (t1, t2, t3, t4, tuple(pool.shape), rois_xy5, levels, spatial_scales)
+        from chainer_maskrcnn.nn import core
+        plan = _plan_beside_forward(xs, rois_xy5, levels, self.roi_size_box, spatial_scales) if core.TRAIN else None
+        self.box_tape = (t1, t2, t3, t4, tuple(pool.shape), rois_xy5, levels, spatial_scales, plan)
         self.last_box_out = o.view(R, self.out_p)
         return o.view(R, self.out_p)          # [:, :n_class] scores, [:, LOC0:LOC0+4] loc
 
@@ -117,7 +177,9 @@ class FPNRoIMaskHead(object):
             m, t2 = self.conv2.fwd(up)
         if self.upsample2x:                    # keypoint head: F.resize_images x2 (fpn_roi_keypoint_head.py:80-81)
             m = ops.bilinear2x_fwd(m)
-        self.mask_tape = (tapes, td, t2, rois_xy5, levels, spatial_scales)
+        from chainer_maskrcnn.nn import core
+        plan = _plan_beside_forward(xs, rois_xy5, levels, self.roi_size_mask, spatial_scales) if core.TRAIN else None
+        self.mask_tape = (tapes, td, t2, rois_xy5, levels, spatial_scales, plan)
         return m                               # (Rm, mask_size, mask_size, pad32(mask_out_channels)) NHWC
 
     def compose_deconv(self, device):
@@ -202,20 +264,20 @@ class FPNRoIMaskHead(object):
             self.backward_mask_pool(self.backward_mask_convs(g_mask), g_feats)
 
     def backward_box(self, g_box_out, g_feats):
-        t1, t2, t3, t4, pool_shape, rois, levels, scales = self.box_tape
+        t1, t2, t3, t4, pool_shape, rois, levels, scales, plan = self.box_tape
         R = g_box_out.shape[0]
         # every layer's input is the ReLU output of the layer below: the ReLU backward rides in the data-gradient epilogue
         g = self.box_out.bwd(t4, g_box_out.view(R, 1, 1, -1), mask_gx=True)
         g = self.fc2.bwd(t3, g, gy_masked=True, mask_gx=True)
         g = self.fc1.bwd(t2, g, gy_masked=True, mask_gx=True)
         g = self.conv1.bwd(t1, g.view(pool_shape), gy_masked=True)
-        roi_align_fpn_bwd(g, g_feats, rois, levels, self.roi_size_box, scales, accumulate=False)
+        roi_align_fpn_bwd(g, g_feats, rois, levels, self.roi_size_box, scales, accumulate=False, plan=plan)
         self.box_tape = None
 
     def backward_mask_convs(self, g_mask):
         """Mask / keypoint branch backward down to the gradient of its pooled input."""
         from chainer_maskrcnn._hip import nn as hnn
-        tapes, td, tc2, rois, levels, scales = self.mask_tape
+        tapes, td, tc2, rois, levels, scales, _ = self.mask_tape
         if self.upsample2x:
             g_mask = ops.bilinear2x_bwd(g_mask)
         if self.merge_deconv:
@@ -243,6 +305,6 @@ class FPNRoIMaskHead(object):
         return g
 
     def backward_mask_pool(self, g_pool, g_feats):
-        tapes, td, tc2, rois, levels, scales = self.mask_tape
-        roi_align_fpn_bwd(g_pool, g_feats, rois, levels, self.roi_size_mask, scales, accumulate=True)
+        tapes, td, tc2, rois, levels, scales, plan = self.mask_tape
+        roi_align_fpn_bwd(g_pool, g_feats, rois, levels, self.roi_size_mask, scales, accumulate=True, plan=plan)
         self.mask_tape = None

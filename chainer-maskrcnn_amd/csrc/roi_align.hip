@@ -807,6 +807,56 @@ __device__ __forceinline__ void drain_wave_queue(const WaveQueue<QC> &q, int n, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// (r5) The backward in two kernels: ENTRY LISTS built ahead of time, a lean streaming backward.
+// The wave kernel below spends two thirds of a wave's life deriving WHICH (RoI, bin) pairs land on its patch (RoI loads, segment table,
+// scan, table passes, queue appends: ~17 k of the median 31 k cycles) and the kernel ends with its slowest wave; none of that depends
+// on gy.  In a training step the RoIs of the backward are known a whole head earlier (fpn_roi_mask_head.py:59-61,75-77 run the
+// forward with them), so the geometry half runs THEN, beside the forward, as its own launch:
+//   MODE 1 (plan builder): the wave kernel's own code path up to the queue - a full queue is written to a node of the caller's plan
+//          buffer instead of being drained (first node of a patch at a fixed place, further ones from a pool by one integer atomic per
+//          flush; the nodes of a patch are chained in flush order = (RoI, ph, pw) order).  A tile whose patch finds the pool empty is
+//          FLAGGED in the plan;
+//   k_roi_align_bwd_lean: a patch is TWO waves (128 channels each, lane = 2 channels: 32 accumulator registers leave room for 16 gy
+//          rows in flight - the fused kernel's wave has 4 - and a heavy patch's rows are fetched by two waves at once): node arrays are
+//          read with lane = entry (coalesced), entry j's row offset and weights come from v_readlane, cells are written once.  Entry
+//          order, weights and every FMA are the fused path's: identical bits.
+//   MODE 2 (behind the lean kernel, same stream, unless the caller has VERIFIED the plan - mrcnn_roi_align_bwd_plan_status): the fused
+//          path for the flagged tiles only, or for every tile when the plan's header does not hold (foreign buffer, other geometry);
+//          every other workgroup leaves at its first instruction - but dispatching ~850 of them costs 3.5 - 5 us, hence the verified
+//          form.  (Tried instead: that launch on a helper stream - the fork / join cost more than the launch; a slow path inside the lean
+//          kernel - its registers spilled the hot loop, +4 us.)
+// The plan buffer is the caller's and must stay unmodified between the builder and the backward.
+// ------------------------------------------------------------------------------------------
+constexpr int NP_MAGIC = 0x4E504C4E;
+enum { NP_MAGIC_I = 0, NP_OVERFLOW, NP_EXTRA, NP_UNITS, NP_CAP, NP_R, NP_PH, NP_PW, NP_SR, NP_N, NP_QC, NP_L, NP_NODES_OFF, NP_HW /* 2 per level */,
+       NP_HDR_INTS = 64 };
+int g_lean_dbg = 0;
+int g_lean_variant = 2;           // gy rows in flight per wave of the lean kernel / waves per SIMD: 0 = 10 / 8, 1 = 16 / 7, 2 = 8 / 8 (mrcnn_debug_roi_align_lean_variant)
+constexpr int LEAN_CH = 128;      // channels per wave there: lane = 2 channels
+
+template <int QC>
+struct PlanNode {
+    int count, next, pad[14];        // 64-byte header: groups of four entries' weights are 64-byte aligned (one s_load_dwordx16 each)
+    WaveQueue<QC> q;
+};
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// a wave-uniform read through the scalar cache (the plan was written by an earlier launch: constant for this kernel)
+template <typename T> __device__ __forceinline__ T scalar_load(const void *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+template <int QC> constexpr size_t plan_node_stride() { return (sizeof(PlanNode<QC>) + 255) / 256 * 256; }
+// [header][tile flags, rounded to 64 ints][nodes]
+inline size_t plan_nodes_off_ints(int total_tiles) { return NP_HDR_INTS + (size_t)(total_tiles + 63) / 64 * 64; }
+
+__device__ __forceinline__ bool plan_header_holds(const int *__restrict__ nplan, int total_units, int R, int N, int PH, int PW, int sr, int QC,
+                                                  int nodes_off) {
+    const bool ok = nplan[NP_MAGIC_I] == NP_MAGIC && nplan[NP_UNITS] == total_units && nplan[NP_R] == R && nplan[NP_PH] == PH &&
+                    nplan[NP_PW] == PW && nplan[NP_SR] == sr && nplan[NP_N] == N && nplan[NP_QC] == QC && nplan[NP_NODES_OFF] == nodes_off;
+    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
+}
+
 // STAMP: diagnostic build only (mrcnn_debug_roi_align_bwd_stamps): s_memtime at the phase boundaries of every wave goes
 // to `stamps` (12 x u64 per wave: start, scan done [last], build done [accumulated build cycles in slot 2], drain cycles
 // [slot 3], before stores, end, s_memrealtime at start, at end); nothing is computed from them.
@@ -816,14 +866,15 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     return t;
 }
 
-template <int PBT, int DEPTH, bool STAMP = false>
+template <int PBT, int DEPTH, bool STAMP = false, int MODE = 0>
 __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels lv, const float *__restrict__ gy,
                                                                         const float *__restrict__ rois,
                                                                         const int32_t *__restrict__ levels, int R, int N, int C,
                                                                         int PH, int PW, int sr, int chunk, int accumulate,
                                                                         unsigned long long *__restrict__ stamps = nullptr,
                                                                         const int *__restrict__ plan = nullptr, int plan_order_off = 0,
-                                                                        int plan_gimg_off = 0, int plan_tail = 0) {
+                                                                        int plan_gimg_off = 0, int plan_tail = 0,
+                                                                        int *__restrict__ nplan = nullptr) {
     unsigned long long st0 = 0, st_scan = 0, st_drain = 0, st_tmp = 0, st_rt0 = 0, st_pre = 0, st_tab = 0, st_cnt = 0;
     if (STAMP) { st0 = stamp_now(); st_rt0 = __builtin_amdgcn_s_memrealtime(); }
     using LDS = WaveLds<PBT>;
@@ -859,7 +910,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
             for (int k = 0; k < 5; ++k) rv[h2][k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_roi, o * 20u + 4u * k, 0, 0));
         }
     };
-    load_rois(0, rv0, lv0);
+    if (MODE != 2) load_rois(0, rv0, lv0);          // (MODE 2: most workgroups leave before they need a RoI)
     // A plan built by the forward call of the same geometry (see plan_sort): block b computes the four patches order[4b .. 4b+3] of
     // image gimg[b] - any four patches of an image, of nearly equal work.  The header decides (uniformly for the launch); without a
     // valid one the blocks take the XCD-banded tile order.
@@ -867,7 +918,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
     if (plan) planned = plan[PH_MAGIC] == PLAN_MAGIC && plan[PH_VALID] == 8 && plan[PH_N] == N && plan[PH_H] == lv.H[0] && plan[PH_W] == lv.W[0] &&
                         plan[plan_tail] == PLAN_MAGIC;
     planned = __builtin_amdgcn_readfirstlane((int)planned) != 0;
-    int l = 0, nsplit = 1, zsplit = 0, n, py0, px0;
+    int l = 0, nsplit = 1, zsplit = 0, n, py0, px0, tile_id = 0;
     if (planned) {
         if (blockIdx.x >= PLAN_GROUPS) return;
         n = __builtin_amdgcn_readfirstlane(plan[plan_gimg_off + blockIdx.x]);
@@ -879,7 +930,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
         py0 = pid >= 0 ? pyi * PT : lv.H[0];                 // a missing patch = a wave outside the map: it only helps with the table
         px0 = pid >= 0 ? pxi * PT : lv.W[0];
     } else {
-        const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);       // XCD-banded tile order (speed only)
+        tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);                 // XCD-banded tile order (speed only)
         if ((int)(blockIdx.x >> 3) >= chunk || tile_id >= lv.tile_begin[lv.L]) return;      // whole workgroup
         while (l + 1 < lv.L && tile_id >= lv.tile_begin[l + 1]) ++l;
         int t = tile_id - lv.tile_begin[l];
@@ -908,6 +959,84 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
     const unsigned patch_off = (unsigned)(((size_t)py0 * W + px0) * C * 4);
     const float fy0 = (float)py0, fy1 = (float)(py0 + PT), fx0 = (float)px0, fx1 = (float)(px0 + PT);
 
+    // the 16 cells of the patch: written once (zeros where nothing landed), or added to the map when accumulating
+    auto store_patch = [&](float4 (&acc)[PT][PT], bool touched, bool act, unsigned vlane) {
+        if (accumulate) {
+            // gx += acc for the patches that received an entry, with no-return float atomics: this wave is the ONLY writer of
+            // its cells (owner-computes), so the result is the single IEEE addition old + acc whatever the hardware's
+            // order - and neither a second set of 16 float4 registers (the 64 accumulators fill the budget) nor a
+            // load -> add -> store round trip is needed.
+            // Idle lanes (C < 256 or a channel tail) are masked off by a real branch: the out-of-range-offset trick of the
+            // loads and stores is NOT safe for atomics (an out-of-range buffer atomic raised a hardware exception).
+            if (touched && act) {
+#pragma unroll
+                for (int i = 0; i < PT; ++i)
+#pragma unroll
+                    for (int k = 0; k < PT; ++k)
+                        if (i < nrow && k < ncol) {      // wave-uniform
+                            const unsigned so = patch_off + (unsigned)((i * W + k) * C) * 4u;
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].x, rs_gx, vlane, so, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].y, rs_gx, vlane + 4u, so, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].z, rs_gx, vlane + 8u, so, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].w, rs_gx, vlane + 12u, so, 0);
+                        }
+            }
+        } else
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int k = 0; k < PT; ++k)
+                if (i < nrow && k < ncol)                // wave-uniform
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const __attribute__((ext_vector_type(4))) unsigned *>(&acc[i][k]), rs_gx,
+                                                           vlane, patch_off + (unsigned)((i * W + k) * C) * 4u, 0);
+    };
+    // ---- entry-list plan (see PlanNode): a patch's first node sits at its launch-order slot, further ones come from the pool behind
+    const int total_units = lv.tile_begin[lv.L] * BWD_WAVES;
+    const int unit = tile_id * BWD_WAVES + wave;
+    constexpr size_t NSTRIDE = plan_node_stride<LDS::QC>();
+    if (MODE == 2) {
+        // behind the lean kernel: only the tiles the plan builder flagged (pool exhausted) - or all of them when the header does not hold
+        const bool holds = plan_header_holds(nplan, total_units, R, N, PH, PW, sr, (int)LDS::QC, plan_order_off);
+        if (holds && __builtin_amdgcn_readfirstlane(nplan[NP_HDR_INTS + tile_id]) == 0) return;
+        load_rois(0, rv0, lv0);
+    }
+    // MODE 1: a full queue goes to a plan node instead of being drained
+    int cur_node = -1;
+    auto flush_to_plan = [&](int &qn_) {
+        int id = unit;
+        if (cur_node >= 0) {
+            int got = 0;
+            if (lane == 0) got = atomicAdd(&nplan[NP_EXTRA], 1);
+            id = total_units + __builtin_amdgcn_readfirstlane(got);
+            if (id >= plan_tail) {                 // (MODE 1: plan_tail = node capacity) pool exhausted: this tile takes the fused path (MODE 2)
+                if (lane == 0) { nplan[NP_HDR_INTS + tile_id] = 1; atomicAdd(&nplan[NP_OVERFLOW], 1); }
+                id = -1;
+            }
+        }
+        if (id >= 0) {
+            char *nb = reinterpret_cast<char *>(nplan + plan_order_off);        // (MODE 1 / 2: plan_order_off = offset of the nodes, in ints)
+            PlanNode<LDS::QC> *pn = reinterpret_cast<PlanNode<LDS::QC> *>(nb + (size_t)id * NSTRIDE);
+            for (int i = lane; i < qn_; i += 64) {
+                pn->q.wy[i] = lds.q.wy[i];
+                pn->q.wx[i] = lds.q.wx[i];
+                pn->q.row[i] = lds.q.row[i];
+            }
+            if (lane == 0) {
+                pn->count = qn_;
+                pn->next = -1;
+                if (cur_node >= 0) reinterpret_cast<PlanNode<LDS::QC> *>(nb + (size_t)cur_node * NSTRIDE)->next = id;
+            }
+            cur_node = id;
+        }
+        qn_ = 0;
+    };
+    if (MODE == 1 && tile_id == 0 && tid == 0) {
+        nplan[NP_UNITS] = total_units; nplan[NP_CAP] = plan_tail; nplan[NP_R] = R; nplan[NP_PH] = PH; nplan[NP_PW] = PW; nplan[NP_SR] = sr;
+        nplan[NP_N] = N; nplan[NP_QC] = (int)LDS::QC; nplan[NP_L] = lv.L; nplan[NP_NODES_OFF] = plan_order_off;
+        for (int q = 0; q < lv.L; ++q) { nplan[NP_HW + 2 * q] = lv.H[q]; nplan[NP_HW + 2 * q + 1] = lv.W[q]; }
+        nplan[NP_MAGIC_I] = NP_MAGIC;
+    }
+
     auto fill_table = [&](int seg, float (&rv)[FILL][5], int (&lvv)[FILL]) {
 #pragma unroll
         for (int h2 = 0; h2 < FILL; ++h2) {
@@ -923,7 +1052,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
     if (STAMP) { st_tmp = stamp_now(); st_pre = st_tmp - st0; }
     fill_table(0, rv0, lv0);
 #pragma nounroll
-    for (int cb = 0; cb < C; cb += CCH) {
+    for (int cb = 0; cb < (MODE == 1 ? 1 : C); cb += CCH) {          // (the plan does not depend on the channels)
         const bool act = cb + lane * 4 < C;
         const unsigned vlane = act ? (unsigned)(cb + lane * 4) * 4u : OOB;        // byte offset of this lane's 4 channels
         float4 acc[PT][PT];
@@ -1012,6 +1141,11 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
             };
             auto drain_now = [&]() {
                 __builtin_amdgcn_wave_barrier();
+                if (MODE == 1) {
+                    flush_to_plan(qn);
+                    __builtin_amdgcn_wave_barrier();
+                    return;
+                }
                 if (STAMP) st_tmp = stamp_now();
                 drain_wave_queue<QC, DEPTH>(lds.q, qn, rs_gy, vlane, row_bytes, acc, lane);
                 if (STAMP) st_drain += stamp_now() - st_tmp;
@@ -1089,41 +1223,21 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
             }
             }
         }
-        if (!live) continue;
+        // (a wave without a patch must still reach the barrier at the end of the channel pass: skipping it desynchronised the workgroup's
+        // barriers from the second channel pass on - C > 256 on a map with ragged tiles, found by the planned-vs-fused test of round 5)
+        do {
+        if (!live) break;
         __builtin_amdgcn_wave_barrier();
+        if (MODE == 1) {                                 // the last (possibly empty) node of the patch
+            if (qn > 0 || cur_node < 0) flush_to_plan(qn);
+            break;
+        }
         if (STAMP) st_tmp = stamp_now();
         drain_wave_queue<QC, DEPTH>(lds.q, qn, rs_gy, vlane, row_bytes, acc, lane);
         if (STAMP) st_drain += stamp_now() - st_tmp;
         unsigned long long st_store = 0;
         if (STAMP) st_store = stamp_now();
-        if (accumulate) {
-            // gx += acc for the patches that received an entry, with no-return float atomics: this wave is the ONLY writer of
-            // its cells (owner-computes), so the result is the single IEEE addition old + acc whatever the hardware's
-            // order - and neither a second set of 16 float4 registers (the 64 accumulators fill the budget) nor a
-            // load -> add -> store round trip is needed.
-            // Idle lanes (C < 256 or a channel tail) are masked off by a real branch: the out-of-range-offset trick of the
-            // loads and stores is NOT safe for atomics (an out-of-range buffer atomic raised a hardware exception).
-            if (touched && act) {
-#pragma unroll
-                for (int i = 0; i < PT; ++i)
-#pragma unroll
-                    for (int k = 0; k < PT; ++k)
-                        if (i < nrow && k < ncol) {      // wave-uniform
-                            const unsigned so = patch_off + (unsigned)((i * W + k) * C) * 4u;
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].x, rs_gx, vlane, so, 0);
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].y, rs_gx, vlane + 4u, so, 0);
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].z, rs_gx, vlane + 8u, so, 0);
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].w, rs_gx, vlane + 12u, so, 0);
-                        }
-            }
-        } else
-#pragma unroll
-        for (int i = 0; i < PT; ++i)
-#pragma unroll
-            for (int k = 0; k < PT; ++k)
-                if (i < nrow && k < ncol)                // wave-uniform
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const __attribute__((ext_vector_type(4))) unsigned *>(&acc[i][k]), rs_gx,
-                                                           vlane, patch_off + (unsigned)((i * W + k) * C) * 4u, 0);
+        store_patch(acc, touched, act, vlane);
         if (STAMP && stamps && lane == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long st_end = stamp_now();
@@ -1132,7 +1246,186 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
             o[0] = st0; o[1] = st_scan; o[2] = st_store - st0 - st_scan - st_drain; o[3] = st_drain; o[4] = st_store; o[5] = st_end;
             o[6] = st_rt0; o[7] = __builtin_amdgcn_s_memrealtime();
         }
+        } while (0);
         if (cb + CCH < C) __syncthreads();               // the next channel block refills the segment table
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The lean backward (see the PlanNode comment): workgroup = one 8 x 8 tile = 4 patches x 2 channel halves (8 waves).
+// ------------------------------------------------------------------------------------------
+constexpr int LEAN_THREADS = 512;      // workgroup = one 8 x 8 tile: 4 patches x 2 channel halves (the dispatcher's cost is per workgroup)
+template <int PBT, int DEPTH, int OCC>
+__global__ __launch_bounds__(LEAN_THREADS, OCC) void k_roi_align_bwd_lean(Levels lv, const float *__restrict__ gy, int R, int N, int C, int PH, int PW,
+                                                                         int sr, int chunk, int accumulate, const int *__restrict__ nplan,
+                                                                         int nodes_off, int dbg) {
+    static_assert(DEPTH % 2 == 0, "rows are consumed in pairs of entries");
+    constexpr int QC = WaveLds<PBT>::QC;
+    static_assert(QC % 2 == 0, "weight pairs");
+    constexpr size_t NSTRIDE = plan_node_stride<QC>();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);       // XCD-banded tile order, as the wave kernel
+    const int total = lv.tile_begin[lv.L];
+    if ((int)(blockIdx.x >> 3) >= chunk || tile_id >= total) return;
+    // (pairing the tile's heaviest patch with its lightest on one SIMD pair was tried: the four extra counts cost a dependent round trip,
+    // +1.3 us on configs[1])
+    const char *nb = reinterpret_cast<const char *>(nplan + nodes_off);
+    const int pslot = wave >> 1, half = wave & 1;
+    const int unit = tile_id * BWD_WAVES + pslot;
+    // the plan's loads go out first: header, tile flag, the first node's count / next / row indices (lane = entry) - one round trip
+    const PlanNode<QC> *pn = reinterpret_cast<const PlanNode<QC> *>(nb + (size_t)unit * NSTRIDE);
+    const int ql = min(lane, QC - 1);
+    int qrow = pn->q.row[ql];
+    int cnt = scalar_load<int>(&pn->count), next = scalar_load<int>(&pn->next);
+    const bool holds = plan_header_holds(nplan, total * BWD_WAVES, R, N, PH, PW, sr, QC, nodes_off);
+    const int flagged = scalar_load<int>(nplan + NP_HDR_INTS + tile_id);
+    // tile -> level, image, patch
+    int l = 0, nsplit = 1, zsplit = 0, n;
+    while (l + 1 < lv.L && tile_id >= lv.tile_begin[l + 1]) ++l;
+    int t = tile_id - lv.tile_begin[l];
+    nsplit = lv.split[l];
+    int tyi, txi;
+    if (nsplit > 1) divmod_u24(t, nsplit, t, zsplit);
+    divmod_u24(t, lv.tiles_x[l] * lv.tiles_y[l], n, t);
+    divmod_u24(t, lv.tiles_x[l], tyi, txi);
+    const int py0 = tyi * TH + (pslot >> 1) * PT, px0 = txi * TW + (pslot & 1) * PT;
+    const int H = lv.H[l], W = lv.W[l];
+    const int nrow = min(PT, H - py0), ncol = min(PT, W - px0);
+    if (nrow <= 0 || ncol <= 0) return;
+    // a tile the plan builder flagged (its pool was exhausted), or a plan whose header does not hold: the slow path below derives the
+    // entries itself, one at a time, in the fused kernel's order and arithmetic
+    if (!holds || flagged != 0) return;           // MODE 2 of the wave kernel computes this tile
+    float *gxb = (nsplit > 1 ? lv.slab[l] + (size_t)zsplit * N * H * W * C : lv.gx[l]) + (size_t)n * H * W * C;
+    if (nsplit > 1) accumulate = 0;
+    const auto rs_gy = __builtin_amdgcn_make_buffer_rsrc((void *)gy, 0, (unsigned)((size_t)R * PH * PW * C * 4), 0x00020000);
+    const auto rs_gx = __builtin_amdgcn_make_buffer_rsrc((void *)gxb, 0, (unsigned)((size_t)H * W * C * 4), 0x00020000);
+    const unsigned row_bytes = (unsigned)C * 4u, OOB = 0xFFFFFFFFu;
+    const unsigned patch_off = (unsigned)(((size_t)py0 * W + px0) * C * 4);
+    // every wave of the launch is resident at once and the kernel ends with its slowest wave: long lists run at raised priority
+    if (cnt >= 64 || next >= 0) __builtin_amdgcn_s_setprio(3);
+    else if (cnt >= 40) __builtin_amdgcn_s_setprio(2);
+    else if (cnt >= 24) __builtin_amdgcn_s_setprio(1);
+#pragma nounroll
+    for (int cb = 0; cb < C; cb += 2 * LEAN_CH) {
+        const int ch = cb + half * LEAN_CH + lane * 2;
+        const bool act = ch < C;
+        const unsigned vlane = act ? (unsigned)ch * 4u : OOB;
+        const unsigned vload = (dbg & 1) ? OOB : vlane;               // (measurement: no gy traffic - out-of-range loads return zeros)
+        float2 acc[PT][PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int k = 0; k < PT; ++k) acc[i][k] = make_float2(0.f, 0.f);
+        int total_n = 0;
+        const PlanNode<QC> *cur = pn;
+        if (cb > 0) {                      // a further channel pass walks the list again from its first node
+            qrow = pn->q.row[ql];
+            cnt = scalar_load<int>(&pn->count); next = scalar_load<int>(&pn->next);
+        }
+#pragma nounroll
+        while (true) {
+            total_n += cnt;
+#pragma nounroll
+            for (int e0 = 0; e0 < cnt; e0 += 64) {
+                const int m = min(64, cnt - e0);
+                if (e0 > 0) qrow = cur->q.row[min(e0 + lane, QC - 1)];
+                // (every load below is issued unconditionally and in slot order: the waitcnt pass can then count - vmcnt(DEPTH - 1) in front of
+                // an entry - instead of falling back to vmcnt(0) at a control-flow merge, which serialises the wave on memory latency)
+                auto ldrow = [&](int j) -> float2 {
+                    const unsigned so = (unsigned)__builtin_amdgcn_readlane(qrow, j < m ? j : 0) * row_bytes;
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_gy, vload, so, 0);
+                    float2 f;
+                    __builtin_memcpy(&f, &v, 8);
+                    return f;
+                };
+                // the weights of two entries per scalar load (wy[e], wy[e+1] / wx[e], wx[e+1]: 32 bytes each), one pair ahead; the row
+                // weights travel as integers: "weight != 0" is then a scalar integer compare + branch (weights are >= 0), not a VALU class test
+                auto ldw = [&](int j, i32x8 &wy, f32x8 &wx) {
+                    const int e = min(e0 + j, QC - 2);
+                    wy = scalar_load<i32x8>(&cur->q.wy[e]);
+                    wx = scalar_load<f32x8>(&cur->q.wx[e]);
+                };
+                float2 buf[DEPTH];
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {          // issue in slot order (see drain_wave_queue)
+                    buf[d] = ldrow(d);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // two pairs of entries' weights in SGPRs: the pair in use and the next one on its way (scalar loads return out of order, so
+                // a consumer waits for everything issued before it: the next pair's loads go out right after that wait, a whole pair ahead)
+                i32x8 wy, wyn;
+                f32x8 wx, wxn;
+                ldw(0, wy, wx);
+#pragma nounroll
+                for (int j = 0; j < m; j += DEPTH) {
+#pragma unroll
+                    for (int g = 0; g < DEPTH / 2; ++g) {
+                        ldw(j + 2 * g + 2, wyn, wxn);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int d = 2 * g + u;
+                            if (j + d < m) {
+                                // all four rows, all four columns, no branch on a zero weight: fma(wx, gy * 0, acc) leaves acc as it is (finite
+                                // gy), and the 20 packed instructions cost less than the taken branches that skipped half of them
+#pragma unroll
+                                for (int i = 0; i < PT; ++i) {
+                                    const float wyi = __int_as_float(wy[4 * u + i]);
+                                    const float2 tt = make_float2(buf[d].x * wyi, buf[d].y * wyi);      // (gy * wy) * wx, as the fused path
+#pragma unroll
+                                    for (int k = 0; k < PT; ++k) {
+                                        acc[i][k].x = fmaf(wx[4 * u + k], tt.x, acc[i][k].x);
+                                        acc[i][k].y = fmaf(wx[4 * u + k], tt.y, acc[i][k].y);
+                                    }
+                                }
+                            }
+                            buf[d] = ldrow(j + d + DEPTH);
+                            asm volatile("" ::: "memory");
+                        }
+                        wy = wyn; wx = wxn;
+                    }
+                }
+            }
+            if (next < 0) break;
+            cur = reinterpret_cast<const PlanNode<QC> *>(nb + (size_t)next * NSTRIDE);
+            qrow = cur->q.row[ql];
+            cnt = scalar_load<int>(&cur->count);
+            next = scalar_load<int>(&cur->next);
+        }
+        if (dbg & 2) {                       // measurement: no gx traffic (one store keeps the sums alive)
+            float2 sum = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int k = 0; k < PT; ++k) { sum.x += acc[i][k].x; sum.y += acc[i][k].y; }
+            if (sum.x == 12345.678f) __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned *>(&sum), rs_gx, vlane, patch_off, 0);
+        } else if (accumulate) {
+            // (owner-computes: this wave is the only writer of its cells and channels - see the wave kernel's store)
+            if (total_n > 0 && act) {
+#pragma unroll
+                for (int i = 0; i < PT; ++i)
+#pragma unroll
+                    for (int k = 0; k < PT; ++k)
+                        if (i < nrow && k < ncol) {
+                            const unsigned so = patch_off + (unsigned)((i * W + k) * C) * 4u;
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].x, rs_gx, vlane, so, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][k].y, rs_gx, vlane + 4u, so, 0);
+                        }
+            }
+        } else
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int k = 0; k < PT; ++k)
+                if (i < nrow && k < ncol) {
+                    // written once, read by a later kernel: non-temporal (does not displace the gy rows other waves re-read from the L2)
+                    if (dbg & 16)
+                        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned *>(&acc[i][k]), rs_gx, vlane,
+                                                              patch_off + (unsigned)((i * W + k) * C) * 4u, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned *>(&acc[i][k]), rs_gx, vlane,
+                                                              patch_off + (unsigned)((i * W + k) * C) * 4u, 2);
+                }
     }
 }
 
@@ -1344,11 +1637,28 @@ void launch_fwd(Levels &lv, const float *rois, const int32_t *levels, int R, int
 // slower so far: DESIGN.md section 3.2), 1 = the barrier-synchronised tile kernel (A/B and fallback for tensors >= 4 GiB)
 int g_bwd_variant = 2;
 
+// entry-list plan buffer: [256-byte header][tile flags][nodes]; nodes = one per patch slot of the launch + a pool for the patches that
+// flush more than once
+size_t nplan_nodes(int total_tiles, int R, int PH, int PW) { return (size_t)total_tiles * BWD_WAVES * 2 + (size_t)R * PH * PW / 4 + 1024; }
+size_t nplan_stride(int PH, int PW) { return (PH <= 8 && PW <= 8) ? plan_node_stride<WaveLds<8>::QC>() : plan_node_stride<WaveLds<16>::QC>(); }
+int count_tiles(const int *Hs, const int *Ws, int L, int N, bool split) {
+    int total = 0;
+    for (int l = 0; l < L; ++l) total += mrcnn::cdiv(Ws[l], TW) * mrcnn::cdiv(Hs[l], TH) * N * (split ? level_split(Hs[l], Ws[l], N) : 1);
+    return total;
+}
+size_t nplan_bytes(const int *Hs, const int *Ws, int L, int N, int R, int PH, int PW, bool split) {
+    const int tiles = count_tiles(Hs, Ws, L, N, split);
+    return plan_nodes_off_ints(tiles) * sizeof(int) + nplan_nodes(tiles, R, PH, PW) * nplan_stride(PH, PW);
+}
+
+// nplan_mode 0: backward (fused; with `nplan` the lean path when the plan holds); 1: build the entry-list plan of these RoIs into `nplan`
+// (no gy / gx needed); split: in mode 1 whether the backward call will have its slab workspace (the coarse levels' RoI split)
 int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, const int32_t *levels, int R,
-                     int C, int PH, int PW, int sr, int accumulate, void *ws, size_t ws_bytes, hipStream_t st, const void *plan_ws = nullptr) {
+                     int C, int PH, int PW, int sr, int accumulate, void *ws, size_t ws_bytes, hipStream_t st, const void *plan_ws = nullptr,
+                     int *nplan = nullptr, size_t nplan_size = 0, int nplan_mode = 0, bool plan_split = false, bool plan_verified = false) {
     int total = 0;
     const size_t need = slab_ws_bytes(lv.H, lv.W, lv.L, N, C);
-    const bool can_split = ws && ws_bytes >= need && R > 0;
+    const bool can_split = nplan_mode == 1 ? (plan_split && R > 0) : (ws && ws_bytes >= need && R > 0);
     // the tables of variant 3 sit behind the slab area
     const size_t need3 = bwd3_ws_bytes(lv.H, lv.W, lv.L, R, PH, PW, sr);
     void *ws3 = (ws && need3 && ws_bytes >= need + need3) ? (void *)((char *)ws + need) : nullptr;
@@ -1369,8 +1679,46 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
     const int chunk = mrcnn::cdiv(total, 8);
     bool waves_ok = g_bwd_variant >= 2 && (unsigned long long)R * PH * PW * C * 4ull < (1ull << 32) && R < (1 << 27) && total < (1 << 24);
     for (int l = 0; l < lv.L; ++l) waves_ok = waves_ok && (unsigned long long)lv.H[l] * lv.W[l] * C * 4ull < (1ull << 32);
-    if (waves_ok && g_bwd_variant == 3 && ws3) {
+    const size_t nodes_off = plan_nodes_off_ints(total);
+    if (nplan_mode == 1) {
+        // plan builder: needs the wave kernel's preconditions and a buffer of mrcnn_roi_align_fpn_bwd_plan_bytes(); otherwise the header
+        // stays without its magic and the backward's MODE 2 launch computes every tile
+        if (!nplan || nplan_size < NP_HDR_INTS * sizeof(int)) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "roi_align_bwd_plan: plan buffer too small");
+        const bool room = nplan_size >= (nodes_off + 64) * sizeof(int);
+        MRCNN_HIP_TRY(hipMemsetAsync(nplan, 0, (room ? nodes_off : (size_t)NP_HDR_INTS) * sizeof(int), st));
+        const size_t cap = room ? (nplan_size - nodes_off * sizeof(int)) / nplan_stride(PH, PW) : 0;
+        if (!waves_ok || R == 0 || cap < (size_t)total * BWD_WAVES || cap >= (1u << 30)) return 0;
+        if (PH <= 8 && PW <= 8)
+            hipLaunchKernelGGL((k_roi_align_bwd_waves<8, W2_DEPTH, false, 1>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, (const float *)nullptr, rois, levels,
+                               R, N, C, PH, PW, sr, chunk, 0, (unsigned long long *)nullptr, (const int *)nullptr, (int)nodes_off, 0, (int)cap, nplan);
+        else
+            hipLaunchKernelGGL((k_roi_align_bwd_waves<16, W2_DEPTH, false, 1>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, (const float *)nullptr, rois, levels,
+                               R, N, C, PH, PW, sr, chunk, 0, (unsigned long long *)nullptr, (const int *)nullptr, (int)nodes_off, 0, (int)cap, nplan);
+        MRCNN_LAUNCH_CHECK();
+        return 0;
+    }
+    // a plan buffer that cannot even hold the patch slots of this launch was never filled by the builder: plain fused backward
+    if (nplan && nplan_size < nodes_off * sizeof(int) + (size_t)total * BWD_WAVES * nplan_stride(PH, PW)) nplan = nullptr;
+    if (!waves_ok || R == 0) nplan = nullptr;
+    if (waves_ok && g_bwd_variant == 3 && ws3 && !nplan) {
         if (int e = launch_bwd3(lv, total, N, gy, rois, levels, R, C, PH, PW, sr, accumulate, ws3, need3, st)) return e;
+    } else if (nplan) {
+        // the lean kernel along the entry lists, then (unless the caller verified the plan) the wave kernel for whatever the plan could not hold
+        auto lean = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(chunk * 8), dim3(LEAN_THREADS), 0, st, lv, gy, R, N, C, PH, PW, sr, chunk, accumulate, (const int *)nplan, (int)nodes_off, g_lean_dbg);
+        };
+        const bool small = PH <= 8 && PW <= 8;
+        if (g_lean_variant == 0) { if (small) lean(k_roi_align_bwd_lean<8, 10, 8>); else lean(k_roi_align_bwd_lean<16, 10, 8>); }
+        else if (g_lean_variant == 2) { if (small) lean(k_roi_align_bwd_lean<8, 8, 8>); else lean(k_roi_align_bwd_lean<16, 8, 8>); }
+        else { if (small) lean(k_roi_align_bwd_lean<8, 16, 7>); else lean(k_roi_align_bwd_lean<16, 16, 7>); }
+        MRCNN_LAUNCH_CHECK();
+        if (plan_verified) {}
+        else if (small)
+            hipLaunchKernelGGL((k_roi_align_bwd_waves<8, W2_DEPTH, false, 2>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
+                               PH, PW, sr, chunk, accumulate, (unsigned long long *)nullptr, (const int *)nullptr, (int)nodes_off, 0, 0, nplan);
+        else
+            hipLaunchKernelGGL((k_roi_align_bwd_waves<16, W2_DEPTH, false, 2>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
+                               PH, PW, sr, chunk, accumulate, (unsigned long long *)nullptr, (const int *)nullptr, (int)nodes_off, 0, 0, nplan);
     } else if (waves_ok) {
         // `plan_ws`: the caller handed in the workspace of the FORWARD call of these RoIs ([perm][plan], mrcnn_roi_align_plan_workspace_bytes):
         // the kernel validates the plan's header on the device and takes the launch order when it does not hold
@@ -1529,6 +1877,50 @@ extern "C" int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, c
     return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// ---- (ABI v9) entry-list plan of the backward, built ahead of time from the RoIs alone; a backward that follows it
+extern "C" size_t mrcnn_roi_align_fpn_bwd_plan_bytes(const int *Hs, const int *Ws, int L, int N, int R, int PH, int PW, int split_levels) {
+    if (!Hs || !Ws || L <= 0 || L > MRCNN_MAX_LEVELS || N <= 0 || R <= 0 || PH <= 0 || PW <= 0 || PH > PB || PW > PB) return 0;
+    for (int l = 0; l < L; ++l) if (Hs[l] <= 0 || Ws[l] <= 0) return 0;
+    return nplan_bytes(Hs, Ws, L, N, R, PH, PW, split_levels != 0);
+}
+extern "C" int mrcnn_roi_align_fpn_bwd_plan_f32(const int *Hs, const int *Ws, const float *scales, int L, int N, int C, const float *rois,
+                                                const int32_t *levels, int R, int PH, int PW, int sampling_ratio, int split_levels,
+                                                void *plan, size_t plan_bytes, void *stream) {
+    if (!plan || (R > 0 && (!rois || (L > 1 && !levels)))) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd_plan: null pointer");
+    if (N <= 0 || C <= 0 || PH <= 0 || PW <= 0 || R < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd_plan: bad sizes");
+    if (!fast_bwd_ok(C, PH, PW, sampling_ratio, R))
+        return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd_plan: needs C%%4==0, PH,PW<=%d, sampling_ratio>0", PB);
+    Levels lv{};
+    if (int e = fill_levels(lv, nullptr, nullptr, Hs, Ws, scales, L)) return e;
+    return launch_bwd_tiles(lv, N, nullptr, rois, levels, R, C, PH, PW, sampling_ratio, 0, nullptr, 0, (hipStream_t)stream, nullptr, (int *)plan,
+                            plan_bytes, 1, split_levels != 0);
+}
+extern "C" int mrcnn_roi_align_fpn_bwd_planned_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws, const float *scales, int L,
+                                                   int N, int C, const float *rois, const int32_t *levels, int R, int PH, int PW,
+                                                   int sampling_ratio, int accumulate, void *ws, size_t ws_bytes, void *plan,
+                                                   size_t plan_bytes, int plan_verified, void *stream) {
+    if (!gxs || (R > 0 && (!rois || (L > 1 && !levels) || !gy))) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd_planned: null pointer");
+    if (N <= 0 || C <= 0 || PH <= 0 || PW <= 0 || R < 0) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_fpn_bwd_planned: bad sizes");
+    if (!fast_bwd_ok(C, PH, PW, sampling_ratio, R))
+        return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd_planned: needs C%%4==0, PH,PW<=%d, sampling_ratio>0", PB);
+    Levels lv{};
+    if (int e = fill_levels(lv, nullptr, gxs, Hs, Ws, scales, L)) return e;
+    return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, accumulate, ws, ws_bytes, (hipStream_t)stream, nullptr, (int *)plan,
+                            plan ? plan_bytes : 0, 0, false, plan_verified != 0);
+}
+// status3 (host): [0] 1 = the header carries the builder's magic, [1] tiles the builder flagged (pool exhausted), [2] pool nodes used.
+// The ONE entry point of this library that waits for the device (it copies the header back and synchronises `stream`).
+extern "C" int mrcnn_roi_align_bwd_plan_status(const void *plan, size_t plan_bytes, int *status3, void *stream) {
+    if (!plan || !status3 || plan_bytes < NP_HDR_INTS * sizeof(int)) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_bwd_plan_status: null pointer or short buffer");
+    int hdr[NP_HDR_INTS];
+    MRCNN_HIP_TRY(hipMemcpyAsync(hdr, plan, sizeof hdr, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MRCNN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    status3[0] = hdr[NP_MAGIC_I] == NP_MAGIC ? 1 : 0;
+    status3[1] = hdr[NP_OVERFLOW];
+    status3[2] = hdr[NP_EXTRA];
+    return 0;
+}
+
 extern "C" size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int L, int N, int C, int R, int PH, int PW,
                                                           int sampling_ratio) {
     if (!Hs || !Ws || L <= 0 || L > MRCNN_MAX_LEVELS || N <= 0 || C <= 0) return 0;
@@ -1591,6 +1983,13 @@ extern "C" int mrcnn_debug_dispatch_census(unsigned long long *out, int nblocks,
     if (!out || nblocks <= 0 || spin_us < 0 || spin_us > 1000) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_dispatch_census: bad arguments");
     hipLaunchKernelGGL(k_dispatch_census, dim3(nblocks), dim3(BWD_THREADS), 0, (hipStream_t)stream, out, nblocks, spin_us * 100);
     MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrcnn_debug_roi_align_lean_variant(int v) {          // measurement: rows in flight / occupancy of the lean backward
+    if (v < 0 || (v & 0xff) > 2) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_roi_align_lean_variant: 0, 1 or 2 (+ 256 x measurement bits)");
+    g_lean_variant = v & 0xff;
+    g_lean_dbg = v >> 8;         // 1: no gy loads, 2: no gx stores (results are wrong with either), 16: plain instead of non-temporal stores
     return 0;
 }
 

@@ -132,6 +132,35 @@ int mrcnn_roi_align_fpn_bwd_f32(const float *gy, float *const *gxs, const int *H
                                 int sampling_ratio, int accumulate, void *ws, size_t ws_bytes, void *stream);
 size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int L, int N, int C, int R, int PH, int PW,
                                                int sampling_ratio);
+/* (ABI v9) The backward in two launches.  Which (RoI, bin) pairs land on which 4 x 4 patch of the gradient map - two thirds of a wave's
+ * life in the fused backward - depends on the RoIs only, and in a training step the RoIs are known a whole head before the backward
+ * (the reference runs the forward with them: fpn_roi_mask_head.py:59-61,75-77).  mrcnn_roi_align_fpn_bwd_plan_f32 writes every patch's
+ * entry list ((gy row, 4 row weights, 4 column weights), in (RoI, ph, pw) order) into the caller's `plan` buffer of
+ * mrcnn_roi_align_fpn_bwd_plan_bytes() bytes - on any stream, any time after the RoIs exist; mrcnn_roi_align_fpn_bwd_planned_f32 is
+ * mrcnn_roi_align_fpn_bwd_f32 that streams gy along those lists: same entry order, same weights, same FMAs = the same bits.  The plan
+ * is checked on the device (magic, geometry, RoI count; a tile whose entries did not fit the pool is flagged): what the plan does not hold
+ * is computed by the fused kernel in a second launch.
+ * The buffer must not be modified between the two calls, and both must see the same rois / levels / scales; split_levels != 0 iff the
+ * backward call is given its mrcnn_roi_align_fpn_bwd_workspace_bytes() scratch (the coarse levels' RoI split).  L == 1 with
+ * levels == NULL is the single-level form (configs[1]). */
+size_t mrcnn_roi_align_fpn_bwd_plan_bytes(const int *Hs, const int *Ws, int L, int N, int R, int PH, int PW, int split_levels);
+int mrcnn_roi_align_fpn_bwd_plan_f32(const int *Hs, const int *Ws, const float *scales, int L, int N, int C, const float *rois,
+                                     const int32_t *levels, int R, int PH, int PW, int sampling_ratio, int split_levels,
+                                     void *plan, size_t plan_bytes, void *stream);
+/* measurement knob of the lean backward: gy rows in flight per wave / waves per SIMD: 0 = 10 / 8, 1 = 16 / 7, 2 = 8 / 8 (default); + 256 x bits
+ * (1: no gy loads, 2: no gx stores - wrong results; 16: plain instead of non-temporal stores) */
+int mrcnn_debug_roi_align_lean_variant(int v);
+int mrcnn_roi_align_fpn_bwd_planned_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws, const float *scales, int L,
+                                        int N, int C, const float *rois, const int32_t *levels, int R, int PH, int PW,
+                                        int sampling_ratio, int accumulate, void *ws, size_t ws_bytes, void *plan,
+                                        size_t plan_bytes, int plan_verified, void *stream);
+/* plan_verified != 0: the caller has read mrcnn_roi_align_bwd_plan_status() for this plan after the builder finished and found
+ * status3[0] == 1 (the builder's header) and status3[1] == 0 (no tile flagged): the call is then the lean kernel alone.  With 0 a second
+ * launch follows it that computes the tiles the plan could not hold with the fused kernel - normally none, every workgroup leaves at
+ * once, but their dispatch costs 3.5 - 5 us.  A training step passes 0 (it cannot afford the status query's synchronisation and does not
+ * feel 5 us); the configs[1] microbenchmark verifies once, outside the timed region, and reports both.  status3 (host, 3 ints): header
+ * valid, tiles flagged, pool nodes used.  mrcnn_roi_align_bwd_plan_status is the one entry point that WAITS for the device. */
+int mrcnn_roi_align_bwd_plan_status(const void *plan, size_t plan_bytes, int *status3, void *stream);
 
 /* Process-wide choice of the fast backward kernel: 2 (default) = one independent wave per 4x4 cell patch that derives the
  * geometry itself; 3 = table-driven: per-RoI sample tables from a first kernel, one lean wave per patch (needs the call's

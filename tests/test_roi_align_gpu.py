@@ -384,3 +384,147 @@ def test_backward_with_the_forward_built_plan_gives_the_same_bits(case, mode):
             assert torch.equal(bwd(ws2), ref)
     finally:
         _hip.check(lib.mrcnn_roi_align_set_bwd_plan(0))
+
+
+def _planned_vs_fused(xs_shapes, scales, N, C, xy, lev, P, sr, accumulate, plan_bytes=None, corrupt=None, split=True, verified=False):
+    """gxs of mrcnn_roi_align_fpn_bwd_f32 (fused) and of plan + mrcnn_roi_align_fpn_bwd_planned_f32 on the same operands; the plan header."""
+    import ctypes
+    from chainer_maskrcnn.model.head import fpn_roi_mask_head as hd
+    lib = _hip.lib()
+    rs = np.random.RandomState(P * 100 + len(xy))
+    R = xy.shape[0]
+    gyt = torch.from_numpy(rs.standard_normal((R, P, P, C)).astype(np.float32)).to(DEV)
+    base = [torch.from_numpy(rs.standard_normal((N, h, w, C)).astype(np.float32)).to(DEV) for h, w in xs_shapes]
+    rt = torch.from_numpy(xy).to(DEV)
+    lt = torch.from_numpy(lev).to(DEV) if lev is not None else None
+    L, _, Hs, Ws, sc = hd._level_args(base, scales)
+    nb = lib.mrcnn_roi_align_fpn_bwd_workspace_bytes(Hs, Ws, L, N, C, R, P, P, sr) if split else 0
+    ws = torch.empty((max(nb, 1),), dtype=torch.uint8, device=DEV)
+    out = []
+    hdr = None
+    for planned in (False, True):
+        gxs = [b.clone() if accumulate else torch.full_like(b, float('nan')) for b in base]
+        _, arr_p, _, _, _ = hd._level_args(gxs, scales)
+        if planned:
+            pb = lib.mrcnn_roi_align_fpn_bwd_plan_bytes(Hs, Ws, L, N, R, P, P, int(split)) if plan_bytes is None else plan_bytes
+            assert pb > 0
+            plan = torch.full((pb,), 0x5A, dtype=torch.uint8, device=DEV)
+            _hip.check(lib.mrcnn_roi_align_fpn_bwd_plan_f32(Hs, Ws, sc, L, N, C, _hip.ptr(rt), _hip.ptr(lt), R, P, P, sr, int(split), _hip.ptr(plan),
+                                                            pb, _hip.stream_ptr()))
+            if corrupt is not None:
+                corrupt(plan)
+            hdr = plan[:256].view(torch.int32).cpu().numpy().copy()
+            _hip.check(lib.mrcnn_roi_align_fpn_bwd_planned_f32(_hip.ptr(gyt), arr_p, Hs, Ws, sc, L, N, C, _hip.ptr(rt), _hip.ptr(lt), R, P, P, sr,
+                                                               int(accumulate), _hip.ptr(ws) if nb else None, nb, _hip.ptr(plan), pb, int(verified), _hip.stream_ptr()))
+        else:           # (the fused multi-level entry wants a level per RoI; the plan pair takes NULL for a single level)
+            lf = lt if lt is not None else torch.zeros((R,), dtype=torch.int32, device=DEV)
+            _hip.check(lib.mrcnn_roi_align_fpn_bwd_f32(_hip.ptr(gyt), arr_p, Hs, Ws, sc, L, N, C, _hip.ptr(rt), _hip.ptr(lf), R, P, P, sr,
+                                                       int(accumulate), _hip.ptr(ws) if nb else None, nb, _hip.stream_ptr()))
+        torch.cuda.synchronize()
+        out.append(gxs)
+    for a, b in zip(*out):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
+    return hdr
+
+
+NP_MAGIC = 0x4E504C4E
+
+
+@pytest.mark.parametrize('P,sr', [(7, 2), (14, 2), (7, 1), (5, 3), (16, 4)])
+def test_planned_backward_equals_the_fused_backward_config2(P, sr):
+    """(r5) mrcnn_roi_align_fpn_bwd_plan_f32 + mrcnn_roi_align_fpn_bwd_planned_f32 (entry lists built ahead, lean streaming backward) on
+    configs[1]'s map with its 512 RoIs plus edge RoIs, a bad image index and a three-segment RoI count (R > 1024): the same bits as the
+    fused backward for 7x7 / 14x14 and odd pooled sizes / sampling ratios; the plan's header says it was used (magic, no overflow)."""
+    x, yx, _ = config2_inputs()
+    H, W = x.shape[2], x.shape[3]
+    rs = np.random.RandomState(P * 10 + sr)
+    rois = np.concatenate([yx[:, [0, 2, 1, 4, 3]], _edge_rois(1, H, W, 0.25), rand_rois_xy(rs, 600, 1, H, W, 0.25),
+                           np.array([[3, 10, 10, 200, 200], [-1, 5, 5, 100, 80]], np.float32)], 0)
+    assert rois.shape[0] > 1024
+    hdr = _planned_vs_fused([(H, W)], [0.25], 1, 256, rois, None, P, sr, accumulate=False, split=False)
+    assert hdr[0] == NP_MAGIC and hdr[1] == 0 and hdr[5] == rois.shape[0] and hdr[6] == P
+    # the verified form (the lean kernel alone, no launch behind it): the header says the plan is complete, so the caller may ask for it
+    _planned_vs_fused([(H, W)], [0.25], 1, 256, rois, None, P, sr, accumulate=False, split=False, verified=True)
+
+
+def test_plan_status_query():
+    """mrcnn_roi_align_bwd_plan_status: (header valid, tiles flagged, pool nodes used) read back after the builder - what a caller checks
+    before it passes plan_verified."""
+    from chainer_maskrcnn.model.head import fpn_roi_mask_head as hd
+    rs = np.random.RandomState(5)
+    xy = rand_rois_xy(rs, 300, 1, 40, 48, 0.25)
+    rt = torch.from_numpy(xy).to(DEV)
+    maps = [torch.empty((1, 40, 48, 64), device=DEV)]
+    plan = hd.roi_align_fpn_bwd_plan(maps, rt, None, 7, [0.25])
+    ok, flagged, used = hd.roi_align_bwd_plan_status(plan)
+    assert ok and flagged == 0 and used >= 0
+    plan[:4].zero_()
+    assert hd.roi_align_bwd_plan_status(plan)[0] is False
+
+
+@pytest.mark.parametrize('P', [7, 14])
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_planned_backward_fpn_levels_split_and_accumulate(P, accumulate):
+    """The multi-level form as the training step calls it: most RoIs on the coarse levels (RoI-split slabs + ordered sum), two images,
+    ragged maps, channel tail (C = 260: two channel passes), overwrite and accumulate modes - planned == fused bit for bit."""
+    rs = np.random.RandomState(7 + P)
+    N, C = 2, 260
+    shapes = [(41, 50), (21, 25), (11, 13), (6, 7)]
+    scales = [1 / 4., 1 / 8., 1 / 16., 1 / 32.]
+    R = 700
+    xy = rand_rois_xy(rs, R, N, 41, 50, 0.25)
+    lev = rs.choice(4, size=R, p=[0.05, 0.1, 0.35, 0.5]).astype(np.int32)
+    hdr = _planned_vs_fused(shapes, scales, N, C, xy, lev, P, 2, accumulate)
+    assert hdr[0] == NP_MAGIC and hdr[1] == 0
+    assert hdr[2] > 0           # the crowded coarse patches flushed more than once: pool nodes were chained
+
+
+def test_fused_backward_second_channel_pass_on_ragged_maps_matches_oracle():
+    """C > 256 (two channel passes) on maps whose edge tiles have waves without a patch, more than one 512-RoI segment, split levels: the
+    waves without a patch used to skip the workgroup barrier between the channel passes (wrong values in channels >= 256; found by the
+    planned-vs-fused comparison above).  Fused and planned backward against the per-level oracle."""
+    from chainer_maskrcnn.model.head import fpn_roi_mask_head as hd
+    rs = np.random.RandomState(14)
+    N, C, P, R = 2, 260, 7, 700
+    shapes = [(41, 50), (21, 25), (11, 13), (6, 7)]
+    scales = [1 / 4., 1 / 8., 1 / 16., 1 / 32.]
+    xy = rand_rois_xy(rs, R, N, 41, 50, 0.25)
+    lev = rs.choice(4, size=R, p=[0.05, 0.1, 0.35, 0.5]).astype(np.int32)
+    gy = rs.standard_normal((R, P, P, C)).astype(np.float32)
+    rt, lt, gyt = torch.from_numpy(xy).to(DEV), torch.from_numpy(lev).to(DEV), torch.from_numpy(gy).to(DEV)
+    for planned in (False, True):
+        gxs = [torch.full((N, h, w, C), float('nan'), device=DEV) for h, w in shapes]
+        plan = hd.roi_align_fpn_bwd_plan(gxs, rt, lt, P, scales) if planned else None
+        hd.roi_align_fpn_bwd(gyt, gxs, rt, lt, P, scales, accumulate=False, plan=plan)
+        for l, (h, w) in enumerate(shapes):
+            sel = np.nonzero(lev == l)[0]
+            want = ora.roi_align_bwd(np.ascontiguousarray(gy[sel].transpose(0, 3, 1, 2)), xy[sel], (N, C, h, w), scales[l], 2).transpose(0, 2, 3, 1)
+            np.testing.assert_allclose(gxs[l].cpu().numpy(), want, rtol=1e-5, atol=2e-5 * np.abs(gy).max(), err_msg='planned %s level %d' % (planned, l))
+
+
+def test_planned_backward_falls_back_when_the_plan_does_not_hold():
+    """A plan buffer too small for the pool (overflow flag set by the builder), a foreign buffer (no magic), a plan built for other RoIs
+    counts: the planned entry point detects it on the device and computes the fused path - the same bits, never garbage."""
+    rs = np.random.RandomState(3)
+    N, C, P = 1, 64, 14
+    shapes, scales = [(8, 8)], [1 / 32.]
+    R = 600
+    xy = rand_rois_xy(rs, R, N, 8, 8, 1 / 32.)
+    import ctypes
+    lib = _hip.lib()
+    Hs, Ws = (ctypes.c_int * 1)(8), (ctypes.c_int * 1)(8)
+    full = lib.mrcnn_roi_align_fpn_bwd_plan_bytes(Hs, Ws, 1, N, R, P, P, 0)
+    hdr = _planned_vs_fused(shapes, scales, N, C, xy, None, P, 2, False, split=False)
+    assert hdr[0] == NP_MAGIC and hdr[1] == 0 and hdr[2] > 8           # 600 RoIs on 4 patches: long chains
+    stride = 3584           # one 14x14 node (96 entries) rounded to 256 bytes
+    small = 256 + (4 * 4 + 3) * stride                                  # room for the patch slots and three pool nodes only
+    assert small < full
+    hdr = _planned_vs_fused(shapes, scales, N, C, xy, None, P, 2, False, plan_bytes=small, split=False)
+    assert hdr[0] == NP_MAGIC and hdr[1] >= 1                           # failed allocations counted, the tile flagged; result still the fused one
+    hdr = _planned_vs_fused(shapes, scales, N, C, xy, None, P, 2, False, split=False, corrupt=lambda p: p[:4].zero_())
+    assert hdr[0] == 0
+    def other_count(p):
+        h = p[:256].view(torch.int32)
+        h[5] = R - 1
+    _planned_vs_fused(shapes, scales, N, C, xy, None, P, 2, False, split=False, corrupt=other_count)

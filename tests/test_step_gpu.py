@@ -676,3 +676,33 @@ def test_composite_bottleneck_calls_give_the_same_bits(arith):
     assert torch.equal(res[0][4], res[1][4])
     assert torch.equal(res[0][1], res[1][1]) and float(res[0][1].abs().max()) > 0
     assert torch.equal(res[0][2], res[1][2])
+
+
+def test_roi_align_backward_plans_built_beside_the_forward_give_the_same_bits():
+    """fpn_roi_mask_head.PLAN_BWD_IN_FORWARD (on by default): the entry lists of both ROIAlign backward calls are built on the weight-gradient
+    stream during the forward pass and the backward follows them (mrcnn_roi_align_fpn_bwd_planned_f32) - the same bits as the fused backward:
+    losses, every gradient, parameters after three updates."""
+    from chainer_maskrcnn.model.head import fpn_roi_mask_head as hd
+    res = []
+    for on in (False, True):
+        hd.PLAN_BWD_IN_FORWARD = on
+        try:
+            m, chain = _build('all')
+            b = _batch()
+            chain.sampler_keys = None
+            chain.proposal_target_creator.set_seed(5)
+            chain.anchor_target_creator.set_seed(9)
+            chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0).backward()
+            torch.cuda.synchronize()
+            g, l = m.ps.grads.clone(), float(chain.observation['loss'])
+            opt = MomentumSGD(lr=1e-2, momentum=0.9).setup(chain)
+            opt.add_hook(WeightDecay(0.0005))
+            for _ in range(3):
+                opt.update(chain, b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+            torch.cuda.synchronize()
+            res.append((l, g, m.ps.params.clone()))
+        finally:
+            hd.PLAN_BWD_IN_FORWARD = True
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and float(res[0][1].abs().max()) > 0
+    assert torch.equal(res[0][2], res[1][2])
