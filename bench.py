@@ -78,10 +78,7 @@ def bench_roialign(args, rank, world):
     algo_bytes = 4 * (N * C * H * W + R * C * PH * PW) + 20 * R
 
     # caller-owned scratch of the forward: the map-order permutation of the RoIs (ranking kernel + forward kernel per call)
-    # (ABI v8, OPT-IN: with mrcnn_roi_align_plan_workspace_bytes() bytes and mrcnn_roi_align_set_bwd_plan(1 | 2) the forward also builds the
-    # backward's work plan for these RoIs inside its own launch and the backward, handed the same buffer, follows it.  Off by default: the
-    # backward alone gains, the forward + backward PAIR a training step pays loses - `roi_align_pair_us` reports both, same process)
-    nbf = max(lib.mrcnn_roi_align_fwd_workspace_bytes(R), lib.mrcnn_roi_align_plan_workspace_bytes(N, H, W, R))
+    nbf = lib.mrcnn_roi_align_fwd_workspace_bytes(R)
     wsf = torch.empty((max(nbf, 1),), dtype=torch.uint8, device=dev)
 
     def fwd(sr=2):
@@ -92,18 +89,45 @@ def bench_roialign(args, rank, world):
     nb = max(lib.mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, R, PH, PW, 2), lib.mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, R, PH, PW, 0))
     ws = torch.empty((max(nb, 1),), dtype=torch.uint8, device=dev)
 
-    def bwd(sr=2):
+    def bwd_fused(sr=2):
         _hip.check(lib.mrcnn_roi_align_bwd_ws_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW,
-                                                  0.25, sr, _hip.ptr(gx), _hip.ptr(wsf), nbf, _hip.stream_ptr()))
+                                                  0.25, sr, _hip.ptr(gx), _hip.ptr(ws), max(nb, 1), _hip.stream_ptr()))
+
+    # (ABI v9) the backward in two launches: the entry lists of the RoIs (geometry only: no gy) are built ahead - in a training step beside the
+    # forward pass, here as its own timed launch - and the backward streams gy along them (same bits as the fused kernel,
+    # tests/test_roi_align_gpu.py).  `verified`: the plan's status was read back once, outside the timed region (header valid, no tile
+    # flagged): the backward is then the lean kernel alone; unverified, a second launch follows for whatever the plan could not hold.
+    import ctypes
+    Hs, Ws, sc = (ctypes.c_int * 1)(H), (ctypes.c_int * 1)(W), (ctypes.c_float * 1)(0.25)
+    gxp = (ctypes.c_void_p * 1)(gx.data_ptr())
+    pb = lib.mrcnn_roi_align_fpn_bwd_plan_bytes(Hs, Ws, 1, N, R, PH, PW, 0)
+    plan = torch.zeros((max(pb, 256),), dtype=torch.uint8, device=dev)
+
+    def plan_build():
+        _hip.check(lib.mrcnn_roi_align_fpn_bwd_plan_f32(Hs, Ws, sc, 1, N, C, _hip.ptr(rois_xy), None, R, PH, PW, 2, 0, _hip.ptr(plan), pb, _hip.stream_ptr()))
+
+    def bwd_planned(verified):
+        _hip.check(lib.mrcnn_roi_align_fpn_bwd_planned_f32(_hip.ptr(gyt), gxp, Hs, Ws, sc, 1, N, C, _hip.ptr(rois_xy), None, R, PH, PW, 2, 0, None, 0,
+                                                           _hip.ptr(plan), pb, int(verified), _hip.stream_ptr()))
+    plan_build()
+    st3 = (ctypes.c_int * 3)()
+    _hip.check(lib.mrcnn_roi_align_bwd_plan_status(_hip.ptr(plan), plan.numel(), st3, _hip.stream_ptr()))
+    plan_ok = bool(st3[0]) and st3[1] == 0
+
+    def bwd(sr=2):
+        if sr == 2 and plan_ok:
+            bwd_planned(True)
+        else:
+            bwd_fused(sr)
 
     for _ in range(args.warmup):
-        fwd(); bwd()
+        fwd(); plan_build(); bwd()
     K = args.steps
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
     sync_all(world)
     t0 = time.perf_counter()
-    for k in range(K):
-        ev[k][0].record(); fwd(); ev[k][1].record(); bwd(); ev[k][2].record()
+    for k in range(K):          # a step of this workload: forward, the backward's plan, backward
+        ev[k][0].record(); fwd(); plan_build(); ev[k][1].record(); bwd(); ev[k][2].record()
     sync_all(world)
     dt = time.perf_counter() - t0
     # a second run with the ADAPTIVE sampling grid (sampling_ratio 0 = ceil(roi / pooled) samples
@@ -139,15 +163,8 @@ def bench_roialign(args, rank, world):
         torch.cuda.synchronize()
         return np.array([es[g].elapsed_time(es[g + 1]) / GROUP for g in range(NG)])
     bwd_b2b, fwd_b2b = back_to_back(bwd), back_to_back(fwd)
-    # A/B in the same process: the OPT-IN forward-built work plan of the backward (mrcnn_roi_align_set_bwd_plan; default 0 = off)
-    plan_ab = {}
-    for pm, nm in ((1, 'groups_of_four_patches_of_equal_work'), (2, 'whole_tiles_dealt_by_work')):
-        lib.mrcnn_roi_align_set_bwd_plan(pm)
-        fwd(); bwd()
-        b_, f_ = back_to_back(bwd), back_to_back(fwd)
-        plan_ab[nm] = {'fwd': round(float(f_.mean()) * 1e3, 3), 'bwd': round(float(b_.mean()) * 1e3, 3), 'fwd_plus_bwd': round(float(f_.mean() + b_.mean()) * 1e3, 3)}
-    lib.mrcnn_roi_align_set_bwd_plan(0)
-    fwd()
+    plan_b2b, fused_b2b = back_to_back(plan_build), back_to_back(bwd_fused)
+    unver_b2b = back_to_back(lambda: bwd_planned(False)) if plan_ok else fused_b2b
     bwd_avg_s = float(bwd_b2b.mean()) * 1e-3
     fwd_avg_s = float(fwd_b2b.mean()) * 1e-3
     bwd_gbps = algo_bytes / bwd_avg_s / 1e9
@@ -158,9 +175,9 @@ def bench_roialign(args, rank, world):
         'config': {'workload': 'configs[1] roi_align_2d fwd+bwd microbench: 512 RoIs, x=(1,256,200,272) NHWC, '
                                '7x7, sampling 2x2, spatial_scale 0.25', 'rois_per_step': R * world,
                    'parallelism': 'independent batch per rank, no collective'},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_roi_align_bwd_waves', 'achieved': round(bwd_gbps, 2),
+        'roofline': {'bound': 'hbm', 'kernel': 'k_roi_align_bwd_lean (entry lists built ahead by k_roi_align_bwd_waves<MODE 1>: plan_build_us)' if plan_ok else 'k_roi_align_bwd_waves', 'achieved': round(bwd_gbps, 2),
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(bwd_gbps / HBM_PEAK_GBPS, 4),
-                     'traffic': _pmc_traffic('k_roi_align_bwd')[0], 'traffic_source': _pmc_traffic('k_roi_align_bwd')[1],
+                     'traffic': _pmc_traffic('k_roi_align_bwd_lean' if plan_ok else 'k_roi_align_bwd')[0], 'traffic_source': _pmc_traffic('k_roi_align_bwd_lean' if plan_ok else 'k_roi_align_bwd')[1],
                      'algorithmic_bytes_per_launch': algo_bytes,
                      'avg_launch_us': round(bwd_avg_s * 1e6, 3), 'median_launch_us': round(float(np.median(bwd_b2b)) * 1e3, 3),
                      'event_pair_per_launch_us': round(float(bwd_ms.mean()) * 1e3, 3),
@@ -171,10 +188,15 @@ def bench_roialign(args, rank, world):
                           'frac': round(algo_bytes / fwd_avg_s / 1e9 / HBM_PEAK_GBPS, 4), 'kernel': 'k_roi_map_order + k_roi_align_fwd_rows (RoIs walked in map order)',
                           'traffic': _pmc_traffic('k_roi_align_fwd')[0]},
         'roi_align_adaptive_sampling': adaptive,
-        'roi_align_pair_us': {'fwd_plus_bwd': round((fwd_avg_s + bwd_avg_s) * 1e6, 3),
-                              'opt_in_forward_built_backward_plan': plan_ab,
-                              'note': 'shipped: no plan.  opt_in_...: mrcnn_roi_align_set_bwd_plan(1 | 2), the forward call builds the backward\'s work plan '
-                                      'inside its own launch (extra workgroups), same process: the backward alone gains, the pair loses'},
+        'roi_align_bwd_forms_us': {
+            'lean_kernel_with_verified_plan': round(bwd_avg_s * 1e6, 3), 'plan_build': round(float(plan_b2b.mean()) * 1e3, 3),
+            'lean_kernel_plus_fallback_launch_unverified_plan': round(float(unver_b2b.mean()) * 1e3, 3),
+            'fused_wave_kernel_no_plan': round(float(fused_b2b.mean()) * 1e3, 3), 'fwd': round(fwd_avg_s * 1e6, 3),
+            'plan_status': {'header_valid': bool(st3[0]), 'tiles_flagged': int(st3[1]), 'pool_nodes_used': int(st3[2]), 'plan_bytes': int(pb)},
+            'note': 'roofline = the backward with the plan verified once outside the timed region (mrcnn_roi_align_bwd_plan_status: the one '
+                    'synchronising query); plan_build = k_roi_align_bwd_waves<MODE 1> on the same RoIs (in a training step it runs on the '
+                    'weight-gradient stream beside the forward pass, model/head/fpn_roi_mask_head.py PLAN_BWD_IN_FORWARD, and the backward there '
+                    'is the unverified form); same bits in all three forms'},
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_roialign(x, yx, gy, algo_bytes)

@@ -44,10 +44,12 @@ def roi_align_fpn_fwd(xs, rois_xy5, levels, out_size, scales, sampling_ratio=2):
     return y
 
 
-# The backward's entry lists are built beside the FORWARD pass (the RoIs are all they need): mrcnn_roi_align_fpn_bwd_plan_f32 on the
-# weight-gradient stream, idle then; the backward follows them (mrcnn_roi_align_fpn_bwd_planned_f32: same bits, the geometry two thirds of
-# the fused kernel's critical path gone from the backward).  False = the fused backward.
-PLAN_BWD_IN_FORWARD = True
+# OPT-IN for the training step: the backward's entry lists built beside the FORWARD pass (the RoIs are all they need:
+# mrcnn_roi_align_fpn_bwd_plan_f32 on the weight-gradient stream, idle then) and the backward following them
+# (mrcnn_roi_align_fpn_bwd_planned_f32: same bits).  On configs[1] the backward goes 27.6 -> 20.8 us (bench.py --workload roialign); in the
+# step the two ROIAlign backward calls are 0.2 of 21.8 ms and the plan's launches and buffers (~100 MB each) eat the gain: same-process
+# A/B 21.88 (on) against 21.82 ms (off), tools/ab_step.py - so the step keeps the fused backward.
+PLAN_BWD_IN_FORWARD = False
 
 
 def roi_align_fpn_bwd_plan(xs, rois_xy5, levels, out_size, scales, sampling_ratio=2, stream=None):

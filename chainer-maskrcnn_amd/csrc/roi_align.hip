@@ -1808,7 +1808,7 @@ extern "C" int mrcnn_roi_align_bwd_ws_f32(const float *gy, int layout, int N, in
         lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
         // a workspace of mrcnn_roi_align_plan_workspace_bytes() that went through the forward call of these RoIs carries the backward's
         // plan (validated on the device); this entry needs no scratch of its own on that path (no RoI split on a single large level)
-        const bool has_plan = ws && plan_ok(N, H, W) && ws_bytes >= fwd_plan_ws_bytes(N, H, W, R) && level_split(H, W, N) == 1 && g_bwd_variant == 2;
+        const bool has_plan = g_bwd_plan != 0 && ws && plan_ok(N, H, W) && ws_bytes >= fwd_plan_ws_bytes(N, H, W, R) && level_split(H, W, N) == 1 && g_bwd_variant == 2;
         if (has_plan) return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, nullptr, 0, st, ws);
         return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, ws, ws_bytes, st);
     }

@@ -679,7 +679,7 @@ def test_composite_bottleneck_calls_give_the_same_bits(arith):
 
 
 def test_roi_align_backward_plans_built_beside_the_forward_give_the_same_bits():
-    """fpn_roi_mask_head.PLAN_BWD_IN_FORWARD (on by default): the entry lists of both ROIAlign backward calls are built on the weight-gradient
+    """fpn_roi_mask_head.PLAN_BWD_IN_FORWARD (opt-in): the entry lists of both ROIAlign backward calls are built on the weight-gradient
     stream during the forward pass and the backward follows them (mrcnn_roi_align_fpn_bwd_planned_f32) - the same bits as the fused backward:
     losses, every gradient, parameters after three updates."""
     from chainer_maskrcnn.model.head import fpn_roi_mask_head as hd
@@ -702,7 +702,7 @@ def test_roi_align_backward_plans_built_beside_the_forward_give_the_same_bits():
             torch.cuda.synchronize()
             res.append((l, g, m.ps.params.clone()))
         finally:
-            hd.PLAN_BWD_IN_FORWARD = True
+            hd.PLAN_BWD_IN_FORWARD = False
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1]) and float(res[0][1].abs().max()) > 0
     assert torch.equal(res[0][2], res[1][2])
