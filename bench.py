@@ -302,10 +302,13 @@ def main():
         torch.cuda.set_device(_local_device())
         # The line should show what RCCL saw (config.rccl.transport) without anybody having to ask for it: unless the launcher chose its
         # own settings, the init / topology / transport messages go to a per-process FILE (never to stdout, where the JSON line goes).
-        if 'NCCL_DEBUG' not in os.environ and 'NCCL_DEBUG_FILE' not in os.environ:
+        # Rank 0 only (the one whose log is read), init-time subsystems only (nothing is logged during the timed steps), and the file is
+        # removed once it has been parsed (optimizers.rccl_evidence) - ADVICE r4.
+        if 'NCCL_DEBUG' not in os.environ and 'NCCL_DEBUG_FILE' not in os.environ and rank == 0:
             os.environ['NCCL_DEBUG'] = 'INFO'
-            os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,P2P,SHM,NET')
+            os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH')
             os.environ['NCCL_DEBUG_FILE'] = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'mrcnn_rccl.%h.%p.log')
+            os.environ['MRCNN_RCCL_LOG_IS_OURS'] = '1'          # rccl_evidence deletes a log this script asked for, never the launcher's
         # RCCL over xGMI; MRCNN_BENCH_BACKEND=gloo only for the 1-GPU functional check of the multi-process path
         from chainer_maskrcnn.optimizers import init_process_group
         init_process_group(os.environ.get('MRCNN_BENCH_BACKEND', 'nccl'))

@@ -236,6 +236,11 @@ def bench_step(args, rank, world):
                      'gemm_ms_per_step': head['gemm_ms_per_step'], 'executed_flops_per_step': head['executed_flops_per_step'],
                      'effective_fp32_TFLOPs': round(head['executed_flops_per_step'] / (6.0 if head_is_emu else 1.0) / (head['gemm_ms_per_step'] * 1e-3) / 1e12, 2)
                      if head['gemm_ms_per_step'] else None,
+                     # the same rate against the float32 MFMA peak (157.3 TFLOP/s), whatever pipe the headline group runs on: comparable
+                     # across rounds and arithmetics
+                     'frac_f32_equivalent': round(head['executed_flops_per_step'] / (6.0 if head_is_emu else 1.0) / (head['gemm_ms_per_step'] * 1e-3) / 157.3e12, 4)
+                     if head['gemm_ms_per_step'] else None,
+                     'in_step': _in_step_gemm(f32, emu),
                      'traffic': pmc['traffic'], 'traffic_source': pmc['traffic_source'],
                      'hbm_bytes_per_step_by_family': pmc.get('hbm_bytes_per_step_by_family'),
                      'hbm_bytes_per_step_whole_step': pmc.get('hbm_bytes_per_step_whole_step'),
@@ -307,6 +312,25 @@ def latest_profile(suffix):
         except Exception:
             continue
     return None, None
+
+
+def _in_step_gemm(f32, emu):
+    """roofline.in_step: the GEMM launches' durations INSIDE the multi-stream step - from the committed kernel trace
+    summary (tools/trace_in_step_gemm.py; a trace needs rocprofv3, so this is a constant of the repository like `traffic`) - and the
+    blended fraction of the two pipes' peaks: (float32 flops / 157.3 TF + bf16 product flops / 2500 TF) / that time."""
+    f, d = latest_profile('step_in_step_gemm.json')
+    if d is None:
+        return None
+    try:
+        t = (d['f32_gemm_ms'] + d['emulated_gemm_ms']) * 1e-3
+        ideal = (f32 or {}).get('executed_flops_per_step', 0.0) / 157.3e12 + (emu or {}).get('executed_flops_per_step', 0.0) / 2500e12
+        return {'gemm_ms_per_step_in_step': round(t * 1e3, 3), 'f32_gemm_ms': d['f32_gemm_ms'], 'emulated_gemm_ms': d['emulated_gemm_ms'],
+                'blended_frac_of_pipe_peaks': round(ideal / t, 4) if t > 0 else None, 'gemm_launches_per_step': d.get('gemm_launches'),
+                'kernels_per_step': d.get('kernels'), 'profiled_step_wall_ms': d.get('wall_ms'),
+                'source': {'file': f, 'collected_at_commit': d.get('_commit'),
+                           'kind': 'constant read from the committed rocprofv3 --kernel-trace summary, not collected by this run'}}
+    except Exception:
+        return None
 
 
 def _gather_over_ranks(v, world, dev):

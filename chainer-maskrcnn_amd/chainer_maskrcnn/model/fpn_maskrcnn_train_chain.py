@@ -159,6 +159,7 @@ class FPNMaskRCNNTrainChain(object):
         self.keep_outputs = False           # parity tests: keep the head outputs of the last step in self.outputs
         self.outputs = {}
         self._aux = {}
+        self._arith_found = None            # the process's GEMM arithmetic before this chain selected its own (restored by backward())
 
     def _aux_stream(self, dev):
         key = (dev.type, dev.index)
@@ -177,6 +178,12 @@ class FPNMaskRCNNTrainChain(object):
         if self.strict_batch1 and n != 1:
             raise ValueError('Currently only batch size 1 is supported. n={}'.format(n))
         if self.gemm_arithmetic is not None:        # (read by the library on the host at call time: forward now, backward later)
+            # the process-wide setting this chain found is put back at the end of backward(): evaluation / predict calls between training
+            # steps and other models of the process keep THEIR arithmetic
+            if self._arith_found is None:
+                from chainer_maskrcnn._hip import nn as hnn
+                from chainer_maskrcnn.nn import core
+                self._arith_found = (hnn.split_operands(), core.FWD_EMULATION_IN_BACKBONE)
             select_gemm_arithmetic(self.gemm_arithmetic)
         if torch.is_tensor(scale) and scale.numel() == 1:
             scale = float(scale.reshape(-1)[0].item())
@@ -353,7 +360,9 @@ class FPNMaskRCNNTrainChain(object):
         if hook:
             hook(self._offset_of('head/'))
         if self._early_rpn is not None:     # computed beside the proposal chain of the forward pass (aux stream, joined at its end)
-            assert upstream is None, 'the early RPN backward assumes d(objective)/d(loss) = 1'
+            if upstream is not None:        # (its parameter gradients are already in the buffer, un-scaled: they cannot be fixed up here)
+                raise RuntimeError('the RPN backward pass ran early with d(objective)/d(loss) = 1 (backward_follows was set): '
+                                   'a scaled loss needs chain.backward_follows = False during the forward call')
             for gf, g in zip(g_feats, self._early_rpn):
                 gf.add_(g)
                 g.record_stream(main)
@@ -368,6 +377,12 @@ class FPNMaskRCNNTrainChain(object):
         if hook:
             hook(0)
         self._bwd = None
+        if self._arith_found is not None:
+            from chainer_maskrcnn._hip import lib, check
+            split, in_backbone = self._arith_found
+            check(lib().mrcnn_conv2d_set_split_operands(*split))
+            core.FWD_EMULATION_IN_BACKBONE = in_backbone
+            self._arith_found = None
 
     def _offset_of(self, prefix):
         cache = self.__dict__.setdefault('_offset_cache', {})

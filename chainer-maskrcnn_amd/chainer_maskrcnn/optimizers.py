@@ -69,6 +69,8 @@ def rccl_evidence(dev, world):
             keys = ('via P2P', 'via SHM', 'via NET', 'via direct', 'Connected all', 'comm ', 'nRanks', 'XGMI', 'Ring ', 'Tree ')
             lines = [l.strip() for l in open(path, errors='replace') if any(k in l for k in keys)]
             ev['transport'] = lines[:40]
+            if os.environ.get('MRCNN_RCCL_LOG_IS_OURS') == '1':       # bench.py asked for this log itself: parsed, so it goes
+                os.remove(path)
         except OSError as e:
             ev['transport'] = ['(could not read %s: %s)' % (log, e)]
     if ev['distinct_devices'] < world and os.environ.get('MRCNN_BENCH_SINGLE_DEVICE') != '1':

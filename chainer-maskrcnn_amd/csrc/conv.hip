@@ -1525,8 +1525,8 @@ __global__ __launch_bounds__(256) void k_wino_input_filter(const float *__restri
 // bn_part (nullable; the layer feeds a training-mode BatchNorm): row blockIdx.x of bn_part (gridDim.x, 2, C) receives the
 // per-channel sums and sums of squares of the pixels the block wrote (a block covers 256 / (C/4) whole tiles: the host
 // passes bn_part only when C/4 divides 256) - the same partials the GEMM epilogue produces for the direct layers.
-template <int M_>
-__global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ Mb, float *__restrict__ y, int N, int H, int W, int C,
+template <int M_, int OCC = 0>
+__global__ __launch_bounds__(256, (OCC ? OCC : 1)) void k_wino_output(const float *__restrict__ Mb, float *__restrict__ y, int N, int H, int W, int C,
                                                      int th, int tw, long long T, long long Tp, const float *__restrict__ bias,
                                                      int relu, int accumulate, const float *__restrict__ relu_x,
                                                      float *__restrict__ bn_part) {
@@ -1838,6 +1838,19 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restric
         MRCNN_LAUNCH_CHECK();                                                                        \
     } while (0)
 
+// k_wino_output<4> holds a 6 x 6 tile of float4 per thread: left alone the compiler takes 248 VGPRs (2 waves per SIMD); g_wino_out_occ = 3 / 4
+// caps it (mrcnn_debug_wino_output_occupancy; 0 = uncapped)
+int g_wino_out_occ = 0;
+#define WINO_LAUNCH_OUT(G, GRID, ...)                                                                                   \
+    do {                                                                                                                \
+        if (g_debug_skip & 2) break;                                                                                    \
+        if ((G).m == 2) hipLaunchKernelGGL((k_wino_output<2>), GRID, dim3(256), 0, st, __VA_ARGS__);                    \
+        else if (g_wino_out_occ == 3) hipLaunchKernelGGL((k_wino_output<4, 3>), GRID, dim3(256), 0, st, __VA_ARGS__);   \
+        else if (g_wino_out_occ == 4) hipLaunchKernelGGL((k_wino_output<4, 4>), GRID, dim3(256), 0, st, __VA_ARGS__);   \
+        else hipLaunchKernelGGL((k_wino_output<4>), GRID, dim3(256), 0, st, __VA_ARGS__);                               \
+        MRCNN_LAUNCH_CHECK();                                                                                           \
+    } while (0)
+
 int g_pg_big = 1, g_pg_min_tiles = 256;
 // Split mode 3 on the Winograd filter-gradient GEMMs of the big layers: k_pgemm_gpp (planes_gemm.h).  The transformed output
 // gradient W is written as bf16 planes by k_wino_gy, the transformed input V stays float32 (the forward pass's, or k_wino_input's).
@@ -1846,13 +1859,16 @@ bool pg_big_g_ok(const WinoGeom &g, int Cin, int Cout) {
     if (Cout % PGB_BM || Cin % PGB_BN || g.Tp % 32) return false;
     return g.Tp >= 2048 && (long long)g.nk * g.Tp * Cout * 6 < (1ll << 32) && (long long)g.nk * g.Tp * Cin * 4 < (1ll << 32);
 }
-struct WinoFLayout { size_t v, w, slabs, du, total; WinoGeom g; int ksplit, kchunk; int big; };
+// ksplit / kchunk: the split-K plan of the launch the layer takes by default (the plane GEMM when `big`); ks32 / kc32: the plan tuned for
+// k_conv_igemm's 128 x 128 tiles, taken when the call arrives with a cached float32 W (WINOGRAD_SHARED_GY_TRANSFORM) - ADVICE r4
+struct WinoFLayout { size_t v, w, slabs, du, total; WinoGeom g; int ksplit, kchunk; int big; int ks32, kc32; };
 WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
     WinoFLayout L;
     L.g = wino_geom(N, H, W, PASS_BWD_FILTER);
     ConvP p = make_p(1, 1, (int)L.g.Tp, Cin, Cout, 1, 1, 1, 0);
     p.wbatch_rows = (int)L.g.Tp; p.wbatch_n = L.g.nk;
     filter_plan(p, L.ksplit, L.kchunk);
+    L.ks32 = L.ksplit; L.kc32 = L.kchunk;
     L.big = pg_big_g_ok(L.g, Cin, Cout) ? 1 : 0;
     if (L.big) {            // k_pgemm_gpp: one 256 x 256 tile per (batch, split), one workgroup per CU: the splits fill one round of CUs
         const long long tiles = (long long)L.g.nk * (Cout / PGB_BM) * (Cin / PGB_BN);
@@ -1865,7 +1881,7 @@ WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
     size_t o = 0;
     L.v = o; o += al((size_t)L.g.nk * L.g.Tp * Cin * 4);
     L.w = o; o += al((size_t)L.g.nk * L.g.Tp * Cout * 6);          // float32, or three bf16 planes (plane GEMM)
-    L.slabs = o; o += al((size_t)L.ksplit * Cout * L.g.nk * Cin * 4);
+    L.slabs = o; o += al((size_t)std::max(L.ksplit, L.ks32) * Cout * L.g.nk * Cin * 4);
     L.du = o; o += al((size_t)Cout * L.g.nk * Cin * 4);
     L.total = o;
     return L;
@@ -1907,16 +1923,16 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     }
     ConvP p = make_p(1, 1, (int)g.Tp, Cin, Cout, 1, 1, 1, 0);
     p.wbatch_rows = (int)g.Tp; p.wbatch_n = g.nk;
-    p.ksplit = L.ksplit; p.kchunk = L.kchunk;
-    p.a = w_cached ? w_cached : Wt; p.b = V; p.c = L.ksplit > 1 ? slabs : dU;
+    p.ksplit = L.ks32; p.kchunk = L.kc32;
+    p.a = w_cached ? w_cached : Wt; p.b = V; p.c = p.ksplit > 1 ? slabs : dU;
     p.bytes_a = (unsigned)((size_t)g.nk * g.Tp * Cout * 4); p.bytes_b = (unsigned)((size_t)g.nk * g.Tp * Cin * 4);
     p.M = Cout; p.Ng = Cin;
     launch_conv<MODE_BWD_FILTER>(p, g.nk * p.ksplit, filter_tile(p), st);
     MRCNN_LAUNCH_CHECK();
-    if (L.ksplit > 1) {     // a separate, fully parallel slab sum: folding it into k_wino_filter_grad (Cout*Cin threads only) was
+    if (p.ksplit > 1) {     // a separate, fully parallel slab sum: folding it into k_wino_filter_grad (Cout*Cin threads only) was
                             // measured 20 % .. 4x slower (tools/wino_sweep.py)
         const size_t n4 = (size_t)Cout * g.nk * Cin / 4;
-        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, L.ksplit, 0);
+        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, p.ksplit, 0);
         MRCNN_LAUNCH_CHECK();
     }
     WINO_LAUNCH(k_wino_filter_grad, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), dU, gw, Cout, Cin, accumulate, 1);
@@ -1979,7 +1995,7 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
         q.ldc = Cout; q.dbg = 0; q.stamps = nullptr;
         if (!(g_debug_skip & 1)) launch_pgemm<4>(q, PGB_BM, PGB_BN, st);
         MRCNN_LAUNCH_CHECK();
-        WINO_LAUNCH(k_wino_output, g, dim3((unsigned)((nout + 255) / 256)), Mb, out, N, H, W, Cout, g.th, g.tw, g.T, g.Tp, bias, relu,
+        WINO_LAUNCH_OUT(g, dim3((unsigned)((nout + 255) / 256)), Mb, out, N, H, W, Cout, g.th, g.tw, g.T, g.Tp, bias, relu,
                     accumulate, relu_x, bn_part);
         return 0;
     }
@@ -1990,7 +2006,7 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
     p.M = (int)(g.nk * g.Tp); p.Ng = Cout;
     p.wbatch_rows = (int)g.Tp; p.wbatch_n = g.nk;
     if (int e = run_data_conv<MODE_FWD>(p, Cin / BK, Cout, base + L.inner, ws_bytes - L.inner, st)) return e;
-    WINO_LAUNCH(k_wino_output, g, dim3((unsigned)((nout + 255) / 256)), Mb, out, N, H, W, Cout, g.th, g.tw, g.T, g.Tp, bias, relu,
+    WINO_LAUNCH_OUT(g, dim3((unsigned)((nout + 255) / 256)), Mb, out, N, H, W, Cout, g.th, g.tw, g.T, g.Tp, bias, relu,
                 accumulate, relu_x, bn_part);
     return 0;
 }
@@ -2016,6 +2032,12 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
     if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD)) bytes = std::max(bytes, wino_ws_bytes(N, H, W, Cin, Cout, PASS_FWD));
     if (wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad, PASS_BWD_DATA)) bytes = std::max(bytes, wino_ws_bytes(N, H, W, Cout, Cin, PASS_BWD_DATA));
     return bytes;
+}
+
+extern "C" int mrcnn_debug_wino_output_occupancy(int occ) {
+    if (occ != 0 && occ != 3 && occ != 4) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_wino_output_occupancy: 0, 3 or 4");
+    g_wino_out_occ = occ;
+    return 0;
 }
 
 extern "C" int mrcnn_debug_conv_parts(int mask) {

@@ -268,3 +268,39 @@ def test_conv_split_operands_all_three_passes(case, planes):
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))
     # and the default is untouched: float32 MFMA again
     assert rel(hnn.conv2d_fwd_raw(xd, wd, bd, 1, p, False), ref_y) < (3e-4 if wino else 2e-6)
+
+
+def test_shared_gy_transform_with_the_emulated_arithmetic():
+    """nn/core.py WINOGRAD_SHARED_GY_TRANSFORM (opt-in: one read of gy for the data gradient, the filter-gradient operand and the
+    bias gradient) together with split mode 3 on a layer large enough for the plane-GEMM plan: the filter-gradient call then arrives with a
+    cached float32 W and takes k_conv_igemm with ITS OWN split-K plan (WinoFLayout ks32 / kc32), not the plane GEMM's.  Gradients against
+    the default path (separate transforms) of the same arithmetic."""
+    from chainer_maskrcnn.nn import core
+    lib = _hip.lib()
+    ps = core.ParamStore()
+    conv = core.Conv(ps, 'c', 256, 256, 3, 1, 1, bias=True)
+    ps.materialise(torch.device(DEV), seed=3)
+    g = torch.Generator(device='cpu').manual_seed(8)
+    x = torch.randn((2, 96, 96, 256), generator=g).to(DEV)
+    gy = (torch.randn((2, 96, 96, 256), generator=g) * 1e-2).to(DEV)
+    out = []
+    keep = hnn.winograd_pass_tiles()
+    try:
+        hnn.set_winograd_pass_tiles(2, 0, 0)
+        _hip.check(lib.mrcnn_conv2d_set_split_operands(3, 3, 3))
+        for shared in (False, True):
+            core.WINOGRAD_SHARED_GY_TRANSFORM = shared
+            ps.grads.zero_()
+            y, ctx = conv.fwd(x)
+            gx = conv.bwd(ctx, gy.clone())
+            core.join_side_stream(torch.device(DEV))
+            torch.cuda.synchronize()
+            out.append((gx.clone(), ps.g('c/W').clone(), ps.g('c/b').clone()))
+    finally:
+        core.WINOGRAD_SHARED_GY_TRANSFORM = False
+        _hip.check(lib.mrcnn_conv2d_set_split_operands(0, 0, 0))
+        hnn.set_winograd_pass_tiles(*keep)
+    for a, b in zip(*out):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max())
+    assert float(out[0][1].abs().max()) > 0

@@ -706,3 +706,30 @@ def test_roi_align_backward_plans_built_beside_the_forward_give_the_same_bits():
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1]) and float(res[0][1].abs().max()) > 0
     assert torch.equal(res[0][2], res[1][2])
+
+
+def test_chain_puts_the_process_arithmetic_back_after_its_step():
+    """a chain built with gemm_arithmetic selects it for ITS forward and backward pass and restores what it found at the end of
+    backward() - an evaluation call or another model between two training steps keeps the process's own setting; a scaled loss after an
+    early RPN backward is an error, not a silently wrong gradient."""
+    from chainer_maskrcnn._hip import nn as hnn
+    from chainer_maskrcnn.nn import core
+    m = MaskRCNN(n_fg_class=80, device=DEV, seed=7, _test_shrink=dict(stages=STAGES, width_div=2))
+    chain = FPNMaskRCNNTrainChain(m, mask_loss_fun=calc_mask_loss, gemm_arithmetic='bf16x6_behind_backbone')
+    b = _batch()
+    assert tuple(hnn.split_operands()) == (0, 0, 0) and core.FWD_EMULATION_IN_BACKBONE is True
+    loss = chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+    assert tuple(hnn.split_operands()) == (3, 3, 3) and core.FWD_EMULATION_IN_BACKBONE is False      # in force until the backward pass is done
+    loss.backward()
+    assert tuple(hnn.split_operands()) == (0, 0, 0) and core.FWD_EMULATION_IN_BACKBONE is True
+    opt = MomentumSGD(lr=1e-3, momentum=0.9).setup(chain)
+    opt.update(chain, b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+    assert tuple(hnn.split_operands()) == (0, 0, 0)
+    # early RPN backward + a scaled loss
+    chain.backward_follows = True
+    try:
+        chain(b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+    finally:
+        chain.backward_follows = False
+    with pytest.raises(RuntimeError, match='early'):
+        chain.backward(upstream=torch.tensor(2.0, device=DEV))

@@ -1,4 +1,5 @@
-"""One configs[1] ROIAlign forward + backward pair for rocprofv3 --pmc passes (few launches, no timing)."""
+"""configs[1] ROIAlign for rocprofv3 --pmc passes (few launches, no timing): forward, the backward's entry-list plan (k_roi_align_bwd_waves<MODE 1>),
+the planned backward with the plan verified (k_roi_align_bwd_lean alone) - and, with a second argument `fused`, the fused wave kernel instead."""
 import os, sys
 R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R_, 'chainer-maskrcnn_amd')); sys.path.insert(0, R_)
@@ -17,7 +18,18 @@ y = torch.empty((R, C, PH, PW), device=dev).contiguous(memory_format=torch.chann
 gx = torch.empty_like(xt)
 nbf = lib.mrcnn_roi_align_fwd_workspace_bytes(R)
 wsf = torch.empty((max(nbf, 1),), dtype=torch.uint8, device=dev)       # the forward's map-order permutation
+import ctypes
+fused = len(sys.argv) > 2 and sys.argv[2] == 'fused'
+Hs, Ws, sc = (ctypes.c_int * 1)(H), (ctypes.c_int * 1)(W), (ctypes.c_float * 1)(0.25)
+gxp = (ctypes.c_void_p * 1)(gx.data_ptr())
+pb = lib.mrcnn_roi_align_fpn_bwd_plan_bytes(Hs, Ws, 1, N, R, PH, PW, 0)
+plan = torch.zeros((pb,), dtype=torch.uint8, device=dev)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     _hip.check(lib.mrcnn_roi_align_fwd_ws_f32(_hip.ptr(xt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW, 0.25, 2, _hip.ptr(y), _hip.ptr(wsf), nbf, _hip.stream_ptr()))
-    _hip.check(lib.mrcnn_roi_align_bwd_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW, 0.25, 2, _hip.ptr(gx), _hip.stream_ptr()))
+    if fused:
+        _hip.check(lib.mrcnn_roi_align_bwd_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_xy), R, PH, PW, 0.25, 2, _hip.ptr(gx), _hip.stream_ptr()))
+        continue
+    _hip.check(lib.mrcnn_roi_align_fpn_bwd_plan_f32(Hs, Ws, sc, 1, N, C, _hip.ptr(rois_xy), None, R, PH, PW, 2, 0, _hip.ptr(plan), pb, _hip.stream_ptr()))
+    _hip.check(lib.mrcnn_roi_align_fpn_bwd_planned_f32(_hip.ptr(gyt), gxp, Hs, Ws, sc, 1, N, C, _hip.ptr(rois_xy), None, R, PH, PW, 2, 0, None, 0,
+                                                       _hip.ptr(plan), pb, 1, _hip.stream_ptr()))
 torch.cuda.synchronize()

@@ -5,9 +5,9 @@ set -o pipefail
 R=$PWD
 O=$R/gpurun_out/round_end
 mkdir -p $O
-python -m pytest tests -m gpu -q --ignore=tests/test_abi_cpu.py -p no:cacheprovider > $O/gpu_tests.txt 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.txt
+( time python -m pytest tests -m gpu -x -q --durations=30 -p no:cacheprovider ) > $O/gpu_tests.txt 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.txt
 tail -3 $O/gpu_tests.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
+( time python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) > $O/smoke.txt 2>&1; tail -4 $O/smoke.txt; cat $O/smoke.txt >> $O/gpu_tests.txt
 python bench.py > $O/bench_step_n1.json 2> $O/bench_step.err; tail -c 600 $O/bench_step_n1.json
 python bench.py --workload roialign > $O/bench_roialign_n1.json 2> $O/bench_roialign.err
 python bench.py --workload keypoint > $O/bench_keypoint_n1.json 2> $O/bench_keypoint.err
@@ -31,5 +31,6 @@ for d in prof_step prof_roi; do f=$(ls $O/$d/*/*_kernel_stats.csv 2>/dev/null | 
 python tools/trace_step.py $O/prof_step 5 > $O/step_breakdown.txt 2>&1
 python tools/trace_streams.py $O/prof_step 5 > $O/step_streams.txt 2>&1
 python tools/trace_fill.py $O/prof_step 5 > $O/step_fill.txt 2>&1
+python tools/trace_in_step_gemm.py $O/prof_step 3 5 > $O/step_in_step_gemm.json 2> $O/in_step.err
 rm -rf $O/prof_step $O/prof_roi
 ls -la $O

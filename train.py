@@ -80,7 +80,11 @@ def run(args, keypoints=False):
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', args.gpu))
-    dev = torch.device('cuda', local % max(1, torch.cuda.device_count()) if 'LOCAL_RANK' in os.environ else local)      # (a launcher may show every rank only its own GPU)
+    ndev = max(1, torch.cuda.device_count())
+    lws = int(os.environ.get('LOCAL_WORLD_SIZE', 1))
+    if lws > ndev and ndev != 1:        # (ndev == 1: a launcher that shows every rank only its own GPU)
+        raise SystemExit('train.py: %d local ranks but %d visible GPUs - one process per GPU is required' % (lws, ndev))
+    dev = torch.device('cuda', local % ndev if 'LOCAL_RANK' in os.environ else local)
     if world > 1:       # one process per GPU: host threads (enqueue loop, loader workers, RCCL proxy) on the GPU's NUMA node
         from chainer_maskrcnn.utils.affinity import pin_rank
         cpus = pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
