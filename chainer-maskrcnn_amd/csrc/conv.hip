@@ -1525,8 +1525,8 @@ __global__ __launch_bounds__(256) void k_wino_input_filter(const float *__restri
 // bn_part (nullable; the layer feeds a training-mode BatchNorm): row blockIdx.x of bn_part (gridDim.x, 2, C) receives the
 // per-channel sums and sums of squares of the pixels the block wrote (a block covers 256 / (C/4) whole tiles: the host
 // passes bn_part only when C/4 divides 256) - the same partials the GEMM epilogue produces for the direct layers.
-template <int M_, int OCC = 0>
-__global__ __launch_bounds__(256, (OCC ? OCC : 1)) void k_wino_output(const float *__restrict__ Mb, float *__restrict__ y, int N, int H, int W, int C,
+template <int M_>
+__global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ Mb, float *__restrict__ y, int N, int H, int W, int C,
                                                      int th, int tw, long long T, long long Tp, const float *__restrict__ bias,
                                                      int relu, int accumulate, const float *__restrict__ relu_x,
                                                      float *__restrict__ bn_part) {
@@ -1838,18 +1838,10 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restric
         MRCNN_LAUNCH_CHECK();                                                                        \
     } while (0)
 
-// k_wino_output<4> holds a 6 x 6 tile of float4 per thread: left alone the compiler takes 248 VGPRs (2 waves per SIMD); g_wino_out_occ = 3 / 4
-// caps it (mrcnn_debug_wino_output_occupancy; 0 = uncapped)
-int g_wino_out_occ = 0;
-#define WINO_LAUNCH_OUT(G, GRID, ...)                                                                                   \
-    do {                                                                                                                \
-        if (g_debug_skip & 2) break;                                                                                    \
-        if ((G).m == 2) hipLaunchKernelGGL((k_wino_output<2>), GRID, dim3(256), 0, st, __VA_ARGS__);                    \
-        else if (g_wino_out_occ == 3) hipLaunchKernelGGL((k_wino_output<4, 3>), GRID, dim3(256), 0, st, __VA_ARGS__);   \
-        else if (g_wino_out_occ == 4) hipLaunchKernelGGL((k_wino_output<4, 4>), GRID, dim3(256), 0, st, __VA_ARGS__);   \
-        else hipLaunchKernelGGL((k_wino_output<4>), GRID, dim3(256), 0, st, __VA_ARGS__);                               \
-        MRCNN_LAUNCH_CHECK();                                                                                           \
-    } while (0)
+// (k_wino_output<4> holds a 6 x 6 tile of float4 per thread and takes 248 VGPRs = 2 waves per SIMD.  Capping it at 3 / 4 waves per SIMD
+// through __launch_bounds__ was measured in round 5: the transforms of a 2 x 256^2 x 256 forward call go 189 -> 240 / 288 us - the 36 plane
+// loads in flight per thread are what the kernel lives on; left uncapped.)
+#define WINO_LAUNCH_OUT(G, GRID, ...) WINO_LAUNCH(k_wino_output, G, GRID, __VA_ARGS__)
 
 int g_pg_big = 1, g_pg_min_tiles = 256;
 // Split mode 3 on the Winograd filter-gradient GEMMs of the big layers: k_pgemm_gpp (planes_gemm.h).  The transformed output
@@ -2032,12 +2024,6 @@ extern "C" size_t mrcnn_conv2d_workspace_bytes(int N, int H, int W, int Cin, int
     if (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD)) bytes = std::max(bytes, wino_ws_bytes(N, H, W, Cin, Cout, PASS_FWD));
     if (wino_ok(N, H, W, Cout, Cin, KH, KW, stride, pad, PASS_BWD_DATA)) bytes = std::max(bytes, wino_ws_bytes(N, H, W, Cout, Cin, PASS_BWD_DATA));
     return bytes;
-}
-
-extern "C" int mrcnn_debug_wino_output_occupancy(int occ) {
-    if (occ != 0 && occ != 3 && occ != 4) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_wino_output_occupancy: 0, 3 or 4");
-    g_wino_out_occ = occ;
-    return 0;
 }
 
 extern "C" int mrcnn_debug_conv_parts(int mask) {

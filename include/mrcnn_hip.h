@@ -255,8 +255,6 @@ int mrcnn_debug_wino_banded(int on);
  * 4 = the epilogue is skipped (results are garbage while one of these bits is set; where does such a kernel's time go?);
  * 8 = the three-plane (bf16x6) kernels run the plain K loop (split + LDS stores between the barriers) instead of the pipelined one
  * (split in registers in the MFMAs' shadow, loads two steps ahead) - same results, for A/B.  Bits 1 and 2 act on the plain loop. */
-/* measurement: waves per SIMD the F(4x4) output transform is compiled for (0 = uncapped: 248 VGPRs, 2 waves; 3; 4) */
-int mrcnn_debug_wino_output_occupancy(int occ);
 int mrcnn_debug_conv_parts(int mask);
 /* Test / measurement entry points of the plane GEMMs (csrc/planes_gemm.h), the kernels behind split mode 3 on the Winograd path.
  * split_planes: float32 (R, C), C % 16 == 0 -> "P16" planes, unsigned short [R][C/16][3][16]: hi, mid, lo bf16 planes of 16

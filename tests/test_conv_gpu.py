@@ -276,6 +276,7 @@ def test_shared_gy_transform_with_the_emulated_arithmetic():
     cached float32 W and takes k_conv_igemm with ITS OWN split-K plan (WinoFLayout ks32 / kc32), not the plane GEMM's.  Gradients against
     the default path (separate transforms) of the same arithmetic."""
     from chainer_maskrcnn.nn import core
+    from chainer_maskrcnn import _hip
     lib = _hip.lib()
     ps = core.ParamStore()
     conv = core.Conv(ps, 'c', 256, 256, 3, 1, 1, bias=True)
