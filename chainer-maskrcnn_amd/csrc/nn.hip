@@ -284,18 +284,8 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__
         };
         const float *yr = relu == 1 ? y : gy;             // only mode 1 reads the third stream
         int r = r0 + rr;
-        for (; r + 3 * RPI < r1; r += 4 * RPI) {          // four rows (8 - 12 loads) in flight, accumulated in row order (same sums as two)
-            float4 g[4], v[4], yy[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const size_t o = (size_t)(r + j * RPI) * C + cg * 4;
-                g[j] = ld4(gy + o); v[j] = ld4(x + o);
-                yy[j] = relu == 1 ? ld4(yr + o) : g[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc(g[j], v[j], yy[j]);
-        }
-        for (; r + RPI < r1; r += 2 * RPI) {              // two rows in flight
+        // (four rows in flight were tried in round 5: the in-step launches went 1012 -> 1392 us per step - more registers, fewer waves)
+        for (; r + RPI < r1; r += 2 * RPI) {              // two rows (six loads) in flight, accumulated in row order
             const size_t o0 = (size_t)r * C + cg * 4, o1 = (size_t)(r + RPI) * C + cg * 4;
             const float4 g0 = ld4(gy + o0), v0 = ld4(x + o0), g1 = ld4(gy + o1), v1 = ld4(x + o1);
             float4 y0 = g0, y1 = g1;
