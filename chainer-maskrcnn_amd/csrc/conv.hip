@@ -912,6 +912,8 @@ void launch_conv(ConvP &p, int zdim, TileChoice t, hipStream_t st) {
     }
     {   // exploratory opt-in: three-term split operands; the planes' type per PASS of the calling entry point
         const int split = g_split_mode[g_cur_pass];
+        // (Sending the emulated launches with 64 x 64 / 128 x 64 / 64 x 128 tiles - MFMA-busy 0.12 - 0.24 - to the float32-MFMA kernel was
+        // measured in round 5, same-process A/B on the step: 21.72 ms emulated everywhere against 21.84 - 21.91 ms with any subset on float32.)
         if (split == 1) {
             if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 128, false, 1>), grid, blk, 0, st, p);
             else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((k_conv_igemm<MODE, 128, 64, false, 1>), grid, blk, 0, st, p);
