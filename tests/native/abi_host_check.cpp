@@ -177,6 +177,33 @@ int main() {
         b.fwd_split = 7;
         EXPECT_ERR(mrcnn_bottleneck_fwd_plan(&b, &plan));
     }
+    // ---- ROIAlign backward plan (ABI v9): the size query is host arithmetic; builder / planned backward / status reject bad arguments
+    {
+        static float host2[16];
+        const float *NCF = host2; void *NV = host2; float *NF = host2;
+        const int Hs[2] = {40, 20}, Ws[2] = {48, 24};
+        const float sc[2] = {0.25f, 0.125f};
+        float *gxs[2] = {NF, NF};
+        for (int P : {7, 14, 16}) for (int R : {1, 300, 2000}) for (int split = 0; split <= 1; ++split) {
+            const size_t b = mrcnn_roi_align_fpn_bwd_plan_bytes(Hs, Ws, 2, 2, R, P, P, split);
+            EXPECT(b > 256);
+            acc += b;
+        }
+        EXPECT(mrcnn_roi_align_fpn_bwd_plan_bytes(nullptr, Ws, 2, 2, 300, 7, 7, 1) == 0);
+        EXPECT(mrcnn_roi_align_fpn_bwd_plan_bytes(Hs, Ws, 2, 2, 300, 17, 17, 1) == 0);       // pooled size beyond the fast path
+        EXPECT(mrcnn_roi_align_fpn_bwd_plan_bytes(Hs, Ws, 0, 2, 300, 7, 7, 1) == 0);
+        EXPECT_ERR(mrcnn_roi_align_fpn_bwd_plan_f32(Hs, Ws, sc, 2, 2, 256, NCF, nullptr, 300, 7, 7, 2, 1, NV, 1u << 20, V));     // two levels need `levels`
+        EXPECT_ERR(mrcnn_roi_align_fpn_bwd_plan_f32(Hs, Ws, sc, 2, 2, 256, NCF, CI ? CI : (const int32_t *)host2, 300, 7, 7, 2, 1, nullptr, 0, V));   // null plan
+        EXPECT_ERR(mrcnn_roi_align_fpn_bwd_plan_f32(Hs, Ws, sc, 2, 2, 255, NCF, (const int32_t *)host2, 300, 7, 7, 2, 1, NV, 1u << 20, V));   // C % 4
+        EXPECT_ERR(mrcnn_roi_align_fpn_bwd_plan_f32(Hs, Ws, sc, 2, 2, 256, NCF, (const int32_t *)host2, 300, 7, 7, 0, 1, NV, 1u << 20, V));   // adaptive sampling
+        EXPECT_ERR(mrcnn_roi_align_fpn_bwd_planned_f32(NCF, nullptr, Hs, Ws, sc, 2, 2, 256, NCF, (const int32_t *)host2, 300, 7, 7, 2, 0, nullptr, 0, NV, 1u << 20, 0, V));
+        EXPECT_ERR(mrcnn_roi_align_fpn_bwd_planned_f32(nullptr, gxs, Hs, Ws, sc, 2, 2, 256, NCF, (const int32_t *)host2, 300, 7, 7, 2, 0, nullptr, 0, NV, 1u << 20, 0, V));
+        int st3[3];
+        EXPECT_ERR(mrcnn_roi_align_bwd_plan_status(nullptr, 1024, st3, V));
+        EXPECT_ERR(mrcnn_roi_align_bwd_plan_status(NV, 1024, nullptr, V));
+        EXPECT_ERR(mrcnn_roi_align_bwd_plan_status(NV, 16, st3, V));
+        EXPECT_ERR(mrcnn_debug_roi_align_lean_variant(3));
+    }
     std::printf("planning checksum %llu, %d failure(s)\n", acc, failures);
     return failures ? 1 : 0;
 }
