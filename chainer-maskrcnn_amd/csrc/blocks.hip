@@ -9,6 +9,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <mutex>
 
 namespace {
 
@@ -65,18 +66,21 @@ struct FwdSplit {
 constexpr int EV_RING = 16, EV_DEVS = 16;
 hipEvent_t g_ev[EV_DEVS][EV_RING];
 bool g_ev_made[EV_DEVS] = {};
-thread_local unsigned g_ev_next = 0;
+unsigned g_ev_next[EV_DEVS] = {};
+std::mutex g_ev_lock;       // the pool is shared by every caller thread: creation, slot choice and the record / wait pair are one critical section
+                            // (two threads recording the same event between each other's record and wait would fence on the wrong point)
 
 int fence(hipStream_t from, hipStream_t to) {
     if (from == to) return 0;
     int dev = 0;
     MRCNN_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= EV_DEVS) return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "bottleneck: device index %d", dev);
+    std::lock_guard<std::mutex> hold(g_ev_lock);
     if (!g_ev_made[dev]) {
         for (int i = 0; i < EV_RING; ++i) MRCNN_HIP_TRY(hipEventCreateWithFlags(&g_ev[dev][i], hipEventDisableTiming));
         g_ev_made[dev] = true;
     }
-    hipEvent_t e = g_ev[dev][g_ev_next++ % EV_RING];
+    hipEvent_t e = g_ev[dev][g_ev_next[dev]++ % EV_RING];
     MRCNN_HIP_TRY(hipEventRecord(e, from));
     MRCNN_HIP_TRY(hipStreamWaitEvent(to, e, 0));
     return 0;
