@@ -240,7 +240,7 @@ def bench_step(args, rank, world):
                      # across rounds and arithmetics
                      'frac_f32_equivalent': round(head['executed_flops_per_step'] / (6.0 if head_is_emu else 1.0) / (head['gemm_ms_per_step'] * 1e-3) / 157.3e12, 4)
                      if head['gemm_ms_per_step'] else None,
-                     'in_step': _in_step_gemm(f32, emu),
+                     'in_step': _in_step_gemm(f32, emu) if not keypoints else None,      # (the committed trace is of the configs[2] step)
                      'traffic': pmc['traffic'], 'traffic_source': pmc['traffic_source'],
                      'hbm_bytes_per_step_by_family': pmc.get('hbm_bytes_per_step_by_family'),
                      'hbm_bytes_per_step_whole_step': pmc.get('hbm_bytes_per_step_whole_step'),
