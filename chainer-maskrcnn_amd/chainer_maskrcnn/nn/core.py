@@ -387,6 +387,8 @@ class Bottleneck(object):
         import ctypes
         from chainer_maskrcnn import _hip
         lib = _hip.lib()
+        if not x.is_contiguous():
+            raise ValueError('non-contiguous tensor passed to a HIP op')
         d = self._descriptor(x)
         plan = _hip.BottleneckPlan()
         _hip.check(lib.mrcnn_bottleneck_fwd_plan(ctypes.byref(d), ctypes.byref(plan)))
@@ -404,6 +406,8 @@ class Bottleneck(object):
         from chainer_maskrcnn import _hip
         lib = _hip.lib()
         _, x, y, fwd_arena, plan = ctx
+        if not gy.is_contiguous() or (gx_acc is not None and not gx_acc.is_contiguous()):
+            raise ValueError('non-contiguous tensor passed to a HIP op')
         d = self._descriptor(x)
         dev = x.device
         sizes = (ctypes.c_size_t * 3)()
