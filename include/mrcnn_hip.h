@@ -13,7 +13,9 @@
  *   - the caller owns every buffer, including workspaces (query *_workspace_bytes first);
  *     the library never allocates or frees device memory and keeps no pointer past return.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
- *     null stream); no call synchronises the device.
+ *     null stream); no call synchronises the device - with ONE exception, the explicit status query
+ *     mrcnn_roi_align_bwd_plan_status (ABI v9).  The composite calls (mrcnn_bottleneck_*) also enqueue on the
+ *     caller's side stream, behind events of a small library-owned pool (no device memory).
  *   - return value: 0 = success; negative = MRCNN_E_* argument error; positive = hipError_t.
  *     mrcnn_last_error() returns a thread-local message for the last failure.
  *   - no C++ exceptions cross this boundary.
