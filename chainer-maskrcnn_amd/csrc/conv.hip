@@ -1909,7 +1909,7 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
         MRCNN_LAUNCH_CHECK();
         if (L.ksplit > 1) {
             const size_t n4 = (size_t)Cout * g.nk * Cin / 4;
-            if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, L.ksplit, 0);
+            if (!(g_debug_skip & 10)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, L.ksplit, 0);
             MRCNN_LAUNCH_CHECK();
         }
         WINO_LAUNCH(k_wino_filter_grad, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), dU, gw, Cout, Cin, accumulate, 1);
@@ -1926,7 +1926,7 @@ int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, in
     if (p.ksplit > 1) {     // a separate, fully parallel slab sum: folding it into k_wino_filter_grad (Cout*Cin threads only) was
                             // measured 20 % .. 4x slower (tools/wino_sweep.py)
         const size_t n4 = (size_t)Cout * g.nk * Cin / 4;
-        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, p.ksplit, 0);
+        if (!(g_debug_skip & 10)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, dU, n4, p.ksplit, 0);
         MRCNN_LAUNCH_CHECK();
     }
     WINO_LAUNCH(k_wino_filter_grad, g, dim3(mrcnn::cdiv(Cout * Cin, 256)), dU, gw, Cout, Cin, accumulate, 1);
@@ -2143,7 +2143,7 @@ extern "C" int mrcnn_conv2d_get_split_operands(int *modes3) {
 }
 
 extern "C" int mrcnn_conv2d_set_debug_skip(int mask) {
-    if (mask < 0 || mask > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_debug_skip: mask in [0,3]");
+    if (mask < 0 || mask > 15) return mrcnn::fail_arg(MRCNN_E_INVALID, "set_debug_skip: mask in [0,15]");
     g_debug_skip = mask;
     return 0;
 }
@@ -2310,6 +2310,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
                                            void *stream) {
     g_cur_pass = 2;
     if (int e = check_conv(x, gy, gw, N, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
+    if (g_debug_skip & 4) return 0;             // timing experiments only (tools/ab_step.py): what the whole pass costs the step
     const size_t need = mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad);
     if (!ws || ws_bytes < need) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "conv2d_bwd_filter: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
@@ -2348,7 +2349,7 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
     MRCNN_LAUNCH_CHECK();
     if (use_slabs) {
         const size_t n4 = wcount / 4;
-        if (!(g_debug_skip & 2)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, gw, n4, p.ksplit, accumulate);
+        if (!(g_debug_skip & 10)) hipLaunchKernelGGL(k_sum_slabs, dim3(mrcnn::cdiv(n4, 256)), dim3(256), 0, st, slabs, gw, n4, p.ksplit, accumulate);
         MRCNN_LAUNCH_CHECK();
     }
     if (gbias) {

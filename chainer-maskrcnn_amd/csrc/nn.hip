@@ -45,6 +45,7 @@ inline int ew_grid(size_t n4) { return (int)std::min<size_t>((n4 + NT - 1) / NT,
 // cg = t % G (G = min(C/4, 256)) and rows t/G, t/G + RPI, ...; a block owns a contiguous chunk of
 // rows.  Partials go to ws[blk][C] (float4 per group), a finalize kernel sums them in order.
 // ---------------------------------------------------------------------------------------------
+int g_red_cap = 1024;         // most row blocks (= partial rows) of a channel-wise reduction (measurement knob: mrcnn_debug_bn_plan)
 struct RedPlan {
     int G, RPI, nblk, rows_per_blk;
 };
@@ -54,7 +55,7 @@ RedPlan red_plan(int P, int C) {
     r.G = std::min(C4, NT);
     r.RPI = NT / r.G;
     long long want = ((long long)P * C4 + (long long)NT * 16 - 1) / ((long long)NT * 16);
-    r.nblk = (int)std::max(1ll, std::min(want, 1024ll));
+    r.nblk = (int)std::max(1ll, std::min(want, (long long)g_red_cap));
     r.rows_per_blk = (int)(((long long)P + r.nblk - 1) / r.nblk);
     r.rows_per_blk = (r.rows_per_blk + r.RPI - 1) / r.RPI * r.RPI;
     r.nblk = (P + r.rows_per_blk - 1) / r.rows_per_blk;
@@ -101,29 +102,36 @@ __global__ __launch_bounds__(NT) void k_bn_stats_partial(const float *__restrict
     }
 }
 
-// Sum of the per-block partials (nblk rows of (2, C) floats: sums, sums of squares) of the block's FIN_CH = 16 channels by
-// a 256-thread block, in double.  These kernels are pure latency on the step's critical chain (a convolution's statistics
-// must be final before its BatchNorm can be applied), so the rows are spread over as many loads in flight as the block has:
-// thread = (row slice of 64, channel quad): slice s adds rows s, s + 64, ... (float4 loads, eight in flight, row order), the
-// 64 slice sums of a channel are then added in slice order by the channel's thread (fixed order => bit-reproducible).
-// 2048 partial rows (the res2 layers): 14.5 -> ~5 us per launch against 16 slices of scalar loads.  Still 256 threads, not
-// 1024: a workgroup of 16 waves cannot start until a whole CU has drained when these run beside GEMMs of another stream.
-// Returns the sums in (a, b) of the threads with threadIdx.x < FIN_CH (channel blockIdx.x * FIN_CH + threadIdx.x).
-constexpr int FIN_SLICES = 16, FIN_CH = 16;         // (the thread layout of the callers' own passes: 16 slices x 16 channels)
-constexpr int RED_SLICES = 64, RED_QUADS = FIN_CH / 4;
+// Sum of the per-block partials (nblk rows of (2, C) floats: sums, sums of squares) of the block's 4 * QUADS channels by a
+// 256-thread block, in double.  These kernels are pure latency on the step's critical chain (a convolution's statistics must be
+// final before its BatchNorm can be applied; measured round 5 by leaving them out: 0.70 ms of a 20.7-ms step for 106 launches),
+// so the rows are spread over as many loads in flight as the block has: thread = (row slice, channel quad), slice s adds rows
+// s, s + SLICES, ... (float4 loads, four rows = eight loads in flight, row order), the slice sums of a channel are then added
+// in slice order in two levels (fixed order => bit-reproducible).  QUADS = 4 (64 slices x 16 channels: 64-byte runs per partial
+// row) is the shipped layout; QUADS = 1 (256 slices of one quad: two rounds of loads instead of eight for the 2048 partial rows
+// of a res2 layer) was measured in round 5 and is SLOWER on every shape (tools/bn_plan_ab.py: 0.97 against 0.93 ms per step
+// forward, 1.84 against 1.78 backward - four times the workgroups, each touching a 16-byte piece of every 128-byte line),
+// as is a higher cap on the reduction passes' row blocks (2048, 4096: +0.02 ms).  Still 256 threads, not 1024: a workgroup
+// of 16 waves cannot start until a whole CU has drained when these run beside GEMMs of another stream.
+// Returns the sums in (a, b) of the threads with threadIdx.x < 4 * QUADS (channel blockIdx.x * 4 * QUADS + threadIdx.x).
+constexpr int FIN_THREADS = 256;
+int g_fin_quads = 4;          // channel quads per finalisation block (measurement knob: mrcnn_debug_bn_plan)
+template <int QUADS>
 __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int nblk, int C, double &a, double &b) {
-    __shared__ double ra[RED_SLICES][FIN_CH], rb[RED_SLICES][FIN_CH];
-    const int quad = threadIdx.x % RED_QUADS, slice = threadIdx.x / RED_QUADS;
-    const int c0 = blockIdx.x * FIN_CH + quad * 4;
+    constexpr int CH = 4 * QUADS, SLICES = FIN_THREADS / QUADS, L2N = SLICES / 16;
+    __shared__ double ra[SLICES][CH], rb[SLICES][CH];
+    __shared__ double ra2[16][CH], rb2[16][CH];
+    const int quad = threadIdx.x % QUADS, slice = threadIdx.x / QUADS;
+    const int c0 = blockIdx.x * CH + quad * 4;
     double sa4[4] = {0.0, 0.0, 0.0, 0.0}, sb4[4] = {0.0, 0.0, 0.0, 0.0};
     if (c0 < C) {           // C is a multiple of 4: a quad is inside or outside as a whole
         int k = slice;
-        for (; k + 3 * RED_SLICES < nblk; k += 4 * RED_SLICES) {
+        for (; k + 3 * SLICES < nblk; k += 4 * SLICES) {
             float4 va[4], vb[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                va[j] = ld4(part + (size_t)(k + j * RED_SLICES) * 2 * C + c0);
-                vb[j] = ld4(part + (size_t)(k + j * RED_SLICES) * 2 * C + C + c0);
+                va[j] = ld4(part + (size_t)(k + j * SLICES) * 2 * C + c0);
+                vb[j] = ld4(part + (size_t)(k + j * SLICES) * 2 * C + C + c0);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -131,7 +139,7 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
                 sb4[0] += (double)vb[j].x; sb4[1] += (double)vb[j].y; sb4[2] += (double)vb[j].z; sb4[3] += (double)vb[j].w;
             }
         }
-        for (; k < nblk; k += RED_SLICES) {
+        for (; k < nblk; k += SLICES) {
             const float4 va = ld4(part + (size_t)k * 2 * C + c0), vb = ld4(part + (size_t)k * 2 * C + C + c0);
             sa4[0] += (double)va.x; sa4[1] += (double)va.y; sa4[2] += (double)va.z; sa4[3] += (double)va.w;
             sb4[0] += (double)vb.x; sb4[1] += (double)vb.y; sb4[2] += (double)vb.z; sb4[3] += (double)vb.w;
@@ -140,16 +148,27 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) { ra[slice][quad * 4 + e] = sa4[e]; rb[slice][quad * 4 + e] = sb4[e]; }
     __syncthreads();
+    if (threadIdx.x < 16 * CH) {            // 16 groups of L2N consecutive slices per channel
+        const int ch = threadIdx.x % CH, g = threadIdx.x / CH;
+        double x = 0.0, y = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < L2N; ++k) { x += ra[g * L2N + k][ch]; y += rb[g * L2N + k][ch]; }
+        ra2[g][ch] = x; rb2[g][ch] = y;
+    }
+    __syncthreads();
     a = 0.0; b = 0.0;
-    if (threadIdx.x < FIN_CH) {
-        for (int k = 0; k < RED_SLICES; ++k) { a += ra[k][threadIdx.x]; b += rb[k][threadIdx.x]; }
+    if (threadIdx.x < CH) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { a += ra2[g][threadIdx.x]; b += rb2[g][threadIdx.x]; }
     }
 }
 
-__global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_stats_final(const float *__restrict__ x, const float *__restrict__ part,
+template <int QUADS>
+__global__ __launch_bounds__(FIN_THREADS) void k_bn_stats_final(const float *__restrict__ x, const float *__restrict__ part,
                                                          int nblk, int P, int C, float eps, float decay, int shifted,
                                                          float *__restrict__ mean, float *__restrict__ invstd,
                                                          float *__restrict__ run_mean, float *__restrict__ run_var) {
+    constexpr int FIN_CH = 4 * QUADS, FIN_SLICES = FIN_THREADS / FIN_CH;    // the thread layout of this kernel's own passes
     __shared__ double sa[FIN_SLICES][FIN_CH], sb[FIN_SLICES][FIN_CH];
     __shared__ double smean[FIN_CH];
     __shared__ int sredo;
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_stats_final(const fl
     const int c = blockIdx.x * FIN_CH + cl, slice = threadIdx.x / FIN_CH;
     double a, b;
     if (threadIdx.x == 0) sredo = 0;
-    reduce_partials(part, nblk, C, a, b);        // (contains a barrier: sredo is visible below)
+    reduce_partials<QUADS>(part, nblk, C, a, b);        // (contains barriers: sredo is visible below)
     // shifted: the partials are sums of (x - K), K = x[0][c] (k_bn_stats_partial); else plain sums (the convolution epilogue)
     double ms = a / P, var = b / P - ms * ms;
     double m = (shifted ? (double)x[c < C ? c : 0] : 0.0) + ms;
@@ -207,6 +226,15 @@ __global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_stats_final(const fl
         const float adj = (float)P / (float)max(P - 1, 1);
         run_var[c] = decay * run_var[c] + (1.0f - decay) * v * adj;
     }
+}
+void launch_stats_final(hipStream_t st, const float *x, const float *part, int nblk, int P, int C, float eps, float decay, int shifted,
+                        float *mean, float *invstd, float *run_mean, float *run_var) {
+    if (g_fin_quads == 1)
+        hipLaunchKernelGGL(k_bn_stats_final<1>, dim3(mrcnn::cdiv(C, 4)), dim3(FIN_THREADS), 0, st, x, part, nblk, P, C, eps, decay, shifted, mean,
+                           invstd, run_mean, run_var);
+    else
+        hipLaunchKernelGGL(k_bn_stats_final<4>, dim3(mrcnn::cdiv(C, 16)), dim3(FIN_THREADS), 0, st, x, part, nblk, P, C, eps, decay, shifted, mean,
+                           invstd, run_mean, run_var);
 }
 
 // y = gamma*(x-mean)*invstd + beta (+ residual) (ReLU).  Bytes: 4*P*C*(2 or 3).
@@ -313,14 +341,19 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float *__restrict__
     }
 }
 
-__global__ __launch_bounds__(FIN_SLICES * FIN_CH) void k_bn_bwd_final(const float *__restrict__ part, int nblk, int C,
+template <int QUADS>
+__global__ __launch_bounds__(FIN_THREADS) void k_bn_bwd_final(const float *__restrict__ part, int nblk, int C,
                                                        float *__restrict__ gbeta, float *__restrict__ ggamma) {
-    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, slice = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * 4 * QUADS + threadIdx.x;
     double a, b;
-    reduce_partials(part, nblk, C, a, b);
-    if (slice != 0 || c >= C) return;
+    reduce_partials<QUADS>(part, nblk, C, a, b);
+    if (threadIdx.x >= 4 * QUADS || c >= C) return;
     gbeta[c] = (float)a;
     ggamma[c] = (float)b;
+}
+void launch_bwd_final(hipStream_t st, const float *part, int nblk, int C, float *gbeta, float *ggamma) {
+    if (g_fin_quads == 1) hipLaunchKernelGGL(k_bn_bwd_final<1>, dim3(mrcnn::cdiv(C, 4)), dim3(FIN_THREADS), 0, st, part, nblk, C, gbeta, ggamma);
+    else hipLaunchKernelGGL(k_bn_bwd_final<4>, dim3(mrcnn::cdiv(C, 16)), dim3(FIN_THREADS), 0, st, part, nblk, C, gbeta, ggamma);
 }
 
 // gx = gamma*invstd*(dz - gbeta/P - xhat*ggamma/P); optionally gres = dz.
@@ -852,6 +885,21 @@ extern "C" size_t mrcnn_bn_workspace_bytes(int P, int C) {
     return (size_t)r.nblk * 2 * C * sizeof(float);
 }
 
+// Timing experiments only (tools/ab_step.py): bit 0 leaves out k_bn_bwd_final, bit 1 k_bn_stats_final of the *_stats form (their outputs
+// keep whatever the buffers held).
+int g_bn_debug_skip = 0;
+extern "C" int mrcnn_debug_bn_skip(int mask) {
+    if (mask < 0 || mask > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_bn_skip: mask in [0,3]");
+    g_bn_debug_skip = mask;
+    return 0;
+}
+
+extern "C" int mrcnn_debug_bn_plan(int red_cap, int fin_quads) {
+    if (red_cap < 1 || red_cap > 8192 || (fin_quads != 1 && fin_quads != 4)) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_bn_plan: red_cap 1..8192, fin_quads 1 or 4");
+    g_red_cap = red_cap; g_fin_quads = fin_quads;
+    return 0;
+}
+
 extern "C" int mrcnn_bn_train_fwd_f32(const float *x, const float *gamma, const float *beta, const float *residual,
                                       float *y, float *save_mean, float *save_invstd, float *running_mean,
                                       float *running_var, int P, int C, float eps, float decay, int relu, void *ws,
@@ -863,8 +911,7 @@ extern "C" int mrcnn_bn_train_fwd_f32(const float *x, const float *gamma, const 
     const RedPlan r = red_plan(P, C);
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(r.nblk), dim3(NT), 0, st, x, P, C, r.G, r.RPI, r.rows_per_blk, (float *)ws);
     MRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_stats_final, dim3(mrcnn::cdiv(C, FIN_CH)), dim3(FIN_SLICES * FIN_CH), 0, st, x, (const float *)ws, r.nblk, P, C,
-                       eps, decay, 1, save_mean, save_invstd, running_mean, running_var);
+    launch_stats_final(st, x, (const float *)ws, r.nblk, P, C, eps, decay, 1, save_mean, save_invstd, running_mean, running_var);
     MRCNN_LAUNCH_CHECK();
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, x, gamma, beta, save_mean, save_invstd, residual, y,
@@ -882,8 +929,8 @@ extern "C" int mrcnn_bn_train_fwd_stats_f32(const float *x, const float *part, i
     if (int e = chk(x && part && gamma && beta && y && save_mean && save_invstd, "bn_train_fwd_stats: null pointer")) return e;
     if (int e = chk(P > 0 && C > 0 && (C % 4) == 0 && rows > 0, "bn_train_fwd_stats: need P>0, C%4==0, rows>0")) return e;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bn_stats_final, dim3(mrcnn::cdiv(C, FIN_CH)), dim3(FIN_SLICES * FIN_CH), 0, st, x, part, rows, P, C, eps, decay, 0,
-                       save_mean, save_invstd, running_mean, running_var);
+    if (!(g_bn_debug_skip & 2))
+    launch_stats_final(st, x, part, rows, P, C, eps, decay, 0, save_mean, save_invstd, running_mean, running_var);
     MRCNN_LAUNCH_CHECK();
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, x, gamma, beta, save_mean, save_invstd, residual, y, n4, C / 4, relu);
@@ -905,7 +952,8 @@ extern "C" int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const flo
     hipLaunchKernelGGL(k_bn_bwd_partial, dim3(r.nblk), dim3(NT), 0, st, gy, x, y, gamma, beta, save_mean, save_invstd, P, C, r.G,
                        r.RPI, r.rows_per_blk, rmode, (float *)ws);
     MRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(mrcnn::cdiv(C, FIN_CH)), dim3(FIN_SLICES * FIN_CH), 0, st, (const float *)ws, r.nblk, C, gbeta, ggamma);
+    if (!(g_bn_debug_skip & 1))
+    launch_bwd_final(st, (const float *)ws, r.nblk, C, gbeta, ggamma);
     MRCNN_LAUNCH_CHECK();
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, gy, x, y, gamma, save_mean, save_invstd, gbeta,

@@ -271,9 +271,17 @@ int mrcnn_debug_planes_gemm(int kind, const void *a, const void *b, float *c, in
                             int ksplit, int bm, int bn, void *stream);
 
 /* Measurement knob for bench.py's roofline split (never set on a product path): bit 0 skips the MFMA GEMM launches of
- * the convolution calls, bit 1 skips every other kernel they launch (Winograd transforms, slab / tail / column sums).
- * Outputs are garbage while a bit is set; 0 restores normal operation. */
+ * the convolution calls, bit 1 skips every other kernel they launch (Winograd transforms, slab / tail / column sums),
+ * bit 2 makes the filter-gradient call return at once, bit 3 skips only that call's split-K slab sums (tools/ab_step.py:
+ * what the weight-gradient stream costs the step).  Outputs are garbage while a bit is set; 0 restores normal operation. */
 int mrcnn_conv2d_set_debug_skip(int mask);
+/* The same kind of knob for the BatchNorm calls: bit 0 leaves out the backward's finalisation launch, bit 1 the forward's (the form fed by
+ * the convolution epilogue's partial sums); the outputs of the skipped launch keep whatever their buffers held. */
+int mrcnn_debug_bn_skip(int mask);
+/* Measurement knobs of the channel-wise reductions (A/B in one process, tools/bn_plan_ab.py; the defaults are 1024, 4): most row
+ * blocks = partial rows a reduction pass may use (also sizes mrcnn_bn_workspace_bytes: set it before the sizes are asked for), and
+ * the channel quads one finalisation workgroup sums (4: 64 row slices x 16 channels; 1: 256 slices of one quad - slower). */
+int mrcnn_debug_bn_plan(int red_cap, int fin_quads);
 /* wino_v (nullable): caller-owned buffer of mrcnn_conv2d_winograd_v_bytes() bytes (0 = the layer does not take the
  * Winograd path).  The forward pass leaves its transformed input there and the filter-gradient pass of the same layer
  * reads it instead of transforming x again (same call geometry, same Winograd settings). */

@@ -49,7 +49,7 @@ int main() {
     EXPECT(mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0) == 0);
     EXPECT_ERR(mrcnn_conv2d_set_winograd_pass_tiles(3, 0, 0));
     EXPECT_ERR(mrcnn_conv2d_get_winograd_pass_tiles(nullptr));
-    EXPECT_ERR(mrcnn_conv2d_set_debug_skip(7));
+    EXPECT_ERR(mrcnn_conv2d_set_debug_skip(16));
     EXPECT_ERR(mrcnn_roi_align_set_bwd_variant(5));
     EXPECT(mrcnn_conv2d_workspace_bytes(0, 0, 0, 0, 0, 0, 0, 0, 0) == 0 || true);
     for (int N = 1; N <= 3; ++N)
