@@ -106,7 +106,7 @@ class GradientSynchronizer(object):
         self.buckets = []                 # (start, end) from the end of the buffer
         end = n
         while end > 0:
-            start = max(0, end - per)
+            start = max(0, (end - per) // 64 * 64)       # 256-byte aligned starts: a bucket is also a unit of the float4 update kernel
             self.buckets.append((start, end))
             end = start
         self.next = 0
@@ -115,6 +115,10 @@ class GradientSynchronizer(object):
         self.stream = torch.cuda.Stream() if grads.is_cuda else None
         self.world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
         self.active = self.world > 1 or (sync_single_rank and torch.distributed.is_initialized())
+        # after_bucket(start, end) (optional): called once per bucket, on the bucket's stream, behind its all-reduce - the optimizer's
+        # update of exactly those parameters (MomentumSGD.sectioned_update).  With a callback the buckets are also walked when there is
+        # nothing to reduce (one rank): the update of a finished section then runs beside the rest of the backward pass.
+        self.after_bucket = None
 
     def begin(self):
         self.next = 0
@@ -137,27 +141,33 @@ class GradientSynchronizer(object):
             from chainer_maskrcnn._hip import nn as hnn
             self.stream.wait_stream(hnn.side_stream(self.grads.device))   # ... on the main and on the weight-gradient stream
             with torch.cuda.stream(self.stream):
-                ev = None
-                if self.timing:
-                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                    ev[0].record()
-                self._all_reduce(sl)
-                if ev is not None:
-                    ev[1].record()
-                    self._events.append((end - start, ev[0], ev[1]))
+                if self.active:
+                    ev = None
+                    if self.timing:
+                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev[0].record()
+                    self._all_reduce(sl)
+                    if ev is not None:
+                        ev[1].record()
+                        self._events.append((end - start, ev[0], ev[1]))
+                if self.after_bucket is not None:
+                    self.after_bucket(start, end)
         else:
-            self._all_reduce(sl)
+            if self.active:
+                self._all_reduce(sl)
+            if self.after_bucket is not None:
+                self.after_bucket(start, end)
 
     def mark_ready(self, offset):
-        if not self.active:
+        if not (self.active or self.after_bucket is not None):
             return
         while self.next < len(self.buckets) and self.buckets[self.next][0] >= offset:
             self._reduce(*self.buckets[self.next])
             self.next += 1
 
     def finish(self):
-        """All buckets reduced and visible to the compute stream."""
-        if not self.active:
+        """All buckets reduced (and updated, with a callback) and visible to the compute stream."""
+        if not (self.active or self.after_bucket is not None):
             return
         self.mark_ready(0)
         if self.stream is not None:
@@ -182,12 +192,31 @@ class GradientSynchronizer(object):
 
 
 class MomentumSGD(object):
-    def __init__(self, lr=0.01, momentum=0.9, high_priority_stream=None):
+    LOCAL_BUCKET_BYTES = 8 << 20        # sections of the one-rank sectioned update (the data-parallel path uses its all-reduce buckets)
+
+    def __init__(self, lr=0.01, momentum=0.9, high_priority_stream=None, sectioned_update=None):
         """high_priority_stream (default: on, MRCNN_STEP_STREAM_PRIORITY=0 turns it off): ``update(lossfun, ...)`` issues the
         step on a HIGH-priority HIP stream.  The step's main stream is the critical path (forward, data gradients); the
         weight-gradient and auxiliary streams only have to be done by the end of the step, and at equal priority their
-        workgroups take CU slots from it - same-process A/B on configs[2] (tools/ab_prio.py): 25.55 -> 25.17 ms."""
+        workgroups take CU slots from it - same-process A/B on configs[2] (tools/ab_prio.py): 25.55 -> 25.17 ms.
+
+        sectioned_update (OPT-IN, MRCNN_SECTIONED_UPDATE=1 or the argument; round 5): ``update(lossfun, ...)`` with a train chain
+        applies the SGD step section by section - a contiguous slice of the flat parameter buffer is updated as soon as the
+        backward pass has left it (the chain's grad_ready_hook; one rank) or as soon as its gradient bucket has been all-reduced
+        (data-parallel: on the collective stream, behind the all-reduce) - instead of one 176-MB pass (155 us at 5.7 TB/s) behind
+        the last gradient.  Element-wise the same arithmetic: parameters and momentum are bit-identical to the single pass
+        (tests/test_step_gpu.py).  Measured on configs[2], one process (tools/ab_step.py): 21.47 ms single pass, 21.52 ms with
+        8-MB sections, 21.57 ms with 25-MB sections - the step is bound by the chip's throughput, the update's 0.9 GB
+        cost the same HBM time beside the backward pass as behind it, so the single pass stays the default.  An exception raised
+        inside the backward pass leaves the sections already finished updated."""
         self.lr, self.momentum = lr, momentum
+        if sectioned_update is None:
+            import os
+            sectioned_update = os.environ.get('MRCNN_SECTIONED_UPDATE', '0') == '1'
+        self.sectioned_update = sectioned_update
+        self._local_sync = None
+        self._updated_down_to = None
+        self._section_views = {}
         self.weight_decay = 0.0
         self.target = None
         self.sync = None
@@ -282,7 +311,48 @@ class MomentumSGD(object):
         cur.wait_stream(hi)                     # the caller's stream sees the updated parameters / loss (no host sync)
         return loss
 
+    def _sgd_section(self, start, end):
+        ps = self.ps
+        key = (start, end, ps.params.data_ptr())
+        views = self._section_views.get(key)
+        if views is None:
+            views = self._section_views[key] = (ps.params[start:end], ps.grads[start:end], ps.momentum[start:end])
+        ops.sgd_momentum_wd(views[0], views[1], views[2], self.lr, self.momentum, self.weight_decay)
+        self._updated_down_to = start
+
+    def _sectioning(self, lossfun):
+        """The synchronizer that walks the sections of this update, or None (plain single pass)."""
+        if not self.sectioned_update or lossfun is None or not hasattr(lossfun, 'grad_ready_hook') or not self.ps.params.is_cuda:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if self.sync is not None:
+            return None if self.sync.average else self.sync          # (--grad-average divides the whole buffer after the last bucket)
+        if lossfun.grad_ready_hook is not None:
+            return None                                             # someone else listens to the chain
+        if self._local_sync is None or self._local_sync.grads is not self.ps.grads:
+            self._local_sync = GradientSynchronizer(self.ps.grads, self.LOCAL_BUCKET_BYTES)
+        return self._local_sync
+
     def _update(self, lossfun=None, *args, **kwds):
+        loss = None
+        sect = self._sectioning(lossfun)
+        self._updated_down_to = None
+        if sect is not None:
+            sect.after_bucket = self._sgd_section
+            if sect is not self.sync:
+                sect.begin()
+                lossfun.grad_ready_hook = sect.mark_ready
+        try:
+            loss = self._step(lossfun, sect, *args, **kwds)
+        finally:
+            if sect is not None:
+                sect.after_bucket = None
+                if sect is not self.sync:
+                    lossfun.grad_ready_hook = None
+        return loss
+
+    def _step(self, lossfun, sect, *args, **kwds):
         loss = None
         if lossfun is not None:
             if self.sync is not None:
@@ -303,7 +373,11 @@ class MomentumSGD(object):
                     lossfun.unit_upstream = False
         if self.sync is not None:
             self.sync.finish()
-        ops.sgd_momentum_wd(self.ps.params, self.ps.grads, self.ps.momentum, self.lr, self.momentum, self.weight_decay)
+        elif sect is not None:
+            sect.finish()
+        rest = self.ps.params.numel() if self._updated_down_to is None else self._updated_down_to
+        if rest > 0:        # everything (no sections), or what no section covered
+            ops.sgd_momentum_wd(self.ps.params[:rest], self.ps.grads[:rest], self.ps.momentum[:rest], self.lr, self.momentum, self.weight_decay)
         self.t += 1
         return loss
 

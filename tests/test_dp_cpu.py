@@ -80,3 +80,75 @@ def test_single_process_is_a_no_op():
     sync = GradientSynchronizer(g, bucket_bytes=1024)
     sync.begin(); sync.mark_ready(0); sync.finish()
     assert torch.equal(g, torch.ones(1000))
+
+
+def test_after_bucket_walks_every_bucket_once_without_a_process_group():
+    """The optimizer's sectioned update (MomentumSGD.sectioned_update) rides on the bucket walk: with a callback the buckets are
+    visited even when there is nothing to all-reduce (one rank), each exactly once, from the end of the buffer, never above the
+    offset the backward pass has reported; bucket starts are 64-float aligned (the float4 update kernel runs on a bucket)."""
+    n = 100003
+    g = torch.arange(n, dtype=torch.float32)
+    sync = GradientSynchronizer(g, bucket_bytes=64 << 10)
+    seen = []
+    sync.after_bucket = lambda s, e: seen.append((s, e))
+    sync.begin()
+    for off in (n, 70000, 70000, 33333, 1):
+        sync.mark_ready(off)
+        assert all(s >= off for s, _ in seen)
+    assert seen and seen[-1][0] > 0
+    sync.finish()
+    assert seen == sync.buckets
+    assert seen[0][1] == n and seen[-1][0] == 0 and all(seen[i][0] == seen[i + 1][1] for i in range(len(seen) - 1))
+    assert all(s % 64 == 0 for s, _ in seen)
+    assert torch.equal(g, torch.arange(n, dtype=torch.float32))         # nothing was reduced
+    sync.after_bucket = None
+    sync.begin(); sync.mark_ready(0); sync.finish()
+    assert len(seen) == len(sync.buckets)                                # without a callback a one-rank walk is a no-op again
+
+
+def _worker_after_bucket(rank, world, port, n, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        p = torch.zeros(n)
+        sync = GradientSynchronizer(g, bucket_bytes=32 << 10)
+
+        def update(s, e):               # the update sees the SUMMED gradient of its bucket
+            p[s:e] -= 0.5 * g[s:e]
+        sync.after_bucket = update
+        sync.begin()
+        for off in (n // 2, 0):
+            sync.mark_ready(off)
+        sync.finish()
+        q.put((rank, p))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_after_bucket_runs_behind_the_all_reduce_two_ranks():
+    n = 50000
+    ctx = mp.get_context('spawn')
+    outs = None
+    for attempt in range(3):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_after_bucket, args=(r, 2, port, n, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            got = [q.get(timeout=120) for _ in procs]
+        except Exception:
+            got = None
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if got is not None and all(p.exitcode == 0 for p in procs):
+            outs = got
+            break
+    assert outs is not None, 'two-rank gloo group failed three times'
+    want = -0.5 * 3 * torch.arange(n, dtype=torch.float32)
+    for rank, p in outs:
+        assert torch.equal(p, want), rank

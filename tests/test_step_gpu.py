@@ -167,6 +167,44 @@ def test_step_is_bit_reproducible_and_sgd_updates():
     assert torch.isfinite(m.ps.params).all()
 
 
+def test_sectioned_update_gives_the_same_bits_as_the_single_pass():
+    """MomentumSGD.sectioned_update (round 5): the SGD step of a slice of the flat parameter buffer is enqueued as soon as the backward pass
+    has left it, on its own stream, instead of one pass over everything behind the last gradient.  Same parameters, momentum and
+    losses bit for bit after three steps; the sections tile the buffer from its end, once per step, and most of them are issued
+    while the backward pass is still being enqueued."""
+    b = _batch()
+    outs = []
+    for sectioned in (False, True):
+        m, chain = _build('positives')
+        chain.proposal_target_creator.set_seed(5)
+        chain.anchor_target_creator.set_seed(9)
+        opt = MomentumSGD(lr=1e-2, momentum=0.9, sectioned_update=sectioned).setup(chain)
+        opt.LOCAL_BUCKET_BYTES = 256 << 10
+        opt.add_hook(WeightDecay(0.0005))
+        calls = []
+        inner = opt._sgd_section
+
+        def spy(start, end, inner=inner, chain=chain, calls=calls):
+            calls.append((start, end, chain._bwd is not None))
+            inner(start, end)
+        opt._sgd_section = spy
+        losses = []
+        for _ in range(3):
+            opt.update(chain, b['imgs'], b['bboxes'], b['labels'], b['masks'], 1.0)
+            losses.append(float(chain.observation['loss']))
+        torch.cuda.synchronize()
+        assert chain.grad_ready_hook is None            # the optimizer listens only during its own update
+        outs.append((m.ps.params.clone(), m.ps.momentum.clone(), losses, calls, m.ps.params.numel()))
+    (p0, v0, l0, c0, n), (p1, v1, l1, c1, _) = outs
+    assert not c0 and len(c1) % 3 == 0 and len(c1) >= 3 * 8
+    step = c1[:len(c1) // 3]
+    assert step[0][1] == n and step[-1][0] == 0 and all(step[i][0] == step[i + 1][1] for i in range(len(step) - 1))
+    assert all(s0 % 64 == 0 for s0, _, _ in step)
+    assert sum(1 for _, _, inside in step if inside) >= len(step) // 2
+    assert l0 == l1
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
 def test_reference_api_surface():
     m, chain = _build('positives')
     with pytest.raises(ValueError):
