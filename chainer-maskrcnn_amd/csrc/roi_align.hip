@@ -832,7 +832,9 @@ constexpr int NP_MAGIC = 0x4E504C4E;
 enum { NP_MAGIC_I = 0, NP_OVERFLOW, NP_EXTRA, NP_UNITS, NP_CAP, NP_R, NP_PH, NP_PW, NP_SR, NP_N, NP_QC, NP_L, NP_NODES_OFF, NP_HW /* 2 per level */,
        NP_HDR_INTS = 64 };
 int g_lean_dbg = 0;
-int g_lean_variant = 2;           // gy rows in flight per wave of the lean kernel / waves per SIMD: 0 = 10 / 8, 1 = 16 / 7, 2 = 8 / 8 (mrcnn_debug_roi_align_lean_variant)
+unsigned long long *g_lean_stamps = nullptr;      // measurement (mrcnn_debug_roi_align_lean_stamps)
+int g_lean_variant = 8;           // gy rows in flight per wave of the lean kernel / waves per SIMD / threads per workgroup: 0 = 10 / 8 / 512, 1 = 16 / 7 / 512,
+                                  // 2 = 8 / 8 / 512, 8 = 8 / 8 / 256 (default), 9 = 8 / 8 / 128 (mrcnn_debug_roi_align_lean_variant)
 constexpr int LEAN_CH = 128;      // channels per wave there: lane = 2 channels
 
 template <int QC>
@@ -846,6 +848,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 template <typename T> __device__ __forceinline__ T scalar_load(const void *p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
 }
+// (a stride that is not a multiple of 2 KiB - 4352 instead of the 7 x 7 node's 4096 - was tried in round 5 against HBM channel conflicts on the
+// first touch of the 3400 lists: no change, 19.9 against 19.8 us)
 template <int QC> constexpr size_t plan_node_stride() { return (sizeof(PlanNode<QC>) + 255) / 256 * 256; }
 // [header][tile flags, rounded to 64 ints][nodes]
 inline size_t plan_nodes_off_ints(int total_tiles) { return NP_HDR_INTS + (size_t)(total_tiles + 63) / 64 * 64; }
@@ -1254,24 +1258,33 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
 // ------------------------------------------------------------------------------------------
 // The lean backward (see the PlanNode comment): workgroup = one 8 x 8 tile = 4 patches x 2 channel halves (8 waves).
 // ------------------------------------------------------------------------------------------
-constexpr int LEAN_THREADS = 512;      // workgroup = one 8 x 8 tile: 4 patches x 2 channel halves (the dispatcher's cost is per workgroup)
-template <int PBT, int DEPTH, int OCC>
-__global__ __launch_bounds__(LEAN_THREADS, OCC) void k_roi_align_bwd_lean(Levels lv, const float *__restrict__ gy, int R, int N, int C, int PH, int PW,
+// WPB waves per workgroup: 8 = one 8 x 8 tile (4 patches x 2 channel halves), 4 = half a tile, 2 = one patch.  Every wave of the launch is
+// resident at once and the kernel is bound by the VALU of its busiest SIMD (tools/roi_lean_stamps.py: SIMD time = 215 ticks x its entries,
+// correlation 0.92): the workgroup is the grain at which the dispatcher spreads the entries over the CUs.
+template <int PBT, int DEPTH, int OCC, int WPB>
+__global__ __launch_bounds__(WPB * 64, OCC) void k_roi_align_bwd_lean(Levels lv, const float *__restrict__ gy, int R, int N, int C, int PH, int PW,
                                                                          int sr, int chunk, int accumulate, const int *__restrict__ nplan,
-                                                                         int nodes_off, int dbg) {
+                                                                         int nodes_off, int dbg, unsigned long long *__restrict__ stamps) {
     static_assert(DEPTH % 2 == 0, "rows are consumed in pairs of entries");
+    // measurement (mrcnn_debug_roi_align_lean_stamps; null otherwise): 8 x u64 per wave - s_memtime at entry, when the first node's
+    // loads have arrived, at the end of the entry loop, when the stores have been acknowledged; entries; HW_ID | XCC_ID << 32;
+    // s_memrealtime (100 MHz, one counter for the chip: s_memtime is not) at entry and at the end
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+    if (stamps) { st0 = stamp_now(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int QC = WaveLds<PBT>::QC;
     static_assert(QC % 2 == 0, "weight pairs");
     constexpr size_t NSTRIDE = plan_node_stride<QC>();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);       // XCD-banded tile order, as the wave kernel
+    constexpr int SUBS = 8 / WPB;                                            // workgroups per tile
+    const int bj = (int)(blockIdx.x >> 3), sub = bj % SUBS;
+    const int tile_id = (blockIdx.x & 7) * chunk + bj / SUBS;               // XCD-banded tile order, as the wave kernel
     const int total = lv.tile_begin[lv.L];
-    if ((int)(blockIdx.x >> 3) >= chunk || tile_id >= total) return;
+    if (bj / SUBS >= chunk || tile_id >= total) return;
     // (pairing the tile's heaviest patch with its lightest on one SIMD pair was tried: the four extra counts cost a dependent round trip,
     // +1.3 us on configs[1])
     const char *nb = reinterpret_cast<const char *>(nplan + nodes_off);
-    const int pslot = wave >> 1, half = wave & 1;
+    const int pslot = sub * (WPB / 2) + (wave >> 1), half = wave & 1;
     const int unit = tile_id * BWD_WAVES + pslot;
     // the plan's loads go out first: header, tile flag, the first node's count / next / row indices (lane = entry) - one round trip
     const PlanNode<QC> *pn = reinterpret_cast<const PlanNode<QC> *>(nb + (size_t)unit * NSTRIDE);
@@ -1319,6 +1332,10 @@ __global__ __launch_bounds__(LEAN_THREADS, OCC) void k_roi_align_bwd_lean(Levels
             for (int k = 0; k < PT; ++k) acc[i][k] = make_float2(0.f, 0.f);
         int total_n = 0;
         const PlanNode<QC> *cur = pn;
+        if (stamps && cb == 0) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            st1 = stamp_now();
+        }
         if (cb > 0) {                      // a further channel pass walks the list again from its first node
             qrow = pn->q.row[ql];
             cnt = scalar_load<int>(&pn->count); next = scalar_load<int>(&pn->next);
@@ -1357,6 +1374,11 @@ __global__ __launch_bounds__(LEAN_THREADS, OCC) void k_roi_align_bwd_lean(Levels
                 i32x8 wy, wyn;
                 f32x8 wx, wxn;
                 ldw(0, wy, wx);
+                // (round 5, late, measured and dropped - tools/roi_plan_bench.py, every form bit-identical: the weights like the row indices, lane = entry
+                // and eight v_readlane per entry: 27.6 us against 19.8 - a v_readlane costs as much VALU time as two packed FMAs; one wave per patch
+                // with four channels per lane and the weights broadcast out of LDS: 23.0 us - the launch lasts as long as the wave of its longest
+                // list, and a wave issues one instruction per ~6 ticks whatever it is: 60 instructions per entry instead of 37; whole groups of
+                // DEPTH entries without the per-entry guard: the same 38 instructions per entry - the guard was never the cost - plus spills)
 #pragma nounroll
                 for (int j = 0; j < m; j += DEPTH) {
 #pragma unroll
@@ -1392,6 +1414,10 @@ __global__ __launch_bounds__(LEAN_THREADS, OCC) void k_roi_align_bwd_lean(Levels
             cnt = scalar_load<int>(&cur->count);
             next = scalar_load<int>(&cur->next);
         }
+        if (stamps && cb == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st2 = stamp_now();
+        }
         if (dbg & 2) {                       // measurement: no gx traffic (one store keeps the sums alive)
             float2 sum = make_float2(0.f, 0.f);
 #pragma unroll
@@ -1426,6 +1452,16 @@ __global__ __launch_bounds__(LEAN_THREADS, OCC) void k_roi_align_bwd_lean(Levels
                         __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned *>(&acc[i][k]), rs_gx, vlane,
                                                               patch_off + (unsigned)((i * W + k) * C) * 4u, 2);
                 }
+        if (stamps && cb == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long st3 = stamp_now();
+            if (lane == 0) {
+                unsigned long long *o = stamps + ((size_t)tile_id * 8 + sub * WPB + wave) * 8;
+                o[6] = rt0; o[7] = __builtin_amdgcn_s_memrealtime();
+                o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = (unsigned long long)total_n;
+                o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+            }
+        }
     }
 }
 
@@ -1704,13 +1740,18 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
         if (int e = launch_bwd3(lv, total, N, gy, rois, levels, R, C, PH, PW, sr, accumulate, ws3, need3, st)) return e;
     } else if (nplan) {
         // the lean kernel along the entry lists, then (unless the caller verified the plan) the wave kernel for whatever the plan could not hold
-        auto lean = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(chunk * 8), dim3(LEAN_THREADS), 0, st, lv, gy, R, N, C, PH, PW, sr, chunk, accumulate, (const int *)nplan, (int)nodes_off, g_lean_dbg);
+        auto lean = [&](auto kern, int wpb) {
+            hipLaunchKernelGGL(kern, dim3(chunk * 8 * (8 / wpb)), dim3(wpb * 64), 0, st, lv, gy, R, N, C, PH, PW, sr, chunk, accumulate, (const int *)nplan, (int)nodes_off,
+                               g_lean_dbg, g_lean_stamps);
         };
         const bool small = PH <= 8 && PW <= 8;
-        if (g_lean_variant == 0) { if (small) lean(k_roi_align_bwd_lean<8, 10, 8>); else lean(k_roi_align_bwd_lean<16, 10, 8>); }
-        else if (g_lean_variant == 2) { if (small) lean(k_roi_align_bwd_lean<8, 8, 8>); else lean(k_roi_align_bwd_lean<16, 8, 8>); }
-        else { if (small) lean(k_roi_align_bwd_lean<8, 16, 7>); else lean(k_roi_align_bwd_lean<16, 16, 7>); }
+        switch (g_lean_variant) {
+        case 0: if (small) lean(k_roi_align_bwd_lean<8, 10, 8, 8>, 8); else lean(k_roi_align_bwd_lean<16, 10, 8, 8>, 8); break;
+        case 1: if (small) lean(k_roi_align_bwd_lean<8, 16, 7, 8>, 8); else lean(k_roi_align_bwd_lean<16, 16, 7, 8>, 8); break;
+        case 2: if (small) lean(k_roi_align_bwd_lean<8, 8, 8, 8>, 8); else lean(k_roi_align_bwd_lean<16, 8, 8, 8>, 8); break;
+        case 9: if (small) lean(k_roi_align_bwd_lean<8, 8, 8, 2>, 2); else lean(k_roi_align_bwd_lean<16, 8, 8, 2>, 2); break;
+        default: if (small) lean(k_roi_align_bwd_lean<8, 8, 8, 4>, 4); else lean(k_roi_align_bwd_lean<16, 8, 8, 4>, 4); break;       // 8
+        }
         MRCNN_LAUNCH_CHECK();
         if (plan_verified) {}
         else if (small)
@@ -1986,8 +2027,13 @@ extern "C" int mrcnn_debug_dispatch_census(unsigned long long *out, int nblocks,
     return 0;
 }
 
+extern "C" int mrcnn_debug_roi_align_lean_stamps(unsigned long long *stamps) {     // 8 x u64 per wave (8 per 8 x 8 tile) of the next planned calls; null = off
+    g_lean_stamps = stamps;
+    return 0;
+}
+
 extern "C" int mrcnn_debug_roi_align_lean_variant(int v) {          // measurement: rows in flight / occupancy of the lean backward
-    if (v < 0 || (v & 0xff) > 2) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_roi_align_lean_variant: 0, 1 or 2 (+ 256 x measurement bits)");
+    if (v < 0 || ((v & 0xff) > 2 && (v & 0xff) != 8 && (v & 0xff) != 9)) return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_roi_align_lean_variant: 0, 1, 2, 8 or 9 (+ 256 x measurement bits)");
     g_lean_variant = v & 0xff;
     g_lean_dbg = v >> 8;         // 1: no gy loads, 2: no gx stores (results are wrong with either), 16: plain instead of non-temporal stores
     return 0;

@@ -56,10 +56,15 @@ for P in (7, 14):
     hdr = plan[:256].view(torch.int32).cpu().numpy()
     print('P=%d: plan bytes %.1f MB, header magic ok %s overflow %d pool nodes used %d units %d; planned == fused bitwise: %s, NaNs %d'
           % (P, pb / 1e6, hdr[0] == 0x4E504C4E, hdr[1], hdr[2], hdr[3], torch.equal(gx[0], gx[1]), int(torch.isnan(gx[1]).sum())))
+    for v in (0, 2, 9):
+        _hip.check(lib.mrcnn_debug_roi_align_lean_variant(v))
+        gx[1].fill_(float('nan')); planned(1); torch.cuda.synchronize()
+        print('   lean variant %d == fused bitwise: %s' % (v, torch.equal(gx[0], gx[1])))
     for rnd in range(2):
-        for name, f, v in (('fused', fused, None), ('plan build', build, None), ('planned 8/8', planned, 2), ('verified 10/8', planned_v, 0), ('verified 16/7', planned_v, 1), ('verified 8/8', planned_v, 2), ('v 8/8 plain st', planned_v, 2 + 16 * 256), ('v 8/8 no gy gx', planned_v, 2 + 3 * 256)):
+        for name, f, v in (('fused', fused, None), ('plan build', build, None), ('planned (default)', planned, 8), ('verified 10/8 512 thr', planned_v, 0), ('verified 8/8 512 thr', planned_v, 2),
+                           ('verified 8/8 256 thr', planned_v, 8), ('verified 8/8 128 thr', planned_v, 9), ('v 256 thr plain st', planned_v, 8 + 16 * 256), ('v 256 thr no gy gx', planned_v, 8 + 3 * 256)):
             if v is not None:
                 _hip.check(lib.mrcnn_debug_roi_align_lean_variant(v))
             mn, med = timed(f)
-            print('configs[1] P=%d %-17s: min %.1f us  median %.1f us   %.0f GB/s algorithmic (%.3f of 8 TB/s)' % (P, name, mn, med, algo / mn / 1e3, algo / mn / 1e3 / 8000))
-    _hip.check(lib.mrcnn_debug_roi_align_lean_variant(2))
+            print('configs[1] P=%d %-22s: min %.1f us  median %.1f us   %.0f GB/s algorithmic (%.3f of 8 TB/s)' % (P, name, mn, med, algo / mn / 1e3, algo / mn / 1e3 / 8000))
+    _hip.check(lib.mrcnn_debug_roi_align_lean_variant(8))
