@@ -1347,10 +1347,13 @@ __global__ __launch_bounds__(WPB * 64, OCC) void k_roi_align_bwd_lean(Levels lv,
             for (int e0 = 0; e0 < cnt; e0 += 64) {
                 const int m = min(64, cnt - e0);
                 if (e0 > 0) qrow = cur->q.row[min(e0 + lane, QC - 1)];
+                // lanes past the list's end name row 0 (one v_cndmask per 64 entries): the prefetch slots beyond the end then need no select
+                // per entry - only the clamp of the lane index
+                qrow = lane < m ? qrow : 0;
                 // (every load below is issued unconditionally and in slot order: the waitcnt pass can then count - vmcnt(DEPTH - 1) in front of
                 // an entry - instead of falling back to vmcnt(0) at a control-flow merge, which serialises the wave on memory latency)
                 auto ldrow = [&](int j) -> float2 {
-                    const unsigned so = (unsigned)__builtin_amdgcn_readlane(qrow, j < m ? j : 0) * row_bytes;
+                    const unsigned so = (unsigned)__builtin_amdgcn_readlane(qrow, min(j, 63)) * row_bytes;
                     const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_gy, vload, so, 0);
                     float2 f;
                     __builtin_memcpy(&f, &v, 8);
@@ -1358,10 +1361,12 @@ __global__ __launch_bounds__(WPB * 64, OCC) void k_roi_align_bwd_lean(Levels lv,
                 };
                 // the weights of two entries per scalar load (wy[e], wy[e+1] / wx[e], wx[e+1]: 32 bytes each), one pair ahead; the row
                 // weights travel as integers: "weight != 0" is then a scalar integer compare + branch (weights are >= 0), not a VALU class test
+                // (no clamp of the pair's index: the furthest pair a list of QC entries asks for starts DEPTH entries past its end - inside the
+                // node's next array, never used)
+                static_assert(sizeof(float4) * (DEPTH + 2) <= sizeof(int) * QC, "the weight prefetch past a full list stays inside the node");
                 auto ldw = [&](int j, i32x8 &wy, f32x8 &wx) {
-                    const int e = min(e0 + j, QC - 2);
-                    wy = scalar_load<i32x8>(&cur->q.wy[e]);
-                    wx = scalar_load<f32x8>(&cur->q.wx[e]);
+                    wy = scalar_load<i32x8>(&cur->q.wy[e0 + j]);
+                    wx = scalar_load<f32x8>(&cur->q.wx[e0 + j]);
                 };
                 float2 buf[DEPTH];
 #pragma unroll
@@ -1374,6 +1379,9 @@ __global__ __launch_bounds__(WPB * 64, OCC) void k_roi_align_bwd_lean(Levels lv,
                 i32x8 wy, wyn;
                 f32x8 wx, wxn;
                 ldw(0, wy, wx);
+                // (also measured and dropped: the row indices like the weights, eight per scalar load one group ahead, as byte offsets made by the
+                // builder - 32 instead of 36 instructions per entry, 14.5 instead of 15.3 us without gy / gx traffic, but 19.1 - 19.8 instead of 18.3 us
+                // with it: the prefetch loads then queue behind the scalar loads' waits)
                 // (round 5, late, measured and dropped - tools/roi_plan_bench.py, every form bit-identical: the weights like the row indices, lane = entry
                 // and eight v_readlane per entry: 27.6 us against 19.8 - a v_readlane costs as much VALU time as two packed FMAs; one wave per patch
                 // with four channels per lane and the weights broadcast out of LDS: 23.0 us - the launch lasts as long as the wave of its longest
