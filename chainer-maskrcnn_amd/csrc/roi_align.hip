@@ -1266,9 +1266,10 @@ __global__ __launch_bounds__(WPB * 64, OCC) void k_roi_align_bwd_lean(Levels lv,
                                                                          int sr, int chunk, int accumulate, const int *__restrict__ nplan,
                                                                          int nodes_off, int dbg, unsigned long long *__restrict__ stamps) {
     static_assert(DEPTH % 2 == 0, "rows are consumed in pairs of entries");
-    // measurement (mrcnn_debug_roi_align_lean_stamps; null otherwise): 8 x u64 per wave - s_memtime at entry, when the first node's
+    // measurement (mrcnn_debug_roi_align_lean_stamps; null otherwise): 10 x u64 per wave - s_memtime at entry, when the first node's
     // loads have arrived, at the end of the entry loop, when the stores have been acknowledged; entries; HW_ID | XCC_ID << 32;
-    // s_memrealtime (100 MHz, one counter for the chip: s_memtime is not) at entry and at the end
+    // s_memrealtime (100 MHz, one counter for the chip: s_memtime is not) at entry and at the end; s_memtime when the kernel arguments / the
+    // node's scalar loads are back
     unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
     if (stamps) { st0 = stamp_now(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int QC = WaveLds<PBT>::QC;
@@ -1289,10 +1290,16 @@ __global__ __launch_bounds__(WPB * 64, OCC) void k_roi_align_bwd_lean(Levels lv,
     // the plan's loads go out first: header, tile flag, the first node's count / next / row indices (lane = entry) - one round trip
     const PlanNode<QC> *pn = reinterpret_cast<const PlanNode<QC> *>(nb + (size_t)unit * NSTRIDE);
     const int ql = min(lane, QC - 1);
+    unsigned long long stA = 0, stB = 0;
+    if (stamps) stA = stamp_now();               // (waits for the kernel arguments: the node's address is known here)
     int qrow = pn->q.row[ql];
+    // (at the start of a launch the scalar loads are back 2 - 6 us before this vector load - tools/roi_lean_stamps.py: kernel arguments 0.4 us,
+    // scalar loads +1.3 us, the row indices +2.3 us, p90 +6 us - but sending the first DEPTH gy rows out on scalar-loaded indices changes
+    // nothing, 18.6 against 18.5 us: it is the FIRST vector access of a wave that is slow, whichever it is)
     int cnt = scalar_load<int>(&pn->count), next = scalar_load<int>(&pn->next);
     const bool holds = plan_header_holds(nplan, total * BWD_WAVES, R, N, PH, PW, sr, QC, nodes_off);
     const int flagged = scalar_load<int>(nplan + NP_HDR_INTS + tile_id);
+    if (stamps) { asm volatile("" :: "s"(cnt), "s"(next), "s"(flagged)); stB = stamp_now(); }      // (the scalar loads of the node and the header are back)
     // tile -> level, image, patch
     int l = 0, nsplit = 1, zsplit = 0, n;
     while (l + 1 < lv.L && tile_id >= lv.tile_begin[l + 1]) ++l;
@@ -1464,8 +1471,8 @@ __global__ __launch_bounds__(WPB * 64, OCC) void k_roi_align_bwd_lean(Levels lv,
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long st3 = stamp_now();
             if (lane == 0) {
-                unsigned long long *o = stamps + ((size_t)tile_id * 8 + sub * WPB + wave) * 8;
-                o[6] = rt0; o[7] = __builtin_amdgcn_s_memrealtime();
+                unsigned long long *o = stamps + ((size_t)tile_id * 8 + sub * WPB + wave) * 10;
+                o[6] = rt0; o[7] = __builtin_amdgcn_s_memrealtime(); o[8] = stA; o[9] = stB;
                 o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = (unsigned long long)total_n;
                 o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
             }
@@ -2035,7 +2042,7 @@ extern "C" int mrcnn_debug_dispatch_census(unsigned long long *out, int nblocks,
     return 0;
 }
 
-extern "C" int mrcnn_debug_roi_align_lean_stamps(unsigned long long *stamps) {     // 8 x u64 per wave (8 per 8 x 8 tile) of the next planned calls; null = off
+extern "C" int mrcnn_debug_roi_align_lean_stamps(unsigned long long *stamps) {     // 10 x u64 per wave (8 per 8 x 8 tile) of the next planned calls; null = off
     g_lean_stamps = stamps;
     return 0;
 }

@@ -153,9 +153,9 @@ int mrcnn_roi_align_fpn_bwd_plan_f32(const int *Hs, const int *Ws, const float *
  * 2 = 8 / 8 / 512 (a workgroup = one 8 x 8 tile), 8 = 8 / 8 / 256 (half a tile: the default), 9 = 8 / 8 / 128 (one patch); + 256 x bits
  * (1: no gy loads, 2: no gx stores - wrong results; 16: plain instead of non-temporal stores) */
 int mrcnn_debug_roi_align_lean_variant(int v);
-/* measurement: device buffer of 8 x u64 per wave (8 waves per 8 x 8 tile, tile-major) that the lean backward of the next planned calls fills -
+/* measurement: device buffer of 10 x u64 per wave (8 waves per 8 x 8 tile, tile-major) that the lean backward of the next planned calls fills -
  * s_memtime at entry / first node's loads back / end of the entry loop / stores acknowledged, entries, HW_ID | XCC_ID << 32, s_memrealtime
- * at entry / at the end; null = off */
+ * at entry / at the end, s_memtime when the kernel arguments / the node's scalar loads are back; null = off */
 int mrcnn_debug_roi_align_lean_stamps(unsigned long long *stamps);
 int mrcnn_roi_align_fpn_bwd_planned_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws, const float *scales, int L,
                                         int N, int C, const float *rois, const int32_t *levels, int R, int PH, int PW,

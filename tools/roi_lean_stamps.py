@@ -33,7 +33,7 @@ _hip.check(lib.mrcnn_debug_roi_align_lean_variant(variant))
 for _ in range(5):
     planned_v()
 torch.cuda.synchronize()
-st = torch.zeros((tiles * 8, 8), dtype=torch.int64, device=dev)
+st = torch.zeros((tiles * 8, 10), dtype=torch.int64, device=dev)
 _hip.check(lib.mrcnn_debug_roi_align_lean_stamps(ctypes.c_void_p(st.data_ptr())))
 planned_v()
 torch.cuda.synchronize()
@@ -51,6 +51,9 @@ MHZ = 2400.0          # s_memtime ticks per microsecond on this part (tools/uben
 us = lambda c: np.asarray(c, dtype=np.float64) / MHZ
 print('waves %d (of %d slots), entries %d; first wave\'s entry to last wave\'s end: %.2f us' % (len(s), tiles * 8, n.sum(), (r1.max() - rbase) / 100.0))
 print('wave start after the first wave: median %.2f us  p90 %.2f  max %.2f' % (np.median(r0 - rbase) / 100.0, np.percentile(r0 - rbase, 90) / 100.0, (r0 - rbase).max() / 100.0))
+tA, tB = s[:, 8], s[:, 9]
+print('   of it: kernel arguments back after %.2f us (median; p90 %.2f), the node\'s and the header\'s scalar loads after another %.2f (p90 %.2f), the row indices (vector load) after another %.2f (p90 %.2f)' % (
+    us(np.median(tA - t0)), us(np.percentile(tA - t0, 90)), us(np.median(tB - tA)), us(np.percentile(tB - tA, 90)), us(np.median(t1 - tB)), us(np.percentile(t1 - tB, 90))))
 print('first round trip (entry -> first node\'s loads back): median %.2f us  p90 %.2f  max %.2f' % (us(np.median(t1 - t0)), us(np.percentile(t1 - t0, 90)), us((t1 - t0).max())))
 print('entry loop: median %.2f us  p90 %.2f  max %.2f;  per entry of a wave: median %.0f ticks  (waves with >= 8 entries)' % (
     us(np.median(t2 - t1)), us(np.percentile(t2 - t1, 90)), us((t2 - t1).max()), np.median(((t2 - t1) / np.maximum(n, 1))[n >= 8])))
