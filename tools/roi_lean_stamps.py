@@ -40,6 +40,8 @@ torch.cuda.synchronize()
 _hip.check(lib.mrcnn_debug_roi_align_lean_stamps(None))
 _hip.check(lib.mrcnn_debug_roi_align_lean_variant(8))
 s = st.cpu().numpy()
+if len(sys.argv) > 2:
+    np.save(sys.argv[2], s)           # raw stamps (tile-major, 8 waves per tile, 10 x u64) for offline analysis
 live = s[:, 0] != 0
 s = s[live]
 t0, t1, t2, t3, n, hw = (s[:, i] for i in range(6))
