@@ -179,6 +179,10 @@ def bench_roialign(args, rank, world):
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(bwd_gbps / HBM_PEAK_GBPS, 4),
                      'traffic': _pmc_traffic('k_roi_align_bwd_lean' if plan_ok else 'k_roi_align_bwd')[0], 'traffic_source': _pmc_traffic('k_roi_align_bwd_lean' if plan_ok else 'k_roi_align_bwd')[1],
                      'algorithmic_bytes_per_launch': algo_bytes,
+                     # informational, not `frac`: the counter traffic over the same duration - what the launch actually asks of the HBM
+                     # (the library's pure streaming kernels reach 5.4 - 5.7 TB/s of the 8 on this part: DESIGN 3.2 / 5.8)
+                     'counter_traffic_GBps': (round(_pmc_traffic('k_roi_align_bwd_lean' if plan_ok else 'k_roi_align_bwd')[0] / bwd_avg_s / 1e9, 1)
+                                              if _pmc_traffic('k_roi_align_bwd_lean' if plan_ok else 'k_roi_align_bwd')[0] else None),
                      'avg_launch_us': round(bwd_avg_s * 1e6, 3), 'median_launch_us': round(float(np.median(bwd_b2b)) * 1e3, 3),
                      'event_pair_per_launch_us': round(float(bwd_ms.mean()) * 1e3, 3),
                      'note': 'avg_launch_us: %d groups of %d back-to-back launches per HIP event pair; event_pair_per_launch_us: one '
