@@ -33,6 +33,7 @@ import json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, 'chainer-maskrcnn_amd')); sys.path.insert(0, R)
 from tests import test_full_width_gpu as t
+from tests.tools.noise_floor_stats import stats, admissible
 from chainer_maskrcnn import _hip
 
 lib = _hip.lib()
@@ -54,19 +55,6 @@ def cpu_errs(c):
         a[n] = float((c['g32'][n] - w64).abs().max()) / scale
         b[n] = float((c['g32b'][n] - w64).abs().max()) / scale
     return a, b
-
-
-def stats(e, others):
-    """e: tensor -> err of the judged realisation; others: list of tensor -> err of the floor set (the judged one excluded)."""
-    names = list(e)
-    floor = {n: max(o[n] for o in others) for n in names}
-    ratios = sorted(e[n] / max(floor[n], 1e-12) for n in names if e[n] >= 1e-3)
-    if not ratios:
-        ratios = [0.0]
-    above3 = sum(1 for n in names if not e[n] < max(1e-3, 3 * floor[n]))
-    above6 = sum(1 for n in names if not e[n] < max(1e-3, 6 * floor[n]))
-    return dict(median=ratios[len(ratios) // 2], p90=ratios[int(0.9 * (len(ratios) - 1))], share3=above3 / len(names), n3=above3, n6=above6,
-                worst=ratios[-1])
 
 
 table = {}           # seed -> label -> tensor -> err
@@ -122,8 +110,7 @@ for fs in ('all', 'strict'):
     null = {k: (max(notes[s][l][fs][k] for s in seeds for l in gpu32), max(sum(notes[s][l][fs][k] for s in seeds) / len(seeds) for l in gpu32)) for k in ('median', 'p90', 'share3')}
     for l in gpu32 + [lab for lab, _ in CANDIDATES]:
         row = {k: (max(notes[s][l][fs][k] for s in seeds), sum(notes[s][l][fs][k] for s in seeds) / len(seeds)) for k in ('median', 'p90', 'share3')}
-        rnd = lambda k, v: round(v, 3 if k == 'share3' else 2)
-        ok = all(rnd(k, row[k][0]) <= rnd(k, null[k][0]) and rnd(k, row[k][1]) <= rnd(k, null[k][1]) for k in row)
+        ok = admissible(row, null)
         if l not in gpu32:
             verdicts.setdefault(l, []).append(ok)
         print('  %-40s median %5.2f / %5.2f   p90 %5.2f / %5.2f   share above 3x %5.1f%% / %5.1f%%   %s' % (
