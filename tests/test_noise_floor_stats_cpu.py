@@ -40,3 +40,29 @@ def test_admission_rule_compares_worst_and_mean_at_the_printed_resolution():
     assert admissible({'median': (0.9312, 0.90), 'p90': (1.034, 1.0), 'share3': (0.0004, 0.0)}, null)      # 1.034 prints as 1.03, 0.04 % as 0.0 %
     assert not admissible({'median': (0.94, 0.90), 'p90': (1.78, 1.24), 'share3': (0.04, 0.008)}, null)
     assert not admissible({'median': (0.94, 0.93), 'p90': (1.00, 1.0), 'share3': (0.0, 0.0)}, null)         # the mean over the batches counts too
+
+
+def test_the_committed_study_gives_its_verdict_again():
+    """profiles/r05_noise_floor_study.json holds the per-tensor errors of every realisation on the seven batches: the verdict of DESIGN 5.9
+    recomputed from them - the shipped arithmetic within the float32 realisations' own range, the emulation in the backbone's forward pass not."""
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r05_noise_floor_study.json')
+    d = json.load(open(path))
+    seeds = [str(s) for s in d['seeds']]
+    assert len(seeds) >= 7
+    gpu32 = ['gpu:shipped', 'gpu:direct', 'gpu:direct/plan', 'gpu:uniform_f2', 'gpu:winograd_f2']
+    f32 = gpu32 + ['cpu:a', 'cpu:b']
+    strict = ['gpu:direct', 'gpu:direct/plan', 'cpu:a', 'cpu:b']
+    cands = [l for l in d['errs'][seeds[0]] if l not in f32]
+    verdict = {}
+    for floor_set in (f32, strict):
+        per = {l: {s: stats(d['errs'][s][l], [d['errs'][s][o] for o in floor_set if o != l]) for s in seeds} for l in gpu32 + cands}
+        agg = lambda l: {k: (max(per[l][s][k] for s in seeds), sum(per[l][s][k] for s in seeds) / len(seeds)) for k in ('median', 'p90', 'share3')}
+        null = {k: (max(agg(l)[k][0] for l in gpu32), max(agg(l)[k][1] for l in gpu32)) for k in ('median', 'p90', 'share3')}
+        for l in cands:
+            verdict.setdefault(l, []).append(admissible(agg(l), null))
+        # the float32 GPU realisations never put a tensor above 3 x the floor of the others, on any batch
+        assert all(per[l][s]['n3'] == 0 for l in gpu32 for s in seeds)
+    ok = {l: all(v) for l, v in verdict.items()}
+    assert ok['bf16x6 behind the backbone (shipped)'] and ok['bf16x6 backward passes only']
+    assert not ok['bf16x6 everywhere'] and not ok['bf16x6 backbone forward only']
