@@ -9,6 +9,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'csrc', 'libmrcnn_hip.so'))
+# measurement only (tools/ab_lib.sh): another BUILD of the same library, for A/B runs of compile-time kernel variants on one box
+if os.environ.get('MRCNN_HIP_LIB_AB'):
+    LIB_PATH = os.path.abspath(os.environ['MRCNN_HIP_LIB_AB'])
 
 c_int = ctypes.c_int
 c_float = ctypes.c_float
@@ -65,7 +68,7 @@ def _parse_header(path):
 SIGNATURES = _parse_header(HEADER_PATH)
 
 _lib = None
-ABI_VERSION = 9          # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
+ABI_VERSION = 10         # MRCNN_ABI_VERSION of include/mrcnn_hip.h this binding was written against
 
 
 class MrcnnHipError(RuntimeError):

@@ -28,11 +28,6 @@ def _layout_of(x):
     return None
 
 
-# OPT-IN (with mrcnn_roi_align_set_bwd_plan(1 | 2)): the forward call also builds the backward's work plan for the same RoIs.  Measured: the
-# backward alone gains 7-9 % on configs[1], the forward + backward pair loses 9 % (csrc/roi_align.hip, g_bwd_plan) - off.
-USE_BWD_PLAN = False
-
-
 class _RoIAlign2D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rois, outh, outw, spatial_scale, sampling_ratio):
@@ -52,18 +47,11 @@ class _RoIAlign2D(torch.autograd.Function):
         y = torch.empty((R, C, outh, outw), dtype=torch.float32, device=x.device, memory_format=fmt)
         from chainer_maskrcnn._hip.nn import workspace
         nb = _hip.lib().mrcnn_roi_align_fwd_workspace_bytes(R)
-        npl = _hip.lib().mrcnn_roi_align_plan_workspace_bytes(N, H, W, R) if (USE_BWD_PLAN and layout == _hip.LAYOUT_NHWC) else 0
-        if npl > nb:
-            # the forward also leaves the backward's work plan for these RoIs (patch -> workgroup assignment balanced over the CUs) in
-            # its workspace: a buffer of its own, kept for the backward call (the shared scratch is reused by other layers in between)
-            ws = torch.empty((npl,), dtype=torch.uint8, device=x.device)
-        else:
-            ws = workspace(nb, x.device) if nb else None       # the map-order permutation of the RoIs
+        ws = workspace(nb, x.device) if nb else None           # the map-order permutation of the RoIs
         _hip.check(_hip.lib().mrcnn_roi_align_fwd_ws_f32(
             _hip.ptr(x), layout, N, C, H, W, _hip.ptr(rois), R, outh, outw,
             float(spatial_scale), int(sampling_ratio), _hip.ptr(y), _hip.ptr(ws), ws.numel() if ws is not None else 0,
             _hip.stream_ptr()))
-        ctx.plan_ws = ws if npl > nb else None
         ctx.save_for_backward(rois)
         ctx.meta = (layout, N, C, H, W, outh, outw, float(spatial_scale), int(sampling_ratio))
         return y
@@ -77,9 +65,7 @@ class _RoIAlign2D(torch.autograd.Function):
         gx = torch.empty((N, C, H, W), dtype=torch.float32, device=gy.device, memory_format=fmt)
         from chainer_maskrcnn._hip.nn import workspace
         nb = _hip.lib().mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, rois.shape[0], outh, outw, sr)
-        ws = workspace(nb, gy.device) if nb else None          # per-RoI sample tables of the table-driven backward
-        if getattr(ctx, 'plan_ws', None) is not None:
-            ws = ctx.plan_ws                                   # the forward's workspace: carries the plan of this call
+        ws = workspace(nb, gy.device) if nb else None          # RoI-split slabs of small maps
         _hip.check(_hip.lib().mrcnn_roi_align_bwd_ws_f32(
             _hip.ptr(gy), layout, N, C, H, W, _hip.ptr(rois), rois.shape[0], outh, outw, scale, sr,
             _hip.ptr(gx), _hip.ptr(ws), ws.numel() if ws is not None else 0, _hip.stream_ptr()))

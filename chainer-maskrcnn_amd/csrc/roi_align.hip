@@ -90,216 +90,11 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_nhwc(Levels lv, const flo
 // result is the same bits in the same place.  Rank by counting (every thread compares its key with all R keys in LDS,
 // ties by index): R <= MAP_ORDER_MAX_R, sixteen lanes per RoI, any number of workgroups.
 // ------------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------------
-// (r4) Backward PLAN, built by the forward call of the same RoIs (single level, no RoI split).
-// The backward kernel's time is the most loaded SIMD's work: every workgroup is resident at once, the work of a 4 x 4 patch
-// (900 + 55 x candidate RoIs + 48 x queue entries instructions) varies 10x over the map, and a CU gets whatever tiles the dispatcher
-// deals it - tools/dispatch_census.py: block b runs on CU slot b % 256 EXACTLY (XCD b % 8, then round robin over the XCD's 32 CUs
-// with period 32), a workgroup's four waves go to the four SIMDs from a varying start.  So the plan (i) estimates every patch's work
-// from the RoIs (count blocks), (ii) sorts the patches of an image by work and makes every workgroup out of FOUR PATCHES OF NEARLY
-// EQUAL WORK (any four patches of one image can share a workgroup: the segment table does not depend on the tile) - the SIMD a wave
-// lands on then does not matter -, (iii) sorts the groups by work and deals them serpentine over the 256 CU slots in four full rounds
-// (1024 blocks, the missing ones empty), so that every CU gets one heavy, two middle and one light group - per XCD band, so that the gy
-// rows of a band stay in its XCD's L2.  The extra blocks ride in the forward kernel's launch (16 blocks in front of its grid: 8 count,
-// 8 sort - one per band) and finish before it does.
-// Correctness never depends on the estimates: `order` is a permutation of the patches, every patch is computed exactly once by the
-// same code in the same summation order (bit-identical gx); a header that does not validate = the launch order of round 3.
-// ------------------------------------------------------------------------------------------
-constexpr int PLAN_MAGIC = 0x504C414E, PLAN_GROUPS = 1024, PLAN_HDR = 64, PLAN_COUNT_BLOCKS = 32, PLAN_EXTRA_BLOCKS = 40;
-constexpr int PLAN_BUCKETS = 1024;
-// header ints
-enum { PH_MAGIC = 0, PH_N, PH_H, PH_W, PH_NPATCH, PH_VALID, PH_DONE, PH_TAIL };
-struct PlanLayout { int npatch, pyn, pxn, per_image, groups_per_image; size_t e, order, gimg, sp, sw, gwork, gpatch, gimg_t, total_ints; };
-inline PlanLayout plan_layout(int N, int H, int W) {
-    PlanLayout p;
-    p.pyn = (H + PT - 1) / PT; p.pxn = (W + PT - 1) / PT;
-    p.per_image = p.pyn * p.pxn;
-    p.npatch = N * p.per_image;
-    p.groups_per_image = (p.per_image + 3) / 4;
-    size_t o = PLAN_HDR;
-    p.e = o; o += (size_t)p.npatch;
-    p.order = o; o += 4 * PLAN_GROUPS;
-    p.gimg = o; o += PLAN_GROUPS;
-    p.sp = o; o += (size_t)p.per_image + 4;
-    p.sw = o; o += (size_t)p.per_image + 4;
-    p.gwork = o; o += PLAN_GROUPS;
-    p.gpatch = o; o += 4 * PLAN_GROUPS;
-    p.gimg_t = o; o += PLAN_GROUPS;
-    p.total_ints = o + 1;           // + tail guard
-    return p;
-}
-inline bool plan_ok(int N, int H, int W) {
-    const long long per = (long long)((H + PT - 1) / PT) * ((W + PT - 1) / PT);
-    return N >= 1 && per * N < (1 << 20) && N * ((per + 3) / 4) <= PLAN_GROUPS;
-}
-
-// count block `cb` of PLAN_COUNT_BLOCKS: one wave per RoI; E[patch] += 55 + 48 * (bins touching the patch's rows) * (bins touching its columns)
-__device__ __forceinline__ void plan_count(int *plan, const PlanLayout pl, const float *rois, int R, int N, int H, int W, int PH, int PW, int sr,
-                                           float scale, int cb) {
-    __shared__ unsigned char s_cnt[4][2][128];          // per wave: bins per patch row / column of the RoI's rectangle (<= 128 each side)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *E = plan + pl.e;
-    for (int r = cb * 4 + wave; r < R; r += PLAN_COUNT_BLOCKS * 4) {
-        const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, PH, PW, sr);
-        if (g.n < 0 || g.n >= N) continue;
-        // lanes 0..15: bin ph = lane, rows; lanes 16..31: bin pw = lane - 16, columns: the range of patch rows / columns the bin's samples touch
-        const int axis = (lane >> 4) & 1, bin = lane & 15;
-        int a = 1 << 30, b = -1;
-        if (lane < 32 && bin < (axis ? PW : PH)) {
-            for (int i = 0; i < sr; ++i) {
-                const Samp sp = axis_sample(axis ? g.x1f : g.y1f, axis ? g.bw : g.bh, bin, i, sr, axis ? W : H);
-                if (sp.lo >= 0) { a = min(a, sp.lo / PT); b = max(b, sp.hi / PT); }
-            }
-        }
-        // candidate rectangle: the kernel's own (conservative) box test
-        const int py_lo = max(0, (int)floorf(g.y1f * (1.0f / PT))), py_hi = min(pl.pyn - 1, (int)floorf((g.y1f + g.rh + 1.0f) * (1.0f / PT)));
-        const int px_lo = max(0, (int)floorf(g.x1f * (1.0f / PT))), px_hi = min(pl.pxn - 1, (int)floorf((g.x1f + g.rw + 1.0f) * (1.0f / PT)));
-        const int npr = min(py_hi - py_lo + 1, 128), npc = min(px_hi - px_lo + 1, 128);      // (an estimate: a larger rectangle is cut)
-        if (npr <= 0 || npc <= 0) continue;
-        // bins per patch row / column: one ballot per row (lanes 0-15 answer for the rows, 16-31 for the columns)
-        for (int k = 0; k < max(npr, npc); ++k) {
-            const int q = (axis ? px_lo : py_lo) + k;
-            const unsigned long long bal = __ballot(lane < 32 && a <= q && q <= b);
-            if (lane == 0) { s_cnt[wave][0][k] = (unsigned char)__popcll(bal & 0xFFFFull); s_cnt[wave][1][k] = (unsigned char)__popcll(bal & 0xFFFF0000ull); }
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int idx = lane; idx < npr * npc; idx += 64) {
-            const int pr = idx / npc, pc = idx - pr * npc;
-            atomicAdd(&E[g.n * pl.per_image + (py_lo + pr) * pl.pxn + px_lo + pc], 55 + 48 * (int)s_cnt[wave][0][pr] * (int)s_cnt[wave][1][pc]);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&plan[PH_DONE], 1);
-}
-
-// Sort block of XCD band x (8 of them): waits for the count blocks, then for every image: the patches of the band's tiles (the tile
-// range the unplanned launch gives this XCD, so that a band's gy rows stay in its XCD's L2) by descending work, four consecutive ones =
-// a group; the band's groups by descending work, dealt serpentine over the band's 32 CU slots in four rounds:
-// group rank k -> block 8 * ((k / 32) * 32 + slot) + x.  Ranking = counting in LDS (<= 512 patches, <= 128 groups per band).
-constexpr int PLAN_BAND_PATCHES = 512, PLAN_BAND_GROUPS = 128;
-// rank of key `k` among the n keys in LDS (all distinct): the number of larger ones; four keys per LDS read, eight reads in flight
-__device__ __forceinline__ int plan_rank(const int *keys, int n4, int k) {
-    int rk = 0;
-    const int4 *k4 = reinterpret_cast<const int4 *>(keys);
-#pragma unroll 8
-    for (int j = 0; j < n4; ++j) {
-        const int4 v = k4[j];
-        rk += (v.x > k) + (v.y > k) + (v.z > k) + (v.w > k);
-    }
-    return rk;
-}
-__device__ __forceinline__ void plan_sort(int *plan, const PlanLayout pl, int N, int H, int W, int x, int mode) {
-    __shared__ __attribute__((aligned(16))) int s_key[PLAN_BAND_PATCHES], s_gkey[PLAN_BAND_GROUPS];
-    __shared__ int s_pid[PLAN_BAND_PATCHES], s_sorted[PLAN_BAND_PATCHES], s_sw[PLAN_BAND_PATCHES];
-    __shared__ int s_gp[PLAN_BAND_GROUPS][4], s_gn[PLAN_BAND_GROUPS], s_ok;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        int ok = 0;
-        for (int spin = 0; spin < 200000; ++spin) {          // bounded: the count blocks are dispatched before this one
-            if (atomicAdd(&plan[PH_DONE], 0) >= PLAN_COUNT_BLOCKS) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        s_ok = ok;
-    }
-    __syncthreads();
-    if (!s_ok) return;                                        // header stays invalid: the backward takes its own order
-    __threadfence();
-    const int *E = plan + pl.e;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, per_img_tiles = tiles_x * tiles_y;
-    const int total_tiles = per_img_tiles * N, chunk = (total_tiles + 7) / 8;
-    const int t0 = x * chunk, t1 = min(total_tiles, t0 + chunk);
-    int ng = 0;
-    bool fits = (t1 - t0) * 4 <= PLAN_BAND_PATCHES;
-    for (int n = 0; n < N && fits; ++n) {
-        const int a0 = max(t0, n * per_img_tiles), a1 = min(t1, (n + 1) * per_img_tiles);
-        if (a1 <= a0) continue;                                // (block-uniform)
-        // the band's patches of image n: slot i = (tile, quarter); key = work << 9 | (511 - i): distinct, a missing patch sorts last
-        const int ns = (a1 - a0) * 4, ns4 = (ns + 3) / 4;
-        int nvalid = 0;
-        for (int i0 = 0; i0 < PLAN_BAND_PATCHES; i0 += 256) {
-            const int i = i0 + tid;
-            int key = 0, pid = -1;
-            if (i < ns) {
-                const int t = a0 + (i >> 2) - n * per_img_tiles, q = i & 3;
-                const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
-                const int pyi = 2 * tyi + (q >> 1), pxi = 2 * txi + (q & 1);
-                if (pyi < pl.pyn && pxi < pl.pxn) {
-                    pid = n * pl.per_image + pyi * pl.pxn + pxi;
-                    const int w = min(900 + __hip_atomic_load(&E[pid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (1 << 21) - 1);
-                    key = (w << 9) | (511 - i);
-                } else key = 511 - i;
-            }
-            s_key[i] = key; s_pid[i] = pid;
-            nvalid += __syncthreads_count(pid >= 0);
-        }
-        __syncthreads();
-        const int np = nvalid;
-        int gcount;
-        if (mode == 0) {
-            // patches by descending work; four consecutive ones = a group of nearly equal work
-            for (int i = tid; i < ns; i += 256) {
-                const int rk = plan_rank(s_key, ns4, s_key[i]);
-                s_sorted[rk] = s_pid[i]; s_sw[rk] = s_key[i] >> 9;
-            }
-            __syncthreads();
-            gcount = (np + 3) / 4;
-            if (ng + gcount > PLAN_BAND_GROUPS) { fits = false; break; }
-            for (int g = tid; g < gcount; g += 256) {
-                int wsum = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = 4 * g + j;
-                    s_gp[ng + g][j] = k < np ? s_sorted[k] : -1;
-                    wsum += k < np ? s_sw[k] : 0;
-                }
-                s_gkey[ng + g] = (min(wsum, (1 << 23) - 1) << 7) | (127 - (ng + g)); s_gn[ng + g] = n;
-            }
-        } else {
-            // groups = the 8 x 8 tiles themselves (their four patches share most of their RoIs: L1 reuse of the gy rows), only dealt by work
-            gcount = a1 - a0;
-            if (ng + gcount > PLAN_BAND_GROUPS) { fits = false; break; }
-            for (int g = tid; g < gcount; g += 256) {
-                int wsum = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { s_gp[ng + g][j] = s_pid[4 * g + j]; wsum += s_pid[4 * g + j] >= 0 ? s_key[4 * g + j] >> 9 : 0; }
-                s_gkey[ng + g] = (min(wsum, (1 << 23) - 1) << 7) | (127 - (ng + g)); s_gn[ng + g] = n;
-            }
-        }
-        ng += gcount;
-        __syncthreads();
-    }
-    if (!fits) return;
-    for (int i = ng + tid; i < PLAN_BAND_GROUPS; i += 256) s_gkey[i] = 127 - i;        // fillers: work 0, behind every group
-    __syncthreads();
-    int *order = plan + pl.order, *gimg = plan + pl.gimg;
-    // the band's groups by descending work, serpentine over the band's 32 CU slots: rank k -> block 8 * ((k / 32) * 32 + slot) + x
-    for (int i = tid; i < PLAN_BAND_GROUPS; i += 256) {
-        const int rk = plan_rank(s_gkey, PLAN_BAND_GROUPS / 4, s_gkey[i]);
-        const int rnd = rk >> 5, pos = rk & 31, b = 8 * (rnd * 32 + ((rnd & 1) ? 31 - pos : pos)) + x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) order[4 * b + j] = i < ng ? s_gp[i][j] : -1;
-        gimg[b] = i < ng ? s_gn[i] : -1;
-    }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-        plan[PH_N] = N; plan[PH_H] = H; plan[PH_W] = W; plan[PH_NPATCH] = pl.npatch;
-        plan[pl.total_ints - 1] = PLAN_MAGIC;
-        plan[PH_MAGIC] = PLAN_MAGIC;
-        __threadfence();
-        atomicAdd(&plan[PH_VALID], 1);                       // valid when all 8 bands have arrived
-    }
-}
-
 constexpr int MAP_ORDER_MAX_R = 8192;
 int g_fwd_map_order = 1;
 __global__ __launch_bounds__(256) void k_roi_map_order(Levels lv, const float *__restrict__ rois, const int32_t *__restrict__ levels,
-                                                       int R, int32_t *__restrict__ perm, int *__restrict__ plan, int plan_zero_ints) {
+                                                       int R, int32_t *__restrict__ perm) {
     extern __shared__ unsigned mo_keys[];
-    // (the backward plan of this call, if any: header and work counters start from zero; the forward launch that follows fills them)
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < plan_zero_ints; i += gridDim.x * 256) plan[i] = 0;
     for (int r = threadIdx.x; r < R; r += 256) {
         int l = levels ? levels[r] : 0;
         l = min(max(l, 0), lv.L - 1);
@@ -338,15 +133,10 @@ __global__ __launch_bounds__(256) void k_roi_map_order(Levels lv, const float *_
 __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(Levels lv, const float *__restrict__ rois,
                                                             const int32_t *__restrict__ levels, int R, int N, int C, int PH, int PW,
                                                             int sr, float *__restrict__ y, int chunk,
-                                                            const int32_t *__restrict__ perm, int *__restrict__ plan, PlanLayout pl, int plan_mode) {
+                                                            const int32_t *__restrict__ perm) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int bid = blockIdx.x;
-    if (plan) {             // PLAN_EXTRA_BLOCKS blocks in front of the forward's grid build the backward plan (single level)
-        if (bid < PLAN_COUNT_BLOCKS) { plan_count(plan, pl, rois, R, N, lv.H[0], lv.W[0], PH, PW, sr, lv.scale[0], bid); return; }
-        if (bid < PLAN_EXTRA_BLOCKS) { plan_sort(plan, pl, N, lv.H[0], lv.W[0], bid - PLAN_COUNT_BLOCKS, plan_mode); return; }
-        bid -= PLAN_EXTRA_BLOCKS;
-    }
+    const int bid = blockIdx.x;
     const int wg = (bid & 7) * chunk + (bid >> 3);
     if ((int)(bid >> 3) >= chunk) return;
     const int pos_id = wg * 4 + wave;                  // (position in processing order, ph)
@@ -854,10 +644,14 @@ template <int QC> constexpr size_t plan_node_stride() { return (sizeof(PlanNode<
 // [header][tile flags, rounded to 64 ints][nodes]
 inline size_t plan_nodes_off_ints(int total_tiles) { return NP_HDR_INTS + (size_t)(total_tiles + 63) / 64 * 64; }
 
-__device__ __forceinline__ bool plan_header_holds(const int *__restrict__ nplan, int total_units, int R, int N, int PH, int PW, int sr, int QC,
-                                                  int nodes_off) {
-    const bool ok = nplan[NP_MAGIC_I] == NP_MAGIC && nplan[NP_UNITS] == total_units && nplan[NP_R] == R && nplan[NP_PH] == PH &&
-                    nplan[NP_PW] == PW && nplan[NP_SR] == sr && nplan[NP_N] == N && nplan[NP_QC] == QC && nplan[NP_NODES_OFF] == nodes_off;
+// (every field the builder wrote is compared: the level count and each level's H x W as well - two pyramids can have equal tile counts -
+// and the builder's node capacity against what THIS call's plan_bytes can hold, so that no `next` index points past the caller's buffer)
+__device__ __forceinline__ bool plan_header_holds(const int *__restrict__ nplan, const Levels &lv, int total_units, int R, int N, int PH, int PW,
+                                                  int sr, int QC, int nodes_off, int node_cap) {
+    bool ok = nplan[NP_MAGIC_I] == NP_MAGIC && nplan[NP_UNITS] == total_units && nplan[NP_R] == R && nplan[NP_PH] == PH &&
+              nplan[NP_PW] == PW && nplan[NP_SR] == sr && nplan[NP_N] == N && nplan[NP_QC] == QC && nplan[NP_NODES_OFF] == nodes_off &&
+              nplan[NP_L] == lv.L && nplan[NP_CAP] <= node_cap;
+    for (int q = 0; q < lv.L; ++q) ok = ok && nplan[NP_HW + 2 * q] == lv.H[q] && nplan[NP_HW + 2 * q + 1] == lv.W[q];
     return __builtin_amdgcn_readfirstlane((int)ok) != 0;
 }
 
@@ -876,8 +670,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
                                                                         const int32_t *__restrict__ levels, int R, int N, int C,
                                                                         int PH, int PW, int sr, int chunk, int accumulate,
                                                                         unsigned long long *__restrict__ stamps = nullptr,
-                                                                        const int *__restrict__ plan = nullptr, int plan_order_off = 0,
-                                                                        int plan_gimg_off = 0, int plan_tail = 0,
+                                                                        int nodes_off = 0, int node_cap = 0,       // MODE 1 / 2: offset of the plan's nodes (ints), node capacity
                                                                         int *__restrict__ nplan = nullptr) {
     unsigned long long st0 = 0, st_scan = 0, st_drain = 0, st_tmp = 0, st_rt0 = 0, st_pre = 0, st_tab = 0, st_cnt = 0;
     if (STAMP) { st0 = stamp_now(); st_rt0 = __builtin_amdgcn_s_memrealtime(); }
@@ -915,25 +708,8 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
         }
     };
     if (MODE != 2) load_rois(0, rv0, lv0);          // (MODE 2: most workgroups leave before they need a RoI)
-    // A plan built by the forward call of the same geometry (see plan_sort): block b computes the four patches order[4b .. 4b+3] of
-    // image gimg[b] - any four patches of an image, of nearly equal work.  The header decides (uniformly for the launch); without a
-    // valid one the blocks take the XCD-banded tile order.
-    bool planned = false;
-    if (plan) planned = plan[PH_MAGIC] == PLAN_MAGIC && plan[PH_VALID] == 8 && plan[PH_N] == N && plan[PH_H] == lv.H[0] && plan[PH_W] == lv.W[0] &&
-                        plan[plan_tail] == PLAN_MAGIC;
-    planned = __builtin_amdgcn_readfirstlane((int)planned) != 0;
     int l = 0, nsplit = 1, zsplit = 0, n, py0, px0, tile_id = 0;
-    if (planned) {
-        if (blockIdx.x >= PLAN_GROUPS) return;
-        n = __builtin_amdgcn_readfirstlane(plan[plan_gimg_off + blockIdx.x]);
-        if (n < 0) return;                                   // an empty group
-        const int pid = __builtin_amdgcn_readfirstlane(plan[plan_order_off + 4 * blockIdx.x + wave]);
-        const int pxn = (lv.W[0] + PT - 1) / PT, pyn = (lv.H[0] + PT - 1) / PT;
-        int rem = 0, pyi = 0, pxi = 0;
-        if (pid >= 0) { rem = pid - n * (pxn * pyn); divmod_u24(rem, pxn, pyi, pxi); }
-        py0 = pid >= 0 ? pyi * PT : lv.H[0];                 // a missing patch = a wave outside the map: it only helps with the table
-        px0 = pid >= 0 ? pxi * PT : lv.W[0];
-    } else {
+    {
         tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);                 // XCD-banded tile order (speed only)
         if ((int)(blockIdx.x >> 3) >= chunk || tile_id >= lv.tile_begin[lv.L]) return;      // whole workgroup
         while (l + 1 < lv.L && tile_id >= lv.tile_begin[l + 1]) ++l;
@@ -1000,7 +776,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
     constexpr size_t NSTRIDE = plan_node_stride<LDS::QC>();
     if (MODE == 2) {
         // behind the lean kernel: only the tiles the plan builder flagged (pool exhausted) - or all of them when the header does not hold
-        const bool holds = plan_header_holds(nplan, total_units, R, N, PH, PW, sr, (int)LDS::QC, plan_order_off);
+        const bool holds = plan_header_holds(nplan, lv, total_units, R, N, PH, PW, sr, (int)LDS::QC, nodes_off, node_cap);
         if (holds && __builtin_amdgcn_readfirstlane(nplan[NP_HDR_INTS + tile_id]) == 0) return;
         load_rois(0, rv0, lv0);
     }
@@ -1012,13 +788,13 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
             int got = 0;
             if (lane == 0) got = atomicAdd(&nplan[NP_EXTRA], 1);
             id = total_units + __builtin_amdgcn_readfirstlane(got);
-            if (id >= plan_tail) {                 // (MODE 1: plan_tail = node capacity) pool exhausted: this tile takes the fused path (MODE 2)
+            if (id >= node_cap) {                  // pool exhausted: this tile takes the fused path (MODE 2)
                 if (lane == 0) { nplan[NP_HDR_INTS + tile_id] = 1; atomicAdd(&nplan[NP_OVERFLOW], 1); }
                 id = -1;
             }
         }
         if (id >= 0) {
-            char *nb = reinterpret_cast<char *>(nplan + plan_order_off);        // (MODE 1 / 2: plan_order_off = offset of the nodes, in ints)
+            char *nb = reinterpret_cast<char *>(nplan + nodes_off);
             PlanNode<LDS::QC> *pn = reinterpret_cast<PlanNode<LDS::QC> *>(nb + (size_t)id * NSTRIDE);
             for (int i = lane; i < qn_; i += 64) {
                 pn->q.wy[i] = lds.q.wy[i];
@@ -1035,8 +811,8 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
         qn_ = 0;
     };
     if (MODE == 1 && tile_id == 0 && tid == 0) {
-        nplan[NP_UNITS] = total_units; nplan[NP_CAP] = plan_tail; nplan[NP_R] = R; nplan[NP_PH] = PH; nplan[NP_PW] = PW; nplan[NP_SR] = sr;
-        nplan[NP_N] = N; nplan[NP_QC] = (int)LDS::QC; nplan[NP_L] = lv.L; nplan[NP_NODES_OFF] = plan_order_off;
+        nplan[NP_UNITS] = total_units; nplan[NP_CAP] = node_cap; nplan[NP_R] = R; nplan[NP_PH] = PH; nplan[NP_PW] = PW; nplan[NP_SR] = sr;
+        nplan[NP_N] = N; nplan[NP_QC] = (int)LDS::QC; nplan[NP_L] = lv.L; nplan[NP_NODES_OFF] = nodes_off;
         for (int q = 0; q < lv.L; ++q) { nplan[NP_HW + 2 * q] = lv.H[q]; nplan[NP_HW + 2 * q + 1] = lv.W[q]; }
         nplan[NP_MAGIC_I] = NP_MAGIC;
     }
@@ -1264,7 +1040,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
 template <int PBT, int DEPTH, int OCC, int WPB>
 __global__ __launch_bounds__(WPB * 64, OCC) void k_roi_align_bwd_lean(Levels lv, const float *__restrict__ gy, int R, int N, int C, int PH, int PW,
                                                                          int sr, int chunk, int accumulate, const int *__restrict__ nplan,
-                                                                         int nodes_off, int dbg, unsigned long long *__restrict__ stamps) {
+                                                                         int nodes_off, int node_cap, int dbg, unsigned long long *__restrict__ stamps) {
     static_assert(DEPTH % 2 == 0, "rows are consumed in pairs of entries");
     // measurement (mrcnn_debug_roi_align_lean_stamps; null otherwise): 10 x u64 per wave - s_memtime at entry, when the first node's
     // loads have arrived, at the end of the entry loop, when the stores have been acknowledged; entries; HW_ID | XCC_ID << 32;
@@ -1297,7 +1073,7 @@ __global__ __launch_bounds__(WPB * 64, OCC) void k_roi_align_bwd_lean(Levels lv,
     // scalar loads +1.3 us, the row indices +2.3 us, p90 +6 us - but sending the first DEPTH gy rows out on scalar-loaded indices changes
     // nothing, 18.6 against 18.5 us: it is the FIRST vector access of a wave that is slow, whichever it is)
     int cnt = scalar_load<int>(&pn->count), next = scalar_load<int>(&pn->next);
-    const bool holds = plan_header_holds(nplan, total * BWD_WAVES, R, N, PH, PW, sr, QC, nodes_off);
+    const bool holds = plan_header_holds(nplan, lv, total * BWD_WAVES, R, N, PH, PW, sr, QC, nodes_off, node_cap);
     const int flagged = scalar_load<int>(nplan + NP_HDR_INTS + tile_id);
     if (stamps) { asm volatile("" :: "s"(cnt), "s"(next), "s"(flagged)); stB = stamp_now(); }      // (the scalar loads of the node and the header are back)
     // tile -> level, image, patch
@@ -1633,25 +1409,12 @@ size_t slab_ws_bytes(const int *Hs, const int *Ws, int L, int N, int C) {
     }
     return (b + 255) / 256 * 256;
 }
-// workspace of one backward call: [RoI-split slabs of the coarse levels][per-RoI tables of variant 3]
+// workspace of one backward call: the RoI-split slabs of the coarse levels
 size_t bwd_ws_bytes(const int *Hs, const int *Ws, int L, int N, int C, int R, int PH, int PW, int sr) {
-    return slab_ws_bytes(Hs, Ws, L, N, C) + bwd3_ws_bytes(Hs, Ws, L, R, PH, PW, sr);
+    return slab_ws_bytes(Hs, Ws, L, N, C);
 }
 
 size_t fwd_ws_bytes(int R) { return R > 0 ? ((size_t)R * sizeof(int32_t) + 255) / 256 * 256 : 0; }
-// forward workspace that also holds the backward plan of the same RoIs: [perm][plan]
-size_t fwd_plan_ws_bytes(int N, int H, int W, int R) {
-    if (R <= 0 || !plan_ok(N, H, W)) return fwd_ws_bytes(R);
-    return fwd_ws_bytes(R) + (plan_layout(N, H, W).total_ints * sizeof(int) + 255) / 256 * 256;
-}
-// mrcnn_roi_align_set_bwd_plan: 0 (DEFAULT) = the forward builds no plan and the backward ignores one; 1 = groups of four patches of equal
-// work; 2 = the 8 x 8 tiles themselves, dealt by work.  OPT-IN: measured on configs[1] (bench.py --workload roialign, same process) the
-// backward alone gains 7-9 % (27.8 -> 25.8 / 25.3 us) - a third of what the VALU-load model promises (tools/roi_balance_model.py: x0.75):
-// the scattered groups lose the tiles' L1 reuse of gy rows, and the kernel's latency chains (table fill, RoI loads) do not shrink with
-// the balance - while the forward pays 7.7 us for the plan (its blocks share the CUs with the forward's waves and finish after them):
-// the PAIR a training step pays goes 56.2 -> 61.4 us.  Kept as a tested option, not shipped.
-int g_bwd_plan = 0;
-
 // Forward: rows kernel when the x samples of a row fit one wave (fixed sampling grid, PW * grid <= 64) and every level is
 // within 32-bit buffer offsets; else the one-wave-per-bin kernel.
 void launch_fwd(Levels &lv, const float *rois, const int32_t *levels, int R, int N, int C, int PH, int PW, int sr, float *y,
@@ -1662,30 +1425,19 @@ void launch_fwd(Levels &lv, const float *rois, const int32_t *levels, int R, int
         const int wgs = mrcnn::cdiv((long long)R * PH, 4), chunk = mrcnn::cdiv(wgs, 8);
         // map order (needs R ints of workspace; worth a second launch from a few waves per CU on)
         int32_t *perm = nullptr;
-        int *plan = nullptr;
-        PlanLayout pl{};
         if (g_fwd_map_order && ws && ws_bytes >= fwd_ws_bytes(R) && R >= 128 && R <= MAP_ORDER_MAX_R) {
             perm = reinterpret_cast<int32_t *>(ws);
-            // the backward plan rides along when the workspace has room for it (single level, fixed sampling grid, pooled <= 16)
-            if (g_bwd_plan && lv.L == 1 && !levels && plan_ok(N, lv.H[0], lv.W[0]) && PH <= PB && PW <= PB &&
-                ws_bytes >= fwd_plan_ws_bytes(N, lv.H[0], lv.W[0], R)) {
-                plan = reinterpret_cast<int *>((char *)ws + fwd_ws_bytes(R));
-                pl = plan_layout(N, lv.H[0], lv.W[0]);
-            }
-            hipLaunchKernelGGL(k_roi_map_order, dim3(mrcnn::cdiv(R, 16)), dim3(256), (size_t)R * sizeof(unsigned), st, lv, rois, levels, R, perm,
-                               plan, plan ? (int)(PLAN_HDR + pl.npatch) : 0);
+            hipLaunchKernelGGL(k_roi_map_order, dim3(mrcnn::cdiv(R, 16)), dim3(256), (size_t)R * sizeof(unsigned), st, lv, rois, levels, R, perm);
         }
-        hipLaunchKernelGGL(k_roi_align_fwd_rows, dim3(chunk * 8 + (plan ? PLAN_EXTRA_BLOCKS : 0)), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW,
-                           sr, y, chunk, perm, plan, pl, g_bwd_plan - 1);
+        hipLaunchKernelGGL(k_roi_align_fwd_rows, dim3(chunk * 8), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW, sr, y, chunk, perm);
     } else {
         const long long waves = (long long)R * PH * PW;
         hipLaunchKernelGGL(k_roi_align_fwd_nhwc, dim3(mrcnn::cdiv(waves, 4)), dim3(256), 0, st, lv, rois, levels, R, N, C, PH, PW, sr, y);
     }
 }
 
-// 2 = independent waves that derive the geometry themselves (default), 3 = table-driven (roi_align_bwd3.hip: per-RoI tables
-// from a first kernel + a lean patch kernel; needs the caller's workspace, else variant 2 runs; same bits as 2 - measured
-// slower so far: DESIGN.md section 3.2), 1 = the barrier-synchronised tile kernel (A/B and fallback for tensors >= 4 GiB)
+// 2 = independent waves that derive the geometry themselves (default), 1 = the barrier-synchronised tile kernel (the fallback for
+// tensors >= 4 GiB; selectable so that the tests reach it on small inputs)
 int g_bwd_variant = 2;
 
 // entry-list plan buffer: [256-byte header][tile flags][nodes]; nodes = one per patch slot of the launch + a pool for the patches that
@@ -1705,14 +1457,11 @@ size_t nplan_bytes(const int *Hs, const int *Ws, int L, int N, int R, int PH, in
 // nplan_mode 0: backward (fused; with `nplan` the lean path when the plan holds); 1: build the entry-list plan of these RoIs into `nplan`
 // (no gy / gx needed); split: in mode 1 whether the backward call will have its slab workspace (the coarse levels' RoI split)
 int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, const int32_t *levels, int R,
-                     int C, int PH, int PW, int sr, int accumulate, void *ws, size_t ws_bytes, hipStream_t st, const void *plan_ws = nullptr,
+                     int C, int PH, int PW, int sr, int accumulate, void *ws, size_t ws_bytes, hipStream_t st,
                      int *nplan = nullptr, size_t nplan_size = 0, int nplan_mode = 0, bool plan_split = false, bool plan_verified = false) {
     int total = 0;
     const size_t need = slab_ws_bytes(lv.H, lv.W, lv.L, N, C);
     const bool can_split = nplan_mode == 1 ? (plan_split && R > 0) : (ws && ws_bytes >= need && R > 0);
-    // the tables of variant 3 sit behind the slab area
-    const size_t need3 = bwd3_ws_bytes(lv.H, lv.W, lv.L, R, PH, PW, sr);
-    void *ws3 = (ws && need3 && ws_bytes >= need + need3) ? (void *)((char *)ws + need) : nullptr;
     float *wp = (float *)ws;
     for (int l = 0; l < lv.L; ++l) {
         lv.tiles_x[l] = mrcnn::cdiv(lv.W[l], TW);
@@ -1741,23 +1490,23 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
         if (!waves_ok || R == 0 || cap < (size_t)total * BWD_WAVES || cap >= (1u << 30)) return 0;
         if (PH <= 8 && PW <= 8)
             hipLaunchKernelGGL((k_roi_align_bwd_waves<8, W2_DEPTH, false, 1>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, (const float *)nullptr, rois, levels,
-                               R, N, C, PH, PW, sr, chunk, 0, (unsigned long long *)nullptr, (const int *)nullptr, (int)nodes_off, 0, (int)cap, nplan);
+                               R, N, C, PH, PW, sr, chunk, 0, (unsigned long long *)nullptr, (int)nodes_off, (int)cap, nplan);
         else
             hipLaunchKernelGGL((k_roi_align_bwd_waves<16, W2_DEPTH, false, 1>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, (const float *)nullptr, rois, levels,
-                               R, N, C, PH, PW, sr, chunk, 0, (unsigned long long *)nullptr, (const int *)nullptr, (int)nodes_off, 0, (int)cap, nplan);
+                               R, N, C, PH, PW, sr, chunk, 0, (unsigned long long *)nullptr, (int)nodes_off, (int)cap, nplan);
         MRCNN_LAUNCH_CHECK();
         return 0;
     }
     // a plan buffer that cannot even hold the patch slots of this launch was never filled by the builder: plain fused backward
     if (nplan && nplan_size < nodes_off * sizeof(int) + (size_t)total * BWD_WAVES * nplan_stride(PH, PW)) nplan = nullptr;
     if (!waves_ok || R == 0) nplan = nullptr;
-    if (waves_ok && g_bwd_variant == 3 && ws3 && !nplan) {
-        if (int e = launch_bwd3(lv, total, N, gy, rois, levels, R, C, PH, PW, sr, accumulate, ws3, need3, st)) return e;
-    } else if (nplan) {
-        // the lean kernel along the entry lists, then (unless the caller verified the plan) the wave kernel for whatever the plan could not hold
+    if (nplan) {
+        // the lean kernel along the entry lists, then (unless the caller verified the plan) the wave kernel for whatever the plan could not hold;
+        // have_cap: the nodes THIS call's buffer can hold - a plan built into a larger buffer does not validate (its chains could leave this one)
+        const int have_cap = (int)std::min<size_t>((nplan_size - nodes_off * sizeof(int)) / nplan_stride(PH, PW), (size_t)1 << 30);
         auto lean = [&](auto kern, int wpb) {
             hipLaunchKernelGGL(kern, dim3(chunk * 8 * (8 / wpb)), dim3(wpb * 64), 0, st, lv, gy, R, N, C, PH, PW, sr, chunk, accumulate, (const int *)nplan, (int)nodes_off,
-                               g_lean_dbg, g_lean_stamps);
+                               have_cap, g_lean_dbg, g_lean_stamps);
         };
         const bool small = PH <= 8 && PW <= 8;
         switch (g_lean_variant) {
@@ -1771,26 +1520,18 @@ int launch_bwd_tiles(Levels &lv, int N, const float *gy, const float *rois, cons
         if (plan_verified) {}
         else if (small)
             hipLaunchKernelGGL((k_roi_align_bwd_waves<8, W2_DEPTH, false, 2>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
-                               PH, PW, sr, chunk, accumulate, (unsigned long long *)nullptr, (const int *)nullptr, (int)nodes_off, 0, 0, nplan);
+                               PH, PW, sr, chunk, accumulate, (unsigned long long *)nullptr, (int)nodes_off, have_cap, nplan);
         else
             hipLaunchKernelGGL((k_roi_align_bwd_waves<16, W2_DEPTH, false, 2>), dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
-                               PH, PW, sr, chunk, accumulate, (unsigned long long *)nullptr, (const int *)nullptr, (int)nodes_off, 0, 0, nplan);
+                               PH, PW, sr, chunk, accumulate, (unsigned long long *)nullptr, (int)nodes_off, have_cap, nplan);
     } else if (waves_ok) {
-        // `plan_ws`: the caller handed in the workspace of the FORWARD call of these RoIs ([perm][plan], mrcnn_roi_align_plan_workspace_bytes):
-        // the kernel validates the plan's header on the device and takes the launch order when it does not hold
-        const int *plan = nullptr;
-        PlanLayout pl{};
-        if (g_bwd_plan && plan_ws && lv.L == 1 && !levels && lv.split[0] == 1 && plan_ok(N, lv.H[0], lv.W[0])) {
-            plan = reinterpret_cast<const int *>((const char *)plan_ws + fwd_ws_bytes(R));
-            pl = plan_layout(N, lv.H[0], lv.W[0]);
-        }
-        const dim3 grid(plan ? std::max(chunk * 8, PLAN_GROUPS) : chunk * 8);
+        const dim3 grid(chunk * 8);
         if (PH <= 8 && PW <= 8)
             hipLaunchKernelGGL((k_roi_align_bwd_waves<8, W2_DEPTH>), grid, dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
-                               PH, PW, sr, chunk, accumulate, (unsigned long long *)nullptr, plan, (int)pl.order, (int)pl.gimg, (int)pl.total_ints - 1);
+                               PH, PW, sr, chunk, accumulate);
         else
             hipLaunchKernelGGL((k_roi_align_bwd_waves<16, W2_DEPTH>), grid, dim3(BWD_THREADS), 0, st, lv, gy, rois, levels, R, N, C,
-                               PH, PW, sr, chunk, accumulate, (unsigned long long *)nullptr, plan, (int)pl.order, (int)pl.gimg, (int)pl.total_ints - 1);
+                               PH, PW, sr, chunk, accumulate);
     }
     else if (PH <= 8 && PW <= 8)
         hipLaunchKernelGGL(k_roi_align_bwd_nhwc<8>, dim3(chunk * 8), dim3(BWD_THREADS), 0, st, lv, gy, rois,
@@ -1839,16 +1580,6 @@ extern "C" int mrcnn_roi_align_fwd_f32(const float *x, int layout, int N, int C,
 
 extern "C" size_t mrcnn_roi_align_fwd_workspace_bytes(int R) { return fwd_ws_bytes(R); }
 
-extern "C" size_t mrcnn_roi_align_plan_workspace_bytes(int N, int H, int W, int R) {
-    if (N <= 0 || H <= 0 || W <= 0 || R <= 0) return 0;
-    return fwd_plan_ws_bytes(N, H, W, R);
-}
-
-extern "C" int mrcnn_roi_align_set_bwd_plan(int on) {          // 0 off, 1 groups of four patches of equal work (default), 2 the tiles themselves, dealt by work
-    g_bwd_plan = on < 0 ? 0 : (on > 2 ? 2 : on);
-    return 0;
-}
-
 extern "C" int mrcnn_roi_align_set_fwd_map_order(int on) {
     g_fwd_map_order = on ? 1 : 0;
     return 0;
@@ -1862,10 +1593,6 @@ extern "C" int mrcnn_roi_align_bwd_ws_f32(const float *gy, int layout, int N, in
     if (layout == MRCNN_LAYOUT_NHWC && fast_bwd_ok(C, PH, PW, sampling_ratio, R)) {
         Levels lv{};
         lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
-        // a workspace of mrcnn_roi_align_plan_workspace_bytes() that went through the forward call of these RoIs carries the backward's
-        // plan (validated on the device); this entry needs no scratch of its own on that path (no RoI split on a single large level)
-        const bool has_plan = g_bwd_plan != 0 && ws && plan_ok(N, H, W) && ws_bytes >= fwd_plan_ws_bytes(N, H, W, R) && level_split(H, W, N) == 1 && g_bwd_variant == 2;
-        if (has_plan) return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, nullptr, 0, st, ws);
         return launch_bwd_tiles(lv, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, ws, ws_bytes, st);
     }
     MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * C * H * W, st));
@@ -1948,7 +1675,7 @@ extern "C" int mrcnn_roi_align_fpn_bwd_plan_f32(const int *Hs, const int *Ws, co
         return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd_plan: needs C%%4==0, PH,PW<=%d, sampling_ratio>0", PB);
     Levels lv{};
     if (int e = fill_levels(lv, nullptr, nullptr, Hs, Ws, scales, L)) return e;
-    return launch_bwd_tiles(lv, N, nullptr, rois, levels, R, C, PH, PW, sampling_ratio, 0, nullptr, 0, (hipStream_t)stream, nullptr, (int *)plan,
+    return launch_bwd_tiles(lv, N, nullptr, rois, levels, R, C, PH, PW, sampling_ratio, 0, nullptr, 0, (hipStream_t)stream, (int *)plan,
                             plan_bytes, 1, split_levels != 0);
 }
 extern "C" int mrcnn_roi_align_fpn_bwd_planned_f32(const float *gy, float *const *gxs, const int *Hs, const int *Ws, const float *scales, int L,
@@ -1961,7 +1688,7 @@ extern "C" int mrcnn_roi_align_fpn_bwd_planned_f32(const float *gy, float *const
         return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "roi_align_fpn_bwd_planned: needs C%%4==0, PH,PW<=%d, sampling_ratio>0", PB);
     Levels lv{};
     if (int e = fill_levels(lv, nullptr, gxs, Hs, Ws, scales, L)) return e;
-    return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, accumulate, ws, ws_bytes, (hipStream_t)stream, nullptr, (int *)plan,
+    return launch_bwd_tiles(lv, N, gy, rois, levels, R, C, PH, PW, sampling_ratio, accumulate, ws, ws_bytes, (hipStream_t)stream, (int *)plan,
                             plan ? plan_bytes : 0, 0, false, plan_verified != 0);
 }
 // status3 (host): [0] 1 = the header carries the builder's magic, [1] tiles the builder flagged (pool exhausted), [2] pool nodes used.
@@ -2007,21 +1734,6 @@ extern "C" int mrcnn_debug_roi_align_bwd_stamps(const float *gy, int N, int C, i
     return 0;
 }
 
-// The same for variant 3 (k_bwd3_patches<STAMP>): 8 x u64 per wave - start, scan, descriptor, entry-generation and drain cycles,
-// store start, end, entries; ws as for mrcnn_roi_align_bwd_ws_f32.
-extern "C" int mrcnn_debug_roi_align_bwd3_stamps(const float *gy, int N, int C, int H, int W, const float *rois, int R, int PH,
-                                                 int PW, float spatial_scale, int sampling_ratio, float *gx, void *ws, size_t ws_bytes,
-                                                 unsigned long long *stamps, void *stream) {
-    if (!gy || !rois || !gx || !stamps || !ws || !fast_bwd_ok(C, PH, PW, sampling_ratio, R))
-        return mrcnn::fail_arg(MRCNN_E_INVALID, "debug_roi_align_bwd3_stamps: bad arguments");
-    Levels lv{};
-    lv.L = 1; lv.gx[0] = gx; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
-    lv.tiles_x[0] = mrcnn::cdiv(W, TW); lv.tiles_y[0] = mrcnn::cdiv(H, TH); lv.split[0] = 1; lv.tile_begin[0] = 0;
-    const int total = lv.tiles_x[0] * lv.tiles_y[0] * N;
-    lv.tile_begin[1] = total;
-    return launch_bwd3(lv, total, N, gy, rois, nullptr, R, C, PH, PW, sampling_ratio, 0, ws, ws_bytes, (hipStream_t)stream, stamps);
-}
-
 // Measurement: where does the hardware put the workgroups of a launch shaped like k_roi_align_bwd_waves (256 threads, every block
 // resident at once)?  out[b] = HW_ID | XCC_ID << 32 of block b's first wave, out[nblocks + b] = its s_memrealtime at start; every block
 // then spins for `spin_us` so that the whole grid is co-resident like the real kernel's.
@@ -2055,7 +1767,7 @@ extern "C" int mrcnn_debug_roi_align_lean_variant(int v) {          // measureme
 }
 
 extern "C" int mrcnn_roi_align_set_bwd_variant(int variant) {
-    if (variant < 1 || variant > 3) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_set_bwd_variant: 1, 2 or 3");
+    if (variant < 1 || variant > 2) return mrcnn::fail_arg(MRCNN_E_INVALID, "roi_align_set_bwd_variant: 1 or 2");
     g_bwd_variant = variant;
     return 0;
 }

@@ -1,5 +1,5 @@
-// Shared device helpers of the ROIAlign kernels (roi_align.hip: forward + the backward variants 1 / 2; roi_align_bwd3.hip:
-// the table-driven backward).  The coordinate arithmetic is compiled with FP contraction OFF and follows oracle/roi_align.py
+// Shared device helpers of the ROIAlign kernels (roi_align.hip: forward, the backward variants 1 / 2, the entry-list plan and the lean
+// backward).  The coordinate arithmetic is compiled with FP contraction OFF and follows oracle/roi_align.py
 // operation for operation, so sample indices and weights are bit-exact in every kernel that uses axis_sample().
 #pragma once
 #include "common.h"
@@ -113,10 +113,5 @@ inline int level_split(int H, int W, int N) {
     return std::min(32, mrcnn::cdiv(512, tiles));
 }
 
-// Table-driven backward (roi_align_bwd3.hip).  bwd3_ws_bytes: scratch for the per-RoI tables of one call (0 = this geometry
-// is not served by variant 3); launch_bwd3 expects lv.tiles_x / tiles_y / split / slab / tile_begin filled like the other variants.
-size_t bwd3_ws_bytes(const int *Hs, const int *Ws, int L, int R, int PH, int PW, int sr);
-int launch_bwd3(const Levels &lv, int total_tiles, int N, const float *gy, const float *rois, const int32_t *levels, int R, int C,
-                int PH, int PW, int sr, int accumulate, void *ws, size_t ws_bytes, hipStream_t st, unsigned long long *stamps = nullptr);
 
 }  // namespace mrcnn_roi

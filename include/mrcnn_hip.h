@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 9
+#define MRCNN_ABI_VERSION 10
 
 enum {
     MRCNN_OK = 0,
@@ -74,27 +74,14 @@ int mrcnn_roi_align_fwd_ws_f32(const float *x, int layout, int N, int C, int H, 
                                const float *rois, int R, int PH, int PW, float spatial_scale,
                                int sampling_ratio, float *y, void *ws, size_t ws_bytes, void *stream);
 size_t mrcnn_roi_align_fwd_workspace_bytes(int R);
-/* (ABI v8) Forward workspace that ALSO carries the backward's work plan for the same RoIs (single-level entry points, NHWC, fixed sampling
- * grid, pooled size <= 16): [the map-order permutation][plan].  mrcnn_roi_align_fwd_ws_f32 given at least this many bytes estimates the
- * work of every 4 x 4 patch of the gradient map from the RoIs (extra workgroups inside its own launch) and leaves a patch -> workgroup
- * assignment in which every workgroup holds four patches of nearly equal work and every CU a balanced share; mrcnn_roi_align_bwd_ws_f32
- * given the SAME buffer (unmodified in between, same N, H, W) validates the plan on the device and follows it - identical bits, every
- * patch is computed once by the same code - and falls back to its launch order otherwise.  Replaces nothing in the reference: the
- * per-RoI loops of model/head/fpn_roi_mask_head.py:59-61,75-77 have no scheduling.  OPT-IN: mrcnn_roi_align_set_bwd_plan(0) = off (the DEFAULT:
- * measured on BASELINE configs[1] the backward alone gains 7-9 %, the forward + backward pair a training step pays loses 9 %), 1 = groups of
- * four patches of equal work, 2 = whole 8 x 8 tiles dealt by work. */
-size_t mrcnn_roi_align_plan_workspace_bytes(int N, int H, int W, int R);
-int mrcnn_roi_align_set_bwd_plan(int on);
 /* A/B switch of the map-order walk (process-wide; default 1 = on when scratch is given). */
 int mrcnn_roi_align_set_fwd_map_order(int on);
 
 /* Backward (adjoint scatter).  gx is fully overwritten (callee zero-fills cells no RoI touches).
  * Fast path (NHWC, C%4==0, PH,PW<=16, sampling_ratio>0): owner-computes tiles, no atomics,
  * bit-reproducible.  Other shapes: memset + atomic scatter.
- * mrcnn_roi_align_bwd_ws_f32 takes the caller's scratch of mrcnn_roi_align_bwd_workspace_bytes() bytes: with it the
- * fast path runs as variant 3 (a small first kernel computes every RoI's sample tables once, the scatter kernel is
- * table-driven - see mrcnn_roi_align_set_bwd_variant); mrcnn_roi_align_bwd_f32 = the same call without scratch (variant 2).
- * Both give identical bits. */
+ * mrcnn_roi_align_bwd_ws_f32 takes the caller's scratch of mrcnn_roi_align_bwd_workspace_bytes() bytes (the RoI-split slabs of small
+ * maps); mrcnn_roi_align_bwd_f32 = the same call without scratch.  Both give identical bits. */
 int mrcnn_roi_align_bwd_f32(const float *gy, int layout, int N, int C, int H, int W,
                             const float *rois, int R, int PH, int PW, float spatial_scale,
                             int sampling_ratio, float *gx, void *stream);
@@ -170,9 +157,10 @@ int mrcnn_roi_align_fpn_bwd_planned_f32(const float *gy, float *const *gxs, cons
 int mrcnn_roi_align_bwd_plan_status(const void *plan, size_t plan_bytes, int *status3, void *stream);
 
 /* Process-wide choice of the fast backward kernel: 2 (default) = one independent wave per 4x4 cell patch that derives the
- * geometry itself; 3 = table-driven: per-RoI sample tables from a first kernel, one lean wave per patch (needs the call's
- * workspace; without it variant 2 runs); 1 = the barrier-synchronised 8x8 tile kernel of round 1 (A/B measurements, tensors
- * >= 4 GiB).  Same results contract; 2 and 3 give identical bits. */
+ * geometry itself; 1 = the barrier-synchronised 8x8 tile kernel of round 1 (what tensors >= 4 GiB fall back to; selectable so
+ * that tests reach it on small inputs).  Same results contract.  (ABI v10: the table-driven variant 3 and the forward-built
+ * work plan of ABI v8 - mrcnn_roi_align_plan_workspace_bytes, mrcnn_roi_align_set_bwd_plan - are gone: both were measured
+ * slower for the forward + backward pair and never shipped.) */
 int mrcnn_roi_align_set_bwd_variant(int variant);
 
 /* Diagnostic build of the backward kernel with s_memtime stamps at the phase boundaries of every wave (tools/roi_stamps.py;
@@ -181,14 +169,6 @@ int mrcnn_debug_roi_align_bwd_stamps(const float *gy, int N, int C, int H, int W
                                      float spatial_scale, int sampling_ratio, float *gx, unsigned long long *stamps,
                                      void *stream);
 
-/* The same for variant 3: 8 x u64 per wave (start, scan / descriptor / entry-generation / drain cycles, store start, end, entries);
- * ws, ws_bytes as for mrcnn_roi_align_bwd_ws_f32. */
-int mrcnn_debug_roi_align_bwd3_stamps(const float *gy, int N, int C, int H, int W, const float *rois, int R, int PH, int PW,
-                                      float spatial_scale, int sampling_ratio, float *gx, void *ws, size_t ws_bytes,
-                                      unsigned long long *stamps, void *stream);
-
-/* Measurement knobs of variant 3: extra dynamic LDS per workgroup (caps resident workgroups per CU) and s_setprio for heavy waves. */
-int mrcnn_debug_roi_align_bwd3_knobs(int pad_lds_bytes, int prio);
 /* Measurement: block -> (XCD, CU) placement of a launch shaped like the ROIAlign backward (256 threads per block, all blocks co-resident
  * for spin_us): out[b] = HW_ID | XCC_ID << 32, out[nblocks + b] = s_memrealtime at the start of block b. */
 int mrcnn_debug_dispatch_census(unsigned long long *out, int nblocks, int spin_us, void *stream);

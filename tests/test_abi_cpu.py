@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'libmrcnn_hip.so lacks %s' % n
         assert n in _hip.SIGNATURES, 'ctypes binding lacks %s' % n
     assert set(_hip.SIGNATURES) == set(names)
-    assert lib.mrcnn_abi_version() == _hip.ABI_VERSION == 9
+    assert lib.mrcnn_abi_version() == _hip.ABI_VERSION == 10
 
 
 def test_argument_errors_do_not_need_a_device():

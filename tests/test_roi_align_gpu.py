@@ -63,18 +63,17 @@ def test_forward_matches_oracle(layout, C, P, sr):
     np.testing.assert_array_equal(got.cpu().numpy(), want)      # bit-exact
 
 
-@pytest.fixture(params=[3, 2, 1], ids=['tables', 'waves', 'tiles'])
+@pytest.fixture(params=[2, 1], ids=['waves', 'tiles'])
 def bwd_variant(request):
-    """The three fast backward kernels: 3 = table-driven (per-RoI sample tables from a first kernel, one lean wave per 4x4
-    patch), 2 = independent waves that derive the geometry themselves (default), 1 = barrier-synchronised 8x8 tiles (the
-    fallback for tensors beyond the 32-bit buffer offsets of variants 2 / 3)."""
+    """The two fast backward kernels: 2 = independent waves that derive the geometry themselves (default), 1 = barrier-synchronised
+    8x8 tiles (the fallback for tensors beyond the 32-bit buffer offsets of variant 2)."""
     _hip.check(_hip.lib().mrcnn_roi_align_set_bwd_variant(request.param))
     yield request.param
     _hip.check(_hip.lib().mrcnn_roi_align_set_bwd_variant(2))
 
 
 def _bwd_ws(gyt, N, C, H, W, rois_t, R, P, scale, sr, gx):
-    """mrcnn_roi_align_bwd_ws_f32 with the workspace its query asks for (variant 3 needs it)."""
+    """mrcnn_roi_align_bwd_ws_f32 with the workspace its query asks for."""
     nb = _hip.lib().mrcnn_roi_align_bwd_workspace_bytes(N, C, H, W, R, P, P, sr)
     ws = torch.empty((max(nb, 1),), dtype=torch.uint8, device=DEV)
     _hip.check(_hip.lib().mrcnn_roi_align_bwd_ws_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rois_t), R, P, P, scale, sr, _hip.ptr(gx),
@@ -199,32 +198,6 @@ def test_config2_all_512_rois_against_the_oracle(sr, bwd_variant):
     np.testing.assert_allclose(xt.grad.cpu().numpy(), want_gx, rtol=1e-5, atol=2e-5 * np.abs(gy).max())
 
 
-@pytest.mark.parametrize('P,sr', [(7, 2), (14, 2), (7, 1), (5, 3), (16, 4)])
-def test_table_driven_backward_equals_the_wave_kernel_bit_for_bit(P, sr):
-    """Variant 3 (per-RoI tables + lean patch kernel) orders its entries (RoI, ph, pw) and computes every weight and FMA like
-    variant 2: identical bits - on configs[1]'s map with its 512 RoIs plus edge RoIs, a bad image index, a three-segment RoI
-    count (R > 1024), for 7x7 / 14x14 and odd pooled sizes and sampling ratios 1..4."""
-    x, yx, _ = config2_inputs()
-    N, C, H, W = 1, 256, x.shape[2], x.shape[3]
-    rs = np.random.RandomState(P * 10 + sr)
-    rois = np.concatenate([yx[:, [0, 2, 1, 4, 3]], _edge_rois(1, H, W, 0.25), rand_rois_xy(rs, 600, 1, H, W, 0.25),
-                           np.array([[3, 10, 10, 200, 200], [-1, 5, 5, 100, 80]], np.float32)], 0)      # image index out of range
-    R = rois.shape[0]
-    assert R > 1024
-    gyt = torch.from_numpy(rs.standard_normal((R, P, P, C)).astype(np.float32)).to(DEV)
-    rt = torch.from_numpy(rois).to(DEV)
-    out = {}
-    try:
-        for v in (2, 3):
-            _hip.check(_hip.lib().mrcnn_roi_align_set_bwd_variant(v))
-            gx = torch.full((N, H, W, C), float('nan'), device=DEV)
-            _bwd_ws(gyt, N, C, H, W, rt, R, P, 0.25, sr, gx)
-            out[v] = gx
-    finally:
-        _hip.check(_hip.lib().mrcnn_roi_align_set_bwd_variant(2))
-    assert torch.isfinite(out[3]).all()
-    assert torch.equal(out[2], out[3])
-
 
 @pytest.mark.parametrize('P', [7, 14])
 def test_fpn_backward_coarse_levels_split_matches_oracle(P, bwd_variant):
@@ -305,85 +278,6 @@ def test_forward_map_order_walk_gives_the_same_rows(R):
     y = torch.full((R, P, P, C), float('nan'), device=DEV)
     _hip.check(lib.mrcnn_roi_align_fwd_f32(_hip.ptr(xs[0]), 1, N, C, 100, 136, _hip.ptr(rt), R, P, P, 0.25, 2, _hip.ptr(y), _hip.stream_ptr()))
     assert torch.equal(y.permute(0, 3, 1, 2), out[0][1])
-
-
-@pytest.mark.parametrize('case', [(1, 200, 272, 256, 7, 2, 'config2'), (2, 100, 136, 64, 7, 2, 'rand'), (1, 61, 83, 128, 14, 2, 'rand'),
-                                  (3, 37, 41, 32, 5, 3, 'rand'), (1, 200, 272, 256, 14, 2, 'config2')],
-                         ids=lambda c: '%dx%dx%dx%d_P%d_sr%d_%s' % c)
-@pytest.mark.parametrize('mode', [1, 2], ids=['equal_work_groups', 'whole_tiles'])
-def test_backward_with_the_forward_built_plan_gives_the_same_bits(case, mode):
-    """ABI v8, opt-in (mrcnn_roi_align_set_bwd_plan(1 | 2); off by default - the pair loses what the backward gains): a forward call given mrcnn_roi_align_plan_workspace_bytes() bytes leaves the backward's work plan in the workspace (every
-    workgroup = four patches of nearly equal estimated work, groups dealt serpentine over the CU slots); the backward given the same
-    buffer follows it.  Every patch is still computed exactly once by the same code: gx is bit-identical to the launch order of round 3
-    (plan switched off), on configs[1] itself and on ragged maps, several images, bad image indices, 14x14 / odd pooled sizes.  The plan
-    is a permutation of the patches: checked on the host.  A workspace that did not go through the forward (header does not validate),
-    a plan of another geometry and a too-small workspace all fall back to the launch order with the same bits."""
-    N, H, W, C, P, sr, kind = case
-    lib = _hip.lib()
-    rs = np.random.RandomState(H * 7 + P)
-    if kind == 'config2':
-        x, yx, _ = config2_inputs()
-        rois = yx[:, [0, 2, 1, 4, 3]].copy()
-    else:
-        rois = rand_rois_xy(rs, 700, N, H, W, 0.25)
-        rois[:6] = _edge_rois(N, H, W, 0.25)
-        rois[20, 0], rois[21, 0] = N + 3, -2                   # image index out of range
-    R = rois.shape[0]
-    rt = torch.from_numpy(rois).to(DEV)
-    xt = torch.from_numpy(rs.standard_normal((N, H, W, C)).astype(np.float32)).to(DEV)
-    gyt = torch.from_numpy(rs.standard_normal((R, P, P, C)).astype(np.float32)).to(DEV)
-    y = torch.empty((R, P, P, C), device=DEV)
-    nb = lib.mrcnn_roi_align_plan_workspace_bytes(N, H, W, R)
-    assert nb > lib.mrcnn_roi_align_fwd_workspace_bytes(R)
-    ws = torch.zeros((nb,), dtype=torch.uint8, device=DEV)
-
-    def fwd(buf):
-        _hip.check(lib.mrcnn_roi_align_fwd_ws_f32(_hip.ptr(xt), 1, N, C, H, W, _hip.ptr(rt), R, P, P, 0.25, sr, _hip.ptr(y), _hip.ptr(buf), buf.numel(),
-                                                  _hip.stream_ptr()))
-
-    def bwd(buf, nbytes=None):
-        gx = torch.full((N, H, W, C), float('nan'), device=DEV)
-        _hip.check(lib.mrcnn_roi_align_bwd_ws_f32(_hip.ptr(gyt), 1, N, C, H, W, _hip.ptr(rt), R, P, P, 0.25, sr, _hip.ptr(gx), _hip.ptr(buf),
-                                                  buf.numel() if nbytes is None else nbytes, _hip.stream_ptr()))
-        return gx
-
-    try:
-        _hip.check(lib.mrcnn_roi_align_set_bwd_plan(0))
-        fwd(ws)
-        y0 = y.clone()
-        ref = bwd(ws)
-        assert torch.isfinite(ref).all()
-        _hip.check(lib.mrcnn_roi_align_set_bwd_plan(mode))
-        fwd(ws)
-        assert torch.equal(y, y0)                               # the extra workgroups do not touch the forward's output
-        hdr_off = lib.mrcnn_roi_align_fwd_workspace_bytes(R) // 4
-        plan = ws.view(torch.int32)[hdr_off:].cpu().numpy()
-        assert plan[0] == 0x504C414E and plan[5] == 8, plan[:8]  # magic, all eight XCD bands arrived
-        pyn, pxn = (H + 3) // 4, (W + 3) // 4
-        npatch = N * pyn * pxn
-        assert plan[4] == npatch
-        order = plan[64 + npatch:64 + npatch + 4096]
-        gimg = plan[64 + npatch + 4096:64 + npatch + 4096 + 1024]
-        live = order[order >= 0]
-        assert live.size == npatch and np.array_equal(np.sort(live), np.arange(npatch))          # a permutation of the patches
-        for b in np.nonzero(gimg >= 0)[0]:                                                        # a group's patches belong to its image
-            grp = order[4 * b:4 * b + 4]
-            assert ((grp[grp >= 0] // (pyn * pxn)) == gimg[b]).all()
-        got = bwd(ws)
-        assert torch.equal(got, ref)
-        assert torch.equal(bwd(ws), ref)                        # the plan survives its use
-        # fall-backs: a fresh buffer (no header), a too-small size, a plan built for another map width
-        assert torch.equal(bwd(torch.zeros_like(ws)), ref)
-        assert torch.equal(bwd(ws, lib.mrcnn_roi_align_fwd_workspace_bytes(R)), ref)
-        if W > 8:
-            nb2 = lib.mrcnn_roi_align_plan_workspace_bytes(N, H, W - 4, R)
-            ws2 = torch.zeros((max(nb, nb2),), dtype=torch.uint8, device=DEV)
-            x2 = xt[:, :, :W - 4].contiguous()
-            _hip.check(lib.mrcnn_roi_align_fwd_ws_f32(_hip.ptr(x2), 1, N, C, H, W - 4, _hip.ptr(rt), R, P, P, 0.25, sr, _hip.ptr(y), _hip.ptr(ws2), ws2.numel(),
-                                                      _hip.stream_ptr()))
-            assert torch.equal(bwd(ws2), ref)
-    finally:
-        _hip.check(lib.mrcnn_roi_align_set_bwd_plan(0))
 
 
 def _planned_vs_fused(xs_shapes, scales, N, C, xy, lev, P, sr, accumulate, plan_bytes=None, corrupt=None, split=True, verified=False):
