@@ -129,12 +129,15 @@ class ParamStore(object):
         self.params = torch.from_numpy(host).to(device)
         self.grads = torch.zeros_like(self.params)
         self.momentum = torch.zeros_like(self.params)
+        self._views = {}            # the views of earlier flat buffers (and the buffers they keep alive) go with them
         return self
 
     def _view(self, flat, name):
         # (views are cached per flat buffer: ~250 parameter / gradient lookups per step were 1.6 ms of slicing)
         cache = self._views.get(id(flat))
         if cache is None or cache[0] is not flat:
+            # a flat buffer this store no longer owns (rebound params / grads, a device move) must not stay alive through its views
+            self._views = {k: c for k, c in self._views.items() if c[0] is self.params or c[0] is self.grads or c[0] is self.momentum}
             cache = self._views[id(flat)] = (flat, {})
         v = cache[1].get(name)
         if v is None:
@@ -366,7 +369,11 @@ class Bottleneck(object):
         ps = self.conv1.ps
         N, H, W, _ = x.shape
         fwd_split = -1 if FWD_EMULATION_IN_BACKBONE else 0
-        key = (N, H, W, ps.params.data_ptr(), ps.grads.data_ptr(), fwd_split)
+        # (every tensor whose raw pointer goes into the descriptor is part of the key: the BatchNorm running statistics live outside the
+        # flat buffers and may be rebound on their own - ADVICE r5)
+        bufs = tuple(ps.buffers[b.name + sfx].data_ptr() for b in ([self.bn1, self.bn2, self.bn3] + ([self.bn4] if self.project else []))
+                     for sfx in ('/avg_mean', '/avg_var'))
+        key = (N, H, W, ps.params.data_ptr(), ps.grads.data_ptr(), fwd_split, bufs)
         if getattr(self, '_desc_key', None) != key:
             from chainer_maskrcnn import _hip
             d = _hip.Bottleneck()

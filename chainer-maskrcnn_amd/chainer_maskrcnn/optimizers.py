@@ -313,9 +313,11 @@ class MomentumSGD(object):
 
     def _sgd_section(self, start, end):
         ps = self.ps
-        key = (start, end, ps.params.data_ptr())
+        key = (start, end, ps.params.data_ptr(), ps.grads.data_ptr(), ps.momentum.data_ptr())
         views = self._section_views.get(key)
         if views is None:
+            if len(self._section_views) > 4096:         # (rebound flat buffers: do not keep the old ones alive through stale views)
+                self._section_views.clear()
             views = self._section_views[key] = (ps.params[start:end], ps.grads[start:end], ps.momentum[start:end])
         ops.sgd_momentum_wd(views[0], views[1], views[2], self.lr, self.momentum, self.weight_decay)
         self._updated_down_to = start

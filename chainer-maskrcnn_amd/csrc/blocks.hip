@@ -47,13 +47,20 @@ inline CG conv_geo(const Geo &g, int i) {
     }
 }
 
-// RAII bracket of the forward arithmetic (the Python path's nn/core.py _layer_tiles): restored on every exit path
+// RAII bracket of the forward arithmetic, the rule of the Python path (nn/core.py _layer_tiles.__enter__) exactly: the forward mode is
+// overridden only when the process runs the float32-accurate emulation (mode 3) - the exploratory modes 1 / 2 are left as they are, in both
+// paths.  Restored on every exit path.  The setting is process-global state of the library: the bracket holds a lock so that
+// two host threads issuing composite calls cannot interleave their set / restore pairs (other callers of mrcnn_conv2d_set_split_operands
+// are on their own: the entry point is documented as process-wide).
+std::mutex g_split_lock;
 struct FwdSplit {
     int keep[3];
     bool on = false;
+    std::unique_lock<std::mutex> hold;
     explicit FwdSplit(int want) {
         if (want < 0) return;
-        if (mrcnn_conv2d_get_split_operands(keep) != 0 || keep[0] == want) return;
+        hold = std::unique_lock<std::mutex>(g_split_lock);
+        if (mrcnn_conv2d_get_split_operands(keep) != 0 || keep[0] != 3 || keep[0] == want) return;
         on = mrcnn_conv2d_set_split_operands(want, keep[1], keep[2]) == 0;
     }
     ~FwdSplit() {

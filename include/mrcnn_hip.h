@@ -126,9 +126,12 @@ size_t mrcnn_roi_align_fpn_bwd_workspace_bytes(const int *Hs, const int *Ws, int
  * (the reference runs the forward with them: fpn_roi_mask_head.py:59-61,75-77).  mrcnn_roi_align_fpn_bwd_plan_f32 writes every patch's
  * entry list ((gy row, 4 row weights, 4 column weights), in (RoI, ph, pw) order) into the caller's `plan` buffer of
  * mrcnn_roi_align_fpn_bwd_plan_bytes() bytes - on any stream, any time after the RoIs exist; mrcnn_roi_align_fpn_bwd_planned_f32 is
- * mrcnn_roi_align_fpn_bwd_f32 that streams gy along those lists: same entry order, same weights, same FMAs = the same bits.  The plan
- * is checked on the device (magic, geometry, RoI count; a tile whose entries did not fit the pool is flagged): what the plan does not hold
- * is computed by the fused kernel in a second launch.
+ * mrcnn_roi_align_fpn_bwd_f32 that streams gy along those lists: same entry order, same weights, same FMAs = the same bits FOR FINITE gy
+ * (the lean kernel multiplies every row of a patch by its weight, zero weights included, where the fused kernel skips a zero-weight row: an
+ * Inf / NaN in gy reaches all 16 cells of the patches it touches instead of the rows it lands on - still non-finite output, other cells).
+ * The plan is checked on the device (magic, level count and every level's H x W, N, RoI count, pooled size, sampling ratio, node capacity
+ * against this call's plan_bytes; a tile whose entries did not fit the pool is flagged): what the plan does not hold is computed by the
+ * fused kernel in a second launch.
  * The buffer must not be modified between the two calls, and both must see the same rois / levels / scales; split_levels != 0 iff the
  * backward call is given its mrcnn_roi_align_fpn_bwd_workspace_bytes() scratch (the coarse levels' RoI split).  L == 1 with
  * levels == NULL is the single-level form (configs[1]). */
