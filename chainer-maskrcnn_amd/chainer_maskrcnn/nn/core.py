@@ -423,7 +423,7 @@ class Bottleneck(object):
         side = hnn.side_stream(dev) if FILTER_GRAD_ON_SIDE_STREAM else main
         arena = torch.empty((max(int(sizes[0]), 1),), dtype=torch.uint8, device=dev)
         ws_main, ws_side = hnn.workspace(sizes[1], dev, main), hnn.workspace(sizes[2], dev, side)
-        g_r = None if gy_masked else torch.empty_like(y)
+        g_r = None if (gy_masked or self.project) else torch.empty_like(y)      # (a projection block never writes the masked gradient)
         gx_new = torch.empty_like(x) if (self.project and gx_acc is None) else None
         _hip.check(lib.mrcnn_bottleneck_bwd_f32(ctypes.byref(d), ctypes.byref(plan), x.data_ptr(), y.data_ptr(), fwd_arena.data_ptr(), gy.data_ptr(),
                                                 int(bool(gy_masked)), _hip.ptr(g_r), _hip.ptr(gx_acc), _hip.ptr(gx_new), int(bool(mask_gx)),

@@ -112,7 +112,7 @@ extern "C" int mrcnn_bottleneck_fwd_plan(const mrcnn_bottleneck_t *b, mrcnn_bott
     put(MRCNN_BN_H1, (size_t)g.Pout * g.mid * f); put(MRCNN_BN_A1, (size_t)g.Pout * g.mid * f);
     put(MRCNN_BN_H2, (size_t)g.Pout * g.mid * f); put(MRCNN_BN_A2, (size_t)g.Pout * g.mid * f);
     put(MRCNN_BN_H3, (size_t)g.Pout * g.cout * f);
-    if (g.project) { put(MRCNN_BN_H4, (size_t)g.Pout * g.cout * f); put(MRCNN_BN_R, (size_t)g.Pout * g.cout * f); }
+    if (g.project) put(MRCNN_BN_H4, (size_t)g.Pout * g.cout * f);       // (the shortcut's BatchNorm output is never written: bn pair below)
     size_t ws = 0;
     for (int i = 0; i < (g.project ? 4 : 3); ++i) {
         const CG c = conv_geo(g, i);
@@ -164,13 +164,15 @@ extern "C" int mrcnn_bottleneck_fwd_f32(const mrcnn_bottleneck_t *b, const mrcnn
     TRY(conv(1, at(MRCNN_BN_A1), at(MRCNN_BN_H2)));
     TRY(bn(1, at(MRCNN_BN_H2), nullptr, at(MRCNN_BN_A2), 1));
     TRY(conv(2, at(MRCNN_BN_A2), at(MRCNN_BN_H3)));
-    const float *r = x;
-    if (g.project) {
-        TRY(conv(3, x, at(MRCNN_BN_H4)));
-        TRY(bn(3, at(MRCNN_BN_H4), nullptr, at(MRCNN_BN_R), 0));
-        r = at(MRCNN_BN_R);
-    }
-    return bn(2, at(MRCNN_BN_H3), r, y, 1);
+    if (!g.project) return bn(2, at(MRCNN_BN_H3), x, y, 1);
+    // projection shortcut: relu(bn3(h3) + bn4(h4)) in one apply kernel - same bits as bn4 -> r, bn3(+ r) (nn.hip k_bn_apply2)
+    TRY(conv(3, x, at(MRCNN_BN_H4)));
+    const int C = g.cout;
+    return mrcnn_bn_train_fwd_pair_f32(at(MRCNN_BN_H3), plan->part_rows[2] ? at(MRCNN_BN_PART + 2) : nullptr, plan->part_rows[2], b->gamma[2], b->beta[2],
+                                       at(MRCNN_BN_MEAN + 2), at(MRCNN_BN_INVSTD + 2), b->run_mean[2], b->run_var[2], at(MRCNN_BN_H4),
+                                       plan->part_rows[3] ? at(MRCNN_BN_PART + 3) : nullptr, plan->part_rows[3], b->gamma[3], b->beta[3],
+                                       at(MRCNN_BN_MEAN + 3), at(MRCNN_BN_INVSTD + 3), b->run_mean[3], b->run_var[3], y, (int)g.Pout, C, b->eps, b->decay, ws,
+                                       ws_bytes, stream);
 }
 
 namespace {
@@ -191,7 +193,7 @@ BwdLayout bwd_layout(const Geo &g) {
     L.total = o;
     for (int i = 0; i < (g.project ? 4 : 3); ++i) {
         const CG c = conv_geo(g, i);
-        L.ws_main = std::max(L.ws_main, mrcnn_bn_workspace_bytes((int)g.Pout, c.Cout));
+        L.ws_main = std::max(L.ws_main, i >= 2 && g.project ? mrcnn_bn_pair_workspace_bytes((int)g.Pout, c.Cout) : mrcnn_bn_workspace_bytes((int)g.Pout, c.Cout));
         L.ws_side = std::max(L.ws_side, mrcnn_conv2d_bwd_filter_workspace_bytes(g.N, c.H, c.W, c.Cin, c.Cout, c.K, c.K, c.stride, c.pad));
         // the data gradient of a strided 1x1 convolution runs on the subsampled lattice (stride 1 there)
         if (c.stride == 1) L.ws_main = std::max(L.ws_main, mrcnn_conv2d_workspace_bytes(g.N, c.H, c.W, c.Cin, c.Cout, c.K, c.K, 1, c.pad));
@@ -218,7 +220,7 @@ extern "C" int mrcnn_bottleneck_bwd_f32(const mrcnn_bottleneck_t *b, const mrcnn
     Geo g;
     TRY(geo_of(b, g));
     if (!plan || !x || !fwd_arena || !gy || !arena) return mrcnn::fail_arg(MRCNN_E_INVALID, "bottleneck_bwd: null pointer");
-    if (!gy_masked && (!g_r || !y)) return mrcnn::fail_arg(MRCNN_E_INVALID, "bottleneck_bwd: an unmasked gy needs y and a g_r buffer");
+    if (!gy_masked && (!y || (!g_r && !b->project))) return mrcnn::fail_arg(MRCNN_E_INVALID, "bottleneck_bwd: an unmasked gy needs y (and a g_r buffer: identity shortcut)");
     if (g.project && !gx_acc && !gx_new) return mrcnn::fail_arg(MRCNN_E_INVALID, "bottleneck_bwd: a projection block needs gx_acc or gx_new");
     const BwdLayout L = bwd_layout(g);
     if (arena_bytes < L.total) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "bottleneck_bwd: arena %zu < %zu", arena_bytes, L.total);
@@ -257,7 +259,13 @@ extern "C" int mrcnn_bottleneck_bwd_f32(const mrcnn_bottleneck_t *b, const mrcnn
                                          ws_main, ws_main_bytes, main);
     };
     const float *gr = gy;
-    if (gy_masked) {
+    if (g.project) {
+        // both BatchNorms of the residual sum in one pass each (sums, apply): the masked gradient is never written - same bits as
+        // bn_bwd(2 -> g_h3, g_r) here and bn_bwd(3, g_r -> g_h4) below (nn.hip k_bn_bwd_partial2 / _apply2)
+        TRY(mrcnn_bn_train_bwd_pair_f32(gy, gy_masked ? nullptr : y, fw(MRCNN_BN_H3), fw(MRCNN_BN_H4), b->gamma[2], fw(MRCNN_BN_MEAN + 2),
+                                        fw(MRCNN_BN_INVSTD + 2), b->gamma[3], fw(MRCNN_BN_MEAN + 3), fw(MRCNN_BN_INVSTD + 3), g_h3, g_h4, b->ggamma[2],
+                                        b->gbeta[2], b->ggamma[3], b->gbeta[3], P, g.cout, ws_main, ws_main_bytes, main));
+    } else if (gy_masked) {
         TRY(bn_bwd(2, gy, fw(MRCNN_BN_H3), nullptr, 0, g_h3, nullptr));
     } else {
         TRY(bn_bwd(2, gy, fw(MRCNN_BN_H3), y, 1, g_h3, g_r));
@@ -279,7 +287,6 @@ extern "C" int mrcnn_bottleneck_bwd_f32(const mrcnn_bottleneck_t *b, const mrcnn
         TRY(filter_grad(0, x, g_h1));
         return data_grad(0, g_h1, acc, 1, relu_x);
     }
-    TRY(bn_bwd(3, gr, fw(MRCNN_BN_H4), fw(MRCNN_BN_R), 0, g_h4, nullptr));
     if (g.stride == 1) {
         float *gx = gx_acc ? gx_acc : gx_new;
         TRY(filter_grad(0, x, g_h1));

@@ -116,8 +116,12 @@ __global__ __launch_bounds__(NT) void k_bn_stats_partial(const float *__restrict
 // Returns the sums in (a, b) of the threads with threadIdx.x < 4 * QUADS (channel blockIdx.x * 4 * QUADS + threadIdx.x).
 constexpr int FIN_THREADS = 256;
 int g_fin_quads = 4;          // channel quads per finalisation block (measurement knob: mrcnn_debug_bn_plan)
+// Rows of `part` are row_floats floats apart (2 C for the (sums, second statistic) rows of one BatchNorm); the second statistic sits off_b
+// floats into the row (C) - the pair kernels below keep three statistics per row and read the third with off_b = 2 C.
 template <int QUADS>
-__device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int nblk, int C, double &a, double &b) {
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int nblk, int C, double &a, double &b, int row_floats = 0,
+                                                int off_b = 0) {
+    if (row_floats == 0) { row_floats = 2 * C; off_b = C; }
     constexpr int CH = 4 * QUADS, SLICES = FIN_THREADS / QUADS, L2N = SLICES / 16;
     __shared__ double ra[SLICES][CH], rb[SLICES][CH];
     __shared__ double ra2[16][CH], rb2[16][CH];
@@ -130,8 +134,8 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
             float4 va[4], vb[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                va[j] = ld4(part + (size_t)(k + j * SLICES) * 2 * C + c0);
-                vb[j] = ld4(part + (size_t)(k + j * SLICES) * 2 * C + C + c0);
+                va[j] = ld4(part + (size_t)(k + j * SLICES) * row_floats + c0);
+                vb[j] = ld4(part + (size_t)(k + j * SLICES) * row_floats + off_b + c0);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -140,7 +144,7 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
             }
         }
         for (; k < nblk; k += SLICES) {
-            const float4 va = ld4(part + (size_t)k * 2 * C + c0), vb = ld4(part + (size_t)k * 2 * C + C + c0);
+            const float4 va = ld4(part + (size_t)k * row_floats + c0), vb = ld4(part + (size_t)k * row_floats + off_b + c0);
             sa4[0] += (double)va.x; sa4[1] += (double)va.y; sa4[2] += (double)va.z; sa4[3] += (double)va.w;
             sb4[0] += (double)vb.x; sb4[1] += (double)vb.y; sb4[2] += (double)vb.z; sb4[3] += (double)vb.w;
         }
@@ -387,6 +391,143 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float *__restrict__ g
         o.w = ga.w * s.w * (g.w - gb.w * invP - ((v.w - m.w) * s.w) * (gg.w * invP));
         st4(gx + i * 4, o);
         if (gres) st4(gres + i * 4, g);
+    }
+}
+
+// ---- (r6) Two BatchNorms that meet in one residual sum: the main branch and the projection shortcut of a ResNet bottleneck
+// (extractor/feature_pyramid_network.py:48-66; Chainer's BottleneckA: relu(bn3(conv3(.)) + bn4(conv4(x)))).  Run layer by layer, the
+// shortcut's BatchNorm output r crosses HBM twice in the forward pass (written by its apply kernel, read as the residual) and the masked
+// gradient g_r three times in the backward pass (written beside g_h3, read by both kernels of the shortcut's BatchNorm backward):
+// 5 x 252 MB per step at 2 x 1024^2.  The pair kernels read the two pre-BatchNorm tensors side by side and never materialise r / g_r.
+// Every value is computed by the expressions of the single-layer kernels in the same order (r first, then o = bn_a + r; the same row
+// blocks, the same order of the partial sums): the results are the same bits as the layer-by-layer sequence.
+__global__ __launch_bounds__(NT) void k_bn_apply2(const float *__restrict__ xa, const float *__restrict__ gamma_a, const float *__restrict__ beta_a,
+                                                  const float *__restrict__ mean_a, const float *__restrict__ invstd_a,
+                                                  const float *__restrict__ xb, const float *__restrict__ gamma_b, const float *__restrict__ beta_b,
+                                                  const float *__restrict__ mean_b, const float *__restrict__ invstd_b, float *__restrict__ y,
+                                                  size_t n4, int C4) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4) * 4;
+        const float4 va = ld4(xa + i * 4), vb = ld4(xb + i * 4);
+        const float4 ga = ld4(gamma_a + c), ba = ld4(beta_a + c), ma = ld4(mean_a + c), sa = ld4(invstd_a + c);
+        const float4 gb = ld4(gamma_b + c), bb = ld4(beta_b + c), mb = ld4(mean_b + c), sb = ld4(invstd_b + c);
+        float4 r, o;
+        r.x = gb.x * ((vb.x - mb.x) * sb.x) + bb.x; r.y = gb.y * ((vb.y - mb.y) * sb.y) + bb.y;
+        r.z = gb.z * ((vb.z - mb.z) * sb.z) + bb.z; r.w = gb.w * ((vb.w - mb.w) * sb.w) + bb.w;
+        o.x = ga.x * ((va.x - ma.x) * sa.x) + ba.x; o.y = ga.y * ((va.y - ma.y) * sa.y) + ba.y;
+        o.z = ga.z * ((va.z - ma.z) * sa.z) + ba.z; o.w = ga.w * ((va.w - ma.w) * sa.w) + ba.w;
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        st4(y + i * 4, o);
+    }
+}
+
+// partial rows (nblk, 3, C): sum(dz), sum(dz * xhat_a), sum(dz * xhat_b); dz = y ? gy * (y > 0) : gy
+__global__ __launch_bounds__(NT) void k_bn_bwd_partial2(const float *__restrict__ gy, const float *__restrict__ y, const float *__restrict__ xa,
+                                                        const float *__restrict__ xb, const float *__restrict__ mean_a,
+                                                        const float *__restrict__ invstd_a, const float *__restrict__ mean_b,
+                                                        const float *__restrict__ invstd_b, int P, int C, int G, int RPI, int rows_per_blk,
+                                                        float *__restrict__ part) {
+    __shared__ float4 s1[NT], s2[NT], s3[NT];
+    const int t = threadIdx.x, cg0 = t % G, rr = t / G;
+    const int C4 = C / 4;
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(P, r0 + rows_per_blk);
+    for (int cg = cg0; cg < C4; cg += G) {
+        const float4 ma = ld4(mean_a + cg * 4), sa = ld4(invstd_a + cg * 4), mb = ld4(mean_b + cg * 4), sb = ld4(invstd_b + cg * 4);
+        float4 a = f4(0.f), b = f4(0.f), c = f4(0.f);
+        auto acc = [&](float4 g, const float4 va, const float4 vb, const float4 yy) {
+            if (y) {
+                g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+                g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+            }
+            a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+            b.x = fmaf(g.x, (va.x - ma.x) * sa.x, b.x); b.y = fmaf(g.y, (va.y - ma.y) * sa.y, b.y);
+            b.z = fmaf(g.z, (va.z - ma.z) * sa.z, b.z); b.w = fmaf(g.w, (va.w - ma.w) * sa.w, b.w);
+            c.x = fmaf(g.x, (vb.x - mb.x) * sb.x, c.x); c.y = fmaf(g.y, (vb.y - mb.y) * sb.y, c.y);
+            c.z = fmaf(g.z, (vb.z - mb.z) * sb.z, c.z); c.w = fmaf(g.w, (vb.w - mb.w) * sb.w, c.w);
+        };
+        const float *yr = y ? y : gy;
+        int r = r0 + rr;
+        for (; r + RPI < r1; r += 2 * RPI) {              // two rows (eight loads) in flight, accumulated in row order
+            const size_t o0 = (size_t)r * C + cg * 4, o1 = (size_t)(r + RPI) * C + cg * 4;
+            const float4 g0 = ld4(gy + o0), a0 = ld4(xa + o0), b0 = ld4(xb + o0), g1 = ld4(gy + o1), a1 = ld4(xa + o1), b1 = ld4(xb + o1);
+            float4 y0 = g0, y1 = g1;
+            if (y) { y0 = ld4(yr + o0); y1 = ld4(yr + o1); }
+            acc(g0, a0, b0, y0);
+            acc(g1, a1, b1, y1);
+        }
+        for (; r < r1; r += RPI) {
+            const size_t o = (size_t)r * C + cg * 4;
+            const float4 g = ld4(gy + o);
+            acc(g, ld4(xa + o), ld4(xb + o), y ? ld4(yr + o) : g);
+        }
+        s1[t] = a; s2[t] = b; s3[t] = c;
+        __syncthreads();
+        if (rr == 0) {
+            for (int k = 1; k < RPI; ++k) {
+                const float4 p = s1[k * G + cg0], q = s2[k * G + cg0], u = s3[k * G + cg0];
+                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+                b.x += q.x; b.y += q.y; b.z += q.z; b.w += q.w;
+                c.x += u.x; c.y += u.y; c.z += u.z; c.w += u.w;
+            }
+            st4(part + ((size_t)blockIdx.x * 3 * C) + cg * 4, a);
+            st4(part + ((size_t)blockIdx.x * 3 * C) + C + cg * 4, b);
+            st4(part + ((size_t)blockIdx.x * 3 * C) + 2 * C + cg * 4, c);
+        }
+        __syncthreads();
+    }
+}
+
+// gbeta_a = gbeta_b = sum(dz), ggamma_a = sum(dz * xhat_a), ggamma_b = sum(dz * xhat_b): the single-layer reduction, twice
+template <int QUADS>
+__global__ __launch_bounds__(FIN_THREADS) void k_bn_bwd_final2(const float *__restrict__ part, int nblk, int C, float *__restrict__ gbeta_a,
+                                                               float *__restrict__ ggamma_a, float *__restrict__ gbeta_b,
+                                                               float *__restrict__ ggamma_b) {
+    const int c = blockIdx.x * 4 * QUADS + threadIdx.x;
+    double a, b, a2, b2;
+    reduce_partials<QUADS>(part, nblk, C, a, b, 3 * C, C);
+    __syncthreads();
+    reduce_partials<QUADS>(part, nblk, C, a2, b2, 3 * C, 2 * C);
+    if (threadIdx.x >= 4 * QUADS || c >= C) return;
+    gbeta_a[c] = (float)a; ggamma_a[c] = (float)b;
+    gbeta_b[c] = (float)a2; ggamma_b[c] = (float)b2;
+}
+
+__global__ __launch_bounds__(NT) void k_bn_bwd_apply2(const float *__restrict__ gy, const float *__restrict__ y, const float *__restrict__ xa,
+                                                      const float *__restrict__ xb, const float *__restrict__ gamma_a,
+                                                      const float *__restrict__ mean_a, const float *__restrict__ invstd_a,
+                                                      const float *__restrict__ gbeta_a, const float *__restrict__ ggamma_a,
+                                                      const float *__restrict__ gamma_b, const float *__restrict__ mean_b,
+                                                      const float *__restrict__ invstd_b, const float *__restrict__ gbeta_b,
+                                                      const float *__restrict__ ggamma_b, float *__restrict__ gxa, float *__restrict__ gxb,
+                                                      size_t n4, int C4, float invP) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C4) * 4;
+        float4 g = ld4(gy + i * 4);
+        const float4 va = ld4(xa + i * 4), vb = ld4(xb + i * 4);
+        if (y) {
+            const float4 yy = ld4(y + i * 4);
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        {
+            const float4 ga = ld4(gamma_a + c), m = ld4(mean_a + c), s = ld4(invstd_a + c), gb = ld4(gbeta_a + c), gg = ld4(ggamma_a + c);
+            float4 o;
+            o.x = ga.x * s.x * (g.x - gb.x * invP - ((va.x - m.x) * s.x) * (gg.x * invP));
+            o.y = ga.y * s.y * (g.y - gb.y * invP - ((va.y - m.y) * s.y) * (gg.y * invP));
+            o.z = ga.z * s.z * (g.z - gb.z * invP - ((va.z - m.z) * s.z) * (gg.z * invP));
+            o.w = ga.w * s.w * (g.w - gb.w * invP - ((va.w - m.w) * s.w) * (gg.w * invP));
+            st4(gxa + i * 4, o);
+        }
+        {
+            const float4 ga = ld4(gamma_b + c), m = ld4(mean_b + c), s = ld4(invstd_b + c), gb = ld4(gbeta_b + c), gg = ld4(ggamma_b + c);
+            float4 o;
+            o.x = ga.x * s.x * (g.x - gb.x * invP - ((vb.x - m.x) * s.x) * (gg.x * invP));
+            o.y = ga.y * s.y * (g.y - gb.y * invP - ((vb.y - m.y) * s.y) * (gg.y * invP));
+            o.z = ga.z * s.z * (g.z - gb.z * invP - ((vb.z - m.z) * s.z) * (gg.z * invP));
+            o.w = ga.w * s.w * (g.w - gb.w * invP - ((vb.w - m.w) * s.w) * (gg.w * invP));
+            st4(gxb + i * 4, o);
+        }
     }
 }
 
@@ -958,6 +1099,71 @@ extern "C" int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const flo
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(NT), 0, st, gy, x, y, gamma, save_mean, save_invstd, gbeta,
                        ggamma, gx, gres, n4, C / 4, 1.0f / (float)P, rmode, beta);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t mrcnn_bn_pair_workspace_bytes(int P, int C) {
+    if (P <= 0 || C <= 0 || (C % 4)) return 0;
+    const RedPlan r = red_plan(P, C);
+    return (size_t)r.nblk * 3 * C * sizeof(float);
+}
+
+// relu(BN_a(xa) + BN_b(xb)): statistics of each layer as in the single-layer entry points (part_* / rows_* = the producing convolution's
+// partial rows, or NULL / 0 = a statistics pass over the tensor through ws), then ONE apply kernel.
+extern "C" int mrcnn_bn_train_fwd_pair_f32(const float *xa, const float *part_a, int rows_a, const float *gamma_a, const float *beta_a,
+                                           float *mean_a, float *invstd_a, float *run_mean_a, float *run_var_a, const float *xb,
+                                           const float *part_b, int rows_b, const float *gamma_b, const float *beta_b, float *mean_b,
+                                           float *invstd_b, float *run_mean_b, float *run_var_b, float *y, int P, int C, float eps, float decay,
+                                           void *ws, size_t ws_bytes, void *stream) {
+    if (int e = chk(xa && gamma_a && beta_a && mean_a && invstd_a && xb && gamma_b && beta_b && mean_b && invstd_b && y, "bn_train_fwd_pair: null pointer")) return e;
+    if (int e = chk(P > 0 && C > 0 && (C % 4) == 0 && rows_a >= 0 && rows_b >= 0, "bn_train_fwd_pair: need P>0, C%4==0, rows>=0")) return e;
+    if (int e = chk((rows_a == 0) == (part_a == nullptr) && (rows_b == 0) == (part_b == nullptr), "bn_train_fwd_pair: part / rows must come together")) return e;
+    if ((!part_a || !part_b) && (!ws || ws_bytes < mrcnn_bn_workspace_bytes(P, C)))
+        return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "bn_train_fwd_pair: a statistics pass needs mrcnn_bn_workspace_bytes() of workspace");
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan r = red_plan(P, C);
+    auto stats = [&](const float *x, const float *part, int rows, float *mean, float *invstd, float *rm, float *rv) {
+        if (part) {
+            launch_stats_final(st, x, part, rows, P, C, eps, decay, 0, mean, invstd, rm, rv);
+        } else {
+            hipLaunchKernelGGL(k_bn_stats_partial, dim3(r.nblk), dim3(NT), 0, st, x, P, C, r.G, r.RPI, r.rows_per_blk, (float *)ws);
+            launch_stats_final(st, x, (const float *)ws, r.nblk, P, C, eps, decay, 1, mean, invstd, rm, rv);
+        }
+    };
+    stats(xb, part_b, rows_b, mean_b, invstd_b, run_mean_b, run_var_b);
+    MRCNN_LAUNCH_CHECK();
+    stats(xa, part_a, rows_a, mean_a, invstd_a, run_mean_a, run_var_a);
+    MRCNN_LAUNCH_CHECK();
+    const size_t n4 = (size_t)P * C / 4;
+    hipLaunchKernelGGL(k_bn_apply2, dim3(ew_grid(n4)), dim3(NT), 0, st, xa, gamma_a, beta_a, mean_a, invstd_a, xb, gamma_b, beta_b, mean_b, invstd_b, y,
+                       n4, C / 4);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of the pair: dz = y ? gy * (y > 0) : gy; gxa / gxb = the two BatchNorm backward passes of dz (gbeta_a == gbeta_b == sum dz).
+extern "C" int mrcnn_bn_train_bwd_pair_f32(const float *gy, const float *y, const float *xa, const float *xb, const float *gamma_a,
+                                           const float *mean_a, const float *invstd_a, const float *gamma_b, const float *mean_b,
+                                           const float *invstd_b, float *gxa, float *gxb, float *ggamma_a, float *gbeta_a, float *ggamma_b,
+                                           float *gbeta_b, int P, int C, void *ws, size_t ws_bytes, void *stream) {
+    if (int e = chk(gy && xa && xb && gamma_a && mean_a && invstd_a && gamma_b && mean_b && invstd_b && gxa && gxb && ggamma_a && gbeta_a && ggamma_b &&
+                        gbeta_b && ws, "bn_train_bwd_pair: null pointer")) return e;
+    if (int e = chk(P > 0 && C > 0 && (C % 4) == 0, "bn_train_bwd_pair: need P>0, C%4==0")) return e;
+    if (ws_bytes < mrcnn_bn_pair_workspace_bytes(P, C)) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "bn_train_bwd_pair: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan r = red_plan(P, C);
+    hipLaunchKernelGGL(k_bn_bwd_partial2, dim3(r.nblk), dim3(NT), 0, st, gy, y, xa, xb, mean_a, invstd_a, mean_b, invstd_b, P, C, r.G, r.RPI,
+                       r.rows_per_blk, (float *)ws);
+    MRCNN_LAUNCH_CHECK();
+    if (g_fin_quads == 1)
+        hipLaunchKernelGGL(k_bn_bwd_final2<1>, dim3(mrcnn::cdiv(C, 4)), dim3(FIN_THREADS), 0, st, (const float *)ws, r.nblk, C, gbeta_a, ggamma_a, gbeta_b, ggamma_b);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_final2<4>, dim3(mrcnn::cdiv(C, 16)), dim3(FIN_THREADS), 0, st, (const float *)ws, r.nblk, C, gbeta_a, ggamma_a, gbeta_b, ggamma_b);
+    MRCNN_LAUNCH_CHECK();
+    const size_t n4 = (size_t)P * C / 4;
+    hipLaunchKernelGGL(k_bn_bwd_apply2, dim3(ew_grid(n4)), dim3(NT), 0, st, gy, y, xa, xb, gamma_a, mean_a, invstd_a, gbeta_a, ggamma_a, gamma_b, mean_b,
+                       invstd_b, gbeta_b, ggamma_b, gxa, gxb, n4, C / 4, 1.0f / (float)P);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

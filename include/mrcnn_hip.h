@@ -337,6 +337,24 @@ int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const float *y, cons
                            const float *save_mean, const float *save_invstd, float *gx, float *gres,
                            float *ggamma, float *gbeta, int P, int C, int relu, void *ws, size_t ws_bytes,
                            void *stream);
+/* (ABI v10) Two training-mode BatchNorms that meet in one residual sum - the main branch and the projection shortcut of a ResNet bottleneck
+ * (extractor/feature_pyramid_network.py:48-66; Chainer's BottleneckA): y = relu(BN_a(xa) + BN_b(xb)).  Statistics of each layer as in the
+ * single-layer entry points (part_x / rows_x: the partial rows its convolution left behind, mrcnn_conv2d_fwd_bnstats_f32; NULL / 0 = a
+ * statistics pass over the tensor through ws of mrcnn_bn_workspace_bytes()), then ONE apply kernel: the shortcut's BatchNorm output is never
+ * written.  The backward pair: dz = y ? gy * (y > 0) : gy (y NULL = gy arrives masked); gxa / gxb = BatchNorm backward of dz through each
+ * layer (ws of mrcnn_bn_pair_workspace_bytes()); the masked gradient is never written either.  Same bits as the layer-by-layer sequence
+ * mrcnn_bn_train_fwd(_stats)_f32(xb -> r), mrcnn_bn_train_fwd(_stats)_f32(xa, residual r, relu) and its two mrcnn_bn_train_bwd_f32 calls:
+ * 5 passes over a (P, C) tensor fewer per projection block and step. */
+size_t mrcnn_bn_pair_workspace_bytes(int P, int C);
+int mrcnn_bn_train_fwd_pair_f32(const float *xa, const float *part_a, int rows_a, const float *gamma_a, const float *beta_a,
+                                float *mean_a, float *invstd_a, float *run_mean_a, float *run_var_a, const float *xb,
+                                const float *part_b, int rows_b, const float *gamma_b, const float *beta_b, float *mean_b,
+                                float *invstd_b, float *run_mean_b, float *run_var_b, float *y, int P, int C, float eps, float decay,
+                                void *ws, size_t ws_bytes, void *stream);
+int mrcnn_bn_train_bwd_pair_f32(const float *gy, const float *y, const float *xa, const float *xb, const float *gamma_a,
+                                const float *mean_a, const float *invstd_a, const float *gamma_b, const float *mean_b,
+                                const float *invstd_b, float *gxa, float *gxb, float *ggamma_a, float *gbeta_a, float *ggamma_b,
+                                float *gbeta_b, int P, int C, void *ws, size_t ws_bytes, void *stream);
 /* Inference-mode BN with the running statistics (chainer.config.train == False, maskrcnn.py:171-172). */
 int mrcnn_bn_infer_fwd_f32(const float *x, const float *gamma, const float *beta, const float *mean,
                            const float *var, const float *residual, float *y, int P, int C, float eps, int relu,

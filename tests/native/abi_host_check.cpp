@@ -60,7 +60,7 @@ int main() {
             }
     acc += mrcnn_rpn_proposals_workspace_bytes(0, 0, 0, 0) + mrcnn_rpn_proposals_workspace_bytes(-1, -5, -7, -9);
     for (int n : {0, 1, 63, 64, 65, 12000}) acc += mrcnn_nms_workspace_bytes(n);
-    for (int P : {1, 100, 524288}) for (int C : chans) acc += mrcnn_bn_workspace_bytes(P, C);
+    for (int P : {1, 100, 524288}) for (int C : chans) acc += mrcnn_bn_workspace_bytes(P, C) + mrcnn_bn_pair_workspace_bytes(P, C);
     acc += mrcnn_loss_workspace_bytes();
     {
         const int Hs[5] = {256, 128, 64, 32, 16}, Ws[5] = {256, 128, 64, 32, 16};
@@ -99,6 +99,15 @@ int main() {
     EXPECT_ERR(mrcnn_bn_train_fwd_f32(CF, CF, CF, CF, F, F, F, F, F, 64, 32, 2e-5f, 0.9f, 1, V, 0, V));
     EXPECT_ERR(mrcnn_bn_train_bwd_f32(CF, CF, CF, CF, CF, CF, CF, F, F, F, F, 64, 32, 1, V, 0, V));
     EXPECT_ERR(mrcnn_bn_infer_fwd_f32(CF, CF, CF, CF, CF, CF, F, 64, 32, 2e-5f, 1, V));
+    EXPECT_ERR(mrcnn_bn_train_fwd_pair_f32(CF, CF, 4, CF, CF, F, F, F, F, CF, CF, 4, CF, CF, F, F, F, F, F, 64, 32, 2e-5f, 0.9f, V, 0, V));
+    EXPECT_ERR(mrcnn_bn_train_bwd_pair_f32(CF, CF, CF, CF, CF, CF, CF, CF, CF, CF, F, F, F, F, F, F, 64, 32, V, 0, V));
+    {   // non-null buffers: part / rows must come together, a statistics pass needs its workspace, the backward its own
+        static float b2[64];
+        EXPECT_ERR(mrcnn_bn_train_fwd_pair_f32(b2, b2, 0, b2, b2, b2, b2, b2, b2, b2, b2, 4, b2, b2, b2, b2, b2, b2, b2, 64, 32, 2e-5f, 0.9f, b2, sizeof(b2), V));
+        EXPECT_ERR(mrcnn_bn_train_fwd_pair_f32(b2, nullptr, 0, b2, b2, b2, b2, b2, b2, b2, b2, 4, b2, b2, b2, b2, b2, b2, b2, 64, 32, 2e-5f, 0.9f, b2, 16, V));
+        EXPECT_ERR(mrcnn_bn_train_bwd_pair_f32(b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, 64, 32, b2, 16, V));
+        EXPECT_ERR(mrcnn_bn_train_bwd_pair_f32(b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, b2, 64, 30, b2, sizeof(b2), V));
+    }
     EXPECT_ERR(mrcnn_relu_bwd_f32(CF, CF, F, 64, V));
     EXPECT_ERR(mrcnn_relu_fwd_f32(CF, F, 64, V));
     EXPECT_ERR(mrcnn_add_f32(CF, CF, F, 64, V));

@@ -161,8 +161,8 @@ def test_every_backbone_marks_its_convolutions():
 
 
 def test_composite_bottleneck_plan_is_host_arithmetic():
-    """mrcnn_bottleneck_fwd_plan / _bwd_sizes (ABI v9, csrc/blocks.hip) need no device: the forward arena holds the seven activations of a
-    projection block, 256-byte aligned and disjoint; fwd_split brackets the plan like the forward call and is restored; bad descriptors are
+    """mrcnn_bottleneck_fwd_plan / _bwd_sizes (ABI v9, csrc/blocks.hip) need no device: the forward arena holds the six activations of a
+    projection block (ABI v10: the shortcut's BatchNorm output is never written - slot 6 stays empty), 256-byte aligned and disjoint; fwd_split brackets the plan like the forward call and is restored; bad descriptors are
     argument errors."""
     import ctypes
     from chainer_maskrcnn import _hip
@@ -178,10 +178,10 @@ def test_composite_bottleneck_plan_is_host_arithmetic():
     finally:
         _hip.check(lib.mrcnn_conv2d_set_split_operands(0, 0, 0))
     P = 2 * 32 * 32
-    sizes = [P * 256 * 4] * 4 + [P * 1024 * 4] * 3
-    offs = [plan.off[i] for i in range(7)]
-    assert all(o % 256 == 0 for o in plan.off) and offs == [sum(sizes[:i]) for i in range(7)]
-    used = sorted((plan.off[i], i) for i in range(_hip.BN_SLOTS) if i < 7 or plan.off[i])
+    sizes = [P * 256 * 4] * 4 + [P * 1024 * 4] * 2
+    offs = [plan.off[i] for i in range(6)]
+    assert all(o % 256 == 0 for o in plan.off) and offs == [sum(sizes[:i]) for i in range(6)] and plan.off[6] == 0
+    used = sorted((plan.off[i], i) for i in range(_hip.BN_SLOTS) if i < 6 or plan.off[i])
     assert all(a[0] < b[0] for a, b in zip(used, used[1:])) and plan.arena_bytes > used[-1][0]
     assert plan.v_bytes[1] == lib.mrcnn_conv2d_winograd_v_bytes(2, 32, 32, 256, 256, 3, 3, 1, 1) and plan.v_bytes[0] == 0
     assert plan.part_rows[1] == lib.mrcnn_conv2d_bnstats_rows(2, 32, 32, 256, 256, 3, 3, 1, 1)
