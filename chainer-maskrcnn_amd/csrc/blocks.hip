@@ -14,6 +14,8 @@
 namespace {
 
 constexpr size_t ALIGN = 256;
+constexpr unsigned long long NOT_MATERIALISED = ~0ull;       // plan->off[] of an activation its consumer recomputes on load
+int g_inbn_on = 1;            // measurement knob (mrcnn_debug_bottleneck_inbn): 0 = bn1's output is materialised as before
 inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct Geo {
@@ -100,6 +102,11 @@ int fence(hipStream_t from, hipStream_t to) {
 
 }  // namespace
 
+extern "C" int mrcnn_debug_bottleneck_inbn(int on) {        // A/B of the bn1-on-load path (tools/ab_step.py); plans are made per call
+    g_inbn_on = on ? 1 : 0;
+    return 0;
+}
+
 extern "C" int mrcnn_bottleneck_fwd_plan(const mrcnn_bottleneck_t *b, mrcnn_bottleneck_plan_t *plan) {
     Geo g;
     TRY(geo_of(b, g));
@@ -109,7 +116,12 @@ extern "C" int mrcnn_bottleneck_fwd_plan(const mrcnn_bottleneck_t *b, mrcnn_bott
     size_t o = 0;
     auto put = [&](int slot, size_t bytes) { plan->off[slot] = o; o += up(bytes); };
     const size_t f = sizeof(float);
-    put(MRCNN_BN_H1, (size_t)g.Pout * g.mid * f); put(MRCNN_BN_A1, (size_t)g.Pout * g.mid * f);
+    // (conv2's Winograd input transforms apply bn1 + ReLU on load where both of its passes take that path: a1 is then never written -
+    // off[A1] = NOT_MATERIALISED)
+    const CG c1 = conv_geo(g, 1);
+    const bool inbn1 = g_inbn_on && mrcnn_conv2d_inbn_ok(g.N, c1.H, c1.W, c1.Cin, c1.Cout, c1.K, c1.K, c1.stride, c1.pad) != 0;
+    put(MRCNN_BN_H1, (size_t)g.Pout * g.mid * f);
+    if (inbn1) plan->off[MRCNN_BN_A1] = NOT_MATERIALISED; else put(MRCNN_BN_A1, (size_t)g.Pout * g.mid * f);
     put(MRCNN_BN_H2, (size_t)g.Pout * g.mid * f); put(MRCNN_BN_A2, (size_t)g.Pout * g.mid * f);
     put(MRCNN_BN_H3, (size_t)g.Pout * g.cout * f);
     if (g.project) put(MRCNN_BN_H4, (size_t)g.Pout * g.cout * f);       // (the shortcut's BatchNorm output is never written: bn pair below)
@@ -160,8 +172,18 @@ extern "C" int mrcnn_bottleneck_fwd_f32(const mrcnn_bottleneck_t *b, const mrcnn
                                       b->run_var[i], (int)g.Pout, C, b->eps, b->decay, relu, ws, ws_bytes, stream);
     };
     TRY(conv(0, x, at(MRCNN_BN_H1)));
-    TRY(bn(0, at(MRCNN_BN_H1), nullptr, at(MRCNN_BN_A1), 1));
-    TRY(conv(1, at(MRCNN_BN_A1), at(MRCNN_BN_H2)));
+    if (plan->off[MRCNN_BN_A1] == NOT_MATERIALISED) {
+        // bn1's statistics only; conv2's input transform applies bn1 + ReLU to h1 as it loads it (conv.hip wino_input_body)
+        const CG c1 = conv_geo(g, 1);
+        TRY(mrcnn_bn_train_stats_f32(at(MRCNN_BN_H1), plan->part_rows[0] ? at(MRCNN_BN_PART + 0) : nullptr, plan->part_rows[0], at(MRCNN_BN_MEAN + 0),
+                                     at(MRCNN_BN_INVSTD + 0), b->run_mean[0], b->run_var[0], (int)g.Pout, g.mid, b->eps, b->decay, ws, ws_bytes, stream));
+        TRY(mrcnn_conv2d_fwd_inbn_f32(at(MRCNN_BN_H1), b->gamma[0], b->beta[0], at(MRCNN_BN_MEAN + 0), at(MRCNN_BN_INVSTD + 0), b->w[1], at(MRCNN_BN_H2), g.N,
+                                      c1.H, c1.W, c1.Cin, c1.Cout, c1.K, c1.K, c1.stride, c1.pad, plan->part_rows[1] ? at(MRCNN_BN_PART + 1) : nullptr,
+                                      plan->v_bytes[1] ? at(MRCNN_BN_V + 1) : nullptr, ws, ws_bytes, stream));
+    } else {
+        TRY(bn(0, at(MRCNN_BN_H1), nullptr, at(MRCNN_BN_A1), 1));
+        TRY(conv(1, at(MRCNN_BN_A1), at(MRCNN_BN_H2)));
+    }
     TRY(bn(1, at(MRCNN_BN_H2), nullptr, at(MRCNN_BN_A2), 1));
     TRY(conv(2, at(MRCNN_BN_A2), at(MRCNN_BN_H3)));
     if (!g.project) return bn(2, at(MRCNN_BN_H3), x, y, 1);
@@ -274,7 +296,15 @@ extern "C" int mrcnn_bottleneck_bwd_f32(const mrcnn_bottleneck_t *b, const mrcnn
     TRY(filter_grad(2, fw(MRCNN_BN_A2), g_h3));
     TRY(data_grad(2, g_h3, g_a2, 0, nullptr));
     TRY(bn_bwd(1, g_a2, fw(MRCNN_BN_H2), nullptr, 2, g_h2, nullptr));
-    TRY(filter_grad(1, fw(MRCNN_BN_A1), g_h2));
+    if (plan->off[MRCNN_BN_A1] == NOT_MATERIALISED) {         // the forward never wrote a1: the filter gradient's input transform rebuilds it from h1
+        const CG c1 = conv_geo(g, 1);
+        TRY(fence(main, side));
+        TRY(mrcnn_conv2d_bwd_filter_inbn_f32(fw(MRCNN_BN_H1), b->gamma[0], b->beta[0], fw(MRCNN_BN_MEAN + 0), fw(MRCNN_BN_INVSTD + 0), g_h2, b->gw[1], g.N, c1.H,
+                                             c1.W, c1.Cin, c1.Cout, c1.K, c1.K, c1.stride, c1.pad, 0, plan->v_bytes[1] ? fw(MRCNN_BN_V + 1) : nullptr, ws_side,
+                                             ws_side_bytes, side));
+    } else {
+        TRY(filter_grad(1, fw(MRCNN_BN_A1), g_h2));
+    }
     TRY(data_grad(1, g_h2, g_a1, 0, nullptr));
     TRY(bn_bwd(0, g_a1, fw(MRCNN_BN_H1), nullptr, 2, g_h1, nullptr));
     const float *relu_x = mask_gx ? x : nullptr;

@@ -1443,9 +1443,14 @@ __device__ __forceinline__ void v4bufst(__amdgpu_buffer_rsrc_t rs, unsigned voff
     const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, soff, 0);
 }
+// (r6) The layer's input may be relu(BatchNorm(x)) of a training-mode BatchNorm whose statistics are final: the transform then applies
+// gamma * ((x - mean) * invstd) + beta and the ReLU to every tap as it loads it - the expression of nn.hip's k_bn_apply, so the values
+// are the bits that kernel would have written - and the normalised activation never crosses HBM (conv -> bn -> relu -> conv 3x3 of a
+// ResNet bottleneck: extractor/feature_pyramid_network.py:48-66).  A tap outside the image stays the zero of the padding.
+struct InBN { const float *gamma, *beta, *mean, *invstd; };
 template <int M_>
 __device__ __forceinline__ void wino_input_body(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
-                                                int th, int tw, long long T, long long Tp, unsigned blk) {
+                                                int th, int tw, long long T, long long Tp, unsigned blk, const InBN bn = InBN{}) {
     constexpr int A_ = M_ + 2;
     // 32-bit index arithmetic (wino_ok(): 16 * Tp * C < 2^30): the 64-bit divisions this replaces were ~600 instructions of
     // branchy software division per thread
@@ -1475,12 +1480,25 @@ __device__ __forceinline__ void wino_input_body(const float *__restrict__ x, flo
         rowo[r] = (unsigned)h < (unsigned)H ? (unsigned)(((size_t)n * H + h) * W * C * 4) : OOB;
         colo[r] = (unsigned)ww < (unsigned)W ? (unsigned)(((size_t)ww * C + c) * 4) : OOB;
     }
+    V4 bg = v4zero(), bb = v4zero(), bm = v4zero(), bs = v4zero();
+    if (bn.gamma) { bg = v4ld(bn.gamma + c); bb = v4ld(bn.beta + c); bm = v4ld(bn.mean + c); bs = v4ld(bn.invstd + c); }
     V4 b[A_][A_];           // B^T d, built column by column
 #pragma unroll
     for (int q = 0; q < A_; ++q) {
         V4 d[A_], r[A_];
 #pragma unroll
         for (int rr = 0; rr < A_; ++rr) d[rr] = v4buf(rsX, (rowo[rr] == OOB || colo[q] == OOB) ? OOB : rowo[rr] + colo[q], 0);
+        if (bn.gamma) {         // (kernel-uniform)
+#pragma unroll
+            for (int rr = 0; rr < A_; ++rr) {
+                const bool in = !(rowo[rr] == OOB || colo[q] == OOB);
+                const V4 v = d[rr];
+                V4 o;
+                o.x = fmaxf(bg.x * ((v.x - bm.x) * bs.x) + bb.x, 0.f); o.y = fmaxf(bg.y * ((v.y - bm.y) * bs.y) + bb.y, 0.f);
+                o.z = fmaxf(bg.z * ((v.z - bm.z) * bs.z) + bb.z, 0.f); o.w = fmaxf(bg.w * ((v.w - bm.w) * bs.w) + bb.w, 0.f);
+                d[rr] = in ? o : v4zero();
+            }
+        }
         wino_bt<M_, V4>(d, r);
 #pragma unroll
         for (int rr = 0; rr < A_; ++rr) b[rr][q] = r[rr];
@@ -1508,8 +1526,8 @@ __device__ __forceinline__ unsigned xcd_banded(unsigned g, unsigned first, unsig
 }
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
-                                                    int th, int tw, long long T, long long Tp, int banded) {
-    wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, 0, gridDim.x, banded));
+                                                    int th, int tw, long long T, long long Tp, int banded, InBN bn) {
+    wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, 0, gridDim.x, banded), bn);
 }
 // Filter and input transform of one convolution call in ONE launch (the first `fblocks` workgroups transform the filter):
 // the two are independent, and a separate 5-8 us filter launch in front of every Winograd GEMM is pure launch latency on the
@@ -1518,9 +1536,9 @@ template <int M_>
 __global__ __launch_bounds__(256) void k_wino_input_filter(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
                                                            int th, int tw, long long T, long long Tp, const float *__restrict__ w,
                                                            float *__restrict__ U, int Cout_w, int Cin_w, int transposed, unsigned fblocks,
-                                                           int banded, int uplanes) {
+                                                           int banded, int uplanes, InBN bn) {
     if (blockIdx.x < fblocks) wino_filter_body<M_>(w, U, Cout_w, Cin_w, transposed, blockIdx.x, uplanes);
-    else wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, fblocks, gridDim.x - fblocks, banded));
+    else wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, fblocks, gridDim.x - fblocks, banded), bn);
 }
 
 // y (m x m pixels of tile t) = A^T M A + bias, then ReLU | + old y (accumulate) | zeroed where relu_x <= 0.
@@ -1881,17 +1899,22 @@ WinoFLayout wino_filter_layout(int N, int H, int W, int Cin, int Cout) {
     return L;
 }
 
+// Set by the *_inbn entry points around their call of the ordinary entry point (which they have checked takes the Winograd path): the
+// input transform of that call applies this BatchNorm + ReLU on load.
+thread_local InBN t_inbn{};
+
 // bias_part / bias_rows (nullable): when the gy transform runs here and its blocks cover whole tiles, it also leaves the
 // bias gradient's partial column sums in bias_part and *bias_rows = their number (else *bias_rows = 0: the caller sums gy)
 int wino_bwd_filter(const float *x, const float *gy, float *gw, int N, int H, int W, int Cin, int Cout, int accumulate, void *ws,
                     hipStream_t st, const float *v_cached, const float *w_cached, float *bias_part = nullptr, int *bias_rows = nullptr) {
+    const InBN inbn = t_inbn;
     const WinoFLayout L = wino_filter_layout(N, H, W, Cin, Cout);
     const WinoGeom &g = L.g;
     char *base = (char *)ws;
     float *Vw = (float *)(base + L.v), *Wt = (float *)(base + L.w), *slabs = (float *)(base + L.slabs), *dU = (float *)(base + L.du);
     const float *V = v_cached ? v_cached : Vw;       // the forward pass's transformed input, kept by the caller
     const long long nin = g.Tp * (Cin / 4), nout = g.Tp * (Cout / 4);      // the transform kernels zero the padded rows
-    if (!v_cached) WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), x, Vw, N, H, W, Cin, g.th, g.tw, g.T, g.Tp, g_wino_banded);
+    if (!v_cached) WINO_LAUNCH(k_wino_input, g, dim3((unsigned)((nin + 255) / 256)), x, Vw, N, H, W, Cin, g.th, g.tw, g.T, g.Tp, g_wino_banded, inbn);
     const int C4o = Cout / 4;
     const bool fuse_bias = bias_part && bias_rows && !w_cached && C4o <= 256 && 256 % C4o == 0 && !(g_debug_skip & 2);
     if (bias_rows) *bias_rows = fuse_bias ? (int)((nout + 255) / 256) : 0;
@@ -1952,6 +1975,7 @@ bool pg_big_ok(int pass, const WinoGeom &g, int K, int Nn) {
 int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, int Cin, int Cout, bool transposed,
               const float *bias, int relu, int accumulate, const float *relu_x, void *ws, size_t ws_bytes, hipStream_t st,
               float *v_keep, float *w_keep = nullptr, float *gbias = nullptr, int gbias_accumulate = 0, float *bn_part = nullptr) {
+    const InBN inbn = transposed ? InBN{} : t_inbn;
     const WinoLayout L = wino_layout(N, H, W, Cin, Cout, transposed ? PASS_BWD_DATA : PASS_FWD);
     const WinoGeom &g = L.g;
     char *base = (char *)ws;
@@ -1980,7 +2004,7 @@ int wino_conv(const float *in, const float *w, float *out, int N, int H, int W, 
         }
     } else
         WINO_LAUNCH(k_wino_input_filter, g, dim3(fblocks + (unsigned)((nin + 255) / 256)), in, V, N, H, W, Cin, g.th, g.tw, g.T, g.Tp, w, U,
-                    transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, fblocks, g_wino_banded, big);
+                    transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, fblocks, g_wino_banded, big, inbn);
     if (big) {          // the plane GEMM: A = V (float32 rows), B = U (P16R4 planes), C = M
         PlaneGemmP q{};
         q.a = reinterpret_cast<const unsigned short *>(V); q.b = reinterpret_cast<const unsigned short *>(U); q.c = Mb;
@@ -2233,6 +2257,33 @@ extern "C" int mrcnn_conv2d_fwd_bnstats_f32(const float *x, const float *w, floa
     return 0;
 }
 
+// ---- (r6, ABI v10) the layer's input is relu(BatchNorm(x)) of a training-mode BatchNorm with final statistics: applied on load by the
+// Winograd input transform (wino_input_body), never written.  Only for geometries whose forward AND filter-gradient passes take the
+// Winograd path under the settings in force (mrcnn_conv2d_inbn_ok): the caller keeps the materialised activation otherwise.
+extern "C" int mrcnn_conv2d_inbn_ok(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || (Cin % 4)) return 0;
+    return (wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_FWD) && wino_ok(N, H, W, Cin, Cout, KH, KW, stride, pad, PASS_BWD_FILTER)) ? 1 : 0;
+}
+static int inbn_args(const float *g, const float *b, const float *m, const float *s, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                     int pad, const char *who) {
+    if (!g || !b || !m || !s) return mrcnn::fail_arg(MRCNN_E_INVALID, "%s: null BatchNorm pointer", who);
+    if (!mrcnn_conv2d_inbn_ok(N, H, W, Cin, Cout, KH, KW, stride, pad))
+        return mrcnn::fail_arg(MRCNN_E_UNSUPPORTED, "%s: this geometry does not take the Winograd path in both passes (mrcnn_conv2d_inbn_ok == 0)", who);
+    return 0;
+}
+extern "C" int mrcnn_conv2d_fwd_inbn_f32(const float *x, const float *in_gamma, const float *in_beta, const float *in_mean, const float *in_invstd,
+                                         const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                         float *bn_part, float *wino_v, void *ws, size_t ws_bytes, void *stream) {
+    if (int e = inbn_args(in_gamma, in_beta, in_mean, in_invstd, N, H, W, Cin, Cout, KH, KW, stride, pad, "conv2d_fwd_inbn")) return e;
+    if (!ws || ws_bytes < wino_ws_bytes(N, H, W, Cin, Cout, PASS_FWD))
+        return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "conv2d_fwd_inbn: workspace %zu < %zu", ws_bytes, wino_ws_bytes(N, H, W, Cin, Cout, PASS_FWD));
+    t_inbn = InBN{in_gamma, in_beta, in_mean, in_invstd};
+    const int rc = bn_part ? mrcnn_conv2d_fwd_bnstats_f32(x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, bn_part, wino_v, ws, ws_bytes, stream)
+                           : mrcnn_conv2d_fwd_f32(x, w, nullptr, y, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, wino_v, ws, ws_bytes, stream);
+    t_inbn = InBN{};
+    return rc;
+}
+
 // Forward convolution with a rectangular kernel and per-axis padding (the 15x1 / 1x15 separable pairs of LightRoIMaskHead,
 // model/head/light_roi_mask_head.py:29-44).  Same kernel as mrcnn_conv2d_fwd_f32 (never the Winograd path).
 extern "C" int mrcnn_conv2d_fwd_rect_f32(const float *x, const float *w, const float *bias, float *y, int N, int H, int W,
@@ -2361,4 +2412,15 @@ extern "C" int mrcnn_conv2d_bwd_filter_f32(const float *x, const float *gy, floa
         MRCNN_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int mrcnn_conv2d_bwd_filter_inbn_f32(const float *x, const float *in_gamma, const float *in_beta, const float *in_mean,
+                                                const float *in_invstd, const float *gy, float *gw, int N, int H, int W, int Cin, int Cout, int KH,
+                                                int KW, int stride, int pad, int accumulate, const float *wino_v, void *ws, size_t ws_bytes,
+                                                void *stream) {
+    if (int e = inbn_args(in_gamma, in_beta, in_mean, in_invstd, N, H, W, Cin, Cout, KH, KW, stride, pad, "conv2d_bwd_filter_inbn")) return e;
+    t_inbn = InBN{in_gamma, in_beta, in_mean, in_invstd};
+    const int rc = mrcnn_conv2d_bwd_filter_f32(x, gy, gw, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, accumulate, wino_v, nullptr, ws, ws_bytes, stream);
+    t_inbn = InBN{};
+    return rc;
 }

@@ -1103,6 +1103,26 @@ extern "C" int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const flo
     return 0;
 }
 
+// Statistics of a training-mode BatchNorm WITHOUT its apply kernel (the consumer applies it on load: mrcnn_conv2d_fwd_inbn_f32): save_mean /
+// save_invstd and the running statistics exactly as mrcnn_bn_train_fwd(_stats)_f32 leaves them.
+extern "C" int mrcnn_bn_train_stats_f32(const float *x, const float *part, int rows, float *save_mean, float *save_invstd, float *running_mean,
+                                        float *running_var, int P, int C, float eps, float decay, void *ws, size_t ws_bytes, void *stream) {
+    if (int e = chk(x && save_mean && save_invstd, "bn_train_stats: null pointer")) return e;
+    if (int e = chk(P > 0 && C > 0 && (C % 4) == 0 && rows >= 0 && (rows == 0) == (part == nullptr), "bn_train_stats: need P>0, C%4==0, part / rows together")) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (part) {
+        launch_stats_final(st, x, part, rows, P, C, eps, decay, 0, save_mean, save_invstd, running_mean, running_var);
+    } else {
+        if (!ws || ws_bytes < mrcnn_bn_workspace_bytes(P, C)) return mrcnn::fail_arg(MRCNN_E_WORKSPACE, "bn_train_stats: workspace too small");
+        const RedPlan r = red_plan(P, C);
+        hipLaunchKernelGGL(k_bn_stats_partial, dim3(r.nblk), dim3(NT), 0, st, x, P, C, r.G, r.RPI, r.rows_per_blk, (float *)ws);
+        MRCNN_LAUNCH_CHECK();
+        launch_stats_final(st, x, (const float *)ws, r.nblk, P, C, eps, decay, 1, save_mean, save_invstd, running_mean, running_var);
+    }
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t mrcnn_bn_pair_workspace_bytes(int P, int C) {
     if (P <= 0 || C <= 0 || (C % 4)) return 0;
     const RedPlan r = red_plan(P, C);

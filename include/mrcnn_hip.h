@@ -345,6 +345,24 @@ int mrcnn_bn_train_bwd_f32(const float *gy, const float *x, const float *y, cons
  * layer (ws of mrcnn_bn_pair_workspace_bytes()); the masked gradient is never written either.  Same bits as the layer-by-layer sequence
  * mrcnn_bn_train_fwd(_stats)_f32(xb -> r), mrcnn_bn_train_fwd(_stats)_f32(xa, residual r, relu) and its two mrcnn_bn_train_bwd_f32 calls:
  * 5 passes over a (P, C) tensor fewer per projection block and step. */
+/* (ABI v10) conv -> BatchNorm -> ReLU -> conv 3x3 without the normalised activation (the middle of a ResNet bottleneck,
+ * extractor/feature_pyramid_network.py:48-66): mrcnn_bn_train_stats_f32 finishes the statistics of the first convolution's output (partial rows
+ * from its epilogue, or NULL / 0 = a statistics pass through ws) and updates the running statistics - no apply kernel; the consumer's Winograd
+ * input transform applies gamma * ((x - mean) * invstd) + beta and the ReLU to every tap as it loads it (taps outside the image stay zero):
+ * mrcnn_conv2d_fwd_inbn_f32 (bn_part nullable: also the statistics partials of ITS output, as mrcnn_conv2d_fwd_bnstats_f32) and
+ * mrcnn_conv2d_bwd_filter_inbn_f32 (wino_v as mrcnn_conv2d_bwd_filter_f32).  Same bits as the materialised sequence; 2 passes over the
+ * (P, C) activation and one launch fewer.  Only where mrcnn_conv2d_inbn_ok() != 0 (3x3 / stride 1 / pad 1 geometries whose forward and
+ * filter-gradient passes both take the Winograd path under the process settings in force); the entry points refuse other geometries. */
+int mrcnn_bn_train_stats_f32(const float *x, const float *part, int rows, float *save_mean, float *save_invstd, float *running_mean,
+                             float *running_var, int P, int C, float eps, float decay, void *ws, size_t ws_bytes, void *stream);
+int mrcnn_conv2d_inbn_ok(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int mrcnn_conv2d_fwd_inbn_f32(const float *x, const float *in_gamma, const float *in_beta, const float *in_mean, const float *in_invstd,
+                              const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                              float *bn_part, float *wino_v, void *ws, size_t ws_bytes, void *stream);
+int mrcnn_conv2d_bwd_filter_inbn_f32(const float *x, const float *in_gamma, const float *in_beta, const float *in_mean,
+                                     const float *in_invstd, const float *gy, float *gw, int N, int H, int W, int Cin, int Cout, int KH,
+                                     int KW, int stride, int pad, int accumulate, const float *wino_v, void *ws, size_t ws_bytes,
+                                     void *stream);
 size_t mrcnn_bn_pair_workspace_bytes(int P, int C);
 int mrcnn_bn_train_fwd_pair_f32(const float *xa, const float *part_a, int rows_a, const float *gamma_a, const float *beta_a,
                                 float *mean_a, float *invstd_a, float *run_mean_a, float *run_var_a, const float *xb,
@@ -479,6 +497,8 @@ typedef struct mrcnn_bottleneck_plan {
     int32_t part_rows[4];               /* statistics partial rows of conv1..4 (0: BatchNorm runs its own statistics pass) */
 } mrcnn_bottleneck_plan_t;
 
+/* measurement: 0 = the composite calls materialise bn1's output as before (A/B of mrcnn_conv2d_fwd_inbn_f32); default 1 */
+int mrcnn_debug_bottleneck_inbn(int on);
 int mrcnn_bottleneck_fwd_plan(const mrcnn_bottleneck_t *b, mrcnn_bottleneck_plan_t *plan);
 int mrcnn_bottleneck_fwd_f32(const mrcnn_bottleneck_t *b, const mrcnn_bottleneck_plan_t *plan, const float *x, float *y,
                              void *arena, size_t arena_bytes, void *ws, size_t ws_bytes, void *stream);

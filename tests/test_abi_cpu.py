@@ -178,10 +178,14 @@ def test_composite_bottleneck_plan_is_host_arithmetic():
     finally:
         _hip.check(lib.mrcnn_conv2d_set_split_operands(0, 0, 0))
     P = 2 * 32 * 32
-    sizes = [P * 256 * 4] * 4 + [P * 1024 * 4] * 2
-    offs = [plan.off[i] for i in range(6)]
-    assert all(o % 256 == 0 for o in plan.off) and offs == [sum(sizes[:i]) for i in range(6)] and plan.off[6] == 0
-    used = sorted((plan.off[i], i) for i in range(_hip.BN_SLOTS) if i < 6 or plan.off[i])
+    # slot 1 (a1 = relu(bn1(h1))) is not materialised where conv2 takes the Winograd path in both passes: its input transforms apply bn1 on load
+    NOT = 2 ** 64 - 1
+    assert plan.off[1] == (NOT if lib.mrcnn_conv2d_inbn_ok(2, 32, 32, 256, 256, 3, 3, 1, 1) else P * 256 * 4)
+    have = [i for i in range(6) if plan.off[i] != NOT]
+    sizes = {0: P * 256 * 4, 1: P * 256 * 4, 2: P * 256 * 4, 3: P * 256 * 4, 4: P * 1024 * 4, 5: P * 1024 * 4}
+    assert all(o % 256 == 0 for o in plan.off if o != NOT) and plan.off[6] == 0
+    assert [plan.off[i] for i in have] == [sum(sizes[j] for j in have[:k]) for k in range(len(have))]
+    used = sorted((plan.off[i], i) for i in range(_hip.BN_SLOTS) if plan.off[i] != NOT and (i in have or plan.off[i]))
     assert all(a[0] < b[0] for a, b in zip(used, used[1:])) and plan.arena_bytes > used[-1][0]
     assert plan.v_bytes[1] == lib.mrcnn_conv2d_winograd_v_bytes(2, 32, 32, 256, 256, 3, 3, 1, 1) and plan.v_bytes[0] == 0
     assert plan.part_rows[1] == lib.mrcnn_conv2d_bnstats_rows(2, 32, 32, 256, 256, 3, 3, 1, 1)
