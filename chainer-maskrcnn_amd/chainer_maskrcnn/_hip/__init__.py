@@ -34,6 +34,8 @@ _MANUAL = {
     'mrcnn_roi_align_fpn_bwd_f32': (c_int, [c_void_p, _P(c_void_p), _P(c_int), _P(c_int), _P(c_float),
                                             c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                             c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mrcnn_rpn_pack_levels_f32': (c_int, [_P(c_void_p), _P(c_int), c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'mrcnn_rpn_unpack_grad_levels_f32': (c_int, [c_void_p, c_void_p, _P(c_void_p), _P(c_int), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'mrcnn_roi_align_fpn_bwd_workspace_bytes': (c_size_t, [_P(c_int), _P(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
 }
 _CTYPE = {'int': c_int, 'float': c_float, 'size_t': c_size_t, 'long long': ctypes.c_longlong,

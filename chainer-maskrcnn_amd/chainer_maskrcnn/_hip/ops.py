@@ -316,6 +316,30 @@ def rpn_pack(head, A, locs, scores, a_off):
                                    stream_ptr()))
 
 
+def rpn_pack_levels(heads, A, locs, scores):
+    """All levels' head outputs (NHWC, same N and padded channel count) into locs / scores in ONE launch; level order = anchor order."""
+    import ctypes
+    _ck(locs, scores, *heads)
+    L = len(heads)
+    N, _, _, Cp = heads[0].shape
+    ptrs = (ctypes.c_void_p * L)(*[h.data_ptr() for h in heads])
+    hws = (ctypes.c_int * L)(*[h.shape[1] * h.shape[2] for h in heads])
+    check(lib().mrcnn_rpn_pack_levels_f32(ptrs, hws, L, N, Cp, A, ptr(locs), ptr(scores), locs.shape[1], stream_ptr()))
+
+
+def rpn_unpack_grad_levels(glocs, gscores, head_shapes, A):
+    """The backward of rpn_pack_levels: one gradient tensor per level, one launch."""
+    import ctypes
+    _ck(glocs, gscores)
+    L = len(head_shapes)
+    N, _, _, Cp = head_shapes[0]
+    gheads = [_empty(sh, glocs.device) for sh in head_shapes]
+    ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in gheads])
+    hws = (ctypes.c_int * L)(*[sh[1] * sh[2] for sh in head_shapes])
+    check(lib().mrcnn_rpn_unpack_grad_levels_f32(ptr(glocs), ptr(gscores), ptrs, hws, L, N, Cp, A, glocs.shape[1], stream_ptr()))
+    return gheads
+
+
 def rpn_unpack_grad(glocs, gscores, head_shape, A, a_off):
     _ck(glocs, gscores)
     N, H, W, Cp = head_shape

@@ -19,6 +19,7 @@ import torch
 from chainer_maskrcnn.nn.core import Conv, ParamStore, normal
 from chainer_maskrcnn._hip import ops, nn as hnn
 
+PACK_LEVELS_IN_ONE_LAUNCH = True        # (r6) one pack / unpack launch for all pyramid levels (A/B switch; same bits)
 SMALL_LEVELS_BESIDE_P2 = False      # A/B switch, see forward_padded
 from chainer_maskrcnn.utils.anchors import generate_anchor_base, enumerate_shifted_anchor
 
@@ -105,11 +106,16 @@ class MultilevelRegionProposalNetwork(object):
         if beside:
             main, side = torch.cuda.current_stream(dev), hnn.side_stream(dev)
             side.wait_stream(main)
+        outs = []
+        one_pack = PACK_LEVELS_IN_ONE_LAUNCH and not beside and len(xs) <= 8
         for i, x in enumerate(xs):
             with (torch.cuda.stream(side) if (beside and i > 0) else contextlib.nullcontext()):
                 h, c1 = self.conv.fwd(x)
                 o, c2 = self.head.fwd(h)
-                ops.rpn_pack(o, self.n_anchor, locs, scores, a_off)
+                if one_pack:
+                    outs.append(o)
+                else:
+                    ops.rpn_pack(o, self.n_anchor, locs, scores, a_off)
             if beside and i > 0:
                 for t_ in tuple(c1) + tuple(c2):        # saved for the backward pass, which runs on other streams
                     if torch.is_tensor(t_):
@@ -118,6 +124,8 @@ class MultilevelRegionProposalNetwork(object):
             a_off += x.shape[1] * x.shape[2] * self.n_anchor
         if beside:
             main.wait_stream(side)
+        if one_pack:            # the concat of rpn/...:143-152 for all levels in one launch (five dependent 6-us launches before)
+            ops.rpn_pack_levels(outs, self.n_anchor, locs, scores)
         self.tape = tape
         if after_heads is not None:
             after_heads(locs, scores, anchors)
@@ -145,8 +153,11 @@ class MultilevelRegionProposalNetwork(object):
         contributions where this call used to be)."""
         first = True
         out = []
+        g_os = None
+        if PACK_LEVELS_IN_ONE_LAUNCH and len(self.tape) <= 8:
+            g_os = ops.rpn_unpack_grad_levels(g_locs, g_scores, [t[2] for t in self.tape], self.n_anchor)
         for i, (c1, c2, oshape, a_off) in enumerate(self.tape):
-            g_o = ops.rpn_unpack_grad(g_locs, g_scores, oshape, self.n_anchor, a_off)
+            g_o = g_os[i] if g_os is not None else ops.rpn_unpack_grad(g_locs, g_scores, oshape, self.n_anchor, a_off)
             g_h = self.head.bwd(c2, g_o, accumulate_params=not first, mask_gx=True)     # + ReLU backward of self.conv
             out.append(self.conv.bwd(c1, g_h, gx_acc=None if g_feats is None else g_feats[i], accumulate_params=not first, gy_masked=True))
             first = False

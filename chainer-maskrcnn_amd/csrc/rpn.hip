@@ -59,6 +59,49 @@ __global__ __launch_bounds__(256) void k_rpn_unpack(const float *__restrict__ gl
     }
 }
 
+// (r6) All pyramid levels in ONE launch each way: the five per-level launches were five dependent 6-us kernels on the forward pass's
+// critical stream.  Level l's HW positions start at pos0[l] of the concatenated position axis; its anchors at pos0[l] * A.
+constexpr int RPN_MAX_LEVELS = 8;
+struct RpnLevels { const float *head[RPN_MAX_LEVELS]; float *ghead[RPN_MAX_LEVELS]; int pos0[RPN_MAX_LEVELS + 1]; int L; };
+__global__ __launch_bounds__(256) void k_rpn_pack_levels(RpnLevels lv, int N, int Cp, int A, float *__restrict__ locs, float *__restrict__ scores,
+                                                         int Atot) {
+    const int PT = lv.pos0[lv.L];                               // positions of all levels
+    const long long total = (long long)N * PT * A;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int a = (int)(i % A);
+        const long long q = i / A;
+        const int gp = (int)(q % PT), n = (int)(q / PT);
+        int l = 0;
+        while (l + 1 < lv.L && gp >= lv.pos0[l + 1]) ++l;
+        const int pos = gp - lv.pos0[l], HW = lv.pos0[l + 1] - lv.pos0[l];
+        const float *h = lv.head[l] + ((size_t)n * HW + pos) * Cp;
+        const float4 v = *reinterpret_cast<const float4 *>(h + a * 4);
+        const float2 sc = *reinterpret_cast<const float2 *>(h + 4 * A + a * 2);
+        const size_t o = (size_t)n * Atot + (size_t)gp * A + a;
+        *reinterpret_cast<float4 *>(locs + o * 4) = v;
+        *reinterpret_cast<float2 *>(scores + o * 2) = sc;
+    }
+}
+__global__ __launch_bounds__(256) void k_rpn_unpack_levels(RpnLevels lv, const float *__restrict__ glocs, const float *__restrict__ gscores, int N,
+                                                           int Cp, int A, int Atot) {
+    const int PT = lv.pos0[lv.L];
+    const long long total = (long long)N * PT * (Cp / 2);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c2 = (int)(i % (Cp / 2));
+        const long long q = i / (Cp / 2);
+        const int gp = (int)(q % PT), n = (int)(q / PT);
+        int l = 0;
+        while (l + 1 < lv.L && gp >= lv.pos0[l + 1]) ++l;
+        const int pos = gp - lv.pos0[l], HW = lv.pos0[l + 1] - lv.pos0[l];
+        const int c = c2 * 2;
+        float2 v = make_float2(0.f, 0.f);
+        const size_t base = (size_t)n * Atot + (size_t)gp * A;
+        if (c < 4 * A) v = *reinterpret_cast<const float2 *>(glocs + (base + c / 4) * 4 + (c & 3));
+        else if (c < 6 * A) v = *reinterpret_cast<const float2 *>(gscores + (base + (c - 4 * A) / 2) * 2);
+        *reinterpret_cast<float2 *>(lv.ghead[l] + ((size_t)n * HW + pos) * Cp + c) = v;
+    }
+}
+
 // ---- decode + clip + filter + sort key ---------------------------------------------------------
 __device__ __forceinline__ unsigned orderable(float f) {     // monotone float -> uint
     const unsigned b = __float_as_uint(f);
@@ -405,6 +448,46 @@ extern "C" int mrcnn_rpn_unpack_grad_f32(const float *glocs, const float *gscore
     const long long total = (long long)N * HW * (Cp / 2);
     hipLaunchKernelGGL(k_rpn_unpack, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
                        (hipStream_t)stream, glocs, gscores, N, HW, Cp, A, ghead, a_off, Atot);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int rpn_levels_of(RpnLevels &lv, const float *const *heads, float *const *gheads, const int *HWs, int L, int N, int Cp, int A, int Atot,
+                         const char *who) {
+    if (L <= 0 || L > RPN_MAX_LEVELS || !HWs || N <= 0 || A <= 0 || Cp < 6 * A || (Cp % 4)) return mrcnn::fail_arg(MRCNN_E_INVALID, "%s: bad arguments", who);
+    lv = RpnLevels{};
+    lv.L = L;
+    long long p = 0;
+    for (int l = 0; l < L; ++l) {
+        if (HWs[l] <= 0 || (heads && !heads[l]) || (gheads && !gheads[l])) return mrcnn::fail_arg(MRCNN_E_INVALID, "%s: null level / empty level", who);
+        if (heads) lv.head[l] = heads[l];
+        if (gheads) lv.ghead[l] = gheads[l];
+        lv.pos0[l] = (int)p;
+        p += HWs[l];
+    }
+    lv.pos0[L] = (int)p;
+    if (p * A != Atot || (long long)N * p * Cp >= (1ll << 31)) return mrcnn::fail_arg(MRCNN_E_INVALID, "%s: the levels' positions x A must equal Atot", who);
+    return 0;
+}
+extern "C" int mrcnn_rpn_pack_levels_f32(const float *const *heads, const int *HWs, int L, int N, int Cp, int A, float *locs, float *scores,
+                                         int Atot, void *stream) {
+    RpnLevels lv;
+    if (!heads || !locs || !scores) return mrcnn::fail_arg(MRCNN_E_INVALID, "rpn_pack_levels: null pointer");
+    if (int e = rpn_levels_of(lv, heads, nullptr, HWs, L, N, Cp, A, Atot, "rpn_pack_levels")) return e;
+    const long long total = (long long)N * lv.pos0[L] * A;
+    hipLaunchKernelGGL(k_rpn_pack_levels, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, lv, N, Cp, A,
+                       locs, scores, Atot);
+    MRCNN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mrcnn_rpn_unpack_grad_levels_f32(const float *glocs, const float *gscores, float *const *gheads, const int *HWs, int L, int N,
+                                                int Cp, int A, int Atot, void *stream) {
+    RpnLevels lv;
+    if (!gheads || !glocs || !gscores) return mrcnn::fail_arg(MRCNN_E_INVALID, "rpn_unpack_grad_levels: null pointer");
+    if (int e = rpn_levels_of(lv, nullptr, gheads, HWs, L, N, Cp, A, Atot, "rpn_unpack_grad_levels")) return e;
+    const long long total = (long long)N * lv.pos0[L] * (Cp / 2);
+    hipLaunchKernelGGL(k_rpn_unpack_levels, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, lv, glocs,
+                       gscores, N, Cp, A, Atot);
     MRCNN_LAUNCH_CHECK();
     return 0;
 }

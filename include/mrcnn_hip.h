@@ -566,6 +566,12 @@ int mrcnn_rpn_pack_f32(const float *head, int N, int HW, int Cp, int A, float *l
                        int Atot, void *stream);
 int mrcnn_rpn_unpack_grad_f32(const float *glocs, const float *gscores, int N, int HW, int Cp, int A,
                               float *ghead, int a_off, int Atot, void *stream);
+/* (ABI v10) The same for ALL pyramid levels in one launch each way (heads / gheads: L host-side device pointers, HWs: positions per level;
+ * level l's anchors follow level l-1's in the concatenated axis, sum(HWs) * A == Atot): the concat of rpn/...:143-152 and its backward. */
+int mrcnn_rpn_pack_levels_f32(const float *const *heads, const int *HWs, int L, int N, int Cp, int A, float *locs, float *scores,
+                              int Atot, void *stream);
+int mrcnn_rpn_unpack_grad_levels_f32(const float *glocs, const float *gscores, float *const *gheads, const int *HWs, int L, int N,
+                                     int Cp, int A, int Atot, void *stream);
 size_t mrcnn_rpn_proposals_workspace_bytes(int N, int A, int n_pre, int n_post);
 int mrcnn_rpn_proposals_f32(const float *locs, const float *scores, const float *anchors, int N, int A,
                             float img_h, float img_w, float min_size, const float *per_image, int n_pre, int n_post, float nms_thresh,

@@ -99,6 +99,16 @@ int main() {
     EXPECT_ERR(mrcnn_bn_train_fwd_f32(CF, CF, CF, CF, F, F, F, F, F, 64, 32, 2e-5f, 0.9f, 1, V, 0, V));
     EXPECT_ERR(mrcnn_bn_train_bwd_f32(CF, CF, CF, CF, CF, CF, CF, F, F, F, F, 64, 32, 1, V, 0, V));
     EXPECT_ERR(mrcnn_bn_infer_fwd_f32(CF, CF, CF, CF, CF, CF, F, 64, 32, 2e-5f, 1, V));
+    {
+        const float *hs[2] = {CF, CF}; float *gs[2] = {F, F}; const int hw[2] = {64, 16};
+        EXPECT_ERR(mrcnn_rpn_pack_levels_f32(hs, hw, 2, 1, 32, 3, F, F, 240, V));               // null levels
+        EXPECT_ERR(mrcnn_rpn_unpack_grad_levels_f32(CF, CF, gs, hw, 2, 1, 32, 3, 240, V));
+        static float hb[64];
+        const float *hs2[2] = {hb, hb}; float *gs2[2] = {hb, hb};
+        EXPECT_ERR(mrcnn_rpn_pack_levels_f32(hs2, hw, 2, 1, 32, 3, hb, hb, 241, V));            // sum(HW) * A != Atot
+        EXPECT_ERR(mrcnn_rpn_pack_levels_f32(hs2, hw, 9, 1, 32, 3, hb, hb, 240, V));            // too many levels
+        EXPECT_ERR(mrcnn_rpn_unpack_grad_levels_f32(hb, hb, gs2, hw, 2, 1, 16, 3, 240, V));     // Cp < 6 A
+    }
     EXPECT_ERR(mrcnn_bn_train_fwd_pair_f32(CF, CF, 4, CF, CF, F, F, F, F, CF, CF, 4, CF, CF, F, F, F, F, F, 64, 32, 2e-5f, 0.9f, V, 0, V));
     EXPECT_ERR(mrcnn_bn_train_bwd_pair_f32(CF, CF, CF, CF, CF, CF, CF, CF, CF, CF, F, F, F, F, F, F, 64, 32, V, 0, V));
     {   // non-null buffers: part / rows must come together, a statistics pass needs its workspace, the backward its own
