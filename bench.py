@@ -345,7 +345,8 @@ def main():
         if rank == 0:       # second half of BASELINE.json's metric: ROIAlign backward HBM GB/s on configs[1]
             ra = argparse.Namespace(steps=100, warmup=10, no_cpu_baseline=True)
             r = bench_roialign(ra, 0, 1)
-            out['roi_align_microbench'] = {'workload': r['config']['workload'], 'bwd': r['roofline'], 'fwd': r['roi_align_fwd']}
+            out['roi_align_microbench'] = {'workload': r['config']['workload'], 'bwd': r['roofline'], 'fwd': r['roi_align_fwd'],
+                                           'forms_us': r['roi_align_bwd_forms_us']}
     else:
         args.steps = args.steps or 200
         args.warmup = 20 if args.warmup is None else args.warmup

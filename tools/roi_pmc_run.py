@@ -1,5 +1,7 @@
-"""configs[1] ROIAlign for rocprofv3 --pmc passes (few launches, no timing): forward, the backward's entry-list plan (k_roi_align_bwd_waves<MODE 1>),
-the planned backward with the plan verified (k_roi_align_bwd_lean alone) - and, with a second argument `fused`, the fused wave kernel instead."""
+"""configs[1] ROIAlign for rocprofv3 --pmc passes (few launches, no timing): forward + the SHIPPED backward (the fused wave kernel
+k_roi_align_bwd_waves, what roi_align_2d(...).backward() launches).  With a second argument `planned`: the opt-in two-launch form instead (the
+entry-list plan k_roi_align_bwd_waves<MODE 1> + k_roi_align_bwd_lean with the plan verified) - the kernel name k_roi_align_bwd_waves then means the
+plan builder, so the two forms go to separate output directories."""
 import os, sys
 R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R_, 'chainer-maskrcnn_amd')); sys.path.insert(0, R_)
@@ -19,7 +21,7 @@ gx = torch.empty_like(xt)
 nbf = lib.mrcnn_roi_align_fwd_workspace_bytes(R)
 wsf = torch.empty((max(nbf, 1),), dtype=torch.uint8, device=dev)       # the forward's map-order permutation
 import ctypes
-fused = len(sys.argv) > 2 and sys.argv[2] == 'fused'
+fused = not (len(sys.argv) > 2 and sys.argv[2] == 'planned')
 Hs, Ws, sc = (ctypes.c_int * 1)(H), (ctypes.c_int * 1)(W), (ctypes.c_float * 1)(0.25)
 gxp = (ctypes.c_void_p * 1)(gx.data_ptr())
 pb = lib.mrcnn_roi_align_fpn_bwd_plan_bytes(Hs, Ws, 1, N, R, PH, PW, 0)
