@@ -304,3 +304,103 @@ def test_composite_bottleneck_equals_the_per_layer_path(case, flags):
     for a, b_ in zip(out[0], out[1]):
         assert torch.isfinite(a).all() and torch.equal(a, b_)
     assert float(out[0][2].abs().max()) > 0 and float(out[0][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize('P,C', [(4096, 64), (2 * 33 * 41, 256), (2048, 2048)])
+@pytest.mark.parametrize('masked', [False, True], ids=['mask_from_y', 'gy_arrives_masked'])
+def test_bn_pair_kernels_equal_the_layer_by_layer_sequence(P, C, masked):
+    """(ABI v10) relu(BN_a(xa) + BN_b(xb)) in one apply kernel and both backward passes from one read of gy (nn.hip k_bn_apply2,
+    k_bn_bwd_partial2 / _final2 / _apply2: the projection block of extractor/feature_pyramid_network.py:48-66) against the single-layer
+    entry points run one after the other: output, saved statistics, running statistics and all four parameter gradients and both input
+    gradients are the same BITS (statistics pass over the tensors here: part = NULL; the composite test covers the partial-row form)."""
+    from chainer_maskrcnn import _hip
+    lib, check, ptr, sp = _hip.lib(), _hip.check, _hip.ptr, _hip.stream_ptr
+    from chainer_maskrcnn._hip.nn import workspace
+    g = torch.Generator(device='cpu').manual_seed(P + C)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    xa, xb = mk(P, C) * 2 + 0.5, mk(P, C) * 0.7 - 1.0
+    ga, ba, gb, bb = mk(C) * 0.5 + 1, mk(C) * 0.1, mk(C) * 0.5 + 1, mk(C) * 0.1
+    rm = [torch.zeros(C, device=DEV) for _ in range(4)]
+    rv = [torch.ones(C, device=DEV) for _ in range(4)]
+    # reference: shortcut first (no ReLU), then the main branch with the residual
+    r, mb_ref, sb_ref = ops.bn_train_fwd(xb, gb, bb, relu=False, running_mean=rm[0], running_var=rv[0])
+    y_ref, ma_ref, sa_ref = ops.bn_train_fwd(xa, ga, ba, residual=r, relu=True, running_mean=rm[1], running_var=rv[1])
+    y = torch.empty_like(xa)
+    ma, sa, mb, sb = (torch.empty(C, device=DEV) for _ in range(4))
+    ws = workspace(max(lib.mrcnn_bn_workspace_bytes(P, C), lib.mrcnn_bn_pair_workspace_bytes(P, C)), xa.device)
+    check(lib.mrcnn_bn_train_fwd_pair_f32(ptr(xa), None, 0, ptr(ga), ptr(ba), ptr(ma), ptr(sa), ptr(rm[3]), ptr(rv[3]), ptr(xb), None, 0, ptr(gb), ptr(bb),
+                                          ptr(mb), ptr(sb), ptr(rm[2]), ptr(rv[2]), ptr(y), P, C, 2e-5, 0.9, ptr(ws), ws.numel(), sp()))
+    for got, want in ((y, y_ref), (ma, ma_ref), (sa, sa_ref), (mb, mb_ref), (sb, sb_ref), (rm[2], rm[0]), (rv[2], rv[0]), (rm[3], rm[1]), (rv[3], rv[1])):
+        assert torch.equal(got, want)
+    gy = mk(P, C) * 1e-3
+    if masked:
+        gy = torch.where(y_ref > 0, gy, torch.zeros_like(gy)).contiguous()
+        gxa_ref, _, gga_ref, gba_ref = ops.bn_train_bwd(gy, xa, None, ga, ma_ref, sa_ref, relu=False)
+        gr = gy
+    else:
+        gxa_ref, gr, gga_ref, gba_ref = ops.bn_train_bwd(gy, xa, y_ref, ga, ma_ref, sa_ref, relu=True, want_gres=True)
+    gxb_ref, _, ggb_ref, gbb_ref = ops.bn_train_bwd(gr, xb, None, gb, mb_ref, sb_ref, relu=False)
+    gxa, gxb = torch.empty_like(xa), torch.empty_like(xb)
+    gga, gba, ggb, gbb = (torch.empty(C, device=DEV) for _ in range(4))
+    check(lib.mrcnn_bn_train_bwd_pair_f32(ptr(gy), None if masked else ptr(y_ref), ptr(xa), ptr(xb), ptr(ga), ptr(ma_ref), ptr(sa_ref), ptr(gb), ptr(mb_ref),
+                                          ptr(sb_ref), ptr(gxa), ptr(gxb), ptr(gga), ptr(gba), ptr(ggb), ptr(gbb), P, C, ptr(ws), ws.numel(), sp()))
+    for got, want in ((gxa, gxa_ref), (gxb, gxb_ref), (gga, gga_ref), (gba, gba_ref), (ggb, ggb_ref), (gbb, gbb_ref)):
+        assert torch.equal(got, want)
+    assert torch.isfinite(gxa).all() and torch.isfinite(gxb).all()
+
+
+@pytest.mark.parametrize('geom', [(2, 32, 32, 256, 256), (2, 64, 64, 64, 64), (1, 47, 61, 128, 128)], ids=lambda g_: 'x'.join(map(str, g_)))
+def test_convolution_with_batchnorm_relu_on_load_equals_the_materialised_sequence(geom):
+    """(ABI v10) conv -> BatchNorm -> ReLU -> conv 3x3 with the normalised activation never written: mrcnn_bn_train_stats_f32 +
+    mrcnn_conv2d_fwd_inbn_f32 / mrcnn_conv2d_bwd_filter_inbn_f32 (the Winograd input transforms apply BatchNorm + ReLU to every tap they
+    load; taps outside the image stay zero) against BatchNorm apply + the ordinary calls on the written activation: the same BITS in the
+    output, the statistics partials of the output and the filter gradient - in the shipped arithmetic and in float32, where the geometry
+    takes the Winograd path in both passes (mrcnn_conv2d_inbn_ok), refused elsewhere."""
+    from chainer_maskrcnn import _hip
+    from chainer_maskrcnn._hip import nn as hnn
+    lib, check, ptr, sp = _hip.lib(), _hip.check, _hip.ptr, _hip.stream_ptr
+    N, H, W, Ci, Co = geom
+    g = torch.Generator(device='cpu').manual_seed(H * W + Ci)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    h1 = mk(N, H, W, Ci) * 1.5 + 0.3
+    gam, bet = mk(Ci) * 0.3 + 1, mk(Ci) * 0.2
+    w = mk(Co, 3, 3, Ci) * 0.03
+    gy = mk(N, H, W, Co) * 1e-3
+    keep = hnn.split_operands()
+    try:
+        for mode in ((0, 0, 0), (3, 3, 3)):
+            check(lib.mrcnn_conv2d_set_split_operands(*mode))
+            ok = lib.mrcnn_conv2d_inbn_ok(N, H, W, Ci, Co, 3, 3, 1, 1)
+            a1, mean, invstd = ops.bn_train_fwd(h1, gam, bet, relu=True)
+            P = N * H * W
+            m2, s2 = torch.empty(Ci, device=DEV), torch.empty(Ci, device=DEV)
+            ws_bn = hnn.workspace(lib.mrcnn_bn_workspace_bytes(P, Ci), h1.device)
+            check(lib.mrcnn_bn_train_stats_f32(ptr(h1), None, 0, ptr(m2), ptr(s2), None, None, P, Ci, 2e-5, 0.9, ptr(ws_bn), ws_bn.numel(), sp()))
+            assert torch.equal(m2, mean) and torch.equal(s2, invstd)
+            nb = lib.mrcnn_conv2d_workspace_bytes(N, H, W, Ci, Co, 3, 3, 1, 1)
+            ws = torch.empty((max(nb, 1),), dtype=torch.uint8, device=DEV)
+            y = torch.empty((N, H, W, Co), device=DEV)
+            rows = lib.mrcnn_conv2d_bnstats_rows(N, H, W, Ci, Co, 3, 3, 1, 1)
+            if not ok:
+                rc = lib.mrcnn_conv2d_fwd_inbn_f32(ptr(h1), ptr(gam), ptr(bet), ptr(mean), ptr(invstd), ptr(w), ptr(y), N, H, W, Ci, Co, 3, 3, 1, 1, None, None,
+                                                   ptr(ws), ws.numel(), sp())
+                assert rc != 0 and b'inbn_ok' in lib.mrcnn_last_error()
+                continue
+            part = torch.empty((rows, 2, Co), device=DEV) if rows else None
+            check(lib.mrcnn_conv2d_fwd_inbn_f32(ptr(h1), ptr(gam), ptr(bet), ptr(mean), ptr(invstd), ptr(w), ptr(y), N, H, W, Ci, Co, 3, 3, 1, 1, ptr(part), None,
+                                                ptr(ws), ws.numel(), sp()))
+            if rows:
+                y_ref, _, part_ref = hnn.conv2d_fwd_bnstats_raw(a1, w, 1, 1)
+                assert torch.equal(part, part_ref)
+            else:
+                y_ref = hnn.conv2d_fwd_raw(a1, w, None, 1, 1, False)
+            assert torch.equal(y, y_ref) and torch.isfinite(y).all()
+            gw_ref, _ = hnn.conv2d_bwd_filter_raw(a1, gy, tuple(w.shape), 1, 1, False)
+            gw = torch.empty_like(w)
+            nbf = lib.mrcnn_conv2d_bwd_filter_workspace_bytes(N, H, W, Ci, Co, 3, 3, 1, 1)
+            wsf = torch.empty((max(nbf, 1),), dtype=torch.uint8, device=DEV)
+            check(lib.mrcnn_conv2d_bwd_filter_inbn_f32(ptr(h1), ptr(gam), ptr(bet), ptr(mean), ptr(invstd), ptr(gy), ptr(gw), N, H, W, Ci, Co, 3, 3, 1, 1, 0, None,
+                                                       ptr(wsf), wsf.numel(), sp()))
+            assert torch.equal(gw, gw_ref)
+    finally:
+        check(lib.mrcnn_conv2d_set_split_operands(*keep))
