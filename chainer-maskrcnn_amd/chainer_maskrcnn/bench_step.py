@@ -201,6 +201,8 @@ def bench_step(args, rank, world):
                                % ('the <=64 positive' if mask_rows == 'positives' else 'all 256 sampled'),
                    'global_batch': N * world, 'launch_mode': mode, 'parallelism': 'dp%d: RCCL all-reduce of the flat gradient buffer in 25 MB '
                    'buckets on a side stream' % world if world > 1 else 'single GPU', 'final_loss': round(loss, 4),
+                   'box_to_box_note': 'identical code measures 20.5 - 21.9 ms per step and a float32-GEMM fraction of 0.60 - 0.68 on different MI355X boxes '
+                                      '(device / DVFS variance, MI355X_MICROARCH.md "DVFS give-back" item 5): compare rounds by same-box A/B (profiles/r06_ab_*), not by this line alone',
                    'gemm_arithmetic': {
                        'name': arith, 'split_operands_fwd_bwddata_bwdfilter': list(smode),
                        'scheme': {'bf16x6_behind_backbone': 'float32-ACCURATE emulation on v_mfma_f32_32x32x16_bf16 - every float32 operand is carried EXACTLY by three bf16 '
