@@ -768,7 +768,7 @@ __global__ __launch_bounds__(BWD_THREADS, 4) void k_roi_align_bwd_waves(Levels l
             for (int k = 0; k < PT; ++k)
                 if (i < nrow && k < ncol)                // wave-uniform
                     __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const __attribute__((ext_vector_type(4))) unsigned *>(&acc[i][k]), rs_gx,
-                                                           vlane, patch_off + (unsigned)((i * W + k) * C) * 4u, 0);
+                                                           vlane, patch_off + (unsigned)((i * W + k) * C) * 4u, 2);       // non-temporal: written once, read by a later kernel
     };
     // ---- entry-list plan (see PlanNode): a patch's first node sits at its launch-order slot, further ones come from the pool behind
     const int total_units = lv.tile_begin[lv.L] * BWD_WAVES;
