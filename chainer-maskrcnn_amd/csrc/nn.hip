@@ -20,6 +20,12 @@ constexpr int NT = 256;
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// streamed-once read (the LAST reader of a big tensor in its pass): non-temporal, does not displace lines other kernels re-read
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4s(const float *p) {
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
 
 // (n, h, w, c) of element i of an (N, Hd, Wd, C4) float4 grid.  32-bit unsigned arithmetic whenever the grid has fewer than 2^32
@@ -248,14 +254,14 @@ __global__ __launch_bounds__(NT) void k_bn_apply(const float *__restrict__ x, co
                                                  float *__restrict__ y, size_t n4, int C4, int relu) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
         const int c = (int)(i % C4) * 4;
-        const float4 v = ld4(x + i * 4), g = ld4(gamma + c), b = ld4(beta + c), m = ld4(mean + c), s = ld4(invstd + c);
+        const float4 v = ld4s(x + i * 4), g = ld4(gamma + c), b = ld4(beta + c), m = ld4(mean + c), s = ld4(invstd + c);
         float4 o;
         o.x = g.x * ((v.x - m.x) * s.x) + b.x;
         o.y = g.y * ((v.y - m.y) * s.y) + b.y;
         o.z = g.z * ((v.z - m.z) * s.z) + b.z;
         o.w = g.w * ((v.w - m.w) * s.w) + b.w;
         if (res) {
-            const float4 r = ld4(res + i * 4);
+            const float4 r = ld4s(res + i * 4);
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
@@ -369,8 +375,8 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float *__restrict__ g
                                                      float invP, int relu, const float *__restrict__ beta) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
         const int c = (int)(i % C4) * 4;
-        float4 g = ld4(gy + i * 4);
-        const float4 v = ld4(x + i * 4);
+        float4 g = ld4s(gy + i * 4);
+        const float4 v = ld4s(x + i * 4);
         const float4 ga = ld4(gamma + c), m = ld4(mean + c), s = ld4(invstd + c), gb = ld4(gbeta + c), gg = ld4(ggamma + c);
         if (relu) {
             float4 yy;
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float *__restrict__ g
                 yy.x = ga.x * ((v.x - m.x) * s.x) + be.x; yy.y = ga.y * ((v.y - m.y) * s.y) + be.y;
                 yy.z = ga.z * ((v.z - m.z) * s.z) + be.z; yy.w = ga.w * ((v.w - m.w) * s.w) + be.w;
             } else {
-                yy = ld4(y + i * 4);
+                yy = ld4s(y + i * 4);
             }
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(NT) void k_bn_apply2(const float *__restrict__ xa, 
                                                   size_t n4, int C4) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
         const int c = (int)(i % C4) * 4;
-        const float4 va = ld4(xa + i * 4), vb = ld4(xb + i * 4);
+        const float4 va = ld4s(xa + i * 4), vb = ld4s(xb + i * 4);
         const float4 ga = ld4(gamma_a + c), ba = ld4(beta_a + c), ma = ld4(mean_a + c), sa = ld4(invstd_a + c);
         const float4 gb = ld4(gamma_b + c), bb = ld4(beta_b + c), mb = ld4(mean_b + c), sb = ld4(invstd_b + c);
         float4 r, o;
@@ -503,10 +509,10 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply2(const float *__restrict__ 
                                                       size_t n4, int C4, float invP) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
         const int c = (int)(i % C4) * 4;
-        float4 g = ld4(gy + i * 4);
-        const float4 va = ld4(xa + i * 4), vb = ld4(xb + i * 4);
+        float4 g = ld4s(gy + i * 4);
+        const float4 va = ld4s(xa + i * 4), vb = ld4s(xb + i * 4);
         if (y) {
-            const float4 yy = ld4(y + i * 4);
+            const float4 yy = ld4s(y + i * 4);
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
