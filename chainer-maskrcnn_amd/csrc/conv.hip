@@ -73,6 +73,12 @@ struct ConvP {
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// read-once stream (split-K slabs, the Winograd GEMM's output M): non-temporal, does not displace lines other kernels re-read
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4s(const float *p) {
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 // ---- MFMA over one staged K step -----------------------------------------------------------
 // The workgroup tile is BM_ x BN_ (128 or 64 each), 2x2 waves, a wave owns (BM_/2) x (BN_/2) = TM x TN MFMA tiles.
 template <bool A_KC, bool B_KC, int BM_, int BN_>
@@ -952,12 +958,12 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ sla
     for (; k + 8 <= ksplit; k += 8) {            // 8 independent loads in flight, added in slab order
         float4 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ldg4(slabs + ((size_t)(k + j) * n4 + i) * 4);
+        for (int j = 0; j < 8; ++j) v[j] = ldg4s(slabs + ((size_t)(k + j) * n4 + i) * 4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
     }
     for (; k < ksplit; ++k) {
-        const float4 v = ldg4(slabs + ((size_t)k * n4 + i) * 4);
+        const float4 v = ldg4s(slabs + ((size_t)k * n4 + i) * 4);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     *reinterpret_cast<float4 *>(out + i * 4) = s;
@@ -1439,6 +1445,10 @@ __device__ __forceinline__ V4 v4buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, un
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
     return {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }
+__device__ __forceinline__ V4 v4buf_nt(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {       // read-once stream
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 2);
+    return {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
 __device__ __forceinline__ void v4bufst(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, V4 v) {
     const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, soff, 0);
@@ -1575,7 +1585,7 @@ __global__ __launch_bounds__(256) void k_wino_output(const float *__restrict__ M
         for (int q = 0; q < A_; ++q) {
             V4 m[A_], r[M_];
 #pragma unroll
-            for (int rr = 0; rr < A_; ++rr) m[rr] = v4buf(rsM, mo, (unsigned)(rr * A_ + q) * ks);
+            for (int rr = 0; rr < A_; ++rr) m[rr] = v4buf_nt(rsM, mo, (unsigned)(rr * A_ + q) * ks);
             wino_at<M_, V4>(m, r);
 #pragma unroll
             for (int a = 0; a < M_; ++a) s[a][q] = r[a];
