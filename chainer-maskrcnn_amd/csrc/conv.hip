@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void k_sum_slabs_ep(const float *__restrict__ 
     if (i >= n4) return;
     float4 s = accumulate ? ldg4(out + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < ksplit; ++k) {
-        const float4 v = ldg4s(slabs + ((size_t)k * n4 + i) * 4);
+        const float4 v = ldg4(slabs + ((size_t)k * n4 + i) * 4);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     if (bias) {
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_tail_sum(const float *__restrict__ slab
     float4 s = accumulate ? ldg4(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float *src = slab + (size_t)blockIdx.y * ks * (bm * bn) + (size_t)e4 * 4;
     for (int k = 0; k < ks; ++k) {
-        const float4 v = ldg4s(src + (size_t)k * (bm * bn));
+        const float4 v = ldg4(src + (size_t)k * (bm * bn));
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     if (bias) {
@@ -1826,13 +1826,13 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float *__restric
 #pragma unroll
     for (int q = 0; q < A_; ++q)
 #pragma unroll
-        for (int j = 0; j < A_; ++j) Dall[q][j] = __builtin_nontemporal_load(dU + o0 + (size_t)(q * A_ + j) * Cin);
+        for (int j = 0; j < A_; ++j) Dall[q][j] = dU[o0 + (size_t)(q * A_ + j) * Cin];
     for (int sl = 1; sl < nslab; ++sl) {            // the split-K slabs of dU are added here, in slab order
         const float *ds = dU + (size_t)sl * Cout * (A_ * A_) * Cin + o0;
 #pragma unroll
         for (int q = 0; q < A_; ++q)
 #pragma unroll
-            for (int j = 0; j < A_; ++j) Dall[q][j] += __builtin_nontemporal_load(ds + (size_t)(q * A_ + j) * Cin);
+            for (int j = 0; j < A_; ++j) Dall[q][j] += ds[(size_t)(q * A_ + j) * Cin];
     }
     float old[3][3];
     if (accumulate) {
