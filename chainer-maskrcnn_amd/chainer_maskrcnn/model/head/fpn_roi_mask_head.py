@@ -265,7 +265,7 @@ class FPNRoIMaskHead(object):
         if g_mask is not None:
             self.backward_mask_pool(self.backward_mask_convs(g_mask), g_feats)
 
-    def backward_box(self, g_box_out, g_feats):
+    def backward_box(self, g_box_out, g_feats, accumulate=False):
         t1, t2, t3, t4, pool_shape, rois, levels, scales, plan = self.box_tape
         R = g_box_out.shape[0]
         # every layer's input is the ReLU output of the layer below: the ReLU backward rides in the data-gradient epilogue
@@ -273,7 +273,8 @@ class FPNRoIMaskHead(object):
         g = self.fc2.bwd(t3, g, gy_masked=True, mask_gx=True)
         g = self.fc1.bwd(t2, g, gy_masked=True, mask_gx=True)
         g = self.conv1.bwd(t1, g.view(pool_shape), gy_masked=True)
-        roi_align_fpn_bwd(g, g_feats, rois, levels, self.roi_size_box, scales, accumulate=False, plan=plan)
+        # accumulate: g_feats already hold a gradient (the RPN's, computed early) - the backward then only touches the patches RoIs land on
+        roi_align_fpn_bwd(g, g_feats, rois, levels, self.roi_size_box, scales, accumulate=accumulate, plan=plan)
         self.box_tape = None
 
     def backward_mask_convs(self, g_mask):
