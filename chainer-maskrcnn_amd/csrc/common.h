@@ -46,8 +46,12 @@ namespace mrcnn {
 // + bitonic sort in LDS; cap <= 16384).  Keys must be < 2^key_bits; workspaces from the *_ws_bytes queries.
 size_t select_ws_bytes(int nseg, int key_bits);
 int select_kth(const unsigned long long *keys, int nseg, size_t seg_len, int key_bits, bool descending, const unsigned *kreq,
-               int kreq_stride, unsigned long long *kth, int kth_stride, void *ws, hipStream_t st);
+               int kreq_stride, unsigned long long *kth, int kth_stride, void *ws, hipStream_t st, bool hist_is_zero = false);
 size_t topk_ws_bytes(int nseg, int key_bits, int cap);
+// words of a top_k_sorted workspace that must be initialised before its first kernel (topk_init_of); prepared = the caller's own previous
+// kernel on the stream has done it
+struct TopkInit { unsigned *zero; int nzero; unsigned *count; int ncount; unsigned *kreq; int nk; unsigned kval; };
+TopkInit topk_init_of(int nseg, int key_bits, int cap, void *ws);
 int top_k_sorted(const unsigned long long *keys, int nseg, size_t seg_len, int key_bits, unsigned long long valid_bit, int cap,
-                 unsigned long long *out, size_t out_stride, void *ws, hipStream_t st);
+                 unsigned long long *out, size_t out_stride, void *ws, hipStream_t st, bool prepared = false);
 }  // namespace mrcnn

@@ -111,7 +111,15 @@ __device__ __forceinline__ unsigned orderable(float f) {     // monotone float -
 __global__ __launch_bounds__(256) void k_decode(const float *__restrict__ locs, const float *__restrict__ scores,
                                                 const float *__restrict__ anchors, int N, int A, float img_h, float img_w,
                                                 float min_size, const float *__restrict__ per_image, float *__restrict__ boxes,
-                                                u64 *__restrict__ keys, int ib, int batched) {
+                                                u64 *__restrict__ keys, int ib, int batched, mrcnn::TopkInit ti, int32_t *__restrict__ n_valid) {
+    // (r6) the words the rest of the chain needs initialised (radix-select histograms, compaction counters, k per image, the valid
+    // counters of the gather): four tiny fill launches on a latency-bound chain before
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ti.nzero; i += gridDim.x * 256) ti.zero[i] = 0u;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < ti.ncount; i += 256) ti.count[i] = 0u;
+        for (int i = threadIdx.x; i < ti.nk; i += 256) ti.kreq[i] = ti.kval;
+        if (n_valid) for (int i = threadIdx.x; i < N; i += 256) n_valid[i] = 0;
+    }
     const long long total = (long long)N * A;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int a = (int)(i % A);
@@ -521,12 +529,13 @@ extern "C" int mrcnn_rpn_proposals_f32(const float *locs, const float *scores, c
     int ib = 1;
     while ((1ll << ib) < A) ++ib;
     hipLaunchKernelGGL(k_decode, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, locs, scores,
-                       anchors, N, A, img_h, img_w, min_size, per_image, boxes, keys, ib, 0);
+                       anchors, N, A, img_h, img_w, min_size, per_image, boxes, keys, ib, 0,
+                       mrcnn::topk_init_of(N, 33 + ib, n_pre, w + L.sort_tmp), n_valid);
     MRCNN_LAUNCH_CHECK();
-    // argsort()[::-1][:n_pre] per image: radix select of the n_pre-th key + compaction + bitonic sort in LDS (sort.hip)
-    if (int e = mrcnn::top_k_sorted(keys, N, (size_t)A, 33 + ib, 1ull << (ib + 32), n_pre, keys_sorted, (size_t)n_pre + 1, w + L.sort_tmp, st))
+    // argsort()[::-1][:n_pre] per image: radix select of the n_pre-th key + compaction + bitonic sort in LDS (sort.hip); its workspace
+    // words and n_valid were initialised by k_decode
+    if (int e = mrcnn::top_k_sorted(keys, N, (size_t)A, 33 + ib, 1ull << (ib + 32), n_pre, keys_sorted, (size_t)n_pre + 1, w + L.sort_tmp, st, true))
         return e;
-    MRCNN_HIP_TRY(hipMemsetAsync(n_valid, 0, sizeof(int32_t) * N, st));
     hipLaunchKernelGGL(k_gather_sorted, dim3(mrcnn::cdiv(n_pre, 256), N), dim3(256), 0, st, keys_sorted, boxes, A, n_pre,
                        sboxes, sidx, n_valid, ib, n_pre + 1);
     MRCNN_LAUNCH_CHECK();

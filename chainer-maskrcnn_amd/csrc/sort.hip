@@ -312,11 +312,11 @@ size_t select_ws_bytes(int nseg, int key_bits) {
 
 // kth[seg * kth_stride] = the kreq[seg * kreq_stride]-th largest (descending) / smallest key of segment seg.  keys < 2^key_bits.
 int select_kth(const u64 *keys, int nseg, size_t seg_len, int key_bits, bool descending, const unsigned *kreq, int kreq_stride, u64 *kth,
-               int kth_stride, void *ws, hipStream_t st) {
+               int kth_stride, void *ws, hipStream_t st, bool hist_is_zero) {
     const int levels = levels_for(key_bits), top = levels * RS_BITS;
     unsigned *hist = (unsigned *)ws;
     SelState *state = (SelState *)((char *)ws + al256((size_t)levels * nseg * RS_BINS * sizeof(unsigned)));
-    MRCNN_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)levels * nseg * RS_BINS * sizeof(unsigned), st));
+    if (!hist_is_zero) MRCNN_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)levels * nseg * RS_BINS * sizeof(unsigned), st));
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>((seg_len + RS_THREADS * 8 - 1) / (RS_THREADS * 8), 256));
     for (int l = 0; l < levels; ++l) {
         hipLaunchKernelGGL(k_select_level, dim3(blocks, nseg), dim3(RS_THREADS), 0, st, keys, seg_len, l, top, descending, kreq, kreq_stride,
@@ -345,8 +345,23 @@ size_t topk_ws_bytes(int nseg, int key_bits, int cap) {
 
 // out[seg][0 .. cap) = the (up to) cap largest keys of segment seg that carry valid_bit, in descending order, zero-filled
 // beyond their number.  cap <= 16384.  keys are unique (composite keys), < 2^key_bits.
+// The words top_k_sorted needs initialised before its first kernel: a caller whose own previous kernel on the stream can write them
+// (TopkInit from topk_init_of; that kernel zeroes [zero, zero + nzero) and [count, count + ncount) and stores kval to kreq[0 .. nk)) passes
+// prepared = true and saves three tiny launches on a latency-bound chain.
+TopkInit topk_init_of(int nseg, int key_bits, int cap, void *ws) {
+    char *w = (char *)ws;
+    TopkInit t;
+    t.zero = (unsigned *)w;
+    t.nzero = (int)((size_t)levels_for(key_bits) * nseg * RS_BINS);
+    size_t o = select_ws_bytes(nseg, key_bits) + al256((size_t)nseg * 8);
+    t.kreq = (unsigned *)(w + o); o += al256((size_t)nseg * 4);
+    t.nk = nseg; t.kval = (unsigned)cap;
+    o += al256((size_t)nseg * cap * 8);
+    t.count = (unsigned *)(w + o); t.ncount = nseg;
+    return t;
+}
 int top_k_sorted(const u64 *keys, int nseg, size_t seg_len, int key_bits, u64 valid_bit, int cap, u64 *out, size_t out_stride, void *ws,
-                 hipStream_t st) {
+                 hipStream_t st, bool prepared) {
     if (cap <= 0 || cap > 16384) {
         set_error("top_k_sorted: cap %d not in [1, 16384]", cap);
         return MRCNN_E_UNSUPPORTED;
@@ -358,9 +373,11 @@ int top_k_sorted(const u64 *keys, int nseg, size_t seg_len, int key_bits, u64 va
     u64 *cand = (u64 *)(w + o); o += al256((size_t)nseg * cap * 8);
     unsigned *count = (unsigned *)(w + o); o += al256((size_t)nseg * 4);
     u64 *runs = (u64 *)(w + o);
-    fill_u32(kreq, (unsigned)cap, nseg, st);              // k = cap for every segment
-    MRCNN_HIP_TRY(hipMemsetAsync(count, 0, (size_t)nseg * 4, st));
-    if (int e = select_kth(keys, nseg, seg_len, key_bits, true, kreq, 1, kth, 1, ws, st)) return e;
+    if (!prepared) {
+        fill_u32(kreq, (unsigned)cap, nseg, st);              // k = cap for every segment
+        MRCNN_HIP_TRY(hipMemsetAsync(count, 0, (size_t)nseg * 4, st));
+    }
+    if (int e = select_kth(keys, nseg, seg_len, key_bits, true, kreq, 1, kth, 1, ws, st, prepared)) return e;
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>((seg_len + RS_THREADS * 8 - 1) / (RS_THREADS * 8), 256));
     hipLaunchKernelGGL(k_compact_ge, dim3(blocks, nseg), dim3(RS_THREADS), 0, st, keys, seg_len, kth, valid_bit, cap, cand, count);
     MRCNN_LAUNCH_CHECK();
