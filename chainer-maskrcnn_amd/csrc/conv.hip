@@ -1241,7 +1241,7 @@ int run_data_conv(ConvP &p, int nsteps, long long ldc, void *ws, size_t ws_bytes
 constexpr int WINO_ROWS = 128;          // Tp = T rounded up to this: a GEMM tile never straddles two k
 
 int g_wino_min_channels = 256, g_wino_min_pixels = 2048, g_wino_tile = 0;      // tile 0 = automatic, 2 or 4 = forced
-int g_wino_banded = 1;        // input transforms: XCD-banded workgroup order (mrcnn_debug_wino_banded(0) = launch order, for A/B)
+int g_wino_banded = 16;       // input transforms: 0 = launch order, 1 = XCD-banded raster order, >= 2 = XCD-banded column panels of that many tiles (mrcnn_debug_wino_banded, for A/B)
 // Per pass (PASS_FWD / PASS_BWD_DATA / PASS_BWD_FILTER) override of the tile: 0 = follow g_wino_tile, 2 / 4 = forced,
 // -1 = the pass never takes the Winograd path.  F(4x4,3x3) amplifies float32 rounding by ~|A|^2 |B|^2 |G|^2: harmless on
 // activations (measured 1.5e-4 of the tensor scale on the full network) but visible in gradients of layers whose own
@@ -1460,17 +1460,35 @@ __device__ __forceinline__ void v4bufst(__amdgpu_buffer_rsrc_t rs, unsigned voff
 struct InBN { const float *gamma, *beta, *mean, *invstd; };
 template <int M_>
 __device__ __forceinline__ void wino_input_body(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
-                                                int th, int tw, long long T, long long Tp, unsigned blk, const InBN bn = InBN{}) {
+                                                int th, int tw, long long T, long long Tp, unsigned blk, const InBN bn = InBN{},
+                                                int panel = 0) {
     constexpr int A_ = M_ + 2;
     // 32-bit index arithmetic (wino_ok(): 16 * Tp * C < 2^30): the 64-bit divisions this replaces were ~600 instructions of
     // branchy software division per thread
     const unsigned C4 = (unsigned)C / 4u;
     const unsigned i = blk * 256u + threadIdx.x;
     if (i >= (unsigned)Tp * C4) return;
-    const unsigned t = i / C4;
+    unsigned t = i / C4;
     const int c = (int)(i - t * C4) * 4;
     const unsigned ks = (unsigned)((size_t)Tp * C * 4);                 // bytes per k plane
     const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void *)V, 0, (unsigned)((size_t)A_ * A_ * Tp * C * 4), 0x00020000);
+    // Tile order inside an image (speed only: every tile is still transformed exactly once into its own rows of V).  Raster order puts
+    // the tiles that share two of their six input rows a whole tile row apart; in column PANELS of `panel` tiles the next tile row of the
+    // panel follows at once, and the shared rows are an L2 hit whatever else the other streams push through the cache meanwhile.
+    if (panel > 1 && t < (unsigned)T) {
+        const unsigned per = (unsigned)th * (unsigned)tw, pw = (unsigned)panel;
+        const unsigned n0 = t / per, q = t - n0 * per;
+        const unsigned full = (unsigned)tw / pw * pw, nf = (unsigned)th * full;
+        unsigned ty0, tx0;
+        if (q < nf) {
+            const unsigned pp = q / ((unsigned)th * pw), r = q - pp * (unsigned)th * pw;
+            ty0 = r / pw; tx0 = pp * pw + (r - ty0 * pw);
+        } else {
+            const unsigned wr = (unsigned)tw - full, q2 = q - nf;
+            ty0 = q2 / wr; tx0 = full + (q2 - ty0 * wr);
+        }
+        t = n0 * per + ty0 * (unsigned)tw + tx0;
+    }
     const unsigned vo = (unsigned)(((size_t)t * C + c) * 4);
     if (t >= (unsigned)T) {           // rows that pad T to a multiple of the GEMM tile: zero (the filter-gradient GEMM sums them)
 #pragma unroll
@@ -1537,7 +1555,7 @@ __device__ __forceinline__ unsigned xcd_banded(unsigned g, unsigned first, unsig
 template <int M_>
 __global__ __launch_bounds__(256) void k_wino_input(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W, int C,
                                                     int th, int tw, long long T, long long Tp, int banded, InBN bn) {
-    wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, 0, gridDim.x, banded), bn);
+    wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, 0, gridDim.x, banded), bn, banded);
 }
 // Filter and input transform of one convolution call in ONE launch (the first `fblocks` workgroups transform the filter):
 // the two are independent, and a separate 5-8 us filter launch in front of every Winograd GEMM is pure launch latency on the
@@ -1548,7 +1566,7 @@ __global__ __launch_bounds__(256) void k_wino_input_filter(const float *__restri
                                                            float *__restrict__ U, int Cout_w, int Cin_w, int transposed, unsigned fblocks,
                                                            int banded, int uplanes, InBN bn) {
     if (blockIdx.x < fblocks) wino_filter_body<M_>(w, U, Cout_w, Cin_w, transposed, blockIdx.x, uplanes);
-    else wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, fblocks, gridDim.x - fblocks, banded), bn);
+    else wino_input_body<M_>(x, V, N, H, W, C, th, tw, T, Tp, xcd_banded(blockIdx.x, fblocks, gridDim.x - fblocks, banded), bn, banded);
 }
 
 // y (m x m pixels of tile t) = A^T M A + bias, then ReLU | + old y (accumulate) | zeroed where relu_x <= 0.
@@ -2128,7 +2146,7 @@ extern "C" int mrcnn_debug_planes_gemm(int kind, const void *a, const void *b, f
 }
 
 extern "C" int mrcnn_debug_wino_banded(int on) {
-    g_wino_banded = on ? 1 : 0;
+    g_wino_banded = on < 0 ? 0 : on;          // 0 launch order, 1 XCD-banded raster, >= 2 XCD-banded column panels of that many tiles
     return 0;
 }
 

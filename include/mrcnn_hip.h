@@ -239,7 +239,8 @@ int mrcnn_conv2d_get_split_operands(int *modes3);
  * for (default 2), the HALF rounds of workgroup slots the filter-gradient split-K fills (default 2 = one round), and a forced forward /
  * backward-data tile (0 = the planner's choice, 1 = 128x64, 2 = 64x64). */
 int mrcnn_debug_conv_plan(int fill, int filter_rounds, int force_tile);
-/* Measurement knob: 0 = the Winograd input transforms walk the tiles in launch order instead of XCD-banded (default 1; same results). */
+/* Measurement knob, tile order of the Winograd input transforms (speed only, same results): 0 = launch order, 1 = XCD-banded raster order,
+ * n >= 2 = XCD-banded column panels n tiles wide (default 16). */
 int mrcnn_debug_wino_banded(int on);
 /* Measurement knob, split-operand GEMM kernels only: 1 = the MFMAs are skipped, 2 = the global loads inside the K loop are skipped,
  * 4 = the epilogue is skipped (results are garbage while one of these bits is set; where does such a kernel's time go?);

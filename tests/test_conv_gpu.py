@@ -149,6 +149,36 @@ def test_conv_winograd_forward_and_backward_data(case, tile, tol, pass_tiles):
         _hip.check(_hip.lib().mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))
 
 
+@pytest.mark.parametrize('case', [(1, 67, 63, 256, 288), (3, 40, 36, 64, 64), (2, 70, 132, 128, 128)])
+def test_winograd_tile_order_is_speed_only(case):
+    """The input transforms walk the tiles in column panels (default 16 tiles wide); every order - launch order, raster, panels that
+    do and do not divide the tile row - writes the same rows of V, so all three passes give the same bits."""
+    from chainer_maskrcnn import _hip
+    lib = _hip.lib()
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(5 + sum(case))
+    x = torch.randn((N, H, W, Cin), generator=g).to(DEV)
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / (9 * Cin) ** 0.5).to(DEV)
+    b = torch.randn((Cout,), generator=g).to(DEV)
+    gy = torch.randn((N, H, W, Cout), generator=g).to(DEV)
+    _hip.check(lib.mrcnn_conv2d_set_winograd_thresholds(64, 2048, 0))
+    _hip.check(lib.mrcnn_conv2d_set_winograd_pass_tiles(0, 0, 0))
+    try:
+        outs = []
+        for order in (16, 0, 1, 2, 5, 64):
+            _hip.check(lib.mrcnn_debug_wino_banded(order))
+            got = (hnn.conv2d_fwd_raw(x, w, b, 1, 1, True), hnn.conv2d_bwd_data_raw(gy, w, (N, H, W, Cin), 1, 1),
+                   hnn.conv2d_bwd_filter_raw(x, gy, tuple(w.shape), 1, 1, True))
+            outs.append([o[0] if isinstance(o, (tuple, list)) else o for o in got])
+        for o in outs[1:]:
+            for a, r in zip(o, outs[0]):
+                assert torch.equal(a, r)
+    finally:
+        _hip.check(lib.mrcnn_debug_wino_banded(16))
+        _hip.check(lib.mrcnn_conv2d_set_winograd_thresholds(256, 2048, 0))
+        _hip.check(lib.mrcnn_conv2d_set_winograd_pass_tiles(2, 0, 0))
+
+
 def _winograd_case(case, tol, shared_gy=True):
     N, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(31 + sum(case))

@@ -9,6 +9,9 @@ from chainer_maskrcnn.model.fpn_maskrcnn_train_chain import FPNMaskRCNNTrainChai
 from chainer_maskrcnn.optimizers import MomentumSGD, WeightDecay
 from chainer_maskrcnn.utils.synthetic import make_batch
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if os.environ.get('MRCNN_WINO_ORDER'):      # measurement: tile order of the Winograd input transforms (mrcnn_debug_wino_banded)
+    from chainer_maskrcnn._hip import lib as _lib
+    _lib().mrcnn_debug_wino_banded(int(os.environ['MRCNN_WINO_ORDER']))
 dev = torch.device('cuda:0')
 model = MaskRCNN(n_fg_class=80, device=dev, seed=1234)
 chain = FPNMaskRCNNTrainChain(model, mask_loss_fun=calc_mask_loss, mask_rows='all', gemm_arithmetic=os.environ.get('MRCNN_GEMM_ARITHMETIC', 'bf16x6_behind_backbone'))
